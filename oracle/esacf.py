@@ -1,0 +1,115 @@
+"""Oracle: ESACF (Tolonen-Karjalainen) chroma (reference method 1).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates reference
+chord_detection/esacf.py:41-129 in float64 NumPy.  Stages a4-a6 (wfir, band
+split, SACF) follow reference code that runs in the authoring container and are
+pinned by fixtures; stages a7-a8 (time_stretch enhancement, peak pick + fit)
+call third-party code that is absent -> restated in oracle/thirdparty.py,
+PARITY UNPINNED.
+"""
+import numpy as np
+
+from . import dsp
+from . import thirdparty as tp
+
+SACF_K = 0.67  # esacf.py:95-96: self.k is never forwarded (quirk A.6)
+
+# Quirk A.18 (found while pinning the oracle against the reference's code):
+# librosa.hz_to_note returns unicode sharps ("C♯"); Chromagram.__getitem__ maps
+# '♯'->'#' (chromagram.py:21) but __setitem__ does not (chromagram.py:29), so
+# `chromagram[note] += v` (esacf.py:69) stores the sum under a NEW key "C♯" that
+# Chromagram.__add__ (chromagram.py:43-44) never reads: every sharp pitch class
+# is silently dropped by the hz_to_note-based methods (1, 3, 4).  Method 2
+# indexes by int and is unaffected.
+SHARP_PITCH_CLASSES = (1, 3, 6, 8, 10)
+
+
+def ham_samples(fs, ham_ms=46.4):
+    """reference esacf.py:27."""
+    return int(fs * ham_ms / 1000.0)
+
+
+def band_split(frames, fs):
+    """reference esacf.py:45-51 on [F,N] float64 frames -> (x_w, x_lo, x_hi)."""
+    x = dsp.wfir(frames, fs, 12)
+    x_hi = dsp.highpass_filter(x, fs)
+    x_hi = np.clip(x_hi, 0, None)
+    x_hi = dsp.lowpass_filter(x_hi, fs, 1000)
+    x_lo = dsp.lowpass_filter(x, fs, 1000)
+    return x, x_lo, x_hi
+
+
+def sacf(x_lo, x_hi):
+    """reference esacf.py:93-105: real(ifft(sum_ch |fft(x_ch)|**0.67))[:(N-1)//2];
+    circular, length-N complex FFT, no window, no zero padding."""
+    x_lo = np.asarray(x_lo, dtype=np.float64)
+    n = x_lo.shape[-1]
+    s = np.abs(np.fft.fft(x_lo, axis=-1)) ** SACF_K + np.abs(np.fft.fft(x_hi, axis=-1)) ** SACF_K
+    return np.real(np.fft.ifft(s, axis=-1))[..., :int((n - 1) / 2)]
+
+
+def esacf_enhance(x2, n_peaks=6, mode="librosa010"):
+    """reference esacf.py:108-129.  mode 'librosa010': librosa>=0.10 time_stretch
+    semantics (oracle/thirdparty.py); 'noop': time_stretch returns an empty
+    array (older librosa on a one-frame STFT; matches the README figure)."""
+    x2tmp = np.array(x2, dtype=np.float64)
+    m = x2tmp.shape[0]
+    for timescale in range(2, n_peaks + 1):
+        x2tmp = np.clip(x2tmp, 0, None)
+        if mode == "noop":
+            stretched = np.zeros(0)
+        elif tp.time_stretch_is_truncation(m):
+            stretched = x2tmp[:int(round(m / timescale))].copy()
+        else:
+            stretched = tp.time_stretch(x2tmp, timescale)
+        s = np.zeros(m)  # ndarray.resize(x2tmp.shape): zero-extend / truncate
+        k = min(m, stretched.shape[0])
+        s[:k] = stretched[:k]
+        x2tmp = x2tmp - s
+        x2tmp = np.clip(x2tmp, 0, None)
+    return x2tmp
+
+
+def frame_chroma(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, detail=False):
+    """reference esacf.py:56-71: peak pick, gaussian interpolation, pitch-class
+    scatter.  The i-th *interpolated* lag is paired with the i-th peak index
+    (quirk A.8)."""
+    peaks = tp.peak_indexes(x_esacf, thres=peak_thresh, min_dist=peak_min_dist)
+    interp = tp.peak_interpolate(np.arange(x_esacf.shape[0]), x_esacf, peaks)
+    chroma = np.zeros(12)
+    for i, tau in enumerate(interp):
+        with np.errstate(all="ignore"):
+            pitch = fs / tau
+        try:
+            pc = tp.hz_to_pitch_class(pitch)
+        except ValueError:
+            continue
+        if pc in SHARP_PITCH_CLASSES:
+            continue
+        chroma[pc] += x_esacf[peaks[i]]
+    if detail:
+        return chroma, peaks, interp
+    return chroma
+
+
+def esacf_frames(x, fs, frame_size=None, hop=None, n_peaks_elim=6, peak_thresh=0.1,
+                 peak_min_dist=10, enhance_mode="librosa010"):
+    if frame_size is None:
+        frame_size = ham_samples(fs)
+    frames = dsp.frame_matrix(x, frame_size, hop)
+    _, x_lo, x_hi = band_split(frames, fs)
+    s = sacf(x_lo, x_hi)
+    out = np.zeros((frames.shape[0], 12))
+    for f in range(frames.shape[0]):
+        e = esacf_enhance(s[f], n_peaks_elim, enhance_mode)
+        out[f] = frame_chroma(e, fs, peak_thresh, peak_min_dist)
+    return out
+
+
+def esacf_compute(x, fs, **kw):
+    """Summed chroma [12] == MultipitchESACF.compute_pitches() (esacf.py:41-91)."""
+    per = esacf_frames(x, fs, **kw)
+    acc = np.zeros(12)
+    for f in range(per.shape[0]):
+        acc = acc + per[f]
+    return acc
