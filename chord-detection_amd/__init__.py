@@ -1,0 +1,10 @@
+"""chord_detection_amd -- MI355X-native drop-in for the hot path of
+sevagh/chord-detection (reference chord_detection/__init__.py:1-7 exports)."""
+from .esacf import MultipitchESACF
+from .harmonic_energy import MultipitchHarmonicEnergy
+from .multipitch import METHODS, Multipitch
+from .chromagram import Chromagram, detect_key
+from .engine import Engine, get_engine, device_count
+
+__all__ = ["MultipitchESACF", "MultipitchHarmonicEnergy", "METHODS", "Multipitch", "Chromagram", "detect_key",
+           "Engine", "get_engine", "device_count"]

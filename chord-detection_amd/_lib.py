@@ -1,0 +1,76 @@
+"""ctypes binding of include/mpx.h (the C-ABI shared library built from csrc/).
+
+There is NO CPU fallback: if libmpx_hip.so is missing or no MI355X is visible,
+every compute entry point raises.
+"""
+import ctypes as C
+import os
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmpx_hip.so")
+
+MPX_OK, MPX_EINVAL, MPX_ENOMEM, MPX_EHIP, MPX_EUNSUPPORTED = 0, -1, -2, -3, -4
+MPX_FLAG_F32 = 0x1
+MPX_ENHANCE_LIBROSA010, MPX_ENHANCE_NOOP = 0, 1
+STAGES = {"wfir": 0, "x_lo": 1, "x_hi": 2, "sacf": 3, "esacf": 4}
+
+
+class HeParams(C.Structure):
+    _fields_ = [("num_harmonic", C.c_int), ("num_octave", C.c_int), ("num_bins", C.c_int)]
+
+
+class EsacfParams(C.Structure):
+    _fields_ = [("n_peaks_elim", C.c_int), ("peak_thresh", C.c_double),
+                ("peak_min_dist", C.c_int), ("enhance_mode", C.c_int)]
+
+
+_fp = C.POINTER(C.c_float)
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/mpx.h declares
+SIGNATURES = {
+    "mpx_abi_version": (C.c_int, []),
+    "mpx_device_count": (C.c_int, []),
+    "mpx_create": (_vp, [C.c_int, C.c_int]),
+    "mpx_destroy": (None, [_vp]),
+    "mpx_last_error": (C.c_char_p, [_vp]),
+    "mpx_synchronize": (C.c_int, [_vp]),
+    "mpx_stream": (_vp, [_vp]),
+    "mpx_num_frames": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "mpx_harmonic_energy": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _dp, _dp]),
+    "mpx_harmonic_energy_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _dp]),
+    "mpx_harmonic_energy_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mpx_esacf": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp, _dp]),
+    "mpx_esacf_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
+    "mpx_esacf_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
+    "mpx_timer_begin": (C.c_int, [_vp, _vp]),
+    "mpx_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmpx_hip.so (once).  If torch is going to be used in this process
+    it must be imported BEFORE this call: torch ships its own libamdhip64 with
+    the same SONAME and the loader then shares that one runtime between us."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "chord_detection_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mpx_abi_version() != 1:
+        raise RuntimeError("libmpx_hip.so ABI version mismatch")
+    _lib = lib
+    return lib

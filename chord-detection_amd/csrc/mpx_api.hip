@@ -1,0 +1,328 @@
+// C ABI (include/mpx.h): context, workspaces, host<->device staging.
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+#include "mpx_internal.hpp"
+
+static thread_local std::string g_create_error;
+
+namespace mpx {
+
+int set_error(mpx_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.bytes) return MPX_OK;
+    if (b.p) {
+        // the old block may still be in use by work queued on our stream
+        hipStreamSynchronize(ctx->stream);
+        hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return set_error(ctx, MPX_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.bytes = want;
+    return MPX_OK;
+}
+
+void* upload(mpx_ctx* ctx, const void* host, size_t bytes) {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes ? bytes : 16) != hipSuccess) {
+        set_error(ctx, MPX_ENOMEM, "hipMalloc(%zu) for a plan table failed", bytes);
+        return nullptr;
+    }
+    if (bytes && hipMemcpy(d, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error(ctx, MPX_EHIP, "hipMemcpy of a plan table failed");
+        hipFree(d);
+        return nullptr;
+    }
+    ctx->owned.push_back(d);
+    return d;
+}
+
+static int64_t num_frames_of(int64_t n, int frame, int hop) {
+    if (n <= 0) return 0;
+    if (hop == frame) return (n + frame - 1) / frame;
+    if (n <= frame) return 1;
+    return 1 + (n - frame + hop - 1) / hop;
+}
+
+// Frame descriptors for C clips packed back to back (each clip framed on its own).
+static int build_descs(const int64_t* offsets, int num_clips, int frame, int hop,
+                       std::vector<FrameDesc>& descs, std::vector<long long>& seg) {
+    seg.assign(1, 0);
+    for (int c = 0; c < num_clips; ++c) {
+        const int64_t len = offsets[c + 1] - offsets[c];
+        if (len < 0) return MPX_EINVAL;
+        const int64_t nf = num_frames_of(len, frame, hop);
+        for (int64_t f = 0; f < nf; ++f) {
+            const int64_t s = f * hop;
+            const int64_t left = len - s;
+            descs.push_back({(long long)(offsets[c] + s), (int)(left >= frame ? frame : (left > 0 ? left : 0)), c});
+        }
+        seg.push_back((long long)descs.size());
+    }
+    return MPX_OK;
+}
+
+}  // namespace mpx
+
+using namespace mpx;
+
+extern "C" {
+
+int mpx_abi_version(void) { return MPX_ABI_VERSION; }
+
+int mpx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+mpx_ctx* mpx_create(int device, int flags) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        set_error(nullptr, MPX_EHIP, "no HIP device available (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= n) {
+        set_error(nullptr, MPX_EINVAL, "device %d out of range [0,%d)", device, n);
+        return nullptr;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        set_error(nullptr, MPX_EHIP, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return nullptr;
+    }
+    mpx_ctx* ctx = new (std::nothrow) mpx_ctx();
+    if (!ctx) {
+        set_error(nullptr, MPX_ENOMEM, "out of host memory");
+        return nullptr;
+    }
+    ctx->device = device;
+    ctx->flags = flags;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+        set_error(nullptr, MPX_EHIP, "stream/event creation failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+void mpx_destroy(mpx_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (void* p : ctx->owned) hipFree(p);
+    for (DevBuf* b : {&ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
+                      &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2})
+        if (b->p) hipFree(b->p);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* mpx_last_error(const mpx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mpx_synchronize(mpx_ctx* ctx) {
+    if (!ctx) return MPX_EINVAL;
+    MPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MPX_OK;
+}
+
+void* mpx_stream(mpx_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int64_t mpx_num_frames(int64_t n, int frame, int hop) {
+    if (frame <= 0 || hop <= 0 || hop > frame) return -1;
+    return num_frames_of(n, frame, hop);
+}
+
+int mpx_timer_begin(mpx_ctx* ctx, void* stream) {
+    if (!ctx) return MPX_EINVAL;
+    MPX_HIP(ctx, hipEventRecord(ctx->ev0, stream ? (hipStream_t)stream : ctx->stream));
+    return MPX_OK;
+}
+
+int mpx_timer_end(mpx_ctx* ctx, void* stream, float* ms) {
+    if (!ctx || !ms) return MPX_EINVAL;
+    MPX_HIP(ctx, hipEventRecord(ctx->ev1, stream ? (hipStream_t)stream : ctx->stream));
+    MPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    MPX_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return MPX_OK;
+}
+
+// ------------------------------------------------------------------ method 2
+static int check_common(mpx_ctx* ctx, const void* sig, int64_t n, int frame, int hop) {
+    if (!ctx) return MPX_EINVAL;
+    ctx->err.clear();
+    if (n < 0 || (n > 0 && !sig)) return set_error(ctx, MPX_EINVAL, "signal pointer/length invalid");
+    if (frame <= 0 || hop <= 0 || hop > frame)
+        return set_error(ctx, MPX_EINVAL, "need 0 < hop <= frame (got frame=%d hop=%d)", frame, hop);
+    MPX_HIP(ctx, hipSetDevice(ctx->device));
+    return MPX_OK;
+}
+
+typedef int (*run_fn)(mpx_ctx*, const float*, int64_t, const FrameDesc*, int64_t, int, const void*, int, int,
+                      double*, hipStream_t);
+
+static int run_he(mpx_ctx* c, const float* s, int64_t n, const FrameDesc* d, int64_t nf, int fs, const void* p,
+                  int frame, int hop, double* out, hipStream_t st) {
+    return he_run(c, s, n, d, nf, fs, (const mpx_he_params*)p, frame, hop, out, st);
+}
+static int run_esacf(mpx_ctx* c, const float* s, int64_t n, const FrameDesc* d, int64_t nf, int fs, const void* p,
+                     int frame, int hop, double* out, hipStream_t st) {
+    return esacf_run(c, s, n, d, nf, fs, (const mpx_esacf_params*)p, frame, hop, out, -1, nullptr, st);
+}
+
+// device-resident single signal
+static int method_dev(mpx_ctx* ctx, run_fn run, const float* d_signal, int64_t n, int fs, const void* params,
+                      int frame, int hop, double* d_chroma_frames, double* d_chroma_sum, void* stream) {
+    int rc = check_common(ctx, d_signal, n, frame, hop);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    const int64_t nf = num_frames_of(n, frame, hop);
+    double* frames_out = d_chroma_frames;
+    if (!frames_out) {
+        if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
+        frames_out = (double*)ctx->d_frames_out.p;
+    }
+    if ((rc = run(ctx, d_signal, n, nullptr, nf, fs, params, frame, hop, frames_out, st))) return rc;
+    if (d_chroma_sum) {
+        if (nf == 0)
+            MPX_HIP(ctx, hipMemsetAsync(d_chroma_sum, 0, 12 * sizeof(double), st));
+        else if ((rc = segment_sum(ctx, frames_out, nullptr, 1, nf, d_chroma_sum, st)))
+            return rc;
+    }
+    return MPX_OK;
+}
+
+// host single signal
+static int method_host(mpx_ctx* ctx, run_fn run, const float* signal, int64_t n, int fs, const void* params,
+                       int frame, int hop, double* chroma_frames, double* chroma_sum) {
+    int rc = check_common(ctx, signal, n, frame, hop);
+    if (rc) return rc;
+    if (!chroma_sum) return set_error(ctx, MPX_EINVAL, "chroma_sum must not be NULL");
+    const int64_t nf = num_frames_of(n, frame, hop);
+    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
+    if (n) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
+                    (double*)ctx->d_frames_out.p, (double*)ctx->d_sum.p, ctx->stream);
+    if (rc) return rc;
+    MPX_HIP(ctx, hipMemcpyAsync(chroma_sum, ctx->d_sum.p, 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (chroma_frames && nf)
+        MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nf * 12 * sizeof(double),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    MPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MPX_OK;
+}
+
+// host batch of clips
+static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const int64_t* offsets, int num_clips,
+                        int fs, const void* params, int frame, int hop, double* chroma_sums) {
+    if (!ctx) return MPX_EINVAL;
+    if (num_clips < 0 || !offsets || (num_clips > 0 && !chroma_sums))
+        return set_error(ctx, MPX_EINVAL, "bad batch arguments");
+    if (num_clips == 0) return MPX_OK;
+    const int64_t total = offsets[num_clips];
+    int rc = check_common(ctx, signals, total, frame, hop);
+    if (rc) return rc;
+    if (offsets[0] != 0) return set_error(ctx, MPX_EINVAL, "offsets[0] must be 0");
+    std::vector<FrameDesc> descs;
+    std::vector<long long> seg;
+    if (build_descs(offsets, num_clips, frame, hop, descs, seg))
+        return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
+    const int64_t nf = (int64_t)descs.size();
+    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_desc, (size_t)(nf ? nf : 1) * sizeof(FrameDesc)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
+    hipStream_t st = ctx->stream;
+    if (total) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyHostToDevice, st));
+    if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    if (nf && (rc = run(ctx, (const float*)ctx->d_signal.p, total, (const FrameDesc*)ctx->d_desc.p, nf, fs, params,
+                        frame, hop, (double*)ctx->d_frames_out.p, st)))
+        return rc;
+    if ((rc = segment_sum(ctx, (const double*)ctx->d_frames_out.p, (const long long*)ctx->d_offsets.p, num_clips, nf,
+                          (double*)ctx->d_sum.p, st)))
+        return rc;
+    MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double),
+                                hipMemcpyDeviceToHost, st));
+    MPX_HIP(ctx, hipStreamSynchronize(st));
+    return MPX_OK;
+}
+
+int mpx_harmonic_energy(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_he_params* params,
+                        int frame, int hop, double* chroma_frames, double* chroma_sum) {
+    return method_host(ctx, run_he, signal, n, fs, params, frame, hop, chroma_frames, chroma_sum);
+}
+
+int mpx_harmonic_energy_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                              const mpx_he_params* params, int frame, int hop, double* chroma_sums) {
+    return method_batch(ctx, run_he, signals, offsets, num_clips, fs, params, frame, hop, chroma_sums);
+}
+
+int mpx_harmonic_energy_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_he_params* params,
+                            int frame, int hop, double* d_chroma_frames, double* d_chroma_sum, void* stream) {
+    return method_dev(ctx, run_he, d_signal, n, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, stream);
+}
+
+// ------------------------------------------------------------------ method 1
+int mpx_esacf(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_esacf_params* params, int frame,
+              int hop, double* chroma_frames, double* chroma_sum) {
+    return method_host(ctx, run_esacf, signal, n, fs, params, frame, hop, chroma_frames, chroma_sum);
+}
+
+int mpx_esacf_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                    const mpx_esacf_params* params, int frame, int hop, double* chroma_sums) {
+    return method_batch(ctx, run_esacf, signals, offsets, num_clips, fs, params, frame, hop, chroma_sums);
+}
+
+int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_esacf_params* params,
+                  int frame, int hop, double* d_chroma_frames, double* d_chroma_sum, void* stream) {
+    return method_dev(ctx, run_esacf, d_signal, n, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, stream);
+}
+
+int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int fs,
+                    const mpx_esacf_params* params, int frame, int hop, double* out) {
+    int rc = check_common(ctx, signal, n, frame, hop);
+    if (rc) return rc;
+    if (stage < MPX_STAGE_WFIR || stage > MPX_STAGE_ESACF || !out)
+        return set_error(ctx, MPX_EINVAL, "bad stage id %d or NULL out", stage);
+    const int64_t nf = num_frames_of(n, frame, hop);
+    if (nf == 0) return MPX_OK;
+    const size_t len = stage <= MPX_STAGE_XHI ? (size_t)frame : (size_t)((frame - 1) / 2);
+    if ((rc = ensure(ctx, ctx->d_signal, (size_t)n * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nf * 12 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ws2, (size_t)nf * len * sizeof(double) + 16))) return rc;
+    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = esacf_run(ctx, (const float*)ctx->d_signal.p, n, nullptr, nf, fs, params, frame, hop,
+                        (double*)ctx->d_frames_out.p, stage, (double*)ctx->d_ws2.p, ctx->stream)))
+        return rc;
+    MPX_HIP(ctx, hipMemcpyAsync(out, ctx->d_ws2.p, (size_t)nf * len * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    MPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MPX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,197 @@
+// LDS-resident power-of-two complex FFT for one workgroup (gfx950 / CDNA4).
+//
+// One workgroup of T threads transforms M complex points that live in LDS.
+// Every thread owns EPT = M/T points in registers during a pass; a pass is a
+// Stockham autosort step of radix R in {2,4,8,16} (natural order in, natural
+// order out, no bit reversal), so the data makes log_R(M) round trips through
+// LDS and none through HBM.  Passes are fully unrolled at compile time; twiddles
+// come from one W_M table (fp64-exact, built on the host) that stays in L2.
+//
+// No reference counterpart: the reference calls numpy.fft (pocketfft) at
+// esacf.py:103-105 and harmonic_energy.py:43.  No rocFFT / hipFFT is used.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpx {
+
+template <typename T>
+struct cx {
+    T x, y;
+};
+
+template <typename T>
+__device__ __forceinline__ cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+// multiply by -i  (forward-transform quarter turn)
+template <typename T>
+__device__ __forceinline__ cx<T> mul_mi(cx<T> a) { return {a.y, -a.x}; }
+
+// ---------------------------------------------------------------- small DFTs
+// In-register forward DFT of R points, natural order in and out.
+template <int R, typename T>
+struct SmallDft;
+
+template <typename T>
+struct SmallDft<2, T> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        cx<T> a = v[0], b = v[1];
+        v[0] = cadd(a, b);
+        v[1] = csub(a, b);
+    }
+};
+
+template <typename T>
+struct SmallDft<4, T> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        cx<T> t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+        cx<T> t2 = cadd(v[1], v[3]), t3 = mul_mi(csub(v[1], v[3]));
+        v[0] = cadd(t0, t2);
+        v[2] = csub(t0, t2);
+        v[1] = cadd(t1, t3);
+        v[3] = csub(t1, t3);
+    }
+};
+
+template <typename T>
+struct SmallDft<8, T> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        const T h = (T)0.70710678118654752440;
+        cx<T> e[4] = {v[0], v[2], v[4], v[6]};
+        cx<T> o[4] = {v[1], v[3], v[5], v[7]};
+        SmallDft<4, T>::run(e);
+        SmallDft<4, T>::run(o);
+        // o[k] *= W8^k
+        o[1] = {h * (o[1].x + o[1].y), h * (o[1].y - o[1].x)};
+        o[2] = mul_mi(o[2]);
+        o[3] = {h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = cadd(e[k], o[k]);
+            v[k + 4] = csub(e[k], o[k]);
+        }
+    }
+};
+
+template <typename T>
+struct SmallDft<16, T> {
+    static __device__ __forceinline__ void run(cx<T>* v) {
+        // W16^k, k = 1..7 (cos, -sin)
+        const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173;
+        const T h = (T)0.70710678118654752440;
+        cx<T> e[8], o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            e[k] = v[2 * k];
+            o[k] = v[2 * k + 1];
+        }
+        SmallDft<8, T>::run(e);
+        SmallDft<8, T>::run(o);
+        o[1] = cmul(o[1], cx<T>{c1, -s1});
+        o[2] = {h * (o[2].x + o[2].y), h * (o[2].y - o[2].x)};
+        o[3] = cmul(o[3], cx<T>{s1, -c1});
+        o[4] = mul_mi(o[4]);
+        o[5] = cmul(o[5], cx<T>{-s1, -c1});
+        o[6] = {h * (o[6].y - o[6].x), -h * (o[6].x + o[6].y)};
+        o[7] = cmul(o[7], cx<T>{-c1, -s1});
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = cadd(e[k], o[k]);
+            v[k + 8] = csub(e[k], o[k]);
+        }
+    }
+};
+
+// ---------------------------------------------------------------- radix plans
+// Radix sequence for M = 2^LOG2M with at most 16 points per butterfly.
+template <int LOG2M>
+struct Plan;
+template <> struct Plan<6>  { static constexpr int n = 2; static constexpr int r[4] = {8, 8, 1, 1}; };
+template <> struct Plan<7>  { static constexpr int n = 2; static constexpr int r[4] = {16, 8, 1, 1}; };
+template <> struct Plan<8>  { static constexpr int n = 2; static constexpr int r[4] = {16, 16, 1, 1}; };
+template <> struct Plan<9>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 8, 1}; };
+template <> struct Plan<10> { static constexpr int n = 3; static constexpr int r[4] = {16, 8, 8, 1}; };
+template <> struct Plan<11> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 8, 1}; };
+template <> struct Plan<12> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 16, 1}; };
+template <> struct Plan<13> { static constexpr int n = 4; static constexpr int r[4] = {16, 8, 8, 8}; };
+template <> struct Plan<14> { static constexpr int n = 4; static constexpr int r[4] = {16, 16, 8, 8}; };
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+// One Stockham pass of radix R over the M points in `buf` (LDS).
+//   P    = product of the radices of the passes already done
+//   tw   = W_M table: tw[j] = exp(-2*pi*i*j/M), j in [0, M)
+//   regs = EPT-element per-thread register file (in: ignored unless FROM_REGS;
+//          out: left holding the pass result when TO_REGS)
+// FROM_REGS: the pass input is already in `regs` in read order
+//            (regs[b*R + r] = point (tid + b*T) + r*(M/R)); skips the LDS read.
+// TO_REGS:   skip the LDS write; regs[b*R + r] = output index
+//            ((i/P)*P*R + i%P) + r*P for butterfly i = tid + b*T.
+template <int M, int T, int R, int P, bool FROM_REGS, bool TO_REGS, typename Real>
+__device__ __forceinline__ void stockham_pass(cx<Real>* buf, const cx<Real>* __restrict__ tw,
+                                              cx<Real>* regs, int tid) {
+    constexpr int EPT = M / T;
+    constexpr int NB = M / R;    // butterflies in this pass
+    constexpr int BPT = EPT / R; // butterflies per thread
+    static_assert(BPT >= 1, "radix larger than the per-thread register file");
+    static_assert(NB % T == 0, "butterflies must divide evenly over threads");
+    if (!FROM_REGS) {
+#pragma unroll
+        for (int b = 0; b < BPT; ++b) {
+            const int i = tid + b * T;
+#pragma unroll
+            for (int r = 0; r < R; ++r) regs[b * R + r] = buf[i + r * NB];
+        }
+        __syncthreads();  // everyone has read before anyone overwrites
+    }
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) {
+        const int i = tid + b * T;
+        cx<Real>* v = regs + b * R;
+        if (P > 1) {
+            const int k = i & (P - 1);
+            constexpr int STRIDE = M / (P * R);
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * k * STRIDE]);
+        }
+        SmallDft<R, Real>::run(v);
+        if (!TO_REGS) {
+            const int k = i & (P - 1);
+            const int j = (i - k) * R + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) buf[j + r * P] = v[r];
+        }
+    }
+    if (!TO_REGS) __syncthreads();
+}
+
+// Forward FFT of the M points in `buf` (LDS).  If FIRST_FROM_REGS the first pass
+// takes its input from `regs` (see stockham_pass) and `buf` need not be
+// initialised; the caller must have issued a __syncthreads() since the last
+// read of `buf`.  Result is in `buf`, natural order, all threads synchronised.
+template <int M, int T, bool FIRST_FROM_REGS, typename Real>
+__device__ __forceinline__ void fft_lds(cx<Real>* buf, const cx<Real>* __restrict__ tw,
+                                        cx<Real>* regs, int tid) {
+    using PL = Plan<ilog2(M)>;
+    constexpr int R0 = PL::r[0], R1 = PL::r[1], R2 = PL::r[2], R3 = PL::r[3];
+    stockham_pass<M, T, R0, 1, FIRST_FROM_REGS, false, Real>(buf, tw, regs, tid);
+    if constexpr (PL::n > 1) stockham_pass<M, T, R1, R0, false, false, Real>(buf, tw, regs, tid);
+    if constexpr (PL::n > 2) stockham_pass<M, T, R2, R0 * R1, false, false, Real>(buf, tw, regs, tid);
+    if constexpr (PL::n > 3) stockham_pass<M, T, R3, R0 * R1 * R2, false, false, Real>(buf, tw, regs, tid);
+}
+
+// First-pass read order helper: the point index that regs[e] must hold when a
+// caller feeds fft_lds<.., FIRST_FROM_REGS=true>.
+template <int M, int T>
+__device__ __forceinline__ int first_pass_index(int tid, int e) {
+    constexpr int R0 = Plan<ilog2(M)>::r[0];
+    constexpr int NB = M / R0;
+    const int b = e / R0, r = e % R0;
+    return tid + b * T + r * NB;
+}
+
+}  // namespace mpx

@@ -1,0 +1,83 @@
+// Host-side context, plan caches and small helpers shared by the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/mpx.h"
+
+namespace mpx {
+
+// Where a frame's samples live: start index into the signal buffer and how many
+// of its `frame` samples exist (the rest is the zero padding of dsp/frame.py:11-12).
+struct FrameDesc {
+    long long start;
+    int valid;
+    int clip;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+// Harmonic-energy plan: everything that depends only on (fs, N, params, dtype).
+struct HePlan {
+    void* window = nullptr;  // Real[N]   symmetric Hamming (harmonic_energy.py:42)
+    void* tw = nullptr;      // cx[M]     W_M^j, M = N/2
+    void* twn = nullptr;     // cx[M+1]   W_N^k (real-FFT split)
+    int* wk0 = nullptr;      // [nwin] window start bin
+    int* wk1 = nullptr;      // [nwin] window end bin (exclusive, harmonic_energy.py:58)
+    void* ww = nullptr;      // Real[nwin] 1/harmonic
+    int nwin = 0;            // 12 * num_octave * num_harmonic
+    int wins_per_note = 0;
+    int num_harmonic = 0;
+    int kmin = 0, kmax = 0;  // bins needed: [kmin, kmax)
+};
+
+}  // namespace mpx
+
+struct mpx_ctx {
+    int device = 0;
+    int flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::map<std::tuple<int, int, int, int, int>, mpx::HePlan> he_plans;
+    std::map<std::string, std::vector<void*>> misc_plans;
+    // grow-only device workspaces
+    mpx::DevBuf d_signal, d_frames_out, d_partials, d_sum, d_desc, d_offsets, d_ws0, d_ws1, d_ws2;
+    std::vector<void*> owned;  // plan tables, freed in mpx_destroy
+};
+
+namespace mpx {
+
+int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
+int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
+void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failure (error set)
+
+#define MPX_HIP(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return mpx::set_error((ctx), MPX_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+// he
+int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
+           int fs, const mpx_he_params* params, int frame, int hop, double* d_chroma_frames,
+           hipStream_t stream);
+// segmented sum of per-frame chroma: out[s] = sum_{f in [seg[s], seg[s+1])} frames[f]
+int segment_sum(mpx_ctx* ctx, const double* d_frames, const long long* d_seg, int num_seg,
+                int64_t num_frames, double* d_out, hipStream_t stream);
+// esacf
+int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc,
+              int64_t num_frames, int fs, const mpx_esacf_params* params, int frame, int hop,
+              double* d_chroma_frames, int stage, double* d_stage_out, hipStream_t stream);
+
+}  // namespace mpx

@@ -1,0 +1,184 @@
+"""Thin host wrapper around one mpx_ctx (one per device per process).
+
+Mirrors the reference's error behaviour: bad arguments -> ValueError (the
+reference raises ValueError/IndexError from NumPy code), device problems ->
+RuntimeError.
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+
+_engines = {}
+_lock = threading.Lock()
+
+
+class MpxError(RuntimeError):
+    pass
+
+
+class Engine:
+    def __init__(self, device=0, f32=False):
+        self.lib = _lib.load()
+        self.device = device
+        self.f32 = bool(f32)
+        self.ctx = self.lib.mpx_create(device, _lib.MPX_FLAG_F32 if f32 else 0)
+        if not self.ctx:
+            msg = self.lib.mpx_last_error(None)
+            raise MpxError("mpx_create(device=%d) failed: %s" % (device, (msg or b"?").decode()))
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mpx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------- helpers
+    def _check(self, rc):
+        if rc == _lib.MPX_OK:
+            return
+        msg = (self.lib.mpx_last_error(self.ctx) or b"").decode()
+        if rc == _lib.MPX_EINVAL:
+            raise ValueError(msg)
+        if rc == _lib.MPX_EUNSUPPORTED:
+            raise NotImplementedError(msg)
+        if rc == _lib.MPX_ENOMEM:
+            raise MemoryError(msg)
+        raise MpxError(msg)
+
+    @staticmethod
+    def _sig(x):
+        x = np.asarray(x)
+        if x.ndim != 1:
+            raise ValueError("Only 1D numpy ndarrays are supported")  # dsp/frame.py:6-7
+        return np.ascontiguousarray(x, dtype=np.float32)
+
+    @staticmethod
+    def _pack(clips):
+        arrs = [Engine._sig(c) for c in clips]
+        offsets = np.zeros(len(arrs) + 1, dtype=np.int64)
+        for i, a in enumerate(arrs):
+            offsets[i + 1] = offsets[i] + a.shape[0]
+        flat = np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.float32)
+        return np.ascontiguousarray(flat, dtype=np.float32), offsets
+
+    def num_frames(self, n, frame, hop=None):
+        return int(self.lib.mpx_num_frames(int(n), int(frame), int(hop or frame)))
+
+    def synchronize(self):
+        self._check(self.lib.mpx_synchronize(self.ctx))
+
+    @property
+    def stream(self):
+        return self.lib.mpx_stream(self.ctx)
+
+    # ------------------------------------------------------------- method 2
+    def harmonic_energy(self, x, fs, frame=8192, hop=None, num_harmonic=2, num_octave=2, num_bins=2,
+                        return_frames=False):
+        x = self._sig(x)
+        hop = int(hop or frame)
+        p = _lib.HeParams(num_harmonic, num_octave, num_bins)
+        nf = max(self.num_frames(x.shape[0], frame, hop), 0)
+        total = np.zeros(12, dtype=np.float64)
+        frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
+        self._check(self.lib.mpx_harmonic_energy(
+            self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p), int(frame), hop,
+            frames.ctypes.data_as(_lib._dp) if return_frames and nf else None, total.ctypes.data_as(_lib._dp)))
+        return (total, frames) if return_frames else total
+
+    def harmonic_energy_batch(self, clips, fs, frame=8192, hop=None, num_harmonic=2, num_octave=2, num_bins=2):
+        flat, offsets = self._pack(clips)
+        p = _lib.HeParams(num_harmonic, num_octave, num_bins)
+        out = np.zeros((len(offsets) - 1, 12), dtype=np.float64)
+        self._check(self.lib.mpx_harmonic_energy_batch(
+            self.ctx, flat.ctypes.data_as(_lib._fp), offsets.ctypes.data_as(_lib._ip), len(offsets) - 1, int(fs),
+            C.byref(p), int(frame), int(hop or frame), out.ctypes.data_as(_lib._dp)))
+        return out
+
+    def harmonic_energy_dev(self, d_signal, n, fs, frame, hop, d_frames, d_sum, stream=None,
+                            num_harmonic=2, num_octave=2, num_bins=2):
+        """Device pointers (ints).  Only enqueues; the caller synchronises."""
+        p = _lib.HeParams(num_harmonic, num_octave, num_bins)
+        self._check(self.lib.mpx_harmonic_energy_dev(self.ctx, d_signal, int(n), int(fs), C.byref(p), int(frame),
+                                                     int(hop), d_frames, d_sum, stream))
+
+    # ------------------------------------------------------------- method 1
+    @staticmethod
+    def _esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode):
+        modes = {"librosa010": _lib.MPX_ENHANCE_LIBROSA010, "noop": _lib.MPX_ENHANCE_NOOP}
+        if enhance_mode not in modes:
+            raise ValueError("enhance_mode must be one of %s" % sorted(modes))
+        return _lib.EsacfParams(int(n_peaks_elim), float(peak_thresh), int(peak_min_dist), modes[enhance_mode])
+
+    def esacf(self, x, fs, frame, hop=None, n_peaks_elim=6, peak_thresh=0.1, peak_min_dist=10,
+              enhance_mode="librosa010", return_frames=False):
+        x = self._sig(x)
+        hop = int(hop or frame)
+        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        nf = max(self.num_frames(x.shape[0], frame, hop), 0)
+        total = np.zeros(12, dtype=np.float64)
+        frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
+        self._check(self.lib.mpx_esacf(
+            self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p), int(frame), hop,
+            frames.ctypes.data_as(_lib._dp) if return_frames and nf else None, total.ctypes.data_as(_lib._dp)))
+        return (total, frames) if return_frames else total
+
+    def esacf_batch(self, clips, fs, frame, hop=None, n_peaks_elim=6, peak_thresh=0.1, peak_min_dist=10,
+                    enhance_mode="librosa010"):
+        flat, offsets = self._pack(clips)
+        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        out = np.zeros((len(offsets) - 1, 12), dtype=np.float64)
+        self._check(self.lib.mpx_esacf_batch(
+            self.ctx, flat.ctypes.data_as(_lib._fp), offsets.ctypes.data_as(_lib._ip), len(offsets) - 1, int(fs),
+            C.byref(p), int(frame), int(hop or frame), out.ctypes.data_as(_lib._dp)))
+        return out
+
+    def esacf_dev(self, d_signal, n, fs, frame, hop, d_frames, d_sum, stream=None, n_peaks_elim=6,
+                  peak_thresh=0.1, peak_min_dist=10, enhance_mode="librosa010"):
+        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        self._check(self.lib.mpx_esacf_dev(self.ctx, d_signal, int(n), int(fs), C.byref(p), int(frame), int(hop),
+                                           d_frames, d_sum, stream))
+
+    def esacf_stage(self, stage, x, fs, frame, hop=None, n_peaks_elim=6, peak_thresh=0.1, peak_min_dist=10,
+                    enhance_mode="librosa010"):
+        """Per-frame intermediates [F, len] for parity tests (wfir, x_lo, x_hi, sacf, esacf)."""
+        x = self._sig(x)
+        hop = int(hop or frame)
+        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        nf = max(self.num_frames(x.shape[0], frame, hop), 0)
+        sid = _lib.STAGES[stage]
+        length = frame if sid <= 2 else (frame - 1) // 2
+        out = np.zeros((nf, length), dtype=np.float64)
+        self._check(self.lib.mpx_esacf_stage(self.ctx, sid, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs),
+                                             C.byref(p), int(frame), hop, out.ctypes.data_as(_lib._dp)))
+        return out
+
+    # ------------------------------------------------------------- timing
+    def timer_begin(self, stream=None):
+        self._check(self.lib.mpx_timer_begin(self.ctx, stream))
+
+    def timer_end(self, stream=None):
+        ms = C.c_float(0.0)
+        self._check(self.lib.mpx_timer_end(self.ctx, stream, C.byref(ms)))
+        return float(ms.value)
+
+
+def get_engine(device=0, f32=False):
+    """Process-wide engine per (device, dtype)."""
+    key = (int(device), bool(f32))
+    with _lock:
+        eng = _engines.get(key)
+        if eng is None:
+            eng = _engines[key] = Engine(device, f32)
+        return eng
+
+
+def device_count():
+    return int(_lib.load().mpx_device_count())

@@ -1,0 +1,38 @@
+"""Method 2 -- drop-in for reference harmonic_energy.py:13-73, HIP-backed."""
+from .chromagram import Chromagram
+from .engine import get_engine
+from .multipitch import Multipitch
+
+
+class MultipitchHarmonicEnergy(Multipitch):
+    def __init__(
+        self, audio_path, frame_size=8192, num_harmonic=2, num_octave=2, num_bins=2, hop=None, fs=None, device=0
+    ):
+        super().__init__(audio_path, fs=fs, device=device)
+        self.frame_size = frame_size
+        self.num_harmonic = num_harmonic
+        self.num_octave = num_octave
+        self.num_bins = num_bins
+        self.hop = hop  # extension: overlapped frames (reference: hop == frame_size)
+
+    @staticmethod
+    def display_name():
+        return "Harmonic Energy (Stark, Plumbley)"
+
+    @staticmethod
+    def method_number():
+        return 2
+
+    def compute_pitches(self, display_plot_frame=-1):
+        # display_plot_frame: accepted and ignored (matplotlib debugging aid in the reference)
+        total = get_engine(self.device).harmonic_energy(
+            self.x, self.fs, self.frame_size, self.hop, self.num_harmonic, self.num_octave, self.num_bins)
+        return Chromagram(total)
+
+    @classmethod
+    def compute_batch(cls, clips, fs, frame_size=8192, num_harmonic=2, num_octave=2, num_bins=2, hop=None,
+                      device=0):
+        """Many clips in one launch -> list of Chromagram."""
+        sums = get_engine(device).harmonic_energy_batch(clips, fs, frame_size, hop, num_harmonic, num_octave,
+                                                        num_bins)
+        return [Chromagram(s) for s in sums]

@@ -1,0 +1,63 @@
+"""Method registry and base class, mirroring reference multipitch.py:6-44.
+
+Differences from the reference, all additive:
+  * besides a path, the constructor accepts in-memory audio: a 1-D array with
+    the keyword `fs=`, or an (x, fs) tuple -- loading/resampling is outside the
+    accelerated path;
+  * `device=` selects the GPU (default 0).
+"""
+from abc import ABCMeta, abstractmethod
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy
+
+METHODS = OrderedDict()
+
+
+class Multipitch(object):
+    __metaclass__ = ABCMeta
+
+    def __init_subclass__(cls, **kwargs):
+        super().__init_subclass__(**kwargs)
+        method_num = cls.method_number()
+        if method_num in METHODS.keys():
+            raise ValueError(
+                "Method number {0} already registered as {1} in {2}".format(
+                    method_num, METHODS[method_num], METHODS
+                )
+            )
+        METHODS[cls.method_number()] = cls
+
+    @abstractmethod
+    def __init__(self, audio_path, fs=None, device=0):
+        if isinstance(audio_path, tuple) and len(audio_path) == 2:
+            x, self.fs = numpy.asarray(audio_path[0]), audio_path[1]
+            self.clip_name = "<array>"
+        elif isinstance(audio_path, numpy.ndarray):
+            if fs is None:
+                raise ValueError("fs= is required when passing samples instead of a path")
+            x, self.fs = audio_path, fs
+            self.clip_name = "<array>"
+        else:
+            from . import audio
+            x, self.fs = audio.load(audio_path)
+            self.clip_name = Path(audio_path).name
+        if len(x.shape) != 1:
+            raise ValueError("Only 1D numpy ndarrays are supported")
+        self.x = numpy.ascontiguousarray(x, dtype=numpy.float32)
+        self.device = device
+
+    @abstractmethod
+    def compute_pitches(self):
+        pass
+
+    @staticmethod
+    @abstractmethod
+    def display_name():
+        raise ValueError("unimplemented")
+
+    @staticmethod
+    @abstractmethod
+    def method_number():
+        raise ValueError("unimplemented")

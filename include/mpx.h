@@ -1,0 +1,148 @@
+/* mpx.h -- C ABI of the MI355X-native multipitch / chromagram engine.
+ *
+ * The reference (sevagh/chord-detection) is pure Python and has no FFI of its
+ * own; its operator interface for this path is the `Multipitch` ABC
+ * (chord_detection/multipitch.py:9-44) and the `Chromagram` value type
+ * (chord_detection/chromagram.py:11-58).  This header is the boundary a
+ * maintainer binds with ctypes to replace the NumPy/SciPy
+ * bodies of
+ *     MultipitchHarmonicEnergy.compute_pitches   harmonic_energy.py:30-73
+ *     MultipitchESACF.compute_pitches            esacf.py:41-91
+ *     dsp.frame_cutter / wfir / lowpass_filter   dsp/frame.py:5-14, dsp/wfir.py:25-43,
+ *                                                dsp/lowpass.py:6-8, esacf.py:132-134
+ * Everything here is plain C: pointers, sizes, PODs.  No torch types.
+ *
+ * Conventions
+ *   - every call returns MPX_OK (0) or a negative mpx_status; the message is
+ *     available from mpx_last_error(ctx) until the next call on that ctx;
+ *   - "host" entry points take host pointers and are synchronous at return;
+ *   - "_dev" entry points take DEVICE pointers (hipMalloc / torch.Tensor.data_ptr)
+ *     plus a hipStream_t passed as void* (NULL = the context's own stream) and
+ *     only enqueue work: the caller synchronises;
+ *   - a context is bound to one device and is not thread-safe;
+ *   - chroma vectors are 12 doubles in pitch-class order C, C#, ... B
+ *     (chromagram.py:8).
+ */
+#ifndef MPX_H
+#define MPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPX_ABI_VERSION 1
+
+typedef enum mpx_status {
+    MPX_OK = 0,
+    MPX_EINVAL = -1,        /* bad argument (the reference raises ValueError / IndexError) */
+    MPX_ENOMEM = -2,        /* host or device allocation failed */
+    MPX_EHIP = -3,          /* HIP runtime error */
+    MPX_EUNSUPPORTED = -4   /* valid request this build has no kernel for */
+} mpx_status;
+
+/* mpx_create flags */
+#define MPX_FLAG_F32 0x1    /* opt-in fp32 arithmetic (default: fp64, the reference's dtype) */
+
+typedef struct mpx_ctx mpx_ctx;
+
+int mpx_abi_version(void);
+int mpx_device_count(void);
+/* NULL on failure; mpx_last_error(NULL) then holds the reason. */
+mpx_ctx* mpx_create(int device, int flags);
+void mpx_destroy(mpx_ctx* ctx);
+const char* mpx_last_error(const mpx_ctx* ctx);
+/* Block until everything enqueued on the context's stream has finished. */
+int mpx_synchronize(mpx_ctx* ctx);
+/* The context's hipStream_t (as void*), for callers that want to order their
+ * own work after ours. */
+void* mpx_stream(mpx_ctx* ctx);
+
+/* ---- framing: dsp/frame.py:5-14 ------------------------------------------
+ * Number of frames cut from n samples: ceil(n/frame) when hop == frame (the
+ * reference's only mode); for hop < frame, frames start every `hop` samples
+ * until one reaches the end of the signal.  The tail is zero padded. */
+int64_t mpx_num_frames(int64_t n, int frame, int hop);
+
+/* ---- Harmonic Energy (method 2): harmonic_energy.py:14-16 ctor kwargs ----- */
+typedef struct mpx_he_params {
+    int num_harmonic;   /* default 2 */
+    int num_octave;     /* default 2 */
+    int num_bins;       /* default 2 */
+} mpx_he_params;
+
+/* One signal, host buffers.  replaces harmonic_energy.py:30-73.
+ *   signal[n] float32 samples at `fs` Hz; frame = FFT size (power of two,
+ *   1024..16384), hop in [1, frame].
+ *   chroma_frames: optional [F,12] per-frame chroma (NULL to skip);
+ *   chroma_sum:    [12] sum over frames == compute_pitches() result. */
+int mpx_harmonic_energy(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
+                        const mpx_he_params* params, int frame, int hop,
+                        double* chroma_frames, double* chroma_sum);
+
+/* C clips packed back to back: clip c is signals[offsets[c] .. offsets[c+1]).
+ * Every clip is framed on its own (hop == frame semantics per clip, tail zero
+ * padded).  chroma_sums: [C,12]. */
+int mpx_harmonic_energy_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets,
+                              int num_clips, int fs, const mpx_he_params* params, int frame,
+                              int hop, double* chroma_sums);
+
+/* Device-resident variant of mpx_harmonic_energy: d_signal, d_chroma_frames
+ * ([F,12], may be NULL) and d_chroma_sum ([12]) are device pointers. */
+int mpx_harmonic_energy_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs,
+                            const mpx_he_params* params, int frame, int hop,
+                            double* d_chroma_frames, double* d_chroma_sum, void* stream);
+
+/* ---- ESACF (method 1): esacf.py:17-31 ctor kwargs ------------------------- */
+#define MPX_ENHANCE_LIBROSA010 0   /* librosa >= 0.10 time_stretch semantics (default) */
+#define MPX_ENHANCE_NOOP 1         /* time_stretch returns nothing: ESACF = clip(SACF, 0) */
+
+typedef struct mpx_esacf_params {
+    int n_peaks_elim;      /* default 6 */
+    double peak_thresh;    /* default 0.1 */
+    int peak_min_dist;     /* default 10 */
+    int enhance_mode;      /* MPX_ENHANCE_* */
+} mpx_esacf_params;
+
+/* One signal, host buffers.  replaces esacf.py:41-91.  frame = ham_samples
+ * (any length in [64, 4096]; the reference default int(fs*46.4/1000) is 1023 at
+ * 22050 Hz and 2046 at 44100 Hz), hop in [1, frame]. */
+int mpx_esacf(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
+              const mpx_esacf_params* params, int frame, int hop,
+              double* chroma_frames, double* chroma_sum);
+
+int mpx_esacf_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips,
+                    int fs, const mpx_esacf_params* params, int frame, int hop,
+                    double* chroma_sums);
+
+int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs,
+                  const mpx_esacf_params* params, int frame, int hop,
+                  double* d_chroma_frames, double* d_chroma_sum, void* stream);
+
+/* Debug taps for parity tests: per-frame intermediates of the ESACF chain,
+ * host buffers, each [F, len]:
+ *   MPX_STAGE_WFIR  len = frame            dsp/wfir.py:25-43
+ *   MPX_STAGE_XLO   len = frame            esacf.py:51
+ *   MPX_STAGE_XHI   len = frame            esacf.py:47-49
+ *   MPX_STAGE_SACF  len = (frame-1)/2      esacf.py:93-105
+ *   MPX_STAGE_ESACF len = (frame-1)/2      esacf.py:108-129                  */
+#define MPX_STAGE_WFIR 0
+#define MPX_STAGE_XLO 1
+#define MPX_STAGE_XHI 2
+#define MPX_STAGE_SACF 3
+#define MPX_STAGE_ESACF 4
+int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int fs,
+                    const mpx_esacf_params* params, int frame, int hop, double* out);
+
+/* ---- timing helper (HIP events on the stream the kernels run on) ----------
+ * mpx_timer_begin records an event on `stream` (NULL = context stream);
+ * mpx_timer_end records the closing event, waits for it and returns the
+ * elapsed milliseconds in *ms. */
+int mpx_timer_begin(mpx_ctx* ctx, void* stream);
+int mpx_timer_end(mpx_ctx* ctx, void* stream, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPX_H */
