@@ -47,6 +47,8 @@ SIGNATURES = {
     "mpx_esacf_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_esacf_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _vp, _vp, _vp]),
     "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
+    "mpx_set_remez_taps": (C.c_int, [_vp, C.c_int, _dp]),
+    "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),
     "mpx_timer_begin": (C.c_int, [_vp, _vp]),
     "mpx_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
 }

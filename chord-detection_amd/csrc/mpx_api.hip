@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "mpx_internal.hpp"
+#include "mpx_lm.hpp"
 
 static thread_local std::string g_create_error;
 
@@ -132,7 +133,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void* p : ctx->owned) hipFree(p);
     for (DevBuf* b : {&ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
-                      &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2})
+                      &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3})
         if (b->p) hipFree(b->p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -302,6 +303,24 @@ int mpx_esacf_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, 
 int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_esacf_params* params,
                   int frame, int hop, double* d_chroma_frames, double* d_chroma_sum, void* stream) {
     return method_dev(ctx, run_esacf, d_signal, n, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, stream);
+}
+
+int mpx_set_remez_taps(mpx_ctx* ctx, int fs, const double* taps13) {
+    if (!ctx || !taps13 || fs <= 0) return MPX_EINVAL;
+    ctx->remez[fs] = std::vector<double>(taps13, taps13 + 13);
+    return MPX_OK;
+}
+
+// host-callable copy of the device peak fit, for CPU-side unit tests of the restatement
+int mpx_test_gaussian_fit(const double* xs, const double* ys, int m, double* center) {
+    if (!xs || !ys || !center || m < 3 || m > mpx::lm::MAXM) return MPX_EINVAL;
+    mpx::lm::Problem pr;
+    pr.m = m;
+    for (int i = 0; i < m; ++i) {
+        pr.xs[i] = xs[i];
+        pr.ys[i] = ys[i];
+    }
+    return mpx::lm::gaussian_fit(pr, center);
 }
 
 int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int fs,

@@ -1,8 +1,657 @@
-// placeholder until the ESACF kernels land
+// ESACF chroma (reference method 1) in fp64.  Four kernels per batch of frames:
+//
+//  1. bandsplit_kernel   one lane per frame: 12-stage warped all-pass cascade +
+//                        13-tap warped FIR residual (dsp/wfir.py:25-43), then
+//                        HP -> half-wave rectify -> LP and LP (esacf.py:47-51,
+//                        132-134, dsp/lowpass.py:6-8); zero state per frame.
+//  2. sacf_kernel        one workgroup per frame: N-point circular DFT of
+//                        x_lo + i*x_hi (direct LDS FFT for power-of-two N,
+//                        Bluestein chirp-z on the same LDS FFT otherwise),
+//                        S = |X_lo|^0.67 + |X_hi|^0.67, DFT again, first
+//                        (N-1)//2 lags (esacf.py:93-105); enhancement
+//                        (esacf.py:108-129); peakutils.indexes peak picking
+//                        (esacf.py:56).
+//  3. peakfit_kernel     one thread per peak: gaussian LM fit (esacf.py:60).
+//  4. scatter_kernel     one thread per frame: fs/tau -> pitch class -> 12 bins
+//                        (esacf.py:64-71).
+#include <cmath>
+
+#include "mpx_fft.hpp"
 #include "mpx_internal.hpp"
+#include "mpx_lm.hpp"
+
 namespace mpx {
-int esacf_run(mpx_ctx* ctx, const float*, int64_t, const FrameDesc*, int64_t, int, const mpx_esacf_params*, int, int,
-              double*, int, double*, hipStream_t) {
-    return set_error(ctx, MPX_EUNSUPPORTED, "ESACF kernels not built yet");
+
+struct BandCoef {
+    double a;        // bark warp coefficient
+    double c[13];    // warped remez taps
+    double lpb[3], lpa[3];
+    double hpb[3], hpa[3];
+};
+
+// ------------------------------------------------------------------ kernel 1
+__global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__ sig, long long n,
+                                                       const FrameDesc* __restrict__ desc, long long frame0,
+                                                       long long num_frames, int N, int hop, BandCoef k,
+                                                       double* __restrict__ xlo, double* __restrict__ xhi,
+                                                       double* __restrict__ xw) {
+    const long long lf = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // frame within this batch
+    if (lf >= num_frames) return;
+    const long long f = frame0 + lf;
+    long long start;
+    int valid;
+    if (desc) {
+        start = desc[f].start;
+        valid = desc[f].valid;
+    } else {
+        start = f * (long long)hop;
+        const long long left = n - start;
+        valid = left >= N ? N : (left > 0 ? (int)left : 0);
+    }
+    const float* __restrict__ x = sig + start;
+    double z[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z[i] = 0.0;
+    double h1 = 0, h2 = 0, g1 = 0, g2 = 0, l1 = 0, l2 = 0;
+    const long long base = lf * (long long)N;
+    for (int t = 0; t < N; ++t) {
+        const double xt = t < valid ? (double)x[t] : 0.0;
+        // warped FIR: ys[i] = allpass(ys[i-1]); x_hat = c0*x + sum c[i+1]*ys[i]
+        double xhat = k.c[0] * xt;
+        double in = xt;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const double y = -k.a * in + z[i];  // b0*x + z
+            z[i] = in + k.a * y;                // b1*x - a1*y with b1 = 1, a1 = -a
+            in = y;
+            xhat += k.c[i + 1] * y;
+        }
+        const double r = xt - xhat;
+        // high-pass -> half-wave rectification -> low-pass
+        const double yh = k.hpb[0] * r + h1;
+        h1 = (h2 + k.hpb[1] * r) - k.hpa[1] * yh;
+        h2 = k.hpb[2] * r - k.hpa[2] * yh;
+        const double rect = yh < 0.0 ? 0.0 : yh;
+        const double yhl = k.lpb[0] * rect + g1;
+        g1 = (g2 + k.lpb[1] * rect) - k.lpa[1] * yhl;
+        g2 = k.lpb[2] * rect - k.lpa[2] * yhl;
+        // low-pass
+        const double yl = k.lpb[0] * r + l1;
+        l1 = (l2 + k.lpb[1] * r) - k.lpa[1] * yl;
+        l2 = k.lpb[2] * r - k.lpa[2] * yl;
+        xlo[base + t] = yl;
+        xhi[base + t] = yhl;
+        if (xw) xw[base + t] = r;
+    }
 }
+
+// ------------------------------------------------------------------ kernel 2
+struct SacfArgs {
+    const double* xlo;
+    const double* xhi;
+    int N, Mh;
+    const cx<double>* tw;     // W_L
+    const cx<double>* chirp;  // b[n] = exp(i*pi*n^2/N), n < N   (Bluestein only)
+    const cx<double>* bhat;   // FFT_L(chirp filter) / L         (Bluestein only)
+    int n_peaks_elim;
+    double peak_thresh;
+    int peak_min_dist;
+    int enhance_mode;
+    int maxp;
+    double* sacf_out;   // optional [F,Mh]
+    double* y_out;      // [F,Mh] enhanced SACF
+    int* peak_count;    // [F]
+    int* peak_idx;      // [F,maxp]
+    int* total_peaks;   // one counter for the whole batch
+    int* worklist;      // [F*maxp] packed (frame << 12 | slot) -- filled through total_peaks
+};
+
+__device__ __forceinline__ cx<double> cconj(cx<double> a) { return {a.x, -a.y}; }
+__device__ __forceinline__ cx<double> cswap(cx<double> a) { return {a.y, a.x}; }
+
+// N-point forward DFT of buf[0..N) in place (LDS).  For BLUE the transform runs
+// as a length-L circular convolution with the chirp (L >= 2N-1).
+template <int L, int T, bool BLUE>
+__device__ __forceinline__ void dft_n(cx<double>* buf, const SacfArgs& a, cx<double>* regs, int tid) {
+    if (BLUE) {
+        const int N = a.N;
+        for (int n = tid; n < L; n += T) buf[n] = n < N ? cmul(buf[n], cconj(a.chirp[n])) : cx<double>{0.0, 0.0};
+        __syncthreads();
+        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+        // multiply by the filter spectrum; swap re/im so that the next forward FFT is an inverse one
+        for (int k = tid; k < L; k += T) buf[k] = cswap(cmul(buf[k], a.bhat[k]));
+        __syncthreads();
+        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+        for (int k = tid; k < N; k += T) buf[k] = cmul(cswap(buf[k]), cconj(a.chirp[k]));
+        __syncthreads();
+    } else {
+        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+    }
+}
+
+// Inclusive Hillis-Steele scans over T ints in LDS (T a power of two).
+template <int T, bool MAXOP>
+__device__ __forceinline__ int block_scan(int* sh, int v, int tid) {
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < T; off <<= 1) {
+        int o = tid >= off ? sh[tid - off] : (MAXOP ? -0x7fffffff : 0);
+        __syncthreads();
+        v = MAXOP ? (o > v ? o : v) : v + o;
+        sh[tid] = v;
+        __syncthreads();
+    }
+    return v;
+}
+
+template <int L, int T, bool BLUE>
+__global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, Mh = a.Mh;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                 // L complex
+    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * L);  // N + 2 doubles
+    // aliases onto buf, valid once the SACF has been copied out to yv
+    double* dy = reinterpret_cast<double*>(smem);          // Mh
+    int* lnz = reinterpret_cast<int*>(dy + Mh + 1);        // Mh
+    int* rnz = lnz + Mh + 1;                               // Mh
+    int* cand = rnz + Mh + 1;                              // Mh
+    int* state = cand + Mh + 1;                            // Mh
+    __shared__ int sh_scan[T];
+    __shared__ double sh_red[2 * T];
+    __shared__ int sh_misc[4];
+
+    const int tid = threadIdx.x;
+    const long long f = blockIdx.x;
+    cx<double> regs[L / T];
+
+    // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N
+    const double* lo = a.xlo + f * (long long)N;
+    const double* hi = a.xhi + f * (long long)N;
+    for (int n = tid; n < N; n += T) buf[n] = {lo[n], hi[n]};
+    __syncthreads();
+    dft_n<L, T, BLUE>(buf, a, regs, tid);
+    for (int k = tid; k < N; k += T) {
+        const cx<double> A = buf[k];
+        const cx<double> B = cconj(buf[k == 0 ? 0 : N - k]);
+        // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
+        const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+        const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+        yv[k] = pow(hypot(lr, li), 0.67) + pow(hypot(hr, hm), 0.67);  // esacf.py:95-103, k fixed at 0.67
+    }
+    __syncthreads();
+    for (int k = tid; k < N; k += T) buf[k] = {yv[k], 0.0};
+    __syncthreads();
+    dft_n<L, T, BLUE>(buf, a, regs, tid);
+    const double inv_n = 1.0 / (double)N;
+    for (int n = tid; n < Mh; n += T) {
+        const double v = buf[n].x * inv_n;
+        yv[n] = v;
+        if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+    }
+    __syncthreads();  // buf is dead from here on; dy/lnz/rnz/cand/state alias it
+
+    // ---- enhancement (esacf.py:108-129)
+    for (int r = 2; r <= a.n_peaks_elim; ++r) {
+        int cut = 0;
+        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+        for (int n = tid; n < Mh; n += T) {
+            double v = yv[n];
+            v = v < 0.0 ? 0.0 : v;          // clip
+            if (n < cut) v = v - v;         // minus the "stretched" copy (== itself for a <=2-frame STFT)
+            v = v < 0.0 ? 0.0 : v;          // clip
+            yv[n] = v;
+        }
+        __syncthreads();
+    }
+    double* yrow = a.y_out + f * (long long)Mh;
+    for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+
+    // ---- peakutils.indexes(y, thres, min_dist)
+    const int D = Mh - 1;  // len(dy)
+    double mx = -INFINITY, mn = INFINITY;
+    for (int n = tid; n < Mh; n += T) {
+        const double v = yv[n];
+        mx = v > mx ? v : mx;
+        mn = v < mn ? v : mn;
+    }
+    sh_red[tid] = mx;
+    sh_red[T + tid] = mn;
+    __syncthreads();
+    for (int s = T / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            sh_red[tid] = sh_red[tid] > sh_red[tid + s] ? sh_red[tid] : sh_red[tid + s];
+            sh_red[T + tid] = sh_red[T + tid] < sh_red[T + tid + s] ? sh_red[T + tid] : sh_red[T + tid + s];
+        }
+        __syncthreads();
+    }
+    const double thres = a.peak_thresh * (sh_red[0] - sh_red[T]) + sh_red[T];
+    for (int i = tid; i < D; i += T) dy[i] = yv[i + 1] - yv[i];
+    __syncthreads();
+    // nearest non-zero of dy to the left / right of every position (plateau rule)
+    const int chunk = (D + T - 1) / T;
+    const int c0 = tid * chunk, c1 = (c0 + chunk < D) ? c0 + chunk : D;
+    int last = -1, first = D, nz = 0;
+    for (int i = c0; i < c1; ++i)
+        if (dy[i] != 0.0) {
+            last = i;
+            if (first == D) first = i;
+            ++nz;
+        }
+    const int tot_nz = block_scan<T, false>(sh_scan, nz, tid);
+    if (tid == T - 1) sh_misc[0] = tot_nz;
+    const int incl_last = block_scan<T, true>(sh_scan, last, tid);
+    int carry_l = tid > 0 ? sh_scan[tid - 1] : -1;
+    (void)incl_last;
+    __syncthreads();
+    // suffix minimum of `first`: scan the reversed sequence with max over negated values
+    const int incl_first_rev = block_scan<T, true>(sh_scan, -first, T - 1 - tid);
+    (void)incl_first_rev;
+    // sh_scan[j] now holds max_{t' >= T-1-j} (-first[t'])  =>  carry for tid is entry (T-2-tid)
+    int carry_r = tid < T - 1 ? -sh_scan[T - 2 - tid] : D;
+    __syncthreads();
+    if (sh_misc[0] == 0 || D <= 0) {  // totally flat signal: no peaks (peakutils returns [])
+        if (tid == 0) a.peak_count[f] = 0;
+        return;
+    }
+    {
+        int run = carry_l;
+        for (int i = c0; i < c1; ++i) {
+            if (dy[i] != 0.0) run = i;
+            lnz[i] = run;
+        }
+        run = carry_r;
+        for (int i = c1 - 1; i >= c0; --i) {
+            if (dy[i] != 0.0) run = i;
+            rnz[i] = run;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += T) {
+        if (dy[i] != 0.0) continue;
+        const int l = lnz[i], r = rnz[i];
+        const int s = l + 1, e = r - 1;  // the zero run containing i
+        double v;
+        if (s == 0)
+            v = dy[r];                   // leading plateau takes the value right after it
+        else if (e == D - 1)
+            v = dy[l];                   // trailing plateau takes the value before it
+        else
+            v = (2 * i < s + e) ? dy[l] : dy[r];  // i < median(run) ? left : right
+        // write after everyone has read: zero positions only read non-zero positions, so in place is safe
+        dy[i] = v;
+    }
+    __syncthreads();
+    // candidates, ascending
+    const int pchunk = (Mh + T - 1) / T;
+    const int p0 = tid * pchunk, p1 = (p0 + pchunk < Mh) ? p0 + pchunk : Mh;
+    int cnt = 0;
+    for (int i = p0; i < p1; ++i)
+        if (i >= 1 && i <= Mh - 2 && dy[i - 1] > 0.0 && dy[i] < 0.0 && yv[i] > thres) ++cnt;
+    const int incl = block_scan<T, false>(sh_scan, cnt, tid);
+    if (tid == T - 1) sh_misc[1] = incl;
+    __syncthreads();
+    const int ncand = sh_misc[1];
+    {
+        int o = incl - cnt;
+        for (int i = p0; i < p1; ++i)
+            if (i >= 1 && i <= Mh - 2 && dy[i - 1] > 0.0 && dy[i] < 0.0 && yv[i] > thres) cand[o++] = i;
+    }
+    for (int c = tid; c < ncand; c += T) state[c] = 0;
+    __syncthreads();
+    // minimum-distance suppression: visit by descending height; a kept peak removes neighbours within min_dist
+    if (ncand > 1 && a.peak_min_dist > 1) {
+        if (tid < 64) {
+            volatile int* vstate = state;
+            for (;;) {
+                double bv = -INFINITY;
+                int bc = -1;
+                for (int c = tid; c < ncand; c += 64)
+                    if (vstate[c] == 0) {
+                        const double v = yv[cand[c]];
+                        if (v > bv || (v == bv && c > bc)) {
+                            bv = v;
+                            bc = c;
+                        }
+                    }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ov = __shfl_xor(bv, off);
+                    const int oc = __shfl_xor(bc, off);
+                    if (oc >= 0 && (bc < 0 || ov > bv || (ov == bv && oc > bc))) {
+                        bv = ov;
+                        bc = oc;
+                    }
+                }
+                if (bc < 0) break;
+                const int pos = cand[bc];
+                for (int c = tid; c < ncand; c += 64)
+                    if (vstate[c] == 0) {
+                        const int d = cand[c] - pos;
+                        if (c == bc)
+                            vstate[c] = 1;
+                        else if (d >= -a.peak_min_dist && d <= a.peak_min_dist)
+                            vstate[c] = 2;
+                    }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+        }
+    } else {
+        for (int c = tid; c < ncand; c += T) state[c] = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int p = 0;
+        int* out = a.peak_idx + f * (long long)a.maxp;
+        for (int c = 0; c < ncand; ++c)
+            if (state[c] == 1 && p < a.maxp) out[p++] = cand[c];
+        a.peak_count[f] = p;
+        if (p > 0) {
+            const int slot = atomicAdd(a.total_peaks, p);
+            for (int j = 0; j < p; ++j) a.worklist[slot + j] = (int)(f << 12) | j;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ kernel 3
+__global__ __launch_bounds__(64) void peakfit_kernel(const int* __restrict__ total_peaks,
+                                                     const int* __restrict__ worklist,
+                                                     const double* __restrict__ y, int Mh, int maxp,
+                                                     const int* __restrict__ peak_idx, double* center,
+                                                     int* ok) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= *total_peaks) return;
+    const int item = worklist[w];
+    const long long f = item >> 12;
+    const int j = item & 0xfff;
+    const int i = peak_idx[f * maxp + j];
+    const long long o = f * maxp + j;
+    // slice(i - 10, i + 11): a negative start wraps around in Python -> empty slice -> fit raises -> peak dropped
+    if (i < 10) {
+        ok[o] = 0;
+        return;
+    }
+    lm::Problem pr;
+    const int stop = i + 11 < Mh ? i + 11 : Mh;
+    pr.m = stop - (i - 10);
+    const double* row = y + f * (long long)Mh;
+    for (int q = 0; q < pr.m; ++q) {
+        pr.xs[q] = (double)(i - 10 + q);
+        pr.ys[q] = row[i - 10 + q];
+    }
+    if (pr.m < 3) {
+        ok[o] = 0;
+        return;
+    }
+    double c = 0.0;
+    const int info = lm::gaussian_fit(pr, &c);
+    ok[o] = (info >= 1 && info <= 4) ? 1 : 0;
+    center[o] = c;
+}
+
+// ------------------------------------------------------------------ kernel 4
+__global__ __launch_bounds__(64) void scatter_kernel(long long frame0, long long num_frames, int fs, int Mh, int maxp,
+                                                     const double* __restrict__ y,
+                                                     const int* __restrict__ peak_count,
+                                                     const int* __restrict__ peak_idx,
+                                                     const double* __restrict__ center,
+                                                     const int* __restrict__ ok, double* chroma_frames) {
+    const long long lf = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lf >= num_frames) return;
+    double chroma[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) chroma[i] = 0.0;
+    const int cnt = peak_count[lf];
+    const double* row = y + lf * (long long)Mh;
+    int s = 0;  // index among the fits that succeeded: pairs with peak_idx[s] (quirk A.8)
+    for (int j = 0; j < cnt; ++j) {
+        if (!ok[lf * maxp + j]) continue;
+        const double tau = center[lf * maxp + j];
+        const double weight = row[peak_idx[lf * maxp + s]];
+        ++s;
+        const double pitch = (double)fs / tau;
+        const double midi = 12.0 * (log2(pitch) - log2(440.0)) + 69.0;
+        if (!(midi == midi) || isinf(midi)) continue;  // NaN -> ValueError -> skipped (esacf.py:70-71)
+        const long long note = (long long)nearbyint(midi);
+        const int pc = (int)(((note % 12) + 12) % 12);
+        // unicode-sharp quirk (A.18): C#, D#, F#, G#, A# land in a stray dict key and are lost
+        if (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10) continue;
+#pragma unroll
+        for (int q = 0; q < 12; ++q)
+            if (q == pc) chroma[q] += weight;
+    }
+    double* out = chroma_frames + (frame0 + lf) * 12;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) out[i] = chroma[i];
+}
+
+// ------------------------------------------------------------------ host side
+static void host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, forward; plan tables only
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const long double ang = -2.0L * M_PIl * (long double)k / (long double)len;
+                const cx<double> w = {(double)cosl(ang), (double)sinl(ang)};
+                const cx<double> u = a[i + k];
+                const cx<double> t = a[i + k + len / 2];
+                const cx<double> v = {t.x * w.x - t.y * w.y, t.x * w.y + t.y * w.x};
+                a[i + k] = {u.x + v.x, u.y + v.y};
+                a[i + k + len / 2] = {u.x - v.x, u.y - v.y};
+            }
+    }
+}
+
+struct EsacfPlan {
+    cx<double>* tw = nullptr;
+    cx<double>* chirp = nullptr;
+    cx<double>* bhat = nullptr;
+    int L = 0;
+    bool blue = false;
+};
+
+static int esacf_plan(mpx_ctx* ctx, int N, EsacfPlan& plan) {
+    const std::string key = "esacf_N" + std::to_string(N);
+    auto it = ctx->misc_plans.find(key);
+    const bool pow2 = (N & (N - 1)) == 0 && N >= 512;  // smaller frames ride the 512-point Bluestein
+    int L = 512;
+    if (pow2)
+        L = N;
+    else
+        while (L < 2 * N - 1) L <<= 1;
+    plan.L = L;
+    plan.blue = !pow2;
+    if (it != ctx->misc_plans.end()) {
+        plan.tw = (cx<double>*)it->second[0];
+        plan.chirp = (cx<double>*)it->second[1];
+        plan.bhat = (cx<double>*)it->second[2];
+        return MPX_OK;
+    }
+    std::vector<cx<double>> tw(L);
+    for (int j = 0; j < L; ++j) {
+        const long double ang = -2.0L * M_PIl * j / (long double)L;
+        tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+    }
+    plan.tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+    if (!plan.tw) return MPX_ENOMEM;
+    if (!pow2) {
+        std::vector<cx<double>> chirp(N), filt(L, cx<double>{0.0, 0.0});
+        for (long long n = 0; n < N; ++n) {
+            const long long q = (n * n) % (2LL * N);  // exact phase reduction
+            const long double ang = M_PIl * (long double)q / (long double)N;
+            chirp[n] = {(double)cosl(ang), (double)sinl(ang)};
+        }
+        filt[0] = chirp[0];
+        for (int m = 1; m < N; ++m) filt[m] = filt[L - m] = chirp[m];
+        host_fft(filt);
+        for (auto& v : filt) {
+            v.x /= L;
+            v.y /= L;
+        }
+        plan.chirp = (cx<double>*)upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
+        plan.bhat = (cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
+        if (!plan.chirp || !plan.bhat) return MPX_ENOMEM;
+    }
+    ctx->misc_plans[key] = {plan.tw, plan.chirp, plan.bhat};
+    return MPX_OK;
+}
+
+// Filter design (host constants): closed forms of dsp/wfir.py:6-21, scipy.signal.butter(2, ...)
+static int band_coefs(mpx_ctx* ctx, int fs, BandCoef& k) {
+    static const double remez22050[13] = {
+        -0.2503141758465685, -0.00010985253437014219, 2.5089273607721457e-05, -0.0002589029075222507,
+        0.00020302128904025308, 0.0002957470030712228, 1.0000257474401701, 0.0002957470030712228,
+        0.00020302128904025308, -0.0002589029075222507, 2.5089273607721457e-05, -0.00010985253437014219,
+        -0.2503141758465685};
+    static const double remez44100[13] = {
+        -0.28459907723604855, 0.07244737666028533, -0.07937698258360983, 0.0848775348433701,
+        -0.08886832893562109, 0.09162147542045991, 0.9077249116355622, 0.09162147542045991,
+        -0.08886832893562109, 0.0848775348433701, -0.07937698258360983, 0.07244737666028533,
+        -0.28459907723604855};
+    const double* taps = fs == 22050 ? remez22050 : (fs == 44100 ? remez44100 : nullptr);
+    auto it = ctx->remez.find(fs);
+    if (!taps && it == ctx->remez.end())
+        return set_error(ctx, MPX_EUNSUPPORTED,
+                         "ESACF: no warped-FIR (remez) taps for fs=%d; built-in tables cover 22050 and 44100 Hz "
+                         "(register others with mpx_set_remez_taps)", fs);
+    for (int i = 0; i < 13; ++i) k.c[i] = taps ? taps[i] : it->second[i];
+    k.a = 1.0674 * std::sqrt((2.0 / M_PI) * std::atan(0.06583 * fs / 1000.0)) - 0.1916;
+    const double kk = std::tan(M_PI * 1000.0 / fs);
+    const double norm = 1.0 / (1.0 + std::sqrt(2.0) * kk + kk * kk);
+    const double a1 = 2.0 * (kk * kk - 1.0) * norm, a2 = (1.0 - std::sqrt(2.0) * kk + kk * kk) * norm;
+    k.lpb[0] = kk * kk * norm;
+    k.lpb[1] = 2.0 * kk * kk * norm;
+    k.lpb[2] = kk * kk * norm;
+    k.hpb[0] = norm;
+    k.hpb[1] = -2.0 * norm;
+    k.hpb[2] = norm;
+    k.lpa[0] = k.hpa[0] = 1.0;
+    k.lpa[1] = k.hpa[1] = a1;
+    k.lpa[2] = k.hpa[2] = a2;
+    return MPX_OK;
+}
+
+template <int L, int T, bool BLUE>
+static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStream_t st) {
+    const size_t lds = sizeof(cx<double>) * L + sizeof(double) * (size_t)(a.N + 2);
+    const size_t alias = (size_t)(a.Mh + 1) * (sizeof(double) + 4 * sizeof(int));
+    if (alias > sizeof(cx<double>) * L)
+        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", a.N);
+    auto kern = sacf_kernel<L, T, BLUE>;
+    if (lds > 48 * 1024)
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)frames), dim3(T), lds, st, a);
+    MPX_HIP(ctx, hipGetLastError());
+    return MPX_OK;
+}
+
+int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
+              int fs, const mpx_esacf_params* params, int frame, int hop, double* d_chroma_frames, int stage,
+              double* d_stage_out, hipStream_t st) {
+    mpx_esacf_params p = params ? *params : mpx_esacf_params{6, 0.1, 10, MPX_ENHANCE_LIBROSA010};
+    const int N = frame, Mh = (N - 1) / 2;
+    if (N < 64 || N > 4096)
+        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: frame length %d outside [64, 4096]", N);
+    if (p.enhance_mode != MPX_ENHANCE_LIBROSA010 && p.enhance_mode != MPX_ENHANCE_NOOP)
+        return set_error(ctx, MPX_EINVAL, "ESACF: unknown enhance_mode %d", p.enhance_mode);
+    if (p.peak_min_dist < 0 || p.n_peaks_elim < 0 || p.n_peaks_elim > 64)
+        return set_error(ctx, MPX_EINVAL, "ESACF: bad peak parameters");
+    if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
+    // librosa.effects.time_stretch is a pure truncation only while its STFT has <= 2 frames
+    if (p.enhance_mode == MPX_ENHANCE_LIBROSA010 && p.n_peaks_elim >= 2 && 1 + Mh / 512 > 2)
+        return set_error(ctx, MPX_EUNSUPPORTED,
+                         "ESACF: enhance_mode librosa010 needs a phase-vocoder for %d lags (frame %d); only frames "
+                         "<= 2048 are built so far (use enhance_mode noop or a shorter frame)", Mh, N);
+    if (num_frames == 0) return MPX_OK;
+    BandCoef coef;
+    int rc = band_coefs(ctx, fs, coef);
+    if (rc) return rc;
+    EsacfPlan plan;
+    if ((rc = esacf_plan(ctx, N, plan))) return rc;
+    if (plan.L > 4096)
+        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: non power-of-two frame %d needs a %d-point FFT (> 4096)", N, plan.L);
+    const int maxp = p.peak_min_dist > 1 ? Mh / (p.peak_min_dist + 1) + 2 : Mh / 2 + 2;
+    if (maxp > 4095) return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: too many peak slots");
+
+    // frames are processed in batches that fit a fixed workspace budget
+    const size_t per_frame = (size_t)N * 16 + (size_t)Mh * 8 + (size_t)maxp * 20 + 8;
+    long long batch = (long long)((size_t(6) << 30) / per_frame);
+    if (batch > num_frames) batch = num_frames;
+    if (batch > (1 << 19)) batch = 1 << 19;  // (frame << 12 | slot) must fit an int
+    if (batch < 1) batch = 1;
+    if ((rc = ensure(ctx, ctx->d_ws0, (size_t)batch * N * 16))) return rc;                   // x_lo | x_hi
+    if ((rc = ensure(ctx, ctx->d_ws1, (size_t)batch * Mh * 8 + 64))) return rc;              // y
+    if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 64))) return rc;
+    double* xlo = (double*)ctx->d_ws0.p;
+    double* xhi = xlo + (size_t)batch * N;
+    double* y = (double*)ctx->d_ws1.p;
+    char* w3 = (char*)ctx->d_ws3.p;
+    double* center = (double*)w3;
+    int* peak_idx = (int*)(w3 + (size_t)batch * maxp * 8);
+    int* okf = peak_idx + (size_t)batch * maxp;
+    int* worklist = okf + (size_t)batch * maxp;
+    int* peak_count = worklist + (size_t)batch * maxp;
+    int* total = peak_count + batch;
+
+    for (long long f0 = 0; f0 < num_frames; f0 += batch) {
+        const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
+        double* xw = (stage == MPX_STAGE_WFIR) ? d_stage_out + (size_t)f0 * N : nullptr;
+        hipLaunchKernelGGL(bandsplit_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
+                           (long long)n, d_desc, f0, nf, N, hop, coef, xlo, xhi, xw);
+        MPX_HIP(ctx, hipGetLastError());
+        if (stage == MPX_STAGE_XLO || stage == MPX_STAGE_XHI)
+            MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * N, stage == MPX_STAGE_XLO ? xlo : xhi,
+                                        (size_t)nf * N * 8, hipMemcpyDeviceToDevice, st));
+        if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, sizeof(int), st));
+        SacfArgs a;
+        a.xlo = xlo;
+        a.xhi = xhi;
+        a.N = N;
+        a.Mh = Mh;
+        a.tw = plan.tw;
+        a.chirp = plan.chirp;
+        a.bhat = plan.bhat;
+        a.n_peaks_elim = p.n_peaks_elim;
+        a.peak_thresh = p.peak_thresh;
+        a.peak_min_dist = p.peak_min_dist;
+        a.enhance_mode = p.enhance_mode;
+        a.maxp = maxp;
+        a.sacf_out = stage == MPX_STAGE_SACF ? d_stage_out + (size_t)f0 * Mh : nullptr;
+        a.y_out = y;
+        a.peak_count = peak_count;
+        a.peak_idx = peak_idx;
+        a.total_peaks = total;
+        a.worklist = worklist;
+        if (plan.blue) {
+            if (plan.L == 512) rc = sacf_launch<512, 64, true>(ctx, a, nf, st);
+            else if (plan.L == 1024) rc = sacf_launch<1024, 64, true>(ctx, a, nf, st);
+            else if (plan.L == 2048) rc = sacf_launch<2048, 128, true>(ctx, a, nf, st);
+            else rc = sacf_launch<4096, 256, true>(ctx, a, nf, st);
+        } else {
+            if (plan.L == 512) rc = sacf_launch<512, 64, false>(ctx, a, nf, st);
+            else if (plan.L == 1024) rc = sacf_launch<1024, 64, false>(ctx, a, nf, st);
+            else if (plan.L == 2048) rc = sacf_launch<2048, 128, false>(ctx, a, nf, st);
+            else rc = sacf_launch<4096, 256, false>(ctx, a, nf, st);
+        }
+        if (rc) return rc;
+        if (stage == MPX_STAGE_ESACF)
+            MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * Mh, y, (size_t)nf * Mh * 8,
+                                        hipMemcpyDeviceToDevice, st));
+        if (stage >= 0) continue;
+        const long long slots = nf * maxp;
+        hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, st, total, worklist, y,
+                           Mh, maxp, peak_idx, center, okf);
+        hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,
+                           y, peak_count, peak_idx, center, okf, d_chroma_frames);
+        MPX_HIP(ctx, hipGetLastError());
+    }
+    return MPX_OK;
+}
+
 }  // namespace mpx

@@ -117,11 +117,25 @@ class Engine:
             raise ValueError("enhance_mode must be one of %s" % sorted(modes))
         return _lib.EsacfParams(int(n_peaks_elim), float(peak_thresh), int(peak_min_dist), modes[enhance_mode])
 
+    def _ensure_remez(self, fs):
+        """Warped-FIR taps are a design constant (dsp/wfir.py:13-21); 22050/44100 Hz are built in, other
+        rates are designed once on the host exactly as the reference does (scipy.signal.remez)."""
+        fs = int(fs)
+        if fs in (22050, 44100) or fs in getattr(self, "_remez_done", set()):
+            return
+        import scipy.signal
+        r = min(20000, fs / 2 - 1)
+        taps = np.ascontiguousarray(scipy.signal.remez(13, [0, 19, 20, r, r + 1, 0.5 * fs], [0, 1, 0], fs=fs),
+                                    dtype=np.float64)
+        self._check(self.lib.mpx_set_remez_taps(self.ctx, fs, taps.ctypes.data_as(_lib._dp)))
+        self._remez_done = getattr(self, "_remez_done", set()) | {fs}
+
     def esacf(self, x, fs, frame, hop=None, n_peaks_elim=6, peak_thresh=0.1, peak_min_dist=10,
               enhance_mode="librosa010", return_frames=False):
         x = self._sig(x)
         hop = int(hop or frame)
         p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        self._ensure_remez(fs)
         nf = max(self.num_frames(x.shape[0], frame, hop), 0)
         total = np.zeros(12, dtype=np.float64)
         frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
@@ -134,6 +148,7 @@ class Engine:
                     enhance_mode="librosa010"):
         flat, offsets = self._pack(clips)
         p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        self._ensure_remez(fs)
         out = np.zeros((len(offsets) - 1, 12), dtype=np.float64)
         self._check(self.lib.mpx_esacf_batch(
             self.ctx, flat.ctypes.data_as(_lib._fp), offsets.ctypes.data_as(_lib._ip), len(offsets) - 1, int(fs),
@@ -143,6 +158,7 @@ class Engine:
     def esacf_dev(self, d_signal, n, fs, frame, hop, d_frames, d_sum, stream=None, n_peaks_elim=6,
                   peak_thresh=0.1, peak_min_dist=10, enhance_mode="librosa010"):
         p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        self._ensure_remez(fs)
         self._check(self.lib.mpx_esacf_dev(self.ctx, d_signal, int(n), int(fs), C.byref(p), int(frame), int(hop),
                                            d_frames, d_sum, stream))
 
@@ -152,6 +168,7 @@ class Engine:
         x = self._sig(x)
         hop = int(hop or frame)
         p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        self._ensure_remez(fs)
         nf = max(self.num_frames(x.shape[0], frame, hop), 0)
         sid = _lib.STAGES[stage]
         length = frame if sid <= 2 else (frame - 1) // 2

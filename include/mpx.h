@@ -135,6 +135,17 @@ int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs,
 int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int fs,
                     const mpx_esacf_params* params, int frame, int hop, double* out);
 
+/* Warped-FIR design constants (dsp/wfir.py:13-21 calls scipy.signal.remez(13, ...)
+ * every frame; here they are host constants).  Tables for fs = 22050 and 44100
+ * are built in; for any other sample rate the host registers the 13 taps once. */
+int mpx_set_remez_taps(mpx_ctx* ctx, int fs, const double* taps13);
+
+/* Host-callable copy of the device gaussian peak fit (peakutils.interpolate ->
+ * scipy curve_fit -> MINPACK lmdif, esacf.py:60) so the restatement can be unit
+ * tested without a GPU.  Returns MINPACK's info code (1..4 = converged) or a
+ * negative mpx_status; m in [3, 21]. */
+int mpx_test_gaussian_fit(const double* xs, const double* ys, int m, double* center);
+
 /* ---- timing helper (HIP events on the stream the kernels run on) ----------
  * mpx_timer_begin records an event on `stream` (NULL = context stream);
  * mpx_timer_end records the closing event, waits for it and returns the
