@@ -92,6 +92,23 @@ def frame_chroma(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, detail=False):
     return chroma
 
 
+def frame_fragility(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, eps=1e-12, trials=2):
+    """Test helper: True when the REFERENCE ALGORITHM ITSELF is ill-conditioned on this frame,
+    i.e. a relative perturbation of 1e-12 of the ESACF row (far below anything float64 FFTs
+    can promise) changes the frame's chroma by more than 1e-6.  That happens when a gaussian
+    fit runs away from its 21-sample window (MINPACK then stops wherever its tolerances say,
+    and the "centre" decides the pitch class) or a pitch rounds on a pitch-class boundary.
+    Such frames are compared on identical inputs only (tests/test_gpu_esacf.py)."""
+    base = frame_chroma(x_esacf, fs, peak_thresh, peak_min_dist)
+    rng = np.random.default_rng(12345)
+    for _ in range(trials):
+        pert = x_esacf * (1.0 + eps * rng.standard_normal(x_esacf.shape[0]))
+        other = frame_chroma(pert, fs, peak_thresh, peak_min_dist)
+        if not np.allclose(base, other, rtol=1e-6, atol=1e-12):
+            return True
+    return False
+
+
 def esacf_frames(x, fs, frame_size=None, hop=None, n_peaks_elim=6, peak_thresh=0.1,
                  peak_min_dist=10, enhance_mode="librosa010"):
     if frame_size is None:
