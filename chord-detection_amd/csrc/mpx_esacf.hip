@@ -115,14 +115,14 @@ template <int L, int T, bool BLUE>
 __device__ __forceinline__ void dft_n(cx<double>* buf, const SacfArgs& a, cx<double>* regs, int tid) {
     if (BLUE) {
         const int N = a.N;
-        for (int n = tid; n < L; n += T) buf[n] = n < N ? cmul(buf[n], cconj(a.chirp[n])) : cx<double>{0.0, 0.0};
+        for (int n = tid; n < L; n += T) buf[lds_slot(n)] = n < N ? cmul(buf[lds_slot(n)], cconj(a.chirp[n])) : cx<double>{0.0, 0.0};
         __syncthreads();
         fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
         // multiply by the filter spectrum; swap re/im so that the next forward FFT is an inverse one
-        for (int k = tid; k < L; k += T) buf[k] = cswap(cmul(buf[k], a.bhat[k]));
+        for (int k = tid; k < L; k += T) buf[lds_slot(k)] = cswap(cmul(buf[lds_slot(k)], a.bhat[k]));
         __syncthreads();
         fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
-        for (int k = tid; k < N; k += T) buf[k] = cmul(cswap(buf[k]), cconj(a.chirp[k]));
+        for (int k = tid; k < N; k += T) buf[lds_slot(k)] = cmul(cswap(buf[lds_slot(k)]), cconj(a.chirp[k]));
         __syncthreads();
     } else {
         fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, Mh = a.Mh;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                 // L complex
-    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * L);  // N + 2 doubles
+    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));  // N + 2 doubles
     // aliases onto buf, valid once the SACF has been copied out to yv
     double* dy = reinterpret_cast<double*>(smem);          // Mh
     int* lnz = reinterpret_cast<int*>(dy + Mh + 1);        // Mh
@@ -167,24 +167,24 @@ __global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
     // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N
     const double* lo = a.xlo + f * (long long)N;
     const double* hi = a.xhi + f * (long long)N;
-    for (int n = tid; n < N; n += T) buf[n] = {lo[n], hi[n]};
+    for (int n = tid; n < N; n += T) buf[lds_slot(n)] = {lo[n], hi[n]};
     __syncthreads();
     dft_n<L, T, BLUE>(buf, a, regs, tid);
     for (int k = tid; k < N; k += T) {
-        const cx<double> A = buf[k];
-        const cx<double> B = cconj(buf[k == 0 ? 0 : N - k]);
+        const cx<double> A = buf[lds_slot(k)];
+        const cx<double> B = cconj(buf[lds_slot(k == 0 ? 0 : N - k)]);
         // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
         const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
         const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
         yv[k] = pow(hypot(lr, li), 0.67) + pow(hypot(hr, hm), 0.67);  // esacf.py:95-103, k fixed at 0.67
     }
     __syncthreads();
-    for (int k = tid; k < N; k += T) buf[k] = {yv[k], 0.0};
+    for (int k = tid; k < N; k += T) buf[lds_slot(k)] = {yv[k], 0.0};
     __syncthreads();
     dft_n<L, T, BLUE>(buf, a, regs, tid);
     const double inv_n = 1.0 / (double)N;
     for (int n = tid; n < Mh; n += T) {
-        const double v = buf[n].x * inv_n;
+        const double v = buf[lds_slot(n)].x * inv_n;
         yv[n] = v;
         if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
     }
@@ -538,7 +538,7 @@ static int band_coefs(mpx_ctx* ctx, int fs, BandCoef& k) {
 
 template <int L, int T, bool BLUE>
 static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStream_t st) {
-    const size_t lds = sizeof(cx<double>) * L + sizeof(double) * (size_t)(a.N + 2);
+    const size_t lds = sizeof(cx<double>) * lds_slots(L) + sizeof(double) * (size_t)(a.N + 2);
     const size_t alias = (size_t)(a.Mh + 1) * (sizeof(double) + 4 * sizeof(int));
     if (alias > sizeof(cx<double>) * L)
         return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", a.N);

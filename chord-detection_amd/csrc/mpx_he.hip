@@ -54,7 +54,7 @@ __global__ __launch_bounds__(T) void he_kernel(HeArgs<Real> a) {
     constexpr int EPT = M / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<Real>* buf = reinterpret_cast<cx<Real>*>(smem);
-    Real* mag = reinterpret_cast<Real*>(smem + sizeof(cx<Real>) * M);
+    Real* mag = reinterpret_cast<Real*>(smem + sizeof(cx<Real>) * lds_slots(M));
     const int nmag = a.kmax - a.kmin;
     Real* winmax = mag + nmag;
 
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(T) void he_kernel(HeArgs<Real> a) {
     // real-split: X[k] = E + (-i) W_N^k D, E=(Z[k]+conj Z[M-k])/2, D=(Z[k]-conj Z[M-k])/2
     for (int i = tid; i < nmag; i += T) {
         const int k = a.kmin + i;
-        const cx<Real> A = buf[k & (M - 1)];
-        cx<Real> B = buf[(M - k) & (M - 1)];
+        const cx<Real> A = buf[lds_slot(k & (M - 1))];
+        cx<Real> B = buf[lds_slot((M - k) & (M - 1))];
         B.y = -B.y;
         const cx<Real> E = {(Real)0.5 * (A.x + B.x), (Real)0.5 * (A.y + B.y)};
         const cx<Real> D = {(Real)0.5 * (A.x - B.x), (Real)0.5 * (A.y - B.y)};
@@ -280,7 +280,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.kmin = plan.kmin;
     a.kmax = plan.kmax;
     a.out = d_out;
-    const size_t lds = sizeof(cx<Real>) * (N / 2) + sizeof(Real) * (size_t)(plan.kmax - plan.kmin + plan.nwin);
+    const size_t lds = sizeof(cx<Real>) * lds_slots(N / 2) + sizeof(Real) * (size_t)(plan.kmax - plan.kmin + plan.nwin);
     if (lds > 160 * 1024)
         return set_error(ctx, MPX_EUNSUPPORTED, "frame %d needs %zu B of LDS (> 160 KiB)", N, lds);
     auto kern = he_kernel<N, T, Real>;
