@@ -118,6 +118,11 @@ mpx_ctx* mpx_create(int device, int flags) {
     }
     ctx->device = device;
     ctx->flags = flags;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            ctx->num_cus = prop.multiProcessorCount;
+    }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
         set_error(nullptr, MPX_EHIP, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -133,7 +138,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void* p : ctx->owned) hipFree(p);
     for (DevBuf* b : {&ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
-                      &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3})
+                      &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3, &ctx->d_counter})
         if (b->p) hipFree(b->p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -181,16 +186,33 @@ static int check_common(mpx_ctx* ctx, const void* sig, int64_t n, int frame, int
     return MPX_OK;
 }
 
+// A method runner fills d_frames ([F,12], may be NULL when the method can do without) and, when
+// it owns a fused cross-frame reduction, d_sum; *did_sum tells the caller whether it did.
 typedef int (*run_fn)(mpx_ctx*, const float*, int64_t, const FrameDesc*, int64_t, int, const void*, int, int,
-                      double*, hipStream_t);
+                      double*, double*, bool*, hipStream_t);
 
 static int run_he(mpx_ctx* c, const float* s, int64_t n, const FrameDesc* d, int64_t nf, int fs, const void* p,
-                  int frame, int hop, double* out, hipStream_t st) {
-    return he_run(c, s, n, d, nf, fs, (const mpx_he_params*)p, frame, hop, out, st);
+                  int frame, int hop, double* out, double* sum, bool* did_sum, hipStream_t st) {
+    // clips (desc mode) are reduced per segment by the caller; a single signal is reduced in the kernel
+    double* fused = d ? nullptr : sum;
+    *did_sum = fused != nullptr;
+    return he_run(c, s, n, d, nf, fs, (const mpx_he_params*)p, frame, hop, out, fused, st);
 }
 static int run_esacf(mpx_ctx* c, const float* s, int64_t n, const FrameDesc* d, int64_t nf, int fs, const void* p,
-                     int frame, int hop, double* out, hipStream_t st) {
-    return esacf_run(c, s, n, d, nf, fs, (const mpx_esacf_params*)p, frame, hop, out, -1, nullptr, st);
+                     int frame, int hop, double* out, double* sum, bool* did_sum, hipStream_t st) {
+    *did_sum = false;
+    if (!out) {  // ESACF always goes through per-frame rows
+        int rc = ensure(c, c->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double));
+        if (rc) return rc;
+        out = (double*)c->d_frames_out.p;
+    }
+    int rc = esacf_run(c, s, n, d, nf, fs, (const mpx_esacf_params*)p, frame, hop, out, -1, nullptr, st);
+    if (rc) return rc;
+    if (sum && !d && nf) {
+        *did_sum = true;
+        return segment_sum(c, out, nullptr, 1, nf, sum, st);
+    }
+    return MPX_OK;
 }
 
 // device-resident single signal
@@ -200,17 +222,14 @@ static int method_dev(mpx_ctx* ctx, run_fn run, const float* d_signal, int64_t n
     if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     const int64_t nf = num_frames_of(n, frame, hop);
-    double* frames_out = d_chroma_frames;
-    if (!frames_out) {
-        if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
-        frames_out = (double*)ctx->d_frames_out.p;
-    }
-    if ((rc = run(ctx, d_signal, n, nullptr, nf, fs, params, frame, hop, frames_out, st))) return rc;
-    if (d_chroma_sum) {
+    bool did_sum = false;
+    if (nf && (rc = run(ctx, d_signal, n, nullptr, nf, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, &did_sum, st)))
+        return rc;
+    if (d_chroma_sum && !did_sum) {
         if (nf == 0)
             MPX_HIP(ctx, hipMemsetAsync(d_chroma_sum, 0, 12 * sizeof(double), st));
-        else if ((rc = segment_sum(ctx, frames_out, nullptr, 1, nf, d_chroma_sum, st)))
-            return rc;
+        else
+            return set_error(ctx, MPX_EHIP, "internal: method did not reduce its frames");
     }
     return MPX_OK;
 }
@@ -227,7 +246,7 @@ static int method_host(mpx_ctx* ctx, run_fn run, const float* signal, int64_t n,
     if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
     if (n) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
-                    (double*)ctx->d_frames_out.p, (double*)ctx->d_sum.p, ctx->stream);
+                    chroma_frames ? (double*)ctx->d_frames_out.p : nullptr, (double*)ctx->d_sum.p, ctx->stream);
     if (rc) return rc;
     MPX_HIP(ctx, hipMemcpyAsync(chroma_sum, ctx->d_sum.p, 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (chroma_frames && nf)
@@ -262,8 +281,9 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if (total) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyHostToDevice, st));
     if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    bool did_sum = false;
     if (nf && (rc = run(ctx, (const float*)ctx->d_signal.p, total, (const FrameDesc*)ctx->d_desc.p, nf, fs, params,
-                        frame, hop, (double*)ctx->d_frames_out.p, st)))
+                        frame, hop, (double*)ctx->d_frames_out.p, nullptr, &did_sum, st)))
         return rc;
     if ((rc = segment_sum(ctx, (const double*)ctx->d_frames_out.p, (const long long*)ctx->d_offsets.p, num_clips, nf,
                           (double*)ctx->d_sum.p, st)))

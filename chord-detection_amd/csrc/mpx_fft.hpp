@@ -116,20 +116,20 @@ __device__ __forceinline__ constexpr int lds_slot(int i) { return i + (i >> 4); 
 constexpr int lds_slots(int m) { return m + (m >> 4); }
 
 // ---------------------------------------------------------------- radix plans
-// Radix sequence for M = 2^LOG2M with at most 16 points per butterfly.
-template <int LOG2M>
-struct Plan;
-template <> struct Plan<6>  { static constexpr int n = 2; static constexpr int r[4] = {8, 8, 1, 1}; };
-template <> struct Plan<7>  { static constexpr int n = 2; static constexpr int r[4] = {16, 8, 1, 1}; };
-template <> struct Plan<8>  { static constexpr int n = 2; static constexpr int r[4] = {16, 16, 1, 1}; };
-template <> struct Plan<9>  { static constexpr int n = 3; static constexpr int r[4] = {8, 8, 8, 1}; };
-template <> struct Plan<10> { static constexpr int n = 3; static constexpr int r[4] = {16, 8, 8, 1}; };
-template <> struct Plan<11> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 8, 1}; };
-template <> struct Plan<12> { static constexpr int n = 3; static constexpr int r[4] = {16, 16, 16, 1}; };
-template <> struct Plan<13> { static constexpr int n = 4; static constexpr int r[4] = {16, 8, 8, 8}; };
-template <> struct Plan<14> { static constexpr int n = 4; static constexpr int r[4] = {16, 16, 8, 8}; };
-
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+// Radix sequence for M points when a thread holds EPT of them: as many passes of
+// radix min(EPT,16) as fit, then one smaller pass for the remainder.
+template <int M, int EPT>
+struct Plan {
+    static constexpr int MAXR = EPT < 16 ? EPT : 16;
+    static constexpr int LR = ilog2(MAXR);
+    static constexpr int LM = ilog2(M);
+    static constexpr int full = LM / LR, rem = LM % LR;
+    static constexpr int n = full + (rem ? 1 : 0);
+    static constexpr int radix(int i) { return i < full ? MAXR : ((i == full && rem) ? (1 << rem) : 1); }
+    static constexpr int done(int i) { return i == 0 ? 1 : done(i - 1) * radix(i - 1); }  // product of earlier radices
+};
 
 // One Stockham pass of radix R over the M points in `buf` (LDS).
 //   P    = product of the radices of the passes already done
@@ -148,12 +148,13 @@ __device__ __forceinline__ void stockham_pass(cx<Real>* buf, const cx<Real>* __r
     constexpr int BPT = EPT / R; // butterflies per thread
     static_assert(BPT >= 1, "radix larger than the per-thread register file");
     static_assert(NB % T == 0, "butterflies must divide evenly over threads");
+    static_assert(NB % 16 == 0, "read stride must keep the pad phase (slot(i + r*NB) = slot(i) + r*slot(NB))");
     if (!FROM_REGS) {
 #pragma unroll
         for (int b = 0; b < BPT; ++b) {
             const int i = tid + b * T;
 #pragma unroll
-            for (int r = 0; r < R; ++r) regs[b * R + r] = buf[lds_slot(i + r * NB)];
+            for (int r = 0; r < R; ++r) regs[b * R + r] = buf[lds_slot(i) + r * lds_slots(NB)];
         }
         __syncthreads();  // everyone has read before anyone overwrites
     }
@@ -168,6 +169,10 @@ __device__ __forceinline__ void stockham_pass(cx<Real>* buf, const cx<Real>* __r
             constexpr int STRIDE = M / (P * R);
             cx<Real> w[R];
             w[1] = tw[k * STRIDE];
+            // Callers loop over frames with this pass inlined: the table load is loop invariant and
+            // gets hoisted (good: 1 register pair per butterfly), but the R-2 powers must NOT be, or
+            // they pin ~4*(R-2) VGPRs per pass and halve occupancy.  Make the base opaque here.
+            asm volatile("" : "+v"(w[1].x), "+v"(w[1].y));
 #pragma unroll
             for (int r = 2; r < R; ++r) {
                 const int hb = 1 << (31 - __builtin_clz(r));  // highest power of two <= r
@@ -180,8 +185,13 @@ __device__ __forceinline__ void stockham_pass(cx<Real>* buf, const cx<Real>* __r
         if (!TO_REGS) {
             const int k = i & (P - 1);
             const int j = (i - k) * R + k;
+            // slot(j + r*P) = slot(j) + slot(r*P): j's low 4 bits never carry into the pad phase
+            // (P = 1: j = R*i, r < R <= 16;  P = 8: j & 15 = i & 7 < 8;  P >= 16: r*P is a multiple of 16)
+            static_assert(P == 1 || P == 8 || P % 16 == 0, "unsupported pass order for padded addressing");
+            static_assert(P != 1 || R == 16 || R == 8, "first pass must be radix 8 or 16");
+            cx<Real>* dst = buf + lds_slot(j);
 #pragma unroll
-            for (int r = 0; r < R; ++r) buf[lds_slot(j + r * P)] = v[r];
+            for (int r = 0; r < R; ++r) dst[lds_slot(r * P)] = v[r];
         }
     }
     if (!TO_REGS) __syncthreads();
@@ -191,22 +201,57 @@ __device__ __forceinline__ void stockham_pass(cx<Real>* buf, const cx<Real>* __r
 // takes its input from `regs` (see stockham_pass) and `buf` need not be
 // initialised; the caller must have issued a __syncthreads() since the last
 // read of `buf`.  Result is in `buf`, natural order, all threads synchronised.
+template <int M, int T, int I, bool FIRST_FROM_REGS, typename Real>
+__device__ __forceinline__ void fft_passes(cx<Real>* buf, const cx<Real>* __restrict__ tw, cx<Real>* regs,
+                                           int tid) {
+    using PL = Plan<M, M / T>;
+    if constexpr (I < PL::n) {
+        stockham_pass<M, T, PL::radix(I), PL::done(I), (I == 0 && FIRST_FROM_REGS), false, Real>(buf, tw, regs, tid);
+        fft_passes<M, T, I + 1, FIRST_FROM_REGS, Real>(buf, tw, regs, tid);
+    }
+}
+
+// Same, but the last pass leaves its outputs in `regs` instead of LDS:
+// regs[e] holds Z[last_pass_index<M,T>(tid, e)].  `buf` is free after the call
+// returns only once the caller synchronises.
+template <int M, int T, int I, bool FIRST_FROM_REGS, typename Real>
+__device__ __forceinline__ void fft_passes_keep(cx<Real>* buf, const cx<Real>* __restrict__ tw, cx<Real>* regs,
+                                                int tid) {
+    using PL = Plan<M, M / T>;
+    if constexpr (I < PL::n) {
+        stockham_pass<M, T, PL::radix(I), PL::done(I), (I == 0 && FIRST_FROM_REGS), (I == PL::n - 1), Real>(
+            buf, tw, regs, tid);
+        fft_passes_keep<M, T, I + 1, FIRST_FROM_REGS, Real>(buf, tw, regs, tid);
+    }
+}
+
+template <int M, int T, bool FIRST_FROM_REGS, typename Real>
+__device__ __forceinline__ void fft_lds_keep_last(cx<Real>* buf, const cx<Real>* __restrict__ tw,
+                                                  cx<Real>* regs, int tid) {
+    fft_passes_keep<M, T, 0, FIRST_FROM_REGS, Real>(buf, tw, regs, tid);
+}
+
+// Output index held by regs[e] after fft_lds_keep_last (last pass: P*R = M).
+template <int M, int T>
+__device__ __forceinline__ int last_pass_index(int tid, int e) {
+    using PL = Plan<M, M / T>;
+    constexpr int R = PL::radix(PL::n - 1);
+    constexpr int P = PL::done(PL::n - 1);
+    const int b = e / R, r = e % R;
+    return tid + b * T + r * P;
+}
+
 template <int M, int T, bool FIRST_FROM_REGS, typename Real>
 __device__ __forceinline__ void fft_lds(cx<Real>* buf, const cx<Real>* __restrict__ tw,
                                         cx<Real>* regs, int tid) {
-    using PL = Plan<ilog2(M)>;
-    constexpr int R0 = PL::r[0], R1 = PL::r[1], R2 = PL::r[2], R3 = PL::r[3];
-    stockham_pass<M, T, R0, 1, FIRST_FROM_REGS, false, Real>(buf, tw, regs, tid);
-    if constexpr (PL::n > 1) stockham_pass<M, T, R1, R0, false, false, Real>(buf, tw, regs, tid);
-    if constexpr (PL::n > 2) stockham_pass<M, T, R2, R0 * R1, false, false, Real>(buf, tw, regs, tid);
-    if constexpr (PL::n > 3) stockham_pass<M, T, R3, R0 * R1 * R2, false, false, Real>(buf, tw, regs, tid);
+    fft_passes<M, T, 0, FIRST_FROM_REGS, Real>(buf, tw, regs, tid);
 }
 
 // First-pass read order helper: the point index that regs[e] must hold when a
 // caller feeds fft_lds<.., FIRST_FROM_REGS=true>.
 template <int M, int T>
 __device__ __forceinline__ int first_pass_index(int tid, int e) {
-    constexpr int R0 = Plan<ilog2(M)>::r[0];
+    constexpr int R0 = Plan<M, M / T>::radix(0);
     constexpr int NB = M / R0;
     const int b = e / R0, r = e % R0;
     return tid + b * T + r * NB;

@@ -27,7 +27,8 @@ struct HeArgs {
     const FrameDesc* desc;  // nullptr => frame f starts at f*hop
     long long num_frames;
     int hop;
-    const Real* window;     // [N]
+    const cx<Real>* wbase;  // [2T]  (cos, sin)(2*pi*s/(N-1)), s < 2T: this thread's two base samples
+    const cx<Real>* woffs;  // [EPT] (cos, sin)(2*pi*o_e/(N-1)), o_e = 2*(first_pass_index(0,e))
     const cx<Real>* tw;     // [M]
     const cx<Real>* twn;    // [M+1]
     const int* wk0;
@@ -35,7 +36,10 @@ struct HeArgs {
     const Real* ww;
     int nwin, wins_per_note, num_harmonic;
     int kmin, kmax;
-    double* out;            // [F,12]
+    double* out;            // [F,12] per-frame chroma, may be null
+    double* partial;        // [gridDim.x,12] per-workgroup sums over its frames, may be null
+    double* sum;            // [12] total over all frames (written by the last workgroup to finish)
+    unsigned* counter;      // arrival ticket for that hand-off; zero before and after every launch
 };
 
 // XCD-aware bijective remap: workgroup b runs on XCD b%8 (observed dispatch
@@ -48,8 +52,41 @@ __device__ __forceinline__ long long xcd_contiguous(long long b, long long g) {
     return base + slot;
 }
 
+// Two consecutive samples of a frame; zero beyond `valid` (the frame_cutter padding).
+__device__ __forceinline__ float2 load_pair(const float* __restrict__ x, int s, int valid, bool aligned) {
+    float2 v = {0.f, 0.f};
+    if (s + 1 < valid) {
+        if (aligned) {
+            v = *reinterpret_cast<const float2*>(x + s);
+        } else {
+            v.x = x[s];
+            v.y = x[s + 1];
+        }
+    } else if (s < valid) {
+        v.x = x[s];
+    }
+    return v;
+}
+
+// Persistent workgroups: workgroup w owns the contiguous frame range
+// [w*per, (w+1)*per).  Everything that does not depend on the frame (this
+// thread's window samples, its twiddle bases) is loaded once and stays in
+// registers; the next frame's samples are prefetched while the current frame is
+// in the FFT; the 12-bin chroma is accumulated across the workgroup's frames so
+// that only one [12] partial per workgroup (plus the optional per-frame rows)
+// goes back to HBM.
+// Waves per SIMD the LDS footprint allows (the register allocator is told to stay inside it).
 template <int N, int T, typename Real>
-__global__ __launch_bounds__(T) void he_kernel(HeArgs<Real> a) {
+constexpr int he_waves_per_simd() {
+    constexpr int lds = (int)sizeof(cx<Real>) * lds_slots(N / 2) + 4096;
+    constexpr int blocks = (160 * 1024 / lds) > 8 ? 8 : (160 * 1024 / lds);
+    constexpr int w = blocks * T / 256;
+    constexpr int cap = (N / 2 / T) > 8 ? 2 : 4;  // 16 points per thread need the registers of <= 2 waves/SIMD
+    return w < 1 ? 1 : (w > cap ? cap : w);
+}
+
+template <int N, int T, typename Real>
+__global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kernel(HeArgs<Real> a) {
     constexpr int M = N / 2;
     constexpr int EPT = M / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,70 +96,167 @@ __global__ __launch_bounds__(T) void he_kernel(HeArgs<Real> a) {
     Real* winmax = mag + nmag;
 
     const int tid = threadIdx.x;
-    const long long f = xcd_contiguous(blockIdx.x, gridDim.x);
-    long long start;
-    int valid;
-    if (a.desc) {
-        start = a.desc[f].start;
-        valid = a.desc[f].valid;
-    } else {
-        start = f * (long long)a.hop;
-        const long long left = a.n - start;
-        valid = left >= N ? N : (left > 0 ? (int)left : 0);
-    }
-    const float* __restrict__ x = a.sig + start;
+    const long long w = xcd_contiguous(blockIdx.x, gridDim.x);
+    const long long per = (a.num_frames + gridDim.x - 1) / gridDim.x;
+    const long long f0 = w * per;
+    long long f1 = f0 + per;
+    if (f1 > a.num_frames) f1 = a.num_frames;
 
-    // windowed load, two real samples packed per complex point
-    cx<Real> regs[EPT];
+    // Loop invariants.  The symmetric Hamming window 0.54 - 0.46 cos(2 pi s/(N-1)) at this thread's
+    // samples s = 2*tid + j + o_e is rebuilt per frame from the angle-addition formula: 4 doubles per
+    // thread (cos/sin at 2*tid, 2*tid+1) + EPT wave-uniform pairs, instead of 2*EPT doubles per thread.
+    const cx<Real> wb0 = a.wbase[2 * tid], wb1 = a.wbase[2 * tid + 1];
+    int pidx[EPT];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int p = first_pass_index<M, T>(tid, e);
-        const int s = 2 * p;
-        const Real x0 = s < valid ? (Real)x[s] : (Real)0;
-        const Real x1 = s + 1 < valid ? (Real)x[s + 1] : (Real)0;
-        regs[e] = {x0 * a.window[s], x1 * a.window[s + 1]};
-    }
-    fft_lds<M, T, true, Real>(buf, a.tw, regs, tid);
+    for (int e = 0; e < EPT; ++e) pidx[e] = 2 * first_pass_index<M, T>(tid, e);
 
-    // real-split: X[k] = E + (-i) W_N^k D, E=(Z[k]+conj Z[M-k])/2, D=(Z[k]-conj Z[M-k])/2
-    for (int i = tid; i < nmag; i += T) {
-        const int k = a.kmin + i;
-        const cx<Real> A = buf[lds_slot(k & (M - 1))];
-        cx<Real> B = buf[lds_slot((M - k) & (M - 1))];
-        B.y = -B.y;
-        const cx<Real> E = {(Real)0.5 * (A.x + B.x), (Real)0.5 * (A.y + B.y)};
-        const cx<Real> D = {(Real)0.5 * (A.x - B.x), (Real)0.5 * (A.y - B.y)};
-        const cx<Real> X = cadd(E, mul_mi(cmul(a.twn[k], D)));
-        mag[i] = sqrt(sqrt(X.x * X.x + X.y * X.y));
-    }
-    __syncthreads();
-    // half-open window maxima (harmonic_energy.py:58-62)
-    for (int w = tid; w < a.nwin; w += T) {
-        Real m = -INFINITY;
-        for (int k = a.wk0[w]; k < a.wk1[w]; ++k) {
-            const Real v = mag[k - a.kmin];
-            m = v > m ? v : m;
+    auto frame_span = [&](long long f, long long& start, int& valid) {
+        if (a.desc) {
+            start = a.desc[f].start;
+            valid = a.desc[f].valid;
+        } else {
+            start = f * (long long)a.hop;
+            const long long left = a.n - start;
+            valid = left >= N ? N : (left > 0 ? (int)left : 0);
         }
-        winmax[w] = m;
+    };
+
+    float2 raw[EPT];
+    if (f0 < f1) {
+        long long start;
+        int valid;
+        frame_span(f0, start, valid);
+        const float* __restrict__ x = a.sig + start;
+        const bool al = ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) raw[e] = load_pair(x, pidx[e], valid, al);
     }
-    __syncthreads();
-    // chroma[n] = sum_octave ( sum_harmonic max/h ), same association as the reference
-    if (tid < 12) {
-        double chroma = 0.0;
-        const int base = tid * a.wins_per_note;
-        for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
-            double note_sum = 0.0;
-            for (int h = 0; h < a.num_harmonic; ++h)
-                note_sum += (double)winmax[base + o + h] * (double)a.ww[base + o + h];
-            chroma += note_sum;
+    double acc = 0.0;  // chroma bin `tid` summed over this workgroup's frames (tid < 12)
+    for (long long f = f0; f < f1; ++f) {
+        cx<Real> regs[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const cx<Real> o = a.woffs[e];  // wave-uniform: scalar loads
+            const Real w0 = (Real)0.54 - (Real)0.46 * (wb0.x * o.x - wb0.y * o.y);
+            const Real w1 = (Real)0.54 - (Real)0.46 * (wb1.x * o.x - wb1.y * o.y);
+            regs[e] = {(Real)raw[e].x * w0, (Real)raw[e].y * w1};
         }
-        a.out[f * 12 + tid] = chroma;
+        if (f + 1 < f1) {  // prefetch the next frame; its latency hides under this frame's FFT
+            long long start;
+            int valid;
+            frame_span(f + 1, start, valid);
+            const float* __restrict__ x = a.sig + start;
+            const bool al = ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) raw[e] = load_pair(x, pidx[e], valid, al);
+        }
+        fft_lds_keep_last<M, T, true, Real>(buf, a.tw, regs, tid);
+        // Only bins [kmin,kmax) and their mirrors M-k are ever looked at: store just those
+        // (the last pass's LDS reads are fenced by its own barrier, so buf can be overwritten)
+        {
+            const int lo2 = M - a.kmax + 1, hi2 = M - a.kmin;  // mirror range [lo2, hi2]
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int q = last_pass_index<M, T>(tid, e);
+                if ((q >= a.kmin && q < a.kmax) || (q >= lo2 && q <= hi2) || q == 0) buf[lds_slot(q)] = regs[e];
+            }
+        }
+        __syncthreads();
+
+        // real-split: X[k] = E + (-i) W_N^k D, E=(Z[k]+conj Z[M-k])/2, D=(Z[k]-conj Z[M-k])/2
+        for (int i = tid; i < nmag; i += T) {
+            const int k = a.kmin + i;
+            const cx<Real> A = buf[lds_slot(k & (M - 1))];
+            cx<Real> B = buf[lds_slot((M - k) & (M - 1))];
+            B.y = -B.y;
+            const cx<Real> E = {(Real)0.5 * (A.x + B.x), (Real)0.5 * (A.y + B.y)};
+            const cx<Real> D = {(Real)0.5 * (A.x - B.x), (Real)0.5 * (A.y - B.y)};
+            const cx<Real> X = cadd(E, mul_mi(cmul(a.twn[k], D)));
+            mag[i] = sqrt(sqrt(X.x * X.x + X.y * X.y));
+        }
+        __syncthreads();
+        // half-open window maxima (harmonic_energy.py:58-62)
+        for (int wi = tid; wi < a.nwin; wi += T) {
+            Real m = -INFINITY;
+            for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) {
+                const Real v = mag[k - a.kmin];
+                m = v > m ? v : m;
+            }
+            winmax[wi] = m;
+        }
+        __syncthreads();
+        // chroma[n] = sum_octave ( sum_harmonic max/h ), same association as the reference
+        if (tid < 12) {
+            double chroma = 0.0;
+            const int base = tid * a.wins_per_note;
+            for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
+                double note_sum = 0.0;
+                for (int h = 0; h < a.num_harmonic; ++h)
+                    note_sum += (double)winmax[base + o + h] * (double)a.ww[base + o + h];
+                chroma += note_sum;
+            }
+            if (a.out) a.out[f * 12 + tid] = chroma;
+            acc += chroma;
+        }
+        // the next iteration's first LDS write (pass 1) is ordered after this iteration's last
+        // LDS read of buf by the two barriers above; winmax/mag are rewritten only after the
+        // FFT's own barriers
+    }
+    if (a.partial) {
+        // Cross-workgroup hand-off (one per launch): every workgroup publishes its 12 partial sums, the last
+        // one to arrive adds all of them in a fixed order -> deterministic, and no second kernel launch.
+        // Protocol (cdna guide G16, form R1): write-through (sc1) 8-byte stores of the payload -> vmcnt(0) in the
+        // storing wave -> barrier -> one lane takes a relaxed agent-scope ticket; the last arriver reads the
+        // payload with sc1 (L1-bypassing) loads, so no release/acquire fence is needed on either side.
+        int* flag = reinterpret_cast<int*>(winmax + a.nwin);
+        using u64 = unsigned long long;
+        u64* part = reinterpret_cast<u64*>(a.partial);
+        if (tid < 12) __hip_atomic_store(part + w * 12 + tid, (u64)__double_as_longlong(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned t = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (t == gridDim.x - 1);
+        }
+        __syncthreads();
+        if (*flag) {
+            // 12 bins x SUBS strided sub-sums, 8 independent loads in flight per lane, then a fixed-order tree
+            constexpr int SUBS = T / 12 < 21 ? T / 12 : 21;
+            double* sh = reinterpret_cast<double*>(smem);  // buf is dead
+            const long long g = gridDim.x;
+            if (tid < 12 * SUBS) {
+                const int bin = tid % 12, sub = tid / 12;
+                double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                long long r = sub;
+                for (; r + 7 * SUBS < g; r += 8 * SUBS) {
+                    u64 v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        v[q] = __hip_atomic_load(part + (r + q * SUBS) * 12 + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) s[q] += __longlong_as_double((long long)v[q]);
+                }
+                for (; r < g; r += SUBS)
+                    s[0] += __longlong_as_double((long long)__hip_atomic_load(part + r * 12 + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                sh[sub * 12 + bin] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+            }
+            __syncthreads();
+            if (tid < 12) {
+                double t = 0.0;
+                for (int s2 = 0; s2 < SUBS; ++s2) t += sh[s2 * 12 + tid];
+                a.sum[tid] = t;
+            }
+            if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
 // ------------------------------------------------------------------ reductions
 // Single segment, stage 1: chunk c sums frames [c*CH, (c+1)*CH) -> partial[c][12]
 constexpr int SUM_CH = 256;
+#ifndef HE4096_T
+#define HE4096_T 256
+#endif
 __global__ __launch_bounds__(64) void sum_chunks_kernel(const double* __restrict__ frames,
                                                         long long num_frames, double* partial) {
     __shared__ double sh[5][12];
@@ -161,20 +295,25 @@ __global__ __launch_bounds__(64) void sum_segments_kernel(const double* __restri
             (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) + sh[4][lane];
 }
 
-// Same, single segment [0, n) without a segment table.
-__global__ __launch_bounds__(64) void sum_all_kernel(const double* __restrict__ rows, long long n,
-                                                     double* out) {
-    __shared__ double sh[5][12];
+// Same, single segment [0, n) without a segment table: 252 lanes = 12 bins x 21 strided
+// sub-sums, combined in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void sum_all_kernel(const double* __restrict__ rows, long long n,
+                                                      double* out) {
+    __shared__ double sh[21][12];
     const int lane = threadIdx.x;
-    if (lane < 60) {
+    if (lane < 252) {
         const int bin = lane % 12, sub = lane / 12;
         double acc = 0.0;
-        for (long long f = sub; f < n; f += 5) acc += rows[f * 12 + bin];
+        for (long long f = sub; f < n; f += 21) acc += rows[f * 12 + bin];
         sh[sub][bin] = acc;
     }
     __syncthreads();
-    if (lane < 12)
-        out[lane] = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) + sh[4][lane];
+    if (lane < 12) {
+        double t = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < 21; ++s2) t += sh[s2][lane];
+        out[lane] = t;
+    }
 }
 
 int segment_sum(mpx_ctx* ctx, const double* d_frames, const long long* d_seg, int num_seg,
@@ -184,7 +323,7 @@ int segment_sum(mpx_ctx* ctx, const double* d_frames, const long long* d_seg, in
             hipLaunchKernelGGL(sum_segments_kernel, dim3(num_seg), dim3(64), 0, stream, d_frames, d_seg,
                                d_out);
     } else if (num_frames <= 2 * SUM_CH) {
-        hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(64), 0, stream, d_frames, (long long)num_frames,
+        hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, stream, d_frames, (long long)num_frames,
                            d_out);
     } else {
         const long long nch = (num_frames + SUM_CH - 1) / SUM_CH;
@@ -193,7 +332,7 @@ int segment_sum(mpx_ctx* ctx, const double* d_frames, const long long* d_seg, in
         double* part = (double*)ctx->d_partials.p;
         hipLaunchKernelGGL(sum_chunks_kernel, dim3((unsigned)nch), dim3(64), 0, stream, d_frames,
                            (long long)num_frames, part);
-        hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(64), 0, stream, part, nch, d_out);
+        hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, stream, part, nch, d_out);
     }
     MPX_HIP(ctx, hipGetLastError());
     return MPX_OK;
@@ -236,9 +375,13 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
     plan.num_harmonic = p.num_harmonic;
     plan.kmin = kmin;
     plan.kmax = kmax;
-    std::vector<Real> win(N);
-    for (int i = 0; i < N; ++i)  // scipy.signal.hamming(N), symmetric
-        win[i] = (Real)(0.54 - 0.46 * std::cos(2.0 * M_PI * i / (double)(N - 1)));
+    // scipy.signal.hamming(N) (symmetric) angles: cos/sin(2 pi s/(N-1)) for every s; the kernel
+    // combines a per-thread base angle with a per-register offset angle
+    std::vector<cx<Real>> wang(N);
+    for (int i = 0; i < N; ++i) {
+        const long double ang = 2.0L * M_PIl * i / (long double)(N - 1);
+        wang[i] = {(Real)cosl(ang), (Real)sinl(ang)};
+    }
     std::vector<cx<Real>> tw(M), twn(M + 1);
     for (int j = 0; j < M; ++j) {
         const long double ang = -2.0L * M_PIl * j / (long double)M;
@@ -248,7 +391,7 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
         const long double ang = -2.0L * M_PIl * k / (long double)N;
         twn[k] = {(Real)cosl(ang), (Real)sinl(ang)};
     }
-    plan.window = upload(ctx, win.data(), win.size() * sizeof(Real));
+    plan.window = upload(ctx, wang.data(), wang.size() * sizeof(cx<Real>));
     plan.tw = upload(ctx, tw.data(), tw.size() * sizeof(cx<Real>));
     plan.twn = upload(ctx, twn.data(), twn.size() * sizeof(cx<Real>));
     plan.wk0 = (int*)upload(ctx, k0.data(), k0.size() * sizeof(int));
@@ -260,7 +403,7 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
 
 template <int N, int T, typename Real>
 static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n,
-                     const FrameDesc* d_desc, int64_t num_frames, int hop, double* d_out,
+                     const FrameDesc* d_desc, int64_t num_frames, int hop, double* d_out, double* d_sum,
                      hipStream_t stream) {
     HeArgs<Real> a;
     a.sig = d_signal;
@@ -268,7 +411,26 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.desc = d_desc;
     a.num_frames = num_frames;
     a.hop = hop;
-    a.window = (const Real*)plan.window;
+    a.wbase = (const cx<Real>*)plan.window;  // angles of samples 0..2T-1
+    {
+        // offset angles of the EPT register slots of thread 0 (first-pass read order)
+        constexpr int M_ = N / 2, EPT_ = M_ / T;
+        constexpr int R0 = Plan<M_, EPT_>::radix(0), NB = M_ / R0;
+        auto key = std::string("he_woffs_") + std::to_string(N) + "_" + std::to_string(T) + (sizeof(Real) == 4 ? "f" : "d");
+        auto it = ctx->misc_plans.find(key);
+        if (it == ctx->misc_plans.end()) {
+            std::vector<cx<Real>> offs(EPT_);
+            for (int e = 0; e < EPT_; ++e) {
+                const int b = e / R0, r = e % R0;
+                const long double ang = 2.0L * M_PIl * (2.0L * (b * T + r * NB)) / (long double)(N - 1);
+                offs[e] = {(Real)cosl(ang), (Real)sinl(ang)};
+            }
+            void* d = upload(ctx, offs.data(), offs.size() * sizeof(cx<Real>));
+            if (!d) return MPX_ENOMEM;
+            it = ctx->misc_plans.emplace(key, std::vector<void*>{d}).first;
+        }
+        a.woffs = (const cx<Real>*)it->second[0];
+    }
     a.tw = (const cx<Real>*)plan.tw;
     a.twn = (const cx<Real>*)plan.twn;
     a.wk0 = plan.wk0;
@@ -280,13 +442,42 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.kmin = plan.kmin;
     a.kmax = plan.kmax;
     a.out = d_out;
-    const size_t lds = sizeof(cx<Real>) * lds_slots(N / 2) + sizeof(Real) * (size_t)(plan.kmax - plan.kmin + plan.nwin);
+    a.partial = nullptr;
+    a.sum = nullptr;
+    a.counter = nullptr;
+    const size_t lds = sizeof(cx<Real>) * lds_slots(N / 2) + sizeof(Real) * (size_t)(plan.kmax - plan.kmin + plan.nwin) + 16;
     if (lds > 160 * 1024)
         return set_error(ctx, MPX_EUNSUPPORTED, "frame %d needs %zu B of LDS (> 160 KiB)", N, lds);
     auto kern = he_kernel<N, T, Real>;
-    if (lds > 64 * 1024)
-        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)num_frames), dim3(T), lds, stream, a);
+    // persistent grid: as many workgroups as the chip holds at once, each owning a contiguous frame range
+    // (occupancy query and LDS opt-in are done once per kernel/LDS size and cached: they cost host time)
+    const std::string okey = "he_occ_" + std::to_string(N) + "_" + std::to_string(T) + "_" + std::to_string(sizeof(Real)) +
+                             "_" + std::to_string(lds);
+    auto oit = ctx->occupancy.find(okey);
+    if (oit == ctx->occupancy.end()) {
+        if (lds > 48 * 1024)
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int o = 0;
+        MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)kern, T, lds));
+        oit = ctx->occupancy.emplace(okey, o < 1 ? 1 : o).first;
+    }
+    const int occ = oit->second;
+    long long g = (long long)occ * ctx->num_cus;
+    if (g > num_frames) g = num_frames;
+    const long long per = (num_frames + g - 1) / g;
+    g = (num_frames + per - 1) / per;
+    if (d_sum) {
+        int rc = ensure(ctx, ctx->d_partials, (size_t)g * 12 * sizeof(double));
+        if (rc) return rc;
+        if (!ctx->d_counter.p) {
+            if ((rc = ensure(ctx, ctx->d_counter, 64))) return rc;
+            MPX_HIP(ctx, hipMemsetAsync(ctx->d_counter.p, 0, 64, stream));
+        }
+        a.partial = (double*)ctx->d_partials.p;
+        a.sum = d_sum;
+        a.counter = (unsigned*)ctx->d_counter.p;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(T), lds, stream, a);
     MPX_HIP(ctx, hipGetLastError());
     return MPX_OK;
 }
@@ -294,13 +485,13 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
 template <typename Real>
 static int he_dispatch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n,
                        const FrameDesc* d_desc, int64_t num_frames, int frame, int hop, double* d_out,
-                       hipStream_t stream) {
+                       double* d_sum, hipStream_t stream) {
     switch (frame) {
-        case 1024: return he_launch<1024, 64, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, stream);
-        case 2048: return he_launch<2048, 64, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, stream);
-        case 4096: return he_launch<4096, 128, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, stream);
-        case 8192: return he_launch<8192, 256, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, stream);
-        case 16384: return he_launch<16384, 512, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, stream);
+        case 1024: return he_launch<1024, 64, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+        case 2048: return he_launch<2048, 64, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+        case 4096: return he_launch<4096, HE4096_T, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+        case 8192: return he_launch<8192, 256, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+        case 16384: return he_launch<16384, 512, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
         default:
             return set_error(ctx, MPX_EUNSUPPORTED,
                              "harmonic energy: frame size %d is not a power of two in [1024, 16384]", frame);
@@ -309,7 +500,7 @@ static int he_dispatch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, 
 
 int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
            int fs, const mpx_he_params* params, int frame, int hop, double* d_chroma_frames,
-           hipStream_t stream) {
+           double* d_chroma_sum, hipStream_t stream) {
     mpx_he_params p = params ? *params : mpx_he_params{2, 2, 2};
     if (p.num_harmonic < 1 || p.num_octave < 1 || p.num_bins < 0 || p.num_harmonic * p.num_octave > 64)
         return set_error(ctx, MPX_EINVAL, "bad harmonic-energy params (%d,%d,%d)", p.num_harmonic,
@@ -328,8 +519,8 @@ int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_de
         if (rc) return rc;
         it = ctx->he_plans.emplace(key, plan).first;
     }
-    return f32 ? he_dispatch<float>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, stream)
-               : he_dispatch<double>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, stream);
+    return f32 ? he_dispatch<float>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, d_chroma_sum, stream)
+               : he_dispatch<double>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, d_chroma_sum, stream);
 }
 
 }  // namespace mpx

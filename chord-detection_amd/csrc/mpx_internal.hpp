@@ -28,7 +28,7 @@ struct DevBuf {
 
 // Harmonic-energy plan: everything that depends only on (fs, N, params, dtype).
 struct HePlan {
-    void* window = nullptr;  // Real[N]   symmetric Hamming (harmonic_energy.py:42)
+    void* window = nullptr;  // cx[N]     (cos, sin)(2 pi s/(N-1)): symmetric Hamming angles (harmonic_energy.py:42)
     void* tw = nullptr;      // cx[M]     W_M^j, M = N/2
     void* twn = nullptr;     // cx[M+1]   W_N^k (real-FFT split)
     int* wk0 = nullptr;      // [nwin] window start bin
@@ -45,13 +45,15 @@ struct HePlan {
 struct mpx_ctx {
     int device = 0;
     int flags = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<std::tuple<int, int, int, int, int>, mpx::HePlan> he_plans;
     std::map<std::string, std::vector<void*>> misc_plans;
     // grow-only device workspaces
-    mpx::DevBuf d_signal, d_frames_out, d_partials, d_sum, d_desc, d_offsets, d_ws0, d_ws1, d_ws2, d_ws3;
+    mpx::DevBuf d_signal, d_frames_out, d_partials, d_sum, d_desc, d_offsets, d_ws0, d_ws1, d_ws2, d_ws3, d_counter;
+    std::map<std::string, int> occupancy;      // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answers
     std::map<int, std::vector<double>> remez;  // user-registered warped-FIR taps per sample rate
     std::vector<void*> owned;  // plan tables, freed in mpx_destroy
 };
@@ -72,7 +74,7 @@ void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failu
 // he
 int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
            int fs, const mpx_he_params* params, int frame, int hop, double* d_chroma_frames,
-           hipStream_t stream);
+           double* d_chroma_sum, hipStream_t stream);
 // segmented sum of per-frame chroma: out[s] = sum_{f in [seg[s], seg[s+1])} frames[f]
 int segment_sum(mpx_ctx* ctx, const double* d_frames, const long long* d_seg, int num_seg,
                 int64_t num_frames, double* d_out, hipStream_t stream);
