@@ -65,7 +65,7 @@ def cpu_baseline(x, budget_s=12.0):
         done += chunk
         f += 1
         el = time.perf_counter() - t0
-        if el > budget_s or done >= 16 * FRAMES:
+        if el > budget_s:
             break
     # the reference's own loop structure (one frame at a time), for honesty
     t1 = time.perf_counter()
@@ -191,7 +191,7 @@ def main():
                        "sharding": "frames per rank, no data-path collective; one RCCL all_gather of 12-vectors at the end"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None,
-                         "kernel": "he_kernel<4096,128,%s>" % ("float" if args.f32 else "double"),
+                         "kernel": "he_kernel<4096,256,%s>" % ("float" if args.f32 else "double"),
                          "kernel_ms": kern_ms, "bytes_per_frame": B_ALG, "frames_per_launch": FRAMES,
                          "step_ms_hip_events": step_ms_events, "host_enqueue_ms_per_step": host_enqueue_ms},
         }
