@@ -170,6 +170,14 @@ def main():
     if steps and not np.allclose(sums[0], d_frames.sum(0).cpu().numpy(), rtol=1e-10):
         sys.exit("bench: fused chroma sum does not match the sum of the per-frame rows")
 
+    traffic = None
+    try:  # HBM bytes per launch from the last PMC probe of this kernel (bench.py cannot run rocprofv3 on itself)
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
+            tr = json.load(fh)
+        if tr.get("kernel") == "he_kernel<4096,256,%s>" % ("float" if args.f32 else "double"):
+            traffic = tr["bytes_per_launch"]
+    except Exception:
+        traffic = None
     if rank == 0:
         total_frames = FRAMES * world * steps
         out = {
@@ -190,7 +198,8 @@ def main():
                        "frames_per_gpu": FRAMES, "fft": N_FFT, "hop": HOP, "fs": FS,
                        "sharding": "frames per rank, no data-path collective; one RCCL all_gather of 12-vectors at the end"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None,
+                         "frac": achieved / HBM_PEAK, "traffic": traffic,
+                         "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE(x1.99 calibrated)+WRITE_SIZE, profiles/r1/traffic_v2.txt; algorithmic = %d" % (B_ALG * FRAMES),
                          "kernel": "he_kernel<4096,256,%s>" % ("float" if args.f32 else "double"),
                          "kernel_ms": kern_ms, "bytes_per_frame": B_ALG, "frames_per_launch": FRAMES,
                          "step_ms_hip_events": step_ms_events, "host_enqueue_ms_per_step": host_enqueue_ms},
