@@ -127,8 +127,13 @@ struct Plan {
     static constexpr int LM = ilog2(M);
     static constexpr int full = LM / LR, rem = LM % LR;
     static constexpr int n = full + (rem ? 1 : 0);
-    static constexpr int radix(int i) { return i < full ? MAXR : ((i == full && rem) ? (1 << rem) : 1); }
-    static constexpr int done(int i) { return i == 0 ? 1 : done(i - 1) * radix(i - 1); }  // product of earlier radices
+    __host__ __device__ __forceinline__ static constexpr int radix(int i) {
+        return i < full ? MAXR : ((i == full && rem) ? (1 << rem) : 1);
+    }
+    // product of the radices of passes 0..i-1 (no recursion: see DifPlan)
+    __host__ __device__ __forceinline__ static constexpr int done(int i) {
+        return i <= full ? (1 << (LR * i)) : (1 << (LR * full + rem));
+    }
 };
 
 // One Stockham pass of radix R over the M points in `buf` (LDS).

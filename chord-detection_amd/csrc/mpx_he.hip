@@ -14,8 +14,10 @@
 // real-split butterfly evaluated only for the bins the 48 windows look at.
 #include <cmath>
 #include <cstdarg>
+#include <type_traits>
 
 #include "mpx_fft.hpp"
+#include "mpx_fft_dif.hpp"
 #include "mpx_internal.hpp"
 
 namespace mpx {
@@ -28,7 +30,7 @@ struct HeArgs {
     long long num_frames;
     int hop;
     const cx<Real>* wbase;  // [2T]  (cos, sin)(2*pi*s/(N-1)), s < 2T: this thread's two base samples
-    const cx<Real>* woffs;  // [EPT] (cos, sin)(2*pi*o_e/(N-1)), o_e = 2*(first_pass_index(0,e))
+    const cx<Real>* woffs;  // [EPT] (cos, sin)(2*pi*o_e/(N-1)), o_e = 2*e*T: staged in LDS by the kernel
     const cx<Real>* tw;     // [M]
     const cx<Real>* twn;    // [M+1]
     const int* wk0;
@@ -52,20 +54,23 @@ __device__ __forceinline__ long long xcd_contiguous(long long b, long long g) {
     return base + slot;
 }
 
-// Two consecutive samples of a frame; zero beyond `valid` (the frame_cutter padding).
-__device__ __forceinline__ float2 load_pair(const float* __restrict__ x, int s, int valid, bool aligned) {
-    float2 v = {0.f, 0.f};
-    if (s + 1 < valid) {
-        if (aligned) {
-            v = *reinterpret_cast<const float2*>(x + s);
-        } else {
-            v.x = x[s];
-            v.y = x[s + 1];
+// This thread's EPT sample pairs of one frame (pair e starts at sample 2*(tid + e*STRIDE)); zero
+// beyond `valid` (the frame_cutter padding).  Full, 8-byte aligned frames -- all but the tail of
+// a signal -- take the branch-free path: one base address plus immediate offsets.
+template <int EPT, int STRIDE, bool FAST>
+__device__ __forceinline__ void load_frame(float2* raw, const float* __restrict__ x, int tid, int valid) {
+    const float* p = x + 2 * tid;
+    if (FAST) {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) raw[e] = *reinterpret_cast<const float2*>(p + 2 * e * STRIDE);
+    } else {
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int s = 2 * (tid + e * STRIDE);
+            raw[e].x = s < valid ? p[2 * e * STRIDE] : 0.f;
+            raw[e].y = s + 1 < valid ? p[2 * e * STRIDE + 1] : 0.f;
         }
-    } else if (s < valid) {
-        v.x = x[s];
     }
-    return v;
 }
 
 // Persistent workgroups: workgroup w owns the contiguous frame range
@@ -75,10 +80,17 @@ __device__ __forceinline__ float2 load_pair(const float* __restrict__ x, int s, 
 // in the FFT; the 12-bin chroma is accumulated across the workgroup's frames so
 // that only one [12] partial per workgroup (plus the optional per-frame rows)
 // goes back to HBM.
+// Which FFT engine a (N, T) instance uses: the in-place wave-local DIF (8 points per thread, M <= 4096)
+// or the generic Stockham engine.
+template <int N, int T>
+constexpr bool he_uses_dif() { return (N / 2) <= 4096 && (N / 2) / T == 8; }
+template <int N, int T>
+constexpr int he_buf_slots() { return he_uses_dif<N, T>() ? N / 2 : lds_slots(N / 2); }
+
 // Waves per SIMD the LDS footprint allows (the register allocator is told to stay inside it).
 template <int N, int T, typename Real>
 constexpr int he_waves_per_simd() {
-    constexpr int lds = (int)sizeof(cx<Real>) * lds_slots(N / 2) + 4096;
+    constexpr int lds = (int)sizeof(cx<Real>) * he_buf_slots<N, T>() + 4096 + 256;
     constexpr int blocks = (160 * 1024 / lds) > 8 ? 8 : (160 * 1024 / lds);
     constexpr int w = blocks * T / 256;
     constexpr int cap = (N / 2 / T) > 8 ? 2 : 4;  // 16 points per thread need the registers of <= 2 waves/SIMD
@@ -90,12 +102,19 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     constexpr int M = N / 2;
     constexpr int EPT = M / T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool DIF = he_uses_dif<N, T>();
     cx<Real>* buf = reinterpret_cast<cx<Real>*>(smem);
-    Real* mag = reinterpret_cast<Real*>(smem + sizeof(cx<Real>) * lds_slots(M));
+    Real* mag = reinterpret_cast<Real*>(smem + sizeof(cx<Real>) * he_buf_slots<N, T>());
     const int nmag = a.kmax - a.kmin;
     Real* winmax = mag + nmag;
+    // [flag: 16 B][window offset angles: EPT complex] live behind winmax, 16-byte aligned
+    char* tail = reinterpret_cast<char*>(winmax + a.nwin);
+    tail += (16 - (reinterpret_cast<uintptr_t>(tail) & 15)) & 15;
+    cx<Real>* woffs_lds = reinterpret_cast<cx<Real>*>(tail + 16);
 
     const int tid = threadIdx.x;
+    if (tid < EPT) woffs_lds[tid] = a.woffs[tid];
+    __syncthreads();
     const long long w = xcd_contiguous(blockIdx.x, gridDim.x);
     const long long per = (a.num_frames + gridDim.x - 1) / gridDim.x;
     const long long f0 = w * per;
@@ -106,9 +125,9 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     // samples s = 2*tid + j + o_e is rebuilt per frame from the angle-addition formula: 4 doubles per
     // thread (cos/sin at 2*tid, 2*tid+1) + EPT wave-uniform pairs, instead of 2*EPT doubles per thread.
     const cx<Real> wb0 = a.wbase[2 * tid], wb1 = a.wbase[2 * tid + 1];
-    int pidx[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) pidx[e] = 2 * first_pass_index<M, T>(tid, e);
+    // first-pass read order: register e holds complex point tid + e*FSTRIDE (one butterfly per thread)
+    constexpr int FSTRIDE = M / EPT;
+    static_assert(Plan<M, EPT>::radix(0) == EPT && FSTRIDE == T, "first pass must be one radix-EPT butterfly per thread");
 
     auto frame_span = [&](long long f, long long& start, int& valid) {
         if (a.desc) {
@@ -121,53 +140,99 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
         }
     };
 
+    // twiddle bases of the DIF passes: loop invariant, 1 complex per pass
+    DifTwiddles<DIF ? M : 512, Real> twd;
+    if constexpr (DIF) twd = dif_load_twiddles<M, Real>(a.tw, tid);
+    double acc = 0.0;  // chroma bin `tid` summed over this workgroup's frames (tid < 12)
+
+    // Every frame of this workgroup full-length and 8-byte aligned (true for all but the workgroup holding
+    // the ragged tail of a signal, and for packed clips of odd length)?  Then the frame loop is instantiated
+    // without any per-sample predicate: the prefetch is 8 plain loads that stay in flight across the FFT.
+    bool fast = f0 < f1 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
+    if (fast) {
+        if (a.desc) {
+            for (long long f = f0; f < f1; ++f) fast = fast && a.desc[f].valid >= N && (a.desc[f].start & 1) == 0;
+        } else {
+            fast = (a.hop & 1) == 0 && (f1 - 1) * (long long)a.hop + N <= a.n;
+        }
+    }
+    // Which of this thread's EPT last-pass outputs does anyone look at?  Bins [kmin,kmax), their mirrors
+    // M-k and bin 0.  Thread-invariant: one bit mask, computed once.
+    unsigned need = 0;
+    {
+        const int lo2 = M - a.kmax + 1, hi2 = M - a.kmin;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            int q;
+            if constexpr (DIF) {
+                constexpr int RL = DifPlan<M>::radix(DifPlan<M>::n - 1);
+                q = dif_freq<M>(dif_last_pos<M>(tid, e / RL, e % RL));
+            } else {
+                q = last_pass_index<M, T>(tid, e);
+            }
+            if ((q >= a.kmin && q < a.kmax) || (q >= lo2 && q <= hi2) || q == 0) need |= 1u << e;
+        }
+    }
+    auto run = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     float2 raw[EPT];
     if (f0 < f1) {
         long long start;
         int valid;
         frame_span(f0, start, valid);
-        const float* __restrict__ x = a.sig + start;
-        const bool al = ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) raw[e] = load_pair(x, pidx[e], valid, al);
+        load_frame<EPT, FSTRIDE, FAST>(raw, a.sig + start, tid, valid);
     }
-    double acc = 0.0;  // chroma bin `tid` summed over this workgroup's frames (tid < 12)
     for (long long f = f0; f < f1; ++f) {
+        // opaque copy of the thread id: LDS addresses / store predicates derived from it are rebuilt every
+        // frame (a few integer ops) instead of being hoisted into dozens of live registers
+        int ot = tid;
+        asm volatile("" : "+v"(ot));
         cx<Real> regs[EPT];
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const cx<Real> o = a.woffs[e];  // wave-uniform: scalar loads
+            const cx<Real> o = woffs_lds[e];  // same address in every lane: one broadcast LDS read
             const Real w0 = (Real)0.54 - (Real)0.46 * (wb0.x * o.x - wb0.y * o.y);
             const Real w1 = (Real)0.54 - (Real)0.46 * (wb1.x * o.x - wb1.y * o.y);
             regs[e] = {(Real)raw[e].x * w0, (Real)raw[e].y * w1};
         }
-        if (f + 1 < f1) {  // prefetch the next frame; its latency hides under this frame's FFT
+        {
+            // Prefetch the next frame; its latency hides under this frame's FFT.  Unconditional on purpose
+            // (the last iteration re-reads its own frame): a conditional prefetch makes the compiler drain
+            // vmcnt(0) at the join right behind the loads, which exposes their full latency every frame.
             long long start;
             int valid;
-            frame_span(f + 1, start, valid);
-            const float* __restrict__ x = a.sig + start;
-            const bool al = ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) raw[e] = load_pair(x, pidx[e], valid, al);
+            frame_span(f + 1 < f1 ? f + 1 : f, start, valid);
+            load_frame<EPT, FSTRIDE, FAST>(raw, a.sig + start, ot, valid);
         }
-        fft_lds_keep_last<M, T, true, Real>(buf, a.tw, regs, tid);
-        // Only bins [kmin,kmax) and their mirrors M-k are ever looked at: store just those
-        // (the last pass's LDS reads are fenced by its own barrier, so buf can be overwritten)
-        {
-            const int lo2 = M - a.kmax + 1, hi2 = M - a.kmin;  // mirror range [lo2, hi2]
+        // FFT; the last pass keeps its outputs in registers and only the bins the windows look at are stored
+        if constexpr (DIF) {
+            dif_fft_keep_last<M, Real>(buf, twd, regs, ot);
+            constexpr int RL = DifPlan<M>::radix(DifPlan<M>::n - 1);
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int q = last_pass_index<M, T>(tid, e);
-                if ((q >= a.kmin && q < a.kmax) || (q >= lo2 && q <= hi2) || q == 0) buf[lds_slot(q)] = regs[e];
-            }
+            for (int e = 0; e < EPT; ++e)
+                if (need & (1u << e)) buf[sigma<M>(dif_last_pos<M>(ot, e / RL, e % RL))] = regs[e];
+        } else {
+            fft_lds_keep_last<M, T, true, Real>(buf, a.tw, regs, tid);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                if (need & (1u << e)) buf[lds_slot(last_pass_index<M, T>(tid, e))] = regs[e];
         }
         __syncthreads();
 
         // real-split: X[k] = E + (-i) W_N^k D, E=(Z[k]+conj Z[M-k])/2, D=(Z[k]-conj Z[M-k])/2
-        for (int i = tid; i < nmag; i += T) {
+        for (int i = ot; i < nmag; i += T) {
             const int k = a.kmin + i;
-            const cx<Real> A = buf[lds_slot(k & (M - 1))];
-            cx<Real> B = buf[lds_slot((M - k) & (M - 1))];
+            const int ka = k & (M - 1), kb = (M - k) & (M - 1);
+            int sa, sb;
+            if constexpr (DIF) {
+                sa = sigma<M>(dif_pos<M>(ka));
+                sb = sigma<M>(dif_pos<M>(kb));
+            } else {
+                sa = lds_slot(ka);
+                sb = lds_slot(kb);
+            }
+            const cx<Real> A = buf[sa];
+            cx<Real> B = buf[sb];
             B.y = -B.y;
             const cx<Real> E = {(Real)0.5 * (A.x + B.x), (Real)0.5 * (A.y + B.y)};
             const cx<Real> D = {(Real)0.5 * (A.x - B.x), (Real)0.5 * (A.y - B.y)};
@@ -202,13 +267,18 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
         // LDS read of buf by the two barriers above; winmax/mag are rewritten only after the
         // FFT's own barriers
     }
+    };  // run
+    if (fast)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
     if (a.partial) {
         // Cross-workgroup hand-off (one per launch): every workgroup publishes its 12 partial sums, the last
         // one to arrive adds all of them in a fixed order -> deterministic, and no second kernel launch.
         // Protocol (cdna guide G16, form R1): write-through (sc1) 8-byte stores of the payload -> vmcnt(0) in the
         // storing wave -> barrier -> one lane takes a relaxed agent-scope ticket; the last arriver reads the
         // payload with sc1 (L1-bypassing) loads, so no release/acquire fence is needed on either side.
-        int* flag = reinterpret_cast<int*>(winmax + a.nwin);
+        int* flag = reinterpret_cast<int*>(tail);
         using u64 = unsigned long long;
         u64* part = reinterpret_cast<u64*>(a.partial);
         if (tid < 12) __hip_atomic_store(part + w * 12 + tid, (u64)__double_as_longlong(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -445,7 +515,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.partial = nullptr;
     a.sum = nullptr;
     a.counter = nullptr;
-    const size_t lds = sizeof(cx<Real>) * lds_slots(N / 2) + sizeof(Real) * (size_t)(plan.kmax - plan.kmin + plan.nwin) + 16;
+    const size_t lds = sizeof(cx<Real>) * he_buf_slots<N, T>() + sizeof(Real) * (size_t)(plan.kmax - plan.kmin + plan.nwin) + 48 + sizeof(cx<Real>) * (N / 2 / T);
     if (lds > 160 * 1024)
         return set_error(ctx, MPX_EUNSUPPORTED, "frame %d needs %zu B of LDS (> 160 KiB)", N, lds);
     auto kern = he_kernel<N, T, Real>;
@@ -488,9 +558,9 @@ static int he_dispatch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, 
                        double* d_sum, hipStream_t stream) {
     switch (frame) {
         case 1024: return he_launch<1024, 64, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
-        case 2048: return he_launch<2048, 64, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+        case 2048: return he_launch<2048, 128, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
         case 4096: return he_launch<4096, HE4096_T, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
-        case 8192: return he_launch<8192, 256, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+        case 8192: return he_launch<8192, 512, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
         case 16384: return he_launch<16384, 512, Real>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
         default:
             return set_error(ctx, MPX_EUNSUPPORTED,
