@@ -353,39 +353,328 @@ __global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
 }
 
 // ------------------------------------------------------------------ kernel 3
-__global__ __launch_bounds__(64) void peakfit_kernel(const int* __restrict__ total_peaks,
-                                                     const int* __restrict__ worklist,
-                                                     const double* __restrict__ y, int Mh, int maxp,
-                                                     const int* __restrict__ peak_idx, double* center,
-                                                     int* ok) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= *total_peaks) return;
-    const int item = worklist[w];
-    const long long f = item >> 12;
-    const int j = item & 0xfff;
-    const int i = peak_idx[f * maxp + j];
-    const long long o = f * maxp + j;
-    // slice(i - 10, i + 11): a negative start wraps around in Python -> empty slice -> fit raises -> peak dropped
-    if (i < 10) {
-        ok[o] = 0;
-        return;
+// Gaussian peak fit, one lane per peak, PERSISTENT lanes with dynamic work fetch.
+// MINPACK's iteration count is data dependent (typically ~50 function evaluations, but 1-2 % of the
+// peaks -- runaway fits near the end of the lag range -- burn the full maxfev = 800).  With a static
+// "lane w fits peak w" mapping nearly every wave contains such a straggler and waits for it (measured:
+// 2.6 M VALU instructions per wave instead of ~0.1 M).  Here lm::gaussian_fit_lane is unrolled into a
+// resumable state machine: a lane that finishes its peak pulls the next one from a global counter
+// (wave-aggregated atomic), so stragglers only delay themselves.
+// Per trip of the main loop a lane runs at most one OUTER step (jacobian, pivoted Householder QR, Q^T f)
+// followed by one INNER step (lmpar, trial point, ratio test); both are straight-line code shared by all
+// lanes in that state.  Jacobian + samples are VGPRs, MINPACK's two m-vectors are LDS [row][lane].
+constexpr int FIT_THREADS = 128;
+enum { FIT_NEED_WORK = 0, FIT_OUTER = 1, FIT_INNER = 2, FIT_DONE = 3 };
+
+__global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restrict__ total_peaks, int* next_item,
+                                                              const int* __restrict__ worklist,
+                                                              const double* __restrict__ y, int Mh, int maxp,
+                                                              const int* __restrict__ peak_idx, double* center,
+                                                              int* ok) {
+    using namespace lm;
+    __shared__ double sh[2 * MAXM * FIT_THREADS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    LaneLds L;
+    L.fvec = sh + (size_t)wave * 2 * MAXM * 64;
+    L.wa4 = L.fvec + MAXM * 64;
+    L.lane = lane;
+    const int total = *total_peaks;
+    const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
+    const int maxfev = 200 * (NP + 1);
+    const double eps = sqrt(EPSMCH);
+
+    int phase = FIT_NEED_WORK;
+    // per-fit state
+    double ys[MAXM];
+    double x0 = 0.0, x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1}, qtf[NP] = {0, 0, 0}, r[NP * NP];
+    double par = 0.0, delta = 0.0, xnorm = 0.0, fnorm = 0.0, gnorm = 0.0;
+    int ipvt[NP] = {0, 1, 2};
+    int m = 0, nfev = 0, it = 1;
+    long long out = 0;
+#pragma unroll
+    for (int q = 0; q < MAXM; ++q) ys[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NP * NP; ++q) r[q] = 0.0;
+
+    for (;;) {
+        // ---------------- fetch
+        if (phase == FIT_NEED_WORK) {
+            const unsigned long long need = __ballot(1);  // lanes inside this branch
+            const int cnt = __popcll(need);
+            const int rank = __popcll(need & ((1ull << lane) - 1ull));
+            int base = 0;
+            if (rank == 0) base = atomicAdd(next_item, cnt);
+            base = __shfl(base, __ffsll((long long)need) - 1);
+            const int wi = base + rank;
+            if (wi >= total) {
+                phase = FIT_DONE;
+            } else {
+                const int item = worklist[wi];
+                const long long f = item >> 12;
+                const int j = item & 0xfff;
+                const int i = peak_idx[f * maxp + j];
+                out = f * maxp + j;
+                const int stop = i + 11 < Mh ? i + 11 : Mh;
+                m = stop - (i - 10);
+                // slice(i-10, i+11): a negative start wraps in Python -> empty slice -> the fit raises -> dropped
+                if (i < 10 || m < 3) {
+                    ok[out] = 0;  // stays in NEED_WORK: fetches again on the next trip
+                } else {
+                    const double* row = y + f * (long long)Mh + (i - 10);
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q) ys[q] = q < m ? row[q] : 0.0;
+                    x0 = (double)(i - 10);
+                    double ymax = ys[0];
+#pragma unroll
+                    for (int q = 1; q < MAXM; ++q)
+                        if (q < m) ymax = ys[q] > ymax ? ys[q] : ymax;
+                    x[0] = ymax;  // peakutils initial guess: [max(y), x[0], 5*(x[1]-x[0])]
+                    x[1] = x0;
+                    x[2] = 5.0;
+                    double s = 0.0;
+#pragma unroll
+                    for (int q = 0; q < MAXM; ++q)
+                        if (q < m) {
+                            const double rr = lane_resid(ys, x0, q, x);
+                            L.f(q) = rr;
+                            s += rr * rr;
+                        }
+                    nfev = 1;
+                    fnorm = sqrt(s);
+                    par = 0.0;
+                    it = 1;
+                    diag[0] = diag[1] = diag[2] = 1.0;
+                    delta = xnorm = 0.0;
+                    phase = FIT_OUTER;
+                }
+            }
+        }
+        if (__all(phase == FIT_DONE)) break;
+
+        int info = 0;
+        // ---------------- OUTER: jacobian, QR, Q^T f
+        if (phase == FIT_OUTER) {
+            double a[MAXM][NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double temp = x[j];
+                double h = eps * fabs(temp);
+                if (h == 0.0) h = eps;
+                x[j] = temp + h;
+#pragma unroll
+                for (int i = 0; i < MAXM; ++i) a[i][j] = i < m ? (lane_resid(ys, x0, i, x) - L.f(i)) / h : 0.0;
+                x[j] = temp;
+            }
+            nfev += NP;
+            ipvt[0] = 0;
+            ipvt[1] = 1;
+            ipvt[2] = 2;
+            double acnorm[NP], rdiag[NP], wa[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                double q = 0.0;
+#pragma unroll
+                for (int i = 0; i < MAXM; ++i) q += a[i][j] * a[i][j];
+                acnorm[j] = sqrt(q);
+                rdiag[j] = wa[j] = acnorm[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                int kmax = j;
+                double rmax = rdiag[j];
+#pragma unroll
+                for (int k = j + 1; k < NP; ++k)
+                    if (rdiag[k] > rmax) {
+                        kmax = k;
+                        rmax = rdiag[k];
+                    }
+                if (kmax != j) {
+#pragma unroll
+                    for (int i = 0; i < MAXM; ++i) {
+                        const double t = a[i][j];
+                        const double o = kmax == 1 ? a[i][1] : a[i][2];
+                        a[i][j] = o;
+                        if (kmax == 1) a[i][1] = t;
+                        else a[i][2] = t;
+                    }
+                    put3(rdiag, kmax, rdiag[j]);
+                    put3(wa, kmax, wa[j]);
+                    const int t = ipvt[j];
+                    ipvt[j] = sel3(ipvt, kmax);
+                    put3(ipvt, kmax, t);
+                }
+                double q = 0.0;
+#pragma unroll
+                for (int i = j; i < MAXM; ++i) q += a[i][j] * a[i][j];
+                double ajnorm = sqrt(q);
+                if (ajnorm != 0.0) {
+                    if (a[j][j] < 0.0) ajnorm = -ajnorm;
+#pragma unroll
+                    for (int i = j; i < MAXM; ++i) a[i][j] /= ajnorm;
+                    a[j][j] += 1.0;
+#pragma unroll
+                    for (int k = j + 1; k < NP; ++k) {
+                        double sum = 0.0;
+#pragma unroll
+                        for (int i = j; i < MAXM; ++i) sum += a[i][j] * a[i][k];
+                        const double temp = sum / a[j][j];
+#pragma unroll
+                        for (int i = j; i < MAXM; ++i) a[i][k] -= temp * a[i][j];
+                        if (rdiag[k] != 0.0) {
+                            const double t = a[j][k] / rdiag[k];
+                            const double u = 1.0 - t * t;
+                            rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
+                            const double qq = rdiag[k] / wa[k];
+                            if (0.05 * qq * qq <= EPSMCH) {
+                                double s2 = 0.0;
+#pragma unroll
+                                for (int i = j + 1; i < MAXM; ++i) s2 += a[i][k] * a[i][k];
+                                rdiag[k] = sqrt(s2);
+                                wa[k] = rdiag[k];
+                            }
+                        }
+                    }
+                }
+                rdiag[j] = -ajnorm;
+            }
+            if (it == 1) {
+                double wa3[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    diag[j] = acnorm[j] != 0.0 ? acnorm[j] : 1.0;
+                    wa3[j] = diag[j] * x[j];
+                }
+                xnorm = enorm3(wa3);
+                delta = factor * xnorm;
+                if (delta == 0.0) delta = factor;
+            }
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i)
+                if (i < m) L.w(i) = L.f(i);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                if (a[j][j] != 0.0) {
+                    double sum = 0.0;
+#pragma unroll
+                    for (int i = j; i < MAXM; ++i)
+                        if (i < m) sum += a[i][j] * L.w(i);
+                    const double temp = -sum / a[j][j];
+#pragma unroll
+                    for (int i = j; i < MAXM; ++i)
+                        if (i < m) L.w(i) += a[i][j] * temp;
+                }
+                a[j][j] = rdiag[j];
+                qtf[j] = L.w(j);
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) r[i * NP + j] = a[i][j];
+            gnorm = 0.0;
+            if (fnorm != 0.0) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double an = sel3(acnorm, ipvt[j]);
+                    if (an != 0.0) {
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int i = 0; i <= j; ++i) s2 += r[i * NP + j] * (qtf[i] / fnorm);
+                        const double g = fabs(s2 / an);
+                        gnorm = g > gnorm ? g : gnorm;
+                    }
+                }
+            }
+            if (gnorm <= gtol) {
+                info = 4;
+            } else {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
+                phase = FIT_INNER;
+            }
+        }
+        // ---------------- INNER: one trust-region trial
+        if (phase == FIT_INNER && info == 0) {
+            double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
+#pragma unroll
+            for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
+            par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                p[j] = -p[j];
+                xnew[j] = x[j] + p[j];
+                wa3[j] = diag[j] * p[j];
+            }
+            const double pnorm = enorm3(wa3);
+            if (it == 1) delta = delta < pnorm ? delta : pnorm;
+            double s1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i)
+                if (i < m) {
+                    const double rn = lane_resid(ys, x0, i, xnew);
+                    L.w(i) = rn;
+                    s1 += rn * rn;
+                }
+            ++nfev;
+            const double fnorm1 = sqrt(s1);
+            double actred = -1.0;
+            if (0.1 * fnorm1 < fnorm) {
+                const double q = fnorm1 / fnorm;
+                actred = 1.0 - q * q;
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double temp = sel3(p, ipvt[j]);
+#pragma unroll
+                for (int i = 0; i <= j; ++i) wa3[i] += r[i * NP + j] * temp;
+            }
+            const double temp1 = enorm3(wa3) / fnorm;
+            const double temp2 = (sqrt(par) * pnorm) / fnorm;
+            const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+            const double dirder = -(temp1 * temp1 + temp2 * temp2);
+            const double ratio = prered != 0.0 ? actred / prered : 0.0;
+            if (ratio <= 0.25) {
+                double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+                if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
+                delta = temp * dm;
+                par = par / temp;
+            } else if (par == 0.0 || ratio >= 0.75) {
+                delta = pnorm / 0.5;
+                par = 0.5 * par;
+            }
+            if (ratio >= 1e-4) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    x[j] = xnew[j];
+                    wa3[j] = diag[j] * x[j];
+                }
+#pragma unroll
+                for (int i = 0; i < MAXM; ++i)
+                    if (i < m) L.f(i) = L.w(i);
+                xnorm = enorm3(wa3);
+                fnorm = fnorm1;
+                ++it;
+            }
+            const bool c1 = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+            if (c1) info = 1;
+            if (delta <= xtol * xnorm) info = 2;
+            if (c1 && info == 2) info = 3;
+            if (info == 0) {
+                if (nfev >= maxfev) info = 5;
+                if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1.0) info = 6;
+                if (delta <= EPSMCH * xnorm) info = 7;
+                if (gnorm <= EPSMCH) info = 8;
+            }
+            if (info == 0 && ratio >= 1e-4) phase = FIT_OUTER;  // step accepted: new jacobian next trip
+        }
+        if (info != 0) {
+            ok[out] = (info >= 1 && info <= 4) ? 1 : 0;
+            center[out] = x[1];
+            phase = FIT_NEED_WORK;
+        }
     }
-    lm::Problem pr;
-    const int stop = i + 11 < Mh ? i + 11 : Mh;
-    pr.m = stop - (i - 10);
-    const double* row = y + f * (long long)Mh;
-    for (int q = 0; q < pr.m; ++q) {
-        pr.xs[q] = (double)(i - 10 + q);
-        pr.ys[q] = row[i - 10 + q];
-    }
-    if (pr.m < 3) {
-        ok[o] = 0;
-        return;
-    }
-    double c = 0.0;
-    const int info = lm::gaussian_fit(pr, &c);
-    ok[o] = (info >= 1 && info <= 4) ? 1 : 0;
-    center[o] = c;
 }
 
 // ------------------------------------------------------------------ kernel 4
@@ -586,7 +875,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if (batch < 1) batch = 1;
     if ((rc = ensure(ctx, ctx->d_ws0, (size_t)batch * N * 16))) return rc;                   // x_lo | x_hi
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)batch * Mh * 8 + 64))) return rc;              // y
-    if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 128))) return rc;
     double* xlo = (double*)ctx->d_ws0.p;
     double* xhi = xlo + (size_t)batch * N;
     double* y = (double*)ctx->d_ws1.p;
@@ -608,7 +897,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * N, stage == MPX_STAGE_XLO ? xlo : xhi,
                                         (size_t)nf * N * 8, hipMemcpyDeviceToDevice, st));
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
-        MPX_HIP(ctx, hipMemsetAsync(total, 0, sizeof(int), st));
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, 2 * sizeof(int), st));  // [0] peaks found, [1] next work item
         SacfArgs a;
         a.xlo = xlo;
         a.xhi = xhi;
@@ -645,8 +934,14 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                         hipMemcpyDeviceToDevice, st));
         if (stage >= 0) continue;
         const long long slots = nf * maxp;
-        hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)((slots + 63) / 64)), dim3(64), 0, st, total, worklist, y,
-                           Mh, maxp, peak_idx, center, okf);
+        {
+            // persistent grid: 3 blocks of 2 waves per CU (LDS-limited); lanes pull peaks until the list is empty
+            long long blocks = (slots + FIT_THREADS - 1) / FIT_THREADS;
+            const long long resident = (long long)ctx->num_cus * 3;
+            if (blocks > resident) blocks = resident;
+            hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
+                               y, Mh, maxp, peak_idx, center, okf);
+        }
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,
                            y, peak_count, peak_idx, center, okf, d_chroma_frames);
         MPX_HIP(ctx, hipGetLastError());
