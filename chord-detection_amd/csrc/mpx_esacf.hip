@@ -97,6 +97,7 @@ struct SacfArgs {
     double peak_thresh;
     int peak_min_dist;
     int enhance_mode;
+    int defer_enhance;  // 1: stop after the SACF (time_stretch is a real phase vocoder for this many lags)
     int maxp;
     double* sacf_out;   // optional [F,Mh]
     double* y_out;      // [F,Mh] enhanced SACF
@@ -144,14 +145,12 @@ __device__ __forceinline__ int block_scan(int* sh, int v, int tid) {
     return v;
 }
 
-template <int L, int T, bool BLUE>
-__global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = a.N, Mh = a.Mh;
-    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                 // L complex
-    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));  // N + 2 doubles
-    // aliases onto buf, valid once the SACF has been copied out to yv
-    double* dy = reinterpret_cast<double*>(smem);          // Mh
+// peakutils.indexes(y, thres, min_dist) on the Mh values in yv (LDS) + publication of the kept peaks.
+// `scratch` is >= (Mh+1)*(8+16) bytes of LDS that nobody else uses any more.
+template <int T>
+__device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double* yv, char* scratch, int tid) {
+    const int Mh = a.Mh;
+    double* dy = reinterpret_cast<double*>(scratch);       // Mh
     int* lnz = reinterpret_cast<int*>(dy + Mh + 1);        // Mh
     int* rnz = lnz + Mh + 1;                               // Mh
     int* cand = rnz + Mh + 1;                              // Mh
@@ -159,53 +158,6 @@ __global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
     __shared__ int sh_scan[T];
     __shared__ double sh_red[2 * T];
     __shared__ int sh_misc[4];
-
-    const int tid = threadIdx.x;
-    const long long f = blockIdx.x;
-    cx<double> regs[L / T];
-
-    // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N
-    const double* lo = a.xlo + f * (long long)N;
-    const double* hi = a.xhi + f * (long long)N;
-    for (int n = tid; n < N; n += T) buf[lds_slot(n)] = {lo[n], hi[n]};
-    __syncthreads();
-    dft_n<L, T, BLUE>(buf, a, regs, tid);
-    for (int k = tid; k < N; k += T) {
-        const cx<double> A = buf[lds_slot(k)];
-        const cx<double> B = cconj(buf[lds_slot(k == 0 ? 0 : N - k)]);
-        // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
-        const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
-        const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-        yv[k] = pow(hypot(lr, li), 0.67) + pow(hypot(hr, hm), 0.67);  // esacf.py:95-103, k fixed at 0.67
-    }
-    __syncthreads();
-    for (int k = tid; k < N; k += T) buf[lds_slot(k)] = {yv[k], 0.0};
-    __syncthreads();
-    dft_n<L, T, BLUE>(buf, a, regs, tid);
-    const double inv_n = 1.0 / (double)N;
-    for (int n = tid; n < Mh; n += T) {
-        const double v = buf[lds_slot(n)].x * inv_n;
-        yv[n] = v;
-        if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
-    }
-    __syncthreads();  // buf is dead from here on; dy/lnz/rnz/cand/state alias it
-
-    // ---- enhancement (esacf.py:108-129)
-    for (int r = 2; r <= a.n_peaks_elim; ++r) {
-        int cut = 0;
-        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-        for (int n = tid; n < Mh; n += T) {
-            double v = yv[n];
-            v = v < 0.0 ? 0.0 : v;          // clip
-            if (n < cut) v = v - v;         // minus the "stretched" copy (== itself for a <=2-frame STFT)
-            v = v < 0.0 ? 0.0 : v;          // clip
-            yv[n] = v;
-        }
-        __syncthreads();
-    }
-    double* yrow = a.y_out + f * (long long)Mh;
-    for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
-
     // ---- peakutils.indexes(y, thres, min_dist)
     const int D = Mh - 1;  // len(dy)
     double mx = -INFINITY, mn = INFINITY;
@@ -350,6 +302,189 @@ __global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
             for (int j = 0; j < p; ++j) a.worklist[slot + j] = (int)(f << 12) | j;
         }
     }
+}
+
+template <int L, int T, bool BLUE>
+__global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, Mh = a.Mh;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                 // L complex
+    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));  // N + 2 doubles
+    const int tid = threadIdx.x;
+    const long long f = blockIdx.x;
+    cx<double> regs[L / T];
+
+    // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N
+    const double* lo = a.xlo + f * (long long)N;
+    const double* hi = a.xhi + f * (long long)N;
+    for (int n = tid; n < N; n += T) buf[lds_slot(n)] = {lo[n], hi[n]};
+    __syncthreads();
+    dft_n<L, T, BLUE>(buf, a, regs, tid);
+    for (int k = tid; k < N; k += T) {
+        const cx<double> A = buf[lds_slot(k)];
+        const cx<double> B = cconj(buf[lds_slot(k == 0 ? 0 : N - k)]);
+        // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
+        const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+        const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+        yv[k] = pow(hypot(lr, li), 0.67) + pow(hypot(hr, hm), 0.67);  // esacf.py:95-103, k fixed at 0.67
+    }
+    __syncthreads();
+    for (int k = tid; k < N; k += T) buf[lds_slot(k)] = {yv[k], 0.0};
+    __syncthreads();
+    dft_n<L, T, BLUE>(buf, a, regs, tid);
+    const double inv_n = 1.0 / (double)N;
+    for (int n = tid; n < Mh; n += T) {
+        const double v = buf[lds_slot(n)].x * inv_n;
+        yv[n] = v;
+        if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+    }
+    __syncthreads();  // buf is dead from here on; the peak-picking scratch aliases it
+    if (a.defer_enhance) {  // phase-vocoder regime: pv_enhance_kernel + peakpick_kernel take over from the raw SACF
+        double* yrow0 = a.y_out + f * (long long)Mh;
+        for (int n = tid; n < Mh; n += T) yrow0[n] = yv[n];
+        return;
+    }
+
+    // ---- enhancement (esacf.py:108-129)
+    for (int r = 2; r <= a.n_peaks_elim; ++r) {
+        int cut = 0;
+        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+        for (int n = tid; n < Mh; n += T) {
+            double v = yv[n];
+            v = v < 0.0 ? 0.0 : v;          // clip
+            if (n < cut) v = v - v;         // minus the "stretched" copy (== itself for a <=2-frame STFT)
+            v = v < 0.0 ? 0.0 : v;          // clip
+            yv[n] = v;
+        }
+        __syncthreads();
+    }
+    double* yrow = a.y_out + f * (long long)Mh;
+    for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+
+    peak_pick<T>(a, f, yv, smem, tid);
+}
+
+// ------------------------------------------------------------------ kernel 2b / 2c
+// Enhancement when librosa.effects.time_stretch is a REAL phase vocoder, i.e. when the STFT of the
+// Mh-lag SACF has more than two frames (Mh >= 1024: ESACF frames above 2048 samples).  Per rate r
+// (esacf.py:117-127, librosa >= 0.10 semantics as restated in oracle/thirdparty.py):
+//   clip -> STFT (n_fft 2048, hop 512, periodic Hann, centered, zero padded) of the columns the
+//   vocoder reads -> phase_vocoder (integer rate => alpha = 0; <= 2 output frames since n_frames <= 4)
+//   -> ISTFT (overlap-add / window sum-square, drop 1024, length round(Mh/r)) -> subtract -> clip.
+// Two real frames share one complex 2048-point LDS FFT in both directions (re/im packing).
+constexpr int PV_T = 256, PV_NFFT = 2048, PV_HOP = 512, PV_BINS = PV_NFFT / 2 + 1;
+
+struct PvArgs {
+    double* y;                 // [F, Mh] SACF in, enhanced SACF out
+    int Mh;
+    int n_peaks_elim;
+    const cx<double>* tw;      // W_2048
+};
+
+__device__ __forceinline__ double pv_hann(const cx<double>* __restrict__ tw, int n) {
+    return 0.5 - 0.5 * tw[n & (PV_NFFT - 1)].x;  // periodic Hann: cos(2 pi n / 2048) = Re W_2048^n
+}
+
+__global__ __launch_bounds__(PV_T) void pv_enhance_kernel(PvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                       // 2048 complex (padded)
+    cx<double>* dout = buf + lds_slots(PV_NFFT);                                  // [2][PV_BINS] synthesis spectra
+    double* phase = reinterpret_cast<double*>(dout + 2 * PV_BINS);                // [PV_BINS] phase accumulator
+    double* x = phase + PV_BINS + 1;                                              // [Mh] working copy of the SACF
+    const int tid = threadIdx.x, Mh = a.Mh;
+    const long long f = blockIdx.x;
+    double* row = a.y + f * (long long)Mh;
+    cx<double> regs[PV_NFFT / PV_T];
+    for (int n = tid; n < Mh; n += PV_T) x[n] = row[n];
+    __syncthreads();
+    const int n_frames = 1 + Mh / PV_HOP;  // centered STFT of Mh samples
+    for (int r = 2; r <= a.n_peaks_elim; ++r) {
+        for (int n = tid; n < Mh; n += PV_T) x[n] = x[n] < 0.0 ? 0.0 : x[n];  // clip
+        __syncthreads();
+        const int len_out = (int)nearbyint((double)Mh / (double)r);          // int(round(len/rate)), half-to-even
+        const int nsteps = (n_frames + r - 1) / r;                            // len(arange(0, n_frames, r)) <= 2
+        for (int t = 0; t < nsteps; ++t) {
+            const int c0 = t * r, c1 = c0 + 1;                                // STFT columns int(step), int(step)+1
+            // analysis: frame c covers xpad[c*512 + n], xpad = [1024 zeros | x | 1024 zeros]
+            for (int n = tid; n < PV_NFFT; n += PV_T) {
+                const int i0 = c0 * PV_HOP + n - PV_NFFT / 2, i1 = c1 * PV_HOP + n - PV_NFFT / 2;
+                const double w = pv_hann(a.tw, n);
+                const double v0 = (i0 >= 0 && i0 < Mh) ? x[i0] * w : 0.0;
+                const double v1 = (c1 < n_frames && i1 >= 0 && i1 < Mh) ? x[i1] * w : 0.0;
+                buf[lds_slot(n)] = {v0, v1};
+            }
+            __syncthreads();
+            fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
+            for (int k = tid; k < PV_BINS; k += PV_T) {
+                const cx<double> Z = buf[lds_slot(k & (PV_NFFT - 1))];
+                const cx<double> Zc = cconj(buf[lds_slot((PV_NFFT - k) & (PV_NFFT - 1))]);
+                const cx<double> A = {0.5 * (Z.x + Zc.x), 0.5 * (Z.y + Zc.y)};   // rfft of column c0
+                const cx<double> B = {0.5 * (Z.y - Zc.y), -0.5 * (Z.x - Zc.x)};  // rfft of column c1
+                const double ang0 = atan2(A.y, A.x), ang1 = atan2(B.y, B.x);
+                double pacc = t == 0 ? ang0 : phase[k];                           // phase_acc = angle(D[:, 0])
+                const double mag = hypot(A.x, A.y);                               // alpha = 0: |column c0|
+                dout[t * PV_BINS + k] = {mag * cos(pacc), mag * sin(pacc)};
+                const double phi = M_PI * (double)PV_HOP * (double)k / (double)(PV_BINS - 1);  // linspace(0, pi*hop, 1025)
+                double dphase = ang1 - ang0 - phi;
+                dphase = dphase - 2.0 * M_PI * nearbyint(dphase / (2.0 * M_PI));
+                phase[k] = pacc + (phi + dphase);
+            }
+            __syncthreads();
+        }
+        // synthesis: irfft of both output frames through one complex inverse FFT (swap trick)
+        for (int k = tid; k < PV_NFFT; k += PV_T) {
+            const int kk = k <= PV_NFFT / 2 ? k : PV_NFFT - k;
+            cx<double> d0 = dout[kk];
+            cx<double> d1 = nsteps > 1 ? dout[PV_BINS + kk] : cx<double>{0.0, 0.0};
+            if (kk == 0 || kk == PV_NFFT / 2) d0.y = d1.y = 0.0;   // irfft ignores the imaginary part there
+            if (k > PV_NFFT / 2) {                                  // Hermitian extension
+                d0.y = -d0.y;
+                d1.y = -d1.y;
+            }
+            const cx<double> u = {d0.x - d1.y, d0.y + d1.x};       // D0 + i*D1
+            buf[lds_slot(k)] = cswap(u);
+        }
+        __syncthreads();
+        fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
+        // overlap-add, normalise by the window sum-square, drop the 1024-sample centre pad, subtract, clip
+        const double inv = 1.0 / (double)PV_NFFT;
+        for (int i = tid; i < Mh; i += PV_T) {
+            double v = x[i];
+            if (i < len_out) {
+                const int n = i + PV_NFFT / 2;  // position in the overlap-add buffer
+                double acc = 0.0, wss = 0.0;
+                if (n < PV_NFFT) {
+                    const double w = pv_hann(a.tw, n);
+                    acc += w * (cswap(buf[lds_slot(n)]).x * inv);
+                    wss += w * w;
+                }
+                if (nsteps > 1 && n >= PV_HOP && n - PV_HOP < PV_NFFT) {
+                    const double w = pv_hann(a.tw, n - PV_HOP);
+                    acc += w * (cswap(buf[lds_slot(n - PV_HOP)]).y * inv);
+                    wss += w * w;
+                }
+                if (wss > 2.2250738585072014e-308) acc /= wss;
+                v -= acc;
+            }
+            x[i] = v < 0.0 ? 0.0 : v;
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < Mh; n += PV_T) row[n] = x[n];
+}
+
+// Peak picking on rows that are already enhanced (phase-vocoder regime).
+template <int T>
+__global__ __launch_bounds__(T) void peakpick_kernel(SacfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Mh = a.Mh, tid = threadIdx.x;
+    const long long f = blockIdx.x;
+    char* scratch = smem;                                                           // (Mh+1)*24 bytes
+    double* yv = reinterpret_cast<double*>(smem + (((size_t)(Mh + 1) * 24 + 15) & ~(size_t)15));
+    const double* row = a.y_out + f * (long long)Mh;
+    for (int n = tid; n < Mh; n += T) yv[n] = row[n];
+    __syncthreads();
+    peak_pick<T>(a, f, yv, scratch, tid);
 }
 
 // ------------------------------------------------------------------ kernel 3
@@ -851,11 +986,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if (p.peak_min_dist < 0 || p.n_peaks_elim < 0 || p.n_peaks_elim > 64)
         return set_error(ctx, MPX_EINVAL, "ESACF: bad peak parameters");
     if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
-    // librosa.effects.time_stretch is a pure truncation only while its STFT has <= 2 frames
-    if (p.enhance_mode == MPX_ENHANCE_LIBROSA010 && p.n_peaks_elim >= 2 && 1 + Mh / 512 > 2)
-        return set_error(ctx, MPX_EUNSUPPORTED,
-                         "ESACF: enhance_mode librosa010 needs a phase-vocoder for %d lags (frame %d); only frames "
-                         "<= 2048 are built so far (use enhance_mode noop or a shorter frame)", Mh, N);
+    // librosa.effects.time_stretch is a pure truncation only while its STFT has <= 2 frames; above that
+    // (Mh >= 1024 lags) the real phase vocoder runs in its own kernel between the SACF and the peak picking
+    const bool pv = p.enhance_mode == MPX_ENHANCE_LIBROSA010 && p.n_peaks_elim >= 2 && 1 + Mh / 512 > 2;
     if (num_frames == 0) return MPX_OK;
     BandCoef coef;
     int rc = band_coefs(ctx, fs, coef);
@@ -910,6 +1043,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.peak_thresh = p.peak_thresh;
         a.peak_min_dist = p.peak_min_dist;
         a.enhance_mode = p.enhance_mode;
+        a.defer_enhance = pv ? 1 : 0;
         a.maxp = maxp;
         a.sacf_out = stage == MPX_STAGE_SACF ? d_stage_out + (size_t)f0 * Mh : nullptr;
         a.y_out = y;
@@ -929,6 +1063,30 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             else rc = sacf_launch<4096, 256, false>(ctx, a, nf, st);
         }
         if (rc) return rc;
+        if (pv) {
+            auto pit = ctx->misc_plans.find("pv_tw2048");
+            if (pit == ctx->misc_plans.end()) {
+                std::vector<cx<double>> tw(PV_NFFT);
+                for (int j = 0; j < PV_NFFT; ++j) {
+                    const long double ang = -2.0L * M_PIl * j / (long double)PV_NFFT;
+                    tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+                }
+                void* d = upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+                if (!d) return MPX_ENOMEM;
+                pit = ctx->misc_plans.emplace("pv_tw2048", std::vector<void*>{d}).first;
+            }
+            PvArgs pa;
+            pa.y = y;
+            pa.Mh = Mh;
+            pa.n_peaks_elim = p.n_peaks_elim;
+            pa.tw = (const cx<double>*)pit->second[0];
+            const size_t pv_lds = sizeof(cx<double>) * (lds_slots(PV_NFFT) + 2 * PV_BINS) + sizeof(double) * (size_t)(PV_BINS + 1 + Mh + 2);
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)pv_enhance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_lds));
+            hipLaunchKernelGGL(pv_enhance_kernel, dim3((unsigned)nf), dim3(PV_T), pv_lds, st, pa);
+            const size_t pk_lds = (((size_t)(Mh + 1) * 24 + 15) & ~(size_t)15) + sizeof(double) * (size_t)(Mh + 2);
+            hipLaunchKernelGGL(peakpick_kernel<256>, dim3((unsigned)nf), dim3(256), pk_lds, st, a);
+            MPX_HIP(ctx, hipGetLastError());
+        }
         if (stage == MPX_STAGE_ESACF)
             MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * Mh, y, (size_t)nf * Mh * 8,
                                         hipMemcpyDeviceToDevice, st));
