@@ -191,8 +191,9 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const cx<Real> o = woffs_lds[e];  // same address in every lane: one broadcast LDS read
-            const Real w0 = (Real)0.54 - (Real)0.46 * (wb0.x * o.x - wb0.y * o.y);
-            const Real w1 = (Real)0.54 - (Real)0.46 * (wb1.x * o.x - wb1.y * o.y);
+            // 0.54 - 0.46 cos(a + b), with -0.46 folded into the offset table: two FMAs per sample
+            const Real w0 = wb0.x * o.x + ((Real)0.54 - wb0.y * o.y);
+            const Real w1 = wb1.x * o.x + ((Real)0.54 - wb1.y * o.y);
             regs[e] = {(Real)raw[e].x * w0, (Real)raw[e].y * w1};
         }
         {
@@ -493,7 +494,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
             for (int e = 0; e < EPT_; ++e) {
                 const int b = e / R0, r = e % R0;
                 const long double ang = 2.0L * M_PIl * (2.0L * (b * T + r * NB)) / (long double)(N - 1);
-                offs[e] = {(Real)cosl(ang), (Real)sinl(ang)};
+                offs[e] = {(Real)(-0.46L * cosl(ang)), (Real)(-0.46L * sinl(ang))};  // -0.46 (cos, sin): see he_kernel
             }
             void* d = upload(ctx, offs.data(), offs.size() * sizeof(cx<Real>));
             if (!d) return MPX_ENOMEM;
