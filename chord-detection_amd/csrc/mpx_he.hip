@@ -274,50 +274,69 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     else
         run(std::false_type{});
     if (a.partial) {
-        // Cross-workgroup hand-off (one per launch): every workgroup publishes its 12 partial sums, the last
-        // one to arrive adds all of them in a fixed order -> deterministic, and no second kernel launch.
-        // Protocol (cdna guide G16, form R1): write-through (sc1) 8-byte stores of the payload -> vmcnt(0) in the
-        // storing wave -> barrier -> one lane takes a relaxed agent-scope ticket; the last arriver reads the
-        // payload with sc1 (L1-bypassing) loads, so no release/acquire fence is needed on either side.
+        // Cross-workgroup reduction inside the launch, two levels of "last arriver adds": every workgroup
+        // publishes its 12 partial sums; the last of each group of 32 workgroups adds that group's rows and
+        // publishes a group row; the last group to finish adds the group rows.  Fixed summation order ->
+        // deterministic; two short dependent reads instead of one long one at the tail of the kernel.
+        // Protocol per hop (cdna guide G16, form R1): write-through (sc1) 8-byte stores -> vmcnt(0) in the
+        // storing wave -> barrier -> one lane takes a relaxed agent-scope ticket; readers use sc1
+        // (L1-bypassing) loads, so no release/acquire fence is needed.  Counters are left at zero.
         int* flag = reinterpret_cast<int*>(tail);
         using u64 = unsigned long long;
+        constexpr int GROUP = 32;
         u64* part = reinterpret_cast<u64*>(a.partial);
-        if (tid < 12) __hip_atomic_store(part + w * 12 + tid, (u64)__double_as_longlong(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned t = __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = (t == gridDim.x - 1);
-        }
-        __syncthreads();
-        if (*flag) {
-            // 12 bins x SUBS strided sub-sums, 8 independent loads in flight per lane, then a fixed-order tree
+        const long long g = gridDim.x;
+        const long long ngroups = (g + GROUP - 1) / GROUP;
+        const long long grp = w / GROUP;
+        const long long grp_first = grp * GROUP;
+        const long long grp_size = (g - grp_first) < GROUP ? (g - grp_first) : GROUP;
+        double* sh = reinterpret_cast<double*>(smem);  // buf is dead
+
+        // sum `count` rows starting at `first`: 12 bins x up to 21 strided sub-sums, all loads in flight at once
+        auto sum_rows = [&](long long first, long long count) -> double {
             constexpr int SUBS = T / 12 < 21 ? T / 12 : 21;
-            double* sh = reinterpret_cast<double*>(smem);  // buf is dead
-            const long long g = gridDim.x;
             if (tid < 12 * SUBS) {
                 const int bin = tid % 12, sub = tid / 12;
-                double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                double s0 = 0.0, s1 = 0.0;
                 long long r = sub;
-                for (; r + 7 * SUBS < g; r += 8 * SUBS) {
-                    u64 v[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        v[q] = __hip_atomic_load(part + (r + q * SUBS) * 12 + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) s[q] += __longlong_as_double((long long)v[q]);
+                for (; r + SUBS < count; r += 2 * SUBS) {
+                    const u64 v0 = __hip_atomic_load(part + (first + r) * 12 + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 v1 = __hip_atomic_load(part + (first + r + SUBS) * 12 + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s0 += __longlong_as_double((long long)v0);
+                    s1 += __longlong_as_double((long long)v1);
                 }
-                for (; r < g; r += SUBS)
-                    s[0] += __longlong_as_double((long long)__hip_atomic_load(part + r * 12 + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                sh[sub * 12 + bin] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+                if (r < count)
+                    s0 += __longlong_as_double((long long)__hip_atomic_load(part + (first + r) * 12 + bin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                sh[sub * 12 + bin] = s0 + s1;
             }
             __syncthreads();
-            if (tid < 12) {
-                double t = 0.0;
+            double t = 0.0;
+            if (tid < 12)
                 for (int s2 = 0; s2 < SUBS; ++s2) t += sh[s2 * 12 + tid];
-                a.sum[tid] = t;
+            __syncthreads();
+            return t;
+        };
+        auto publish_and_ticket = [&](long long row, double value, unsigned* counter, unsigned last_ticket) -> bool {
+            if (tid < 12) __hip_atomic_store(part + row * 12 + tid, (u64)__double_as_longlong(value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = (t == last_ticket);
+                if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = last;
             }
-            if (tid == 0) __hip_atomic_store(a.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const bool last = *flag != 0;
+            __syncthreads();
+            return last;
+        };
+        if (publish_and_ticket(w, acc, a.counter + 1 + grp, (unsigned)(grp_size - 1))) {
+            const double gsum = sum_rows(grp_first, grp_size);
+            if (publish_and_ticket(g + grp, gsum, a.counter, (unsigned)(ngroups - 1))) {
+                const double total = sum_rows(g, ngroups);
+                if (tid < 12) a.sum[tid] = total;
+            }
         }
     }
 }
@@ -538,11 +557,12 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     const long long per = (num_frames + g - 1) / g;
     g = (num_frames + per - 1) / per;
     if (d_sum) {
-        int rc = ensure(ctx, ctx->d_partials, (size_t)g * 12 * sizeof(double));
+        const size_t groups = (size_t)(g + 31) / 32;
+        int rc = ensure(ctx, ctx->d_partials, ((size_t)g + groups) * 12 * sizeof(double));
         if (rc) return rc;
-        if (!ctx->d_counter.p) {
-            if ((rc = ensure(ctx, ctx->d_counter, 64))) return rc;
-            MPX_HIP(ctx, hipMemsetAsync(ctx->d_counter.p, 0, 64, stream));
+        if (ctx->d_counter.bytes < (groups + 1) * sizeof(unsigned)) {
+            if ((rc = ensure(ctx, ctx->d_counter, (groups + 1) * sizeof(unsigned) + 4096))) return rc;
+            MPX_HIP(ctx, hipMemsetAsync(ctx->d_counter.p, 0, ctx->d_counter.bytes, stream));
         }
         a.partial = (double*)ctx->d_partials.p;
         a.sum = d_sum;
