@@ -20,6 +20,11 @@ class HeParams(C.Structure):
     _fields_ = [("num_harmonic", C.c_int), ("num_octave", C.c_int), ("num_bins", C.c_int)]
 
 
+class PrimeParams(C.Structure):
+    _fields_ = [("num_harmonic", C.c_int), ("num_octave", C.c_int), ("harmonic_multiples_elim", C.c_int),
+                ("harmonic_elim_runs", C.c_int)]
+
+
 class EsacfParams(C.Structure):
     _fields_ = [("n_peaks_elim", C.c_int), ("peak_thresh", C.c_double),
                 ("peak_min_dist", C.c_int), ("enhance_mode", C.c_int)]
@@ -46,6 +51,8 @@ SIGNATURES = {
     "mpx_esacf": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp, _dp]),
     "mpx_esacf_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_esacf_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mpx_prime_multif0": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(PrimeParams), _dp]),
+    "mpx_prime_multif0_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(PrimeParams), _dp]),
     "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_set_remez_taps": (C.c_int, [_vp, C.c_int, _dp]),
     "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),

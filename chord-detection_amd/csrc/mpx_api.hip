@@ -325,6 +325,27 @@ int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const 
     return method_dev(ctx, run_esacf, d_signal, n, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, stream);
 }
 
+// ------------------------------------------------------------------ method 4
+int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                            const mpx_prime_params* params, double* chroma_sums) {
+    if (!ctx) return MPX_EINVAL;
+    ctx->err.clear();
+    if (num_clips < 0 || !offsets || (num_clips > 0 && !chroma_sums)) return set_error(ctx, MPX_EINVAL, "bad batch arguments");
+    if (num_clips == 0) return MPX_OK;
+    if (offsets[0] != 0) return set_error(ctx, MPX_EINVAL, "offsets[0] must be 0");
+    if (offsets[num_clips] > 0 && !signals) return set_error(ctx, MPX_EINVAL, "signal pointer/length invalid");
+    MPX_HIP(ctx, hipSetDevice(ctx->device));
+    return prime_run_host(ctx, signals, offsets, num_clips, fs, params, chroma_sums);
+}
+
+int mpx_prime_multif0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_prime_params* params,
+                      double* chroma_sum) {
+    if (!ctx) return MPX_EINVAL;
+    if (n < 0 || !chroma_sum) return set_error(ctx, MPX_EINVAL, "bad arguments");
+    const int64_t offsets[2] = {0, n};
+    return mpx_prime_multif0_batch(ctx, signal, offsets, 1, fs, params, chroma_sum);
+}
+
 int mpx_set_remez_taps(mpx_ctx* ctx, int fs, const double* taps13) {
     if (!ctx || !taps13 || fs <= 0) return MPX_EINVAL;
     ctx->remez[fs] = std::vector<double>(taps13, taps13 + 13);

@@ -1,0 +1,320 @@
+// Prime-multiF0 chroma (reference method 4, prime_multif0.py:41-91) in fp64.
+//
+// One workgroup per (candidate frequency, frame): Hann window (numpy.hanning, symmetric), N-point
+// DFT of the real frame by Bluestein's chirp-z on the LDS FFT (N = int(8/f*fs) is never a power of
+// two), |X|/sum(window) for the lower half of the one-sided spectrum (prime_multif0.py:59-61), then
+// harmonic_elim_runs rounds of block argmax -> pitch class -> exact-frequency harmonic elimination
+// (prime_multif0.py:66-82).  Every item writes its <= runs (pitch class, value) pairs to a fixed slot;
+// one workgroup per clip adds them up in item order (deterministic).
+#include <cmath>
+
+#include "mpx_fft.hpp"
+#include "mpx_internal.hpp"
+
+namespace mpx {
+
+struct PrimeCand {          // per candidate frequency, device resident
+    int N, L, half;         // frame length, Bluestein FFT length, bins kept = int((N//2+1)/2)
+    double val;             // frequency step: 1.0/(N*(1/fs)) exactly as numpy.fft.fftfreq builds it
+    double wsum;            // sum(numpy.hanning(N))
+    const double* win;      // [N]
+    const cx<double>* chirp;  // [N]
+    const cx<double>* bhat;   // [L] FFT_L(chirp filter)/L
+    const cx<double>* tw;     // [L] W_L
+};
+
+struct PrimeItem {
+    long long start;        // first sample of the frame in the packed signal
+    int valid;              // samples that exist (rest is frame_cutter's zero padding)
+    int cand;
+    long long slot;         // output slot (clip-major, reference loop order)
+};
+
+constexpr int PRIME_MAX_RUNS = 4;
+
+template <int L, int T>
+__global__ __launch_bounds__(T) void prime_kernel(const float* __restrict__ sig, const PrimeItem* __restrict__ items,
+                                                  const PrimeCand* __restrict__ cands, int runs, int elim,
+                                                  int* out_pc, double* out_val) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    double* mag = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));
+    __shared__ double red_v[T];
+    __shared__ int red_i[T];
+    const int tid = threadIdx.x;
+    const PrimeItem it = items[blockIdx.x];
+    const PrimeCand c = cands[it.cand];
+    const int N = c.N, half = c.half;
+    const float* __restrict__ x = sig + it.start;
+    cx<double> regs[L / T];
+
+    for (int n = tid; n < L; n += T) {
+        cx<double> v = {0.0, 0.0};
+        if (n < N) {
+            const double s = (n < it.valid ? (double)x[n] : 0.0) * c.win[n];
+            const cx<double> ch = c.chirp[n];
+            v = {s * ch.x, -s * ch.y};  // s * conj(chirp)
+        }
+        buf[lds_slot(n)] = v;
+    }
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, c.tw, regs, tid);
+    for (int k = tid; k < L; k += T) {
+        const cx<double> p = cmul(buf[lds_slot(k)], c.bhat[k]);
+        buf[lds_slot(k)] = {p.y, p.x};  // swapped: the next forward FFT acts as the inverse
+    }
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, c.tw, regs, tid);
+    for (int k = tid; k < half; k += T) {
+        const cx<double> b = buf[lds_slot(k)];
+        const cx<double> ch = c.chirp[k];
+        const cx<double> z = cmul(cx<double>{b.y, b.x}, cx<double>{ch.x, -ch.y});
+        mag[k] = hypot(z.x, z.y) / c.wsum;  // mlab: np.abs(result) / window.sum()
+    }
+    __syncthreads();
+
+    for (int run = 0; run < runs; ++run) {
+        // numpy argmax: first index of the maximum
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int k = tid; k < half; k += T) {
+            const double v = mag[k];
+            if (v > bv) {
+                bv = v;
+                bi = k;
+            }
+        }
+        red_v[tid] = bv;
+        red_i[tid] = bi;
+        __syncthreads();
+        for (int s = T / 2; s > 0; s >>= 1) {
+            if (tid < s) {
+                const double ov = red_v[tid + s];
+                const int oi = red_i[tid + s];
+                if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) {
+                    red_v[tid] = ov;
+                    red_i[tid] = oi;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int pc = -1;
+            double val = 0.0;
+            if (half > 0) {
+                const int idx = red_i[0] == 0x7fffffff ? 0 : red_i[0];
+                const double max_f = (double)idx * c.val;
+                const double midi = 12.0 * (log2(max_f) - log2(440.0)) + 69.0;
+                // hz_to_note raises on NaN (ValueError) and on +-inf (OverflowError, e.g. the DC bin): the
+                // reference `continue`s: nothing is added and nothing is eliminated (prime_multif0.py:73-74)
+                if (midi == midi && !isinf(midi)) {
+                    const long long note = (long long)nearbyint(midi);
+                    pc = (int)(((note % 12) + 12) % 12);
+                    val = mag[idx];
+                    for (int k = 1; k < elim; ++k) {
+                        const double target = (double)k * max_f;  // f == k * max_f, exact comparison (:80)
+                        for (int j = k * idx - 1; j <= k * idx + 1; ++j)
+                            if (j >= 0 && j < half && (double)j * c.val == target) mag[j] = 0.0;
+                    }
+                    // unicode-sharp quirk A.18: sharps land in a stray key and are lost
+                    if (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10) pc = -1;
+                }
+            }
+            out_pc[it.slot * PRIME_MAX_RUNS + run] = pc;
+            out_val[it.slot * PRIME_MAX_RUNS + run] = val;
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per clip: chroma[clip] = sum over its item slots, in slot order per pitch class
+__global__ __launch_bounds__(64) void prime_sum_kernel(const long long* __restrict__ seg, int runs,
+                                                       const int* __restrict__ pc, const double* __restrict__ val,
+                                                       double* out) {
+    const int lane = threadIdx.x;
+    const long long s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
+    if (lane < 12) {
+        double acc = 0.0;
+        for (long long s = s0; s < s1; ++s)
+            for (int r = 0; r < runs; ++r)
+                if (pc[s * PRIME_MAX_RUNS + r] == lane) acc += val[s * PRIME_MAX_RUNS + r];
+        out[(long long)blockIdx.x * 12 + lane] = acc;
+    }
+}
+
+static void prime_host_fft(std::vector<cx<double>>& a) {
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1)
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const long double ang = -2.0L * M_PIl * (long double)k / (long double)len;
+                const cx<double> w = {(double)cosl(ang), (double)sinl(ang)};
+                const cx<double> u = a[i + k], t = a[i + k + len / 2];
+                const cx<double> v = {t.x * w.x - t.y * w.y, t.x * w.y + t.y * w.x};
+                a[i + k] = {u.x + v.x, u.y + v.y};
+                a[i + k + len / 2] = {u.x - v.x, u.y - v.y};
+            }
+}
+
+struct PrimePlan {
+    std::vector<PrimeCand> cands;  // host copy (pointers are device pointers)
+    PrimeCand* d_cands = nullptr;
+};
+
+static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan*& out) {
+    static std::map<std::string, PrimePlan> plans;  // keyed per context below
+    const std::string key = std::to_string((uintptr_t)ctx) + "_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) +
+                            "_" + std::to_string(p.num_octave);
+    auto it = plans.find(key);
+    if (it != plans.end()) {
+        out = &it->second;
+        return MPX_OK;
+    }
+    PrimePlan plan;
+    const double c3 = 440.0 * std::pow(2.0, (48.0 - 69.0) / 12.0);
+    std::map<int, void*> twl;
+    for (int n = 0; n < 12; ++n) {
+        const double note = c3 * std::pow(2.0, n / 12.0);
+        for (int oct = 1; oct <= p.num_octave; ++oct)
+            for (int h = 1; h <= p.num_harmonic; ++h) {
+                const double f = note * oct * h;
+                const int N = (int)((8 / f) * fs);  // prime_multif0.py:53
+                if (N < 2 || N > 2048)
+                    return set_error(ctx, MPX_EUNSUPPORTED,
+                                     "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..2048)", N, f);
+                PrimeCand c;
+                c.N = N;
+                c.L = N <= 512 ? 1024 : (N <= 1024 ? 2048 : 4096);
+                c.half = (N / 2 + 1) / 2;
+                c.val = 1.0 / (N * (1.0 / fs));
+                std::vector<double> win(N);
+                double wsum = 0.0;
+                for (int i = 0; i < N; ++i) {  // numpy.hanning(N)
+                    win[i] = N == 1 ? 1.0 : 0.5 - 0.5 * std::cos(2.0 * M_PI * i / (double)(N - 1));
+                }
+                // numpy's pairwise summation differs from a left-to-right sum by a few ulp; the value only
+                // scales the magnitudes (1e-16 relative), never a comparison
+                for (int i = 0; i < N; ++i) wsum += win[i];
+                c.wsum = wsum;
+                std::vector<cx<double>> chirp(N), filt(c.L, cx<double>{0.0, 0.0});
+                for (long long i = 0; i < N; ++i) {
+                    const long long q = (i * i) % (2LL * N);
+                    const long double ang = M_PIl * (long double)q / (long double)N;
+                    chirp[i] = {(double)cosl(ang), (double)sinl(ang)};
+                }
+                filt[0] = chirp[0];
+                for (int m = 1; m < N; ++m) filt[m] = filt[c.L - m] = chirp[m];
+                prime_host_fft(filt);
+                for (auto& v : filt) {
+                    v.x /= c.L;
+                    v.y /= c.L;
+                }
+                if (!twl.count(c.L)) {
+                    std::vector<cx<double>> tw(c.L);
+                    for (int j = 0; j < c.L; ++j) {
+                        const long double ang = -2.0L * M_PIl * j / (long double)c.L;
+                        tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+                    }
+                    twl[c.L] = upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+                    if (!twl[c.L]) return MPX_ENOMEM;
+                }
+                c.tw = (const cx<double>*)twl[c.L];
+                c.win = (const double*)upload(ctx, win.data(), win.size() * sizeof(double));
+                c.chirp = (const cx<double>*)upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
+                c.bhat = (const cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
+                if (!c.win || !c.chirp || !c.bhat) return MPX_ENOMEM;
+                plan.cands.push_back(c);
+            }
+    }
+    plan.d_cands = (PrimeCand*)upload(ctx, plan.cands.data(), plan.cands.size() * sizeof(PrimeCand));
+    if (!plan.d_cands) return MPX_ENOMEM;
+    out = &plans.emplace(key, plan).first->second;
+    return MPX_OK;
+}
+
+template <int L, int T>
+static void prime_launch(const float* d_sig, const PrimeItem* d_items, size_t count, const PrimeCand* d_cands, int runs,
+                         int elim, int* d_pc, double* d_val, hipStream_t st) {
+    if (!count) return;
+    const size_t lds = sizeof(cx<double>) * lds_slots(L) + sizeof(double) * (L / 4 + 8);
+    auto kern = prime_kernel<L, T>;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, st, d_sig, d_items, d_cands, runs, elim, d_pc, d_val);
+}
+
+// signals: packed clips on the HOST; offsets[C+1]; out: [C,12] on the host
+int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                   const mpx_prime_params* params, double* chroma_sums) {
+    mpx_prime_params p = params ? *params : mpx_prime_params{1, 2, 5, 2};
+    if (p.num_harmonic < 1 || p.num_octave < 1 || p.num_harmonic * p.num_octave > 64 || p.harmonic_multiples_elim < 1 ||
+        p.harmonic_multiples_elim > 64 || p.harmonic_elim_runs < 0 || p.harmonic_elim_runs > PRIME_MAX_RUNS)
+        return set_error(ctx, MPX_EINVAL, "bad prime-multiF0 params");
+    if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
+    PrimePlan* plan = nullptr;
+    int rc = prime_plan(ctx, fs, p, plan);
+    if (rc) return rc;
+    const int64_t total = offsets[num_clips];
+    // items in the reference's loop order per clip: candidate-major, then frame
+    std::vector<PrimeItem> items[3];
+    std::vector<long long> seg(1, 0);
+    long long slot = 0;
+    for (int cidx = 0; cidx < num_clips; ++cidx) {
+        const int64_t len = offsets[cidx + 1] - offsets[cidx];
+        if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
+        for (size_t k = 0; k < plan->cands.size(); ++k) {
+            const PrimeCand& c = plan->cands[k];
+            const int64_t nf = len <= 0 ? 0 : (len + c.N - 1) / c.N;
+            for (int64_t f = 0; f < nf; ++f) {
+                const int64_t s = f * c.N, left = len - s;
+                PrimeItem it;
+                it.start = offsets[cidx] + s;
+                it.valid = (int)(left >= c.N ? c.N : left);
+                it.cand = (int)k;
+                it.slot = slot++;
+                items[c.L == 1024 ? 0 : (c.L == 2048 ? 1 : 2)].push_back(it);
+            }
+        }
+        seg.push_back(slot);
+    }
+    hipStream_t st = ctx->stream;
+    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
+    const size_t nitems = (size_t)slot;
+    size_t item_bytes = 0;
+    for (auto& v : items) item_bytes += v.size() * sizeof(PrimeItem);
+    if ((rc = ensure(ctx, ctx->d_desc, item_bytes + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ws0, (nitems + 1) * PRIME_MAX_RUNS * (sizeof(int) + sizeof(double)) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_sum, (size_t)(num_clips ? num_clips : 1) * 12 * sizeof(double)))) return rc;
+    if (total) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyHostToDevice, st));
+    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    double* d_val = (double*)ctx->d_ws0.p;
+    int* d_pc = (int*)(d_val + (nitems + 1) * PRIME_MAX_RUNS);
+    char* d_items = (char*)ctx->d_desc.p;
+    size_t off = 0;
+    for (int cls = 0; cls < 3; ++cls) {
+        const size_t bytes = items[cls].size() * sizeof(PrimeItem);
+        if (bytes) MPX_HIP(ctx, hipMemcpyAsync(d_items + off, items[cls].data(), bytes, hipMemcpyHostToDevice, st));
+        const PrimeItem* di = (const PrimeItem*)(d_items + off);
+        if (cls == 0) prime_launch<1024, 64>((const float*)ctx->d_signal.p, di, items[cls].size(), plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st);
+        if (cls == 1) prime_launch<2048, 128>((const float*)ctx->d_signal.p, di, items[cls].size(), plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st);
+        if (cls == 2) prime_launch<4096, 256>((const float*)ctx->d_signal.p, di, items[cls].size(), plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st);
+        off += bytes;
+    }
+    if (num_clips)
+        hipLaunchKernelGGL(prime_sum_kernel, dim3(num_clips), dim3(64), 0, st, (const long long*)ctx->d_offsets.p,
+                           p.harmonic_elim_runs, d_pc, d_val, (double*)ctx->d_sum.p);
+    MPX_HIP(ctx, hipGetLastError());
+    if (num_clips)
+        MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    // the item vectors are read by the async copies above: wait before they go out of scope
+    MPX_HIP(ctx, hipStreamSynchronize(st));
+    return MPX_OK;
+}
+
+}  // namespace mpx

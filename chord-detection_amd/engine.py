@@ -177,6 +177,25 @@ class Engine:
                                              C.byref(p), int(frame), hop, out.ctypes.data_as(_lib._dp)))
         return out
 
+    # ------------------------------------------------------------- method 4
+    def prime_multif0(self, x, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5, harmonic_elim_runs=2):
+        x = self._sig(x)
+        p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs)
+        total = np.zeros(12, dtype=np.float64)
+        self._check(self.lib.mpx_prime_multif0(self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p),
+                                               total.ctypes.data_as(_lib._dp)))
+        return total
+
+    def prime_multif0_batch(self, clips, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5,
+                            harmonic_elim_runs=2):
+        flat, offsets = self._pack(clips)
+        p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs)
+        out = np.zeros((len(offsets) - 1, 12), dtype=np.float64)
+        self._check(self.lib.mpx_prime_multif0_batch(
+            self.ctx, flat.ctypes.data_as(_lib._fp), offsets.ctypes.data_as(_lib._ip), len(offsets) - 1, int(fs),
+            C.byref(p), out.ctypes.data_as(_lib._dp)))
+        return out
+
     # ------------------------------------------------------------- timing
     def timer_begin(self, stream=None):
         self._check(self.lib.mpx_timer_begin(self.ctx, stream))

@@ -120,6 +120,26 @@ int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs,
                   const mpx_esacf_params* params, int frame, int hop,
                   double* d_chroma_frames, double* d_chroma_sum, void* stream);
 
+/* ---- Prime-multiF0 (method 4): prime_multif0.py:19-26 ctor kwargs --------------
+ * replaces prime_multif0.py:41-91.  For each of 12*num_octave*num_harmonic candidate
+ * frequencies the signal is cut into frames of int(8/f*fs) samples (357..1348 at 22050 Hz),
+ * Hann windowed, |FFT|/sum(window), lower half of the one-sided spectrum, and
+ * harmonic_elim_runs rounds of (argmax -> pitch class += peak; zero the bins whose
+ * frequency EQUALS 1..harmonic_multiples_elim-1 times the peak frequency).
+ * Frame lengths up to 2048 samples are supported (fs <= ~33 kHz with the defaults). */
+typedef struct mpx_prime_params {
+    int num_harmonic;              /* default 1 */
+    int num_octave;                /* default 2 */
+    int harmonic_multiples_elim;   /* default 5 */
+    int harmonic_elim_runs;        /* default 2 */
+} mpx_prime_params;
+
+int mpx_prime_multif0(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
+                      const mpx_prime_params* params, double* chroma_sum);
+
+int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips,
+                            int fs, const mpx_prime_params* params, double* chroma_sums);
+
 /* Debug taps for parity tests: per-frame intermediates of the ESACF chain,
  * host buffers, each [F, len]:
  *   MPX_STAGE_WFIR  len = frame            dsp/wfir.py:25-43

@@ -311,6 +311,26 @@ def main():
         es[name + "/peaks"] = np.array(pk)
         es[name + "/peaks_interp"] = np.array(pi)
     np.savez_compressed(os.path.join(HERE, "esacf_e2e.npz"), **es)
+
+    # ------------------------------------------------------ Prime-multiF0 (ref-code: real matplotlib.mlab inside)
+    from oracle import prime_multif0 as o_prime
+    pr = {"provenance": np.array("ref-code")}
+    for name, x in clips.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            total = chord_detection.MultipitchPrimeMultiF0(name).compute_pitches()
+            pr[name + "/sum"] = np.array([total[i] for i in range(12)])
+            pr[name + "/repr"] = np.array(repr(total))
+            pr[name + "/key"] = np.array(total.key())
+            np.testing.assert_allclose(o_prime.prime_compute(x, fs), pr[name + "/sum"], rtol=1e-12, atol=0)
+    _CLIPS["__kw__"] = (clips["poly_seed1"], fs)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        c = chord_detection.MultipitchPrimeMultiF0("__kw__", num_harmonic=2, num_octave=3, harmonic_multiples_elim=3,
+                                                   harmonic_elim_runs=3).compute_pitches()
+    pr["kwargs_h2_o3_e3_r3/sum"] = np.array([c[i] for i in range(12)])
+    np.testing.assert_allclose(o_prime.prime_compute(clips["poly_seed1"], fs, 2, 3, 3, 3), pr["kwargs_h2_o3_e3_r3/sum"], rtol=1e-12)
+    np.savez_compressed(os.path.join(HERE, "prime_multif0.npz"), **pr)
     print("golden fixtures written to", HERE)
 
 

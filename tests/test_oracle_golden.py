@@ -177,3 +177,23 @@ def test_time_stretch_truncation_identity():
         assert out.shape[0] == int(round(511 / r))
         np.testing.assert_allclose(out, y[:out.shape[0]], atol=1e-14)
     assert tp.time_stretch_is_truncation(1022) and not tp.time_stretch_is_truncation(2047)
+
+
+def test_prime_multif0(golden_dir, clips):
+    """Method 4 (next-tier row f2): pinned by the reference's code + the real matplotlib.mlab."""
+    from oracle import prime_multif0 as o_prime
+    d = np.load(os.path.join(golden_dir, "prime_multif0.npz"))
+    assert str(d["provenance"]) == "ref-code"
+    for name, x in clips.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            total = o_prime.prime_compute(x, FS)
+        np.testing.assert_allclose(total, d[name + "/sum"], rtol=1e-12, atol=0)
+        assert o_chroma.pack(total) == str(d[name + "/repr"])
+        assert o_chroma.detect_key(total) == str(d[name + "/key"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(o_prime.prime_compute(clips["poly_seed1"], FS, 2, 3, 3, 3),
+                                   d["kwargs_h2_o3_e3_r3/sum"], rtol=1e-12)
+    ws = [w for _, w in o_prime.candidates(FS)]
+    assert min(ws) == 357 and max(ws) == 1348 and len(ws) == 24   # SURVEY 2 #10
