@@ -25,6 +25,13 @@ class PrimeParams(C.Structure):
                 ("harmonic_elim_runs", C.c_int)]
 
 
+class If0Params(C.Structure):
+    _fields_ = [("frame_size", C.c_int), ("power", C.c_double), ("channels", C.c_int), ("zeta0", C.c_double),
+                ("zeta1", C.c_double), ("max_voices", C.c_int), ("tau_min", C.c_double), ("tau_max", C.c_double),
+                ("tau_prec", C.c_double), ("Q", C.c_int), ("M", C.c_int), ("epsilon1", C.c_double),
+                ("epsilon2", C.c_double), ("gamma", C.c_double)]
+
+
 class EsacfParams(C.Structure):
     _fields_ = [("n_peaks_elim", C.c_int), ("peak_thresh", C.c_double),
                 ("peak_min_dist", C.c_int), ("enhance_mode", C.c_int)]
@@ -53,6 +60,9 @@ SIGNATURES = {
     "mpx_esacf_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _vp, _vp, _vp]),
     "mpx_prime_multif0": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(PrimeParams), _dp]),
     "mpx_prime_multif0_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(PrimeParams), _dp]),
+    "mpx_iterative_f0": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(If0Params), _dp, _dp]),
+    "mpx_iterative_f0_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(If0Params), _dp]),
+    "mpx_iterative_f0_spectra": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(If0Params), _dp]),
     "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_set_remez_taps": (C.c_int, [_vp, C.c_int, _dp]),
     "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),

@@ -325,6 +325,46 @@ int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const 
     return method_dev(ctx, run_esacf, d_signal, n, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, stream);
 }
 
+// ------------------------------------------------------------------ method 3
+static int if0_common(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips) {
+    if (!ctx) return MPX_EINVAL;
+    ctx->err.clear();
+    if (num_clips < 0 || !offsets) return set_error(ctx, MPX_EINVAL, "bad batch arguments");
+    if (num_clips && offsets[0] != 0) return set_error(ctx, MPX_EINVAL, "offsets[0] must be 0");
+    if (num_clips && offsets[num_clips] > 0 && !signals) return set_error(ctx, MPX_EINVAL, "signal pointer/length invalid");
+    MPX_HIP(ctx, hipSetDevice(ctx->device));
+    return MPX_OK;
+}
+
+int mpx_iterative_f0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                           const mpx_if0_params* params, double* chroma_sums) {
+    int rc = if0_common(ctx, signals, offsets, num_clips);
+    if (rc) return rc;
+    if (num_clips == 0) return MPX_OK;
+    if (!chroma_sums) return set_error(ctx, MPX_EINVAL, "chroma_sums must not be NULL");
+    return if0_run_host(ctx, signals, offsets, num_clips, fs, params, nullptr, chroma_sums, nullptr);
+}
+
+int mpx_iterative_f0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,
+                     double* chroma_frames, double* chroma_sum) {
+    if (!ctx) return MPX_EINVAL;
+    if (n < 0 || !chroma_sum) return set_error(ctx, MPX_EINVAL, "bad arguments");
+    const int64_t offsets[2] = {0, n};
+    int rc = if0_common(ctx, signal, offsets, 1);
+    if (rc) return rc;
+    return if0_run_host(ctx, signal, offsets, 1, fs, params, chroma_frames, chroma_sum, nullptr);
+}
+
+int mpx_iterative_f0_spectra(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,
+                             double* ut) {
+    if (!ctx) return MPX_EINVAL;
+    if (n < 0 || !ut) return set_error(ctx, MPX_EINVAL, "bad arguments");
+    const int64_t offsets[2] = {0, n};
+    int rc = if0_common(ctx, signal, offsets, 1);
+    if (rc) return rc;
+    return if0_run_host(ctx, signal, offsets, 1, fs, params, nullptr, nullptr, ut);
+}
+
 // ------------------------------------------------------------------ method 4
 int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                             const mpx_prime_params* params, double* chroma_sums) {

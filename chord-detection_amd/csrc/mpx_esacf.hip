@@ -925,8 +925,20 @@ static int esacf_plan(mpx_ctx* ctx, int N, EsacfPlan& plan) {
     return MPX_OK;
 }
 
+struct BandCoef;
+int remez_taps_for(mpx_ctx* ctx, int fs, double* c13);
+static int band_coefs_rest(int fs, BandCoef& k);
+
 // Filter design (host constants): closed forms of dsp/wfir.py:6-21, scipy.signal.butter(2, ...)
 static int band_coefs(mpx_ctx* ctx, int fs, BandCoef& k) {
+    int rc0 = remez_taps_for(ctx, fs, k.c);
+    if (rc0) return rc0;
+    return band_coefs_rest(fs, k);
+}
+
+// 13 warped-FIR taps = scipy.signal.remez(13, [0,19,20,r,r+1,fs/2], [0,1,0], fs) (dsp/wfir.py:13-21):
+// built-in for 22050 / 44100 Hz, otherwise registered by the host through mpx_set_remez_taps.
+int remez_taps_for(mpx_ctx* ctx, int fs, double* c13) {
     static const double remez22050[13] = {
         -0.2503141758465685, -0.00010985253437014219, 2.5089273607721457e-05, -0.0002589029075222507,
         0.00020302128904025308, 0.0002957470030712228, 1.0000257474401701, 0.0002957470030712228,
@@ -943,7 +955,11 @@ static int band_coefs(mpx_ctx* ctx, int fs, BandCoef& k) {
         return set_error(ctx, MPX_EUNSUPPORTED,
                          "ESACF: no warped-FIR (remez) taps for fs=%d; built-in tables cover 22050 and 44100 Hz "
                          "(register others with mpx_set_remez_taps)", fs);
-    for (int i = 0; i < 13; ++i) k.c[i] = taps ? taps[i] : it->second[i];
+    for (int i = 0; i < 13; ++i) c13[i] = taps ? taps[i] : it->second[i];
+    return MPX_OK;
+}
+
+static int band_coefs_rest(int fs, BandCoef& k) {
     k.a = 1.0674 * std::sqrt((2.0 / M_PI) * std::atan(0.06583 * fs / 1000.0)) - 0.1916;
     const double kk = std::tan(M_PI * 1000.0 / fs);
     const double norm = 1.0 / (1.0 + std::sqrt(2.0) * kk + kk * kk);

@@ -1,0 +1,551 @@
+// Iterative-F0 (Klapuri) chroma (reference method 3) in fp64.  Three kernels:
+//
+//  1. if0_frontend_kernel   one lane per (chunk, channel): the whole per-channel chain of
+//                           iterative_f0.py:58-65 sample by sample -- 2x resonator 1, 2x resonator 2
+//                           (iterative_f0.py:171-193, swapped-argument quirk A.1 is in the host-built
+//                           coefficients), 12-stage warped all-pass + 13-tap FIR residual (dsp/wfir.py),
+//                           |.|, (y + butter2-LP(y, fc))/2.  Output [t][channel] so that the 70 lanes of a
+//                           chunk store contiguously.  The reference filters the WHOLE signal
+//                           sequentially; every stage is stable with pole radius <= 0.999, so a chunk that
+//                           starts from zero state 65536 samples early reproduces the sequential result to
+//                           fp64 rounding (0.999^65536 ~ 1e-29) and chunks run in parallel.
+//  2. if0_spectrum_kernel   one workgroup per frame: for every channel, Hamming x frame, zero-pad to
+//                           2*frame (iterative_f0.py:72-77), real FFT as a frame-point complex LDS FFT,
+//                           |X|^power accumulated over channels in registers (iterative_f0.py:80-85).
+//  3. if0_periodicity_kernel one workgroup per frame: periodicity.py:48-163 -- interval-halving period
+//                           search (one wave per harmonic m for the range maxima), harmonic
+//                           cancellation, pitch-class scatter (quirks A.10-A.13, A.18).
+#include <cmath>
+#include <cstring>
+
+#include "mpx_fft.hpp"
+#include "mpx_internal.hpp"
+
+namespace mpx {
+
+constexpr int IF0_MAXCH = 128;
+constexpr long long IF0_CHUNK = 262144;   // samples per front-end chunk (multiple of every frame size)
+constexpr long long IF0_WARMUP = 65536;   // zero-state run-in before a chunk that does not start a clip
+
+struct If0ChanCoef {   // per channel, built on the host in double
+    double r1b0, r1b2, r1a1, r1a2;   // resonator 1: b = [rho1, 0, -rho1], a = [1, -A cos1, A^2]
+    double r2b0, r2a1, r2a2;         // resonator 2: b = [rho2],         a = [1, -A cos2, A^2]
+    double lpb0, lpb1, lpb2, lpa1, lpa2;  // butter(2, fc/(fs/2)) low-pass
+};
+
+struct If0Chunk {
+    long long sig_start;   // first sample of the chunk in the packed signal buffer
+    long long clip_start;  // first sample of the clip in the packed signal buffer
+    int len;               // samples to produce (<= IF0_CHUNK)
+    int clip_left;         // samples of the clip from sig_start on (>= len unless the clip ends inside)
+    int warm;              // run-in samples before sig_start (0 at the start of a clip)
+    int pad;
+};
+
+struct If0Wfir {
+    double a;
+    double c[13];
+};
+
+__global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
+                                                          long long num_items, int channels,
+                                                          const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
+                                                          double* __restrict__ yc) {
+    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= num_items) return;
+    const long long ck = w / channels;
+    const int ch = (int)(w - ck * channels);
+    const If0Chunk c = chunks[ck];
+    const If0ChanCoef k = coefs[ch];
+    double a1 = 0, a2 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, d1 = 0, d2 = 0, l1 = 0, l2 = 0;
+    double z[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z[i] = 0.0;
+    const float* __restrict__ x = sig + c.sig_start;
+    double* __restrict__ out = yc + (size_t)ck * IF0_CHUNK * channels + ch;
+    for (int t = -c.warm; t < c.len; ++t) {
+        const double xt = t < c.clip_left ? (double)x[t] : 0.0;
+        // resonator 1 twice (DF2T, like scipy.signal.lfilter)
+        double y = k.r1b0 * xt + a1;
+        a1 = a2 - k.r1a1 * y;               // b1 = 0
+        a2 = k.r1b2 * xt - k.r1a2 * y;
+        double u = k.r1b0 * y + b1;
+        b1 = b2 - k.r1a1 * u;
+        b2 = k.r1b2 * y - k.r1a2 * u;
+        // resonator 2 twice
+        double v = k.r2b0 * u + c1;
+        c1 = c2 - k.r2a1 * v;
+        c2 = -k.r2a2 * v;
+        double s = k.r2b0 * v + d1;
+        d1 = d2 - k.r2a1 * s;
+        d2 = -k.r2a2 * s;
+        // warped FIR residual (dsp/wfir.py:25-43)
+        double xhat = wf.c[0] * s;
+        double in = s;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const double o = -wf.a * in + z[i];
+            z[i] = in + wf.a * o;
+            in = o;
+            xhat += wf.c[i + 1] * o;
+        }
+        double r = s - xhat;
+        r = r < 0.0 ? -r : r;               // full-wave rectification (iterative_f0.py:60)
+        const double lp = k.lpb0 * r + l1;
+        l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
+        l2 = k.lpb2 * r - k.lpa2 * lp;
+        if (t >= 0) out[(size_t)t * channels] = (r + lp) / 2.0;
+    }
+}
+
+// ------------------------------------------------------------------ spectrum
+struct If0Frame {
+    long long yc_row;   // row (sample index) of the frame's first sample in yc
+    int valid;          // samples of the frame that exist (tail of a clip is zero padded)
+    int clip;
+};
+
+template <int NF, int T>   // NF = frame size = complex FFT length (2*NF real points, upper half zero)
+__global__ __launch_bounds__(T) void if0_spectrum_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
+                                                         int channels, double power, const double* __restrict__ window,
+                                                         const cx<double>* __restrict__ tw,   // W_NF
+                                                         const cx<double>* __restrict__ twn,  // W_{2NF}^k, k <= NF
+                                                         double* __restrict__ ut) {           // [F, 2*NF]
+    constexpr int M = NF;           // complex points
+    constexpr int EPT = M / T;
+    constexpr int KPT = (M + T) / T;  // bins k = tid + j*T, k <= M  (M/T + 1 slots)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    const int tid = threadIdx.x;
+    const If0Frame fr = frames[blockIdx.x];
+    double acc[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) acc[j] = 0.0;
+    for (int ch = 0; ch < channels; ++ch) {
+        cx<double> regs[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int p = first_pass_index<M, T>(tid, e);  // complex point p = real samples 2p, 2p+1
+            const int s = 2 * p;
+            double x0 = 0.0, x1 = 0.0;
+            if (s < NF) {  // the second half of the 2*NF-point frame is the zero padding
+                if (s < fr.valid) x0 = yc[(size_t)(fr.yc_row + s) * channels + ch] * window[s];
+                if (s + 1 < fr.valid) x1 = yc[(size_t)(fr.yc_row + s + 1) * channels + ch] * window[s + 1];
+            }
+            regs[e] = {x0, x1};
+        }
+        fft_lds<M, T, true, double>(buf, tw, regs, tid);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + j * T;
+            if (k <= M) {
+                const cx<double> A = buf[lds_slot(k & (M - 1))];
+                cx<double> B = buf[lds_slot((M - k) & (M - 1))];
+                B.y = -B.y;
+                const cx<double> E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
+                const cx<double> D = {0.5 * (A.x - B.x), 0.5 * (A.y - B.y)};
+                const cx<double> X = cadd(E, mul_mi(cmul(twn[k], D)));
+                const double mag = hypot(X.x, X.y);
+                acc[j] += power == 1.0 ? mag : pow(mag, power);
+            }
+        }
+        __syncthreads();  // buf is rewritten by the next channel's first pass
+    }
+    double* row = ut + (size_t)blockIdx.x * 2 * NF;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * T;
+        if (k <= M) {
+            row[k] = acc[j];
+            if (k > 0 && k < M) row[2 * NF - k] = acc[j];  // |X[N-k]| = |X[k]| for a real frame
+        }
+    }
+}
+
+// ------------------------------------------------------------------ periodicity
+struct If0PerArgs {
+    const double* ut;   // [F, n]
+    double* ur;         // [F, n] residual spectrum (scratch)
+    double* ud;         // [F, n] detected spectrum (scratch)
+    int n;              // 2*frame_size
+    double fs, K;       // K = window_size / fs
+    double wsize;       // window_size (frame_size) as a double
+    int max_voices, Q, M;
+    double tau_min, tau_max, tau_prec, epsilon1, epsilon2, gamma;
+    double* chroma;     // [F, 12]
+};
+
+constexpr int PER_T = 256;
+__constant__ double IF0_HAMMING9[9] = {0.0011244659258033, 0.11559343551383, 0.42817348241183, 0.81822361914331, 1.0,
+                                       0.81822361914331, 0.42817348241183, 0.11559343551383, 0.0011244659258033};
+
+// max over ur[lo..hi] by ONE wave (no workgroup barrier)
+__device__ __forceinline__ double wave_range_max(const double* __restrict__ ur, int lo, int hi, int lane) {
+    double m = -INFINITY;
+    for (int i = lo + lane; i <= hi; i += 64) {
+        const double v = ur[i];
+        m = v > m ? v : m;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
+    __shared__ double tau_low[32], tau_up[32], smax[32];
+    __shared__ double umax[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long f = blockIdx.x;
+    const int n = a.n;
+    const double* __restrict__ uk = a.ut + f * (long long)n;
+    double* __restrict__ ur = a.ur + f * (long long)n;
+    double* __restrict__ ud = a.ud + f * (long long)n;
+    for (int i = tid; i < n; i += PER_T) {
+        ur[i] = uk[i];
+        ud[i] = 0.0;
+    }
+    __syncthreads();
+    __threadfence_block();
+
+    // periodicity.py:144-163; executed by every thread with identical (uniform) results
+    auto smax_fn = [&](int q) -> double {
+        const double tl = tau_low[q], tu = tau_up[q];
+        const double tau = 0.5 * (tl + tu);
+        const double deltatau = tu - tl;
+        // one wave per harmonic m: range maxima without workgroup barriers
+        for (int m = 1 + wave; m < a.M; m += PER_T / 64) {
+            const int lowk = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
+            int highk = (int)(m * a.K / (tau - 0.5 * deltatau) + 0.5);
+            if (highk > n - 1) highk = n - 1;  // numpy slicing clips silently
+            const double mx = wave_range_max(ur, lowk, highk, lane);
+            if (lane == 0) umax[m] = mx;
+        }
+        __syncthreads();
+        double salience = 0.0;
+        for (int m = 1; m < a.M; ++m) salience += (m * a.fs / tu + a.epsilon2) * umax[m];
+        salience *= a.fs / tl + a.epsilon1;
+        __syncthreads();
+        return salience;
+    };
+
+    double voice_sal[8], voice_per[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) voice_sal[i] = voice_per[i] = 0.0;
+    int voices = 0;
+    double prevmix = 0.0, mix = 0.0;
+    for (;;) {
+        // ---- min_search (periodicity.py:114-142)
+        int q = 0, qbest = 0;
+        if (tid == 0) {
+            tau_low[0] = a.tau_min;
+            tau_up[0] = a.tau_max;
+        }
+        __syncthreads();
+        while ((tau_up[qbest] - tau_low[qbest]) > a.tau_prec && q < a.Q - 1) {
+            ++q;
+            __syncthreads();
+            if (tid == 0) {
+                tau_low[q] = (tau_low[qbest] + tau_up[qbest]) * 0.5;
+                tau_up[q] = tau_up[qbest];
+                tau_up[qbest] = tau_low[q];
+            }
+            __syncthreads();
+            const double sq = smax_fn(q);
+            const double sb = smax_fn(qbest);
+            if (tid == 0) {
+                smax[q] = sq;
+                smax[qbest] = sb;
+            }
+            __syncthreads();
+            int whichq = 0;
+            double maxval = smax[0];
+            for (int j = 1; j <= q; ++j) {
+                const double valnow = smax[j];
+                if (valnow > maxval) {
+                    maxval = valnow;
+                    whichq = j;
+                }
+            }
+            qbest = whichq;
+        }
+        const double tau = (tau_low[qbest] + tau_up[qbest]) * 0.5;
+        const double best = smax[qbest];
+        __syncthreads();
+        if (voices < 8) {
+            // static indexing of the per-voice registers
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i == voices) {
+                    voice_sal[i] = best;
+                    voice_per[i] = tau;
+                }
+        }
+        ++voices;
+        mix += best;
+        const double test = mix / pow((double)voices, a.gamma);
+        if (voices >= a.max_voices || test <= prevmix) break;
+        prevmix = test;
+        // ---- harmonic cancellation (periodicity.py:76-99); partials of different m never overlap
+        const int topm = (int)(tau * (a.fs / a.wsize) * n);  // periodicity.py:78
+        const double srovertau = a.fs / tau;
+        const double weight = srovertau + a.epsilon1;
+        for (int m = 1 + tid; m < topm; m += PER_T) {
+            const double partialK = m * a.K / tau + 0.5;
+            if (partialK <= n) {
+                const int ip = (int)partialK;
+                if (ip < n) {  // the reference would raise IndexError at exactly n; unreachable with the defaults
+                    double urw = ur[ip];
+                    urw *= weight / (m * srovertau + a.epsilon2);
+                    int lowk = (int)(partialK - 4);
+                    if (lowk < 0) lowk = 0;
+                    int highk = (int)(partialK + 4);
+                    if (highk > n) highk = n;
+                    for (int j = lowk; j <= highk && j < n; ++j) ud[j] += IF0_HAMMING9[(int)(j - partialK + 4)] * urw;
+                }
+            }
+        }
+        __syncthreads();
+        __threadfence_block();
+        for (int i = tid; i < n; i += PER_T) {
+            const double d = uk[i] - 1.0 * ud[i];  // cancellation_weight = 1.0
+            ur[i] = d > 0.0 ? d : 0.0;
+        }
+        __syncthreads();
+        __threadfence_block();
+    }
+    if (tid == 0) {
+        double chroma[12];
+        for (int i = 0; i < 12; ++i) chroma[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < a.max_voices) {
+                const double pitch = a.fs / voice_per[i];  // quirk A.10: tau is in seconds
+                const double midi = 12.0 * (log2(pitch) - log2(440.0)) + 69.0;
+                if (midi == midi && !isinf(midi)) {  // unused voices: fs/0 = inf -> OverflowError -> skipped (A.13)
+                    const long long note = (long long)nearbyint(midi);
+                    const int pc = (int)(((note % 12) + 12) % 12);
+                    if (!(pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) chroma[pc] += voice_sal[i];  // A.18
+                }
+            }
+        }
+        for (int i = 0; i < 12; ++i) a.chroma[f * 12 + i] = chroma[i];
+    }
+}
+
+// ------------------------------------------------------------------ host side
+struct If0Plan {
+    If0ChanCoef* d_coefs = nullptr;
+    double* d_window = nullptr;
+    cx<double>* d_tw = nullptr;
+    cx<double>* d_twn = nullptr;
+    If0Wfir wf;
+};
+
+int remez_taps_for(mpx_ctx* ctx, int fs, double* c13);  // mpx_esacf.hip
+
+static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan) {
+    char keyb[256];
+    snprintf(keyb, sizeof keyb, "if0_%d_%d_%d_%.17g_%.17g", fs, p.frame_size, p.channels, p.zeta0, p.zeta1);
+    const std::string key = keyb;
+    int rc = remez_taps_for(ctx, fs, plan.wf.c);
+    if (rc) return rc;
+    plan.wf.a = 1.0674 * std::sqrt((2.0 / M_PI) * std::atan(0.06583 * fs / 1000.0)) - 0.1916;
+    auto it = ctx->misc_plans.find(key);
+    if (it != ctx->misc_plans.end()) {
+        plan.d_coefs = (If0ChanCoef*)it->second[0];
+        plan.d_window = (double*)it->second[1];
+        plan.d_tw = (cx<double>*)it->second[2];
+        plan.d_twn = (cx<double>*)it->second[3];
+        return MPX_OK;
+    }
+    std::vector<If0ChanCoef> coefs(p.channels);
+    for (int c = 0; c < p.channels; ++c) {
+        const double fc = 229 * (std::pow(10.0, (p.zeta1 * c + p.zeta0) / 21.4) - 1);  // iterative_f0.py:37-39
+        // _auditory_filterbank(x, fc, fs) is CALLED as (x, fs, fc) (quirk A.1): inside, "fc" is the sample
+        // rate and "fs" is the channel frequency
+        const double in_fc = (double)fs, in_fs = fc;
+        const int J = 4;
+        const double A = std::exp(-(3.0 / J) * M_PI / (in_fs * std::sqrt(std::pow(2.0, 1.0 / J) - 1)));
+        const double cos_theta1 = (1 + A * A) / (2 * A) * std::cos(2 * M_PI * in_fc / in_fs);
+        const double cos_theta2 = (2 * A) / (1 + A * A) * std::cos(2 * M_PI * in_fc / in_fs);
+        const double rho1 = (1.0 / 2) * (1 - A * A);
+        const double rho2 = (1 - A * A) * std::sqrt(1 - cos_theta2 * cos_theta2);
+        If0ChanCoef k;
+        k.r1b0 = rho1;
+        k.r1b2 = -rho1;
+        k.r1a1 = -A * cos_theta1;
+        k.r1a2 = A * A;
+        k.r2b0 = rho2;
+        k.r2a1 = -A * cos_theta2;
+        k.r2a2 = A * A;
+        if (!(fc > 0.0 && fc < fs / 2.0))
+            return set_error(ctx, MPX_EINVAL, "iterative F0: channel %d centre %.1f Hz is outside (0, fs/2): scipy's "
+                             "butter raises ValueError here", c, fc);
+        const double kk = std::tan(M_PI * fc / fs);  // lowpass_filter(yc, fs, fc)
+        const double norm = 1.0 / (1.0 + std::sqrt(2.0) * kk + kk * kk);
+        k.lpb0 = kk * kk * norm;
+        k.lpb1 = 2.0 * kk * kk * norm;
+        k.lpb2 = kk * kk * norm;
+        k.lpa1 = 2.0 * (kk * kk - 1.0) * norm;
+        k.lpa2 = (1.0 - std::sqrt(2.0) * kk + kk * kk) * norm;
+        coefs[c] = k;
+    }
+    const int NF = p.frame_size;
+    std::vector<double> win(NF);
+    for (int i = 0; i < NF; ++i) win[i] = 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (double)(NF - 1));
+    std::vector<cx<double>> tw(NF), twn(NF + 1);
+    for (int j = 0; j < NF; ++j) {
+        const long double ang = -2.0L * M_PIl * j / (long double)NF;
+        tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+    }
+    for (int k = 0; k <= NF; ++k) {
+        const long double ang = -2.0L * M_PIl * k / (long double)(2 * NF);
+        twn[k] = {(double)cosl(ang), (double)sinl(ang)};
+    }
+    plan.d_coefs = (If0ChanCoef*)upload(ctx, coefs.data(), coefs.size() * sizeof(If0ChanCoef));
+    plan.d_window = (double*)upload(ctx, win.data(), win.size() * sizeof(double));
+    plan.d_tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+    plan.d_twn = (cx<double>*)upload(ctx, twn.data(), twn.size() * sizeof(cx<double>));
+    if (!plan.d_coefs || !plan.d_window || !plan.d_tw || !plan.d_twn) return MPX_ENOMEM;
+    ctx->misc_plans[key] = {plan.d_coefs, plan.d_window, plan.d_tw, plan.d_twn};
+    return MPX_OK;
+}
+
+template <int NF, int T>
+static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int channels,
+                               double power, const If0Plan& plan, double* ut, hipStream_t st) {
+    const size_t lds = sizeof(cx<double>) * lds_slots(NF);
+    auto kern = if0_spectrum_kernel<NF, T>;
+    if (lds > 48 * 1024)
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, channels, power, plan.d_window, plan.d_tw,
+                       plan.d_twn, ut);
+    MPX_HIP(ctx, hipGetLastError());
+    return MPX_OK;
+}
+
+// Packed clips on the HOST.  chroma_frames ([F,12], may be NULL), chroma_sums ([C,12], may be NULL),
+// ut ([F, 2*frame], may be NULL) are host buffers.
+int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                 const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out) {
+    mpx_if0_params p = params ? *params
+                              : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66};
+    if (p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192)
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: 2048, 4096, 8192)", p.frame_size);
+    if (p.channels < 1 || p.channels > IF0_MAXCH || p.max_voices < 1 || p.max_voices > 8 || p.Q < 2 || p.Q > 32 || p.M < 2 ||
+        p.M > 64 || !(p.tau_min > 0) || !(p.tau_max > p.tau_min) || fs <= 0)
+        return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
+    const int NF = p.frame_size, n2 = 2 * NF;
+    // periodicity.py indexes Ur up to M*K/tau_min: must stay inside the 2*frame spectrum
+    if ((p.M - 1) * ((double)NF / fs) / p.tau_min + 1.5 >= n2)
+        return set_error(ctx, MPX_EINVAL, "iterative F0: harmonic %d of tau_min falls outside the %d-bin spectrum (the "
+                         "reference raises ValueError on the empty slice)", p.M - 1, n2);
+    If0Plan plan;
+    int rc = if0_plan(ctx, fs, p, plan);
+    if (rc) return rc;
+
+    // chunks and frames
+    std::vector<If0Chunk> chunks;
+    std::vector<If0Frame> frames;
+    std::vector<long long> seg(1, 0);
+    for (int c = 0; c < num_clips; ++c) {
+        const int64_t len = offsets[c + 1] - offsets[c];
+        if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
+        const int64_t nfr = len <= 0 ? 0 : (len + NF - 1) / NF;
+        for (int64_t t0 = 0; t0 < nfr * NF; t0 += IF0_CHUNK) {
+            If0Chunk ck;
+            ck.sig_start = offsets[c] + t0;
+            ck.clip_start = offsets[c];
+            const int64_t want = nfr * NF - t0;            // produce whole frames (zero input beyond the clip)
+            ck.len = (int)(want < IF0_CHUNK ? want : IF0_CHUNK);
+            const int64_t left = len - t0;
+            ck.clip_left = (int)(left > IF0_CHUNK + IF0_WARMUP ? IF0_CHUNK + IF0_WARMUP : (left > 0 ? left : 0));
+            ck.warm = (int)(t0 < IF0_WARMUP ? t0 : IF0_WARMUP);
+            ck.pad = 0;
+            const long long chunk_id = (long long)chunks.size();
+            chunks.push_back(ck);
+            for (int64_t fo = 0; fo < ck.len; fo += NF) {
+                If0Frame fr;
+                fr.yc_row = chunk_id * IF0_CHUNK + fo;
+                const int64_t fl = len - (t0 + fo);
+                fr.valid = (int)(fl >= NF ? NF : (fl > 0 ? fl : 0));
+                fr.clip = c;
+                frames.push_back(fr);
+            }
+        }
+        seg.push_back((long long)frames.size());
+    }
+    const long long nframes = (long long)frames.size(), nchunks = (long long)chunks.size();
+    const int64_t total = offsets[num_clips];
+    hipStream_t st = ctx->stream;
+    if (nframes == 0) {
+        if (chroma_sums) std::memset(chroma_sums, 0, (size_t)num_clips * 12 * sizeof(double));
+        return MPX_OK;
+    }
+    // the [t][channel] buffer of the front end is the big one: 560 B per sample at 70 channels
+    const size_t yc_bytes = (size_t)nchunks * IF0_CHUNK * p.channels * sizeof(double);
+    if (yc_bytes > ((size_t)96 << 30))
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: %lld chunks need %zu GiB of workspace; split the call", nchunks,
+                         yc_bytes >> 30);
+    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + IF0_WARMUP * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ws1, (size_t)nframes * n2 * sizeof(double) * 3))) return rc;   // ut | ur | ud
+    if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + frames.size() * sizeof(If0Frame) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * 12 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
+    If0Chunk* d_chunks = (If0Chunk*)ctx->d_desc.p;
+    If0Frame* d_frames = (If0Frame*)((char*)ctx->d_desc.p + ((chunks.size() * sizeof(If0Chunk) + 15) & ~(size_t)15));
+    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyHostToDevice, st));
+    MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
+    MPX_HIP(ctx, hipMemcpyAsync(d_frames, frames.data(), frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
+    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    double* yc = (double*)ctx->d_ws0.p;
+    double* ut = (double*)ctx->d_ws1.p;
+    double* ur = ut + (size_t)nframes * n2;
+    double* ud = ur + (size_t)nframes * n2;
+    const long long items = nchunks * p.channels;
+    hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, (const float*)ctx->d_signal.p,
+                       d_chunks, items, p.channels, plan.d_coefs, plan.wf, yc);
+    MPX_HIP(ctx, hipGetLastError());
+    if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
+    else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
+    else rc = if0_spectrum_launch<8192, 512>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
+    if (rc) return rc;
+    if (ut_out) MPX_HIP(ctx, hipMemcpyAsync(ut_out, ut, (size_t)nframes * n2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    If0PerArgs a;
+    a.ut = ut;
+    a.ur = ur;
+    a.ud = ud;
+    a.n = n2;
+    a.fs = (double)fs;
+    a.K = (double)NF / (double)fs;
+    a.wsize = (double)NF;
+    a.max_voices = p.max_voices;
+    a.Q = p.Q;
+    a.M = p.M;
+    a.tau_min = p.tau_min;
+    a.tau_max = p.tau_max;
+    a.tau_prec = p.tau_prec;
+    a.epsilon1 = p.epsilon1;
+    a.epsilon2 = p.epsilon2;
+    a.gamma = p.gamma;
+    a.chroma = (double*)ctx->d_frames_out.p;
+    hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    MPX_HIP(ctx, hipGetLastError());
+    if (chroma_frames)
+        MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nframes * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (chroma_sums) {
+        if ((rc = segment_sum(ctx, (const double*)ctx->d_frames_out.p, (const long long*)ctx->d_offsets.p, num_clips, nframes,
+                              (double*)ctx->d_sum.p, st)))
+            return rc;
+        MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    MPX_HIP(ctx, hipStreamSynchronize(st));
+    return MPX_OK;
+}
+
+}  // namespace mpx

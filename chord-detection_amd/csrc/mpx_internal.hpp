@@ -83,6 +83,8 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
               int64_t num_frames, int fs, const mpx_esacf_params* params, int frame, int hop,
               double* d_chroma_frames, int stage, double* d_stage_out, hipStream_t stream);
 
+int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                 const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out);
 int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                    const mpx_prime_params* params, double* chroma_sums);
 

@@ -177,6 +177,49 @@ class Engine:
                                              C.byref(p), int(frame), hop, out.ctypes.data_as(_lib._dp)))
         return out
 
+    # ------------------------------------------------------------- method 3
+    @staticmethod
+    def _if0_params(frame_size=8192, power=1.0, channels=70, zeta0=2.3, zeta1=0.39, max_voices=4,
+                    tau_min=1.0 / 2100.0, tau_max=1.0 / 40.0, tau_prec=0.0000001, Q=20, M=20, epsilon1=20,
+                    epsilon2=320, gamma=0.66):
+        return _lib.If0Params(int(frame_size), float(power), int(channels), float(zeta0), float(zeta1),
+                              int(max_voices), float(tau_min), float(tau_max), float(tau_prec), int(Q), int(M),
+                              float(epsilon1), float(epsilon2), float(gamma))
+
+    def iterative_f0(self, x, fs, return_frames=False, **kw):
+        x = self._sig(x)
+        p = self._if0_params(**kw)
+        self._ensure_remez(fs)
+        nf = max(self.num_frames(x.shape[0], p.frame_size, p.frame_size), 0)
+        total = np.zeros(12, dtype=np.float64)
+        frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
+        self._check(self.lib.mpx_iterative_f0(
+            self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p),
+            frames.ctypes.data_as(_lib._dp) if return_frames and nf else None, total.ctypes.data_as(_lib._dp)))
+        return (total, frames) if return_frames else total
+
+    def iterative_f0_batch(self, clips, fs, **kw):
+        flat, offsets = self._pack(clips)
+        p = self._if0_params(**kw)
+        self._ensure_remez(fs)
+        out = np.zeros((len(offsets) - 1, 12), dtype=np.float64)
+        self._check(self.lib.mpx_iterative_f0_batch(
+            self.ctx, flat.ctypes.data_as(_lib._fp), offsets.ctypes.data_as(_lib._ip), len(offsets) - 1, int(fs),
+            C.byref(p), out.ctypes.data_as(_lib._dp)))
+        return out
+
+    def iterative_f0_spectra(self, x, fs, **kw):
+        """Summary spectra Ut [F, 2*frame_size] (iterative_f0.py:80-85), for parity tests."""
+        x = self._sig(x)
+        p = self._if0_params(**kw)
+        self._ensure_remez(fs)
+        nf = max(self.num_frames(x.shape[0], p.frame_size, p.frame_size), 0)
+        ut = np.zeros((nf, 2 * p.frame_size), dtype=np.float64)
+        if nf:
+            self._check(self.lib.mpx_iterative_f0_spectra(self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs),
+                                                          C.byref(p), ut.ctypes.data_as(_lib._dp)))
+        return ut
+
     # ------------------------------------------------------------- method 4
     def prime_multif0(self, x, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5, harmonic_elim_runs=2):
         x = self._sig(x)

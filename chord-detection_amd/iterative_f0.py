@@ -1,0 +1,56 @@
+"""Method 3 -- drop-in for reference iterative_f0.py:20-96 (+ periodicity.py), HIP-backed."""
+import math
+
+from .chromagram import Chromagram
+from .engine import get_engine
+from .multipitch import Multipitch
+
+
+class MultipitchIterativeF0(Multipitch):
+    def __init__(
+        self,
+        audio_path,
+        frame_size=8192,
+        power=1.0,
+        channels=70,
+        zeta0=2.3,
+        zeta1=0.39,
+        peak_thresh=0.5,
+        peak_min_dist=10,
+        harmonic_multiples_elim=5,
+        fs=None,
+        device=0,
+    ):
+        super().__init__(audio_path, fs=fs, device=device)
+        self.frame_size = frame_size
+        self.num_frames = math.ceil(self.x.shape[0] / self.frame_size)
+        self.power = power
+        self.num_channels = channels
+        self.zeta0, self.zeta1 = zeta0, zeta1
+        self.channels = [
+            229 * (10 ** ((zeta1 * c + zeta0) / 21.4) - 1) for c in range(channels)
+        ]
+        # accepted for signature parity; the reference never reads them (iterative_f0.py:40-42)
+        self.peak_thresh = peak_thresh
+        self.peak_min_dist = peak_min_dist
+        self.harmonic_multiples_elim = harmonic_multiples_elim
+
+    @staticmethod
+    def display_name():
+        return "Iterative F0 (Klapuri, Anssi)"
+
+    @staticmethod
+    def method_number():
+        return 3
+
+    def compute_pitches(self, display_plot_frame=-1):
+        total = get_engine(self.device).iterative_f0(
+            self.x, self.fs, frame_size=self.frame_size, power=self.power, channels=self.num_channels,
+            zeta0=self.zeta0, zeta1=self.zeta1)
+        return Chromagram(total)
+
+    @classmethod
+    def compute_batch(cls, clips, fs, frame_size=8192, power=1.0, channels=70, zeta0=2.3, zeta1=0.39, device=0):
+        sums = get_engine(device).iterative_f0_batch(clips, fs, frame_size=frame_size, power=power,
+                                                     channels=channels, zeta0=zeta0, zeta1=zeta1)
+        return [Chromagram(s) for s in sums]

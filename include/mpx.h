@@ -140,6 +140,40 @@ int mpx_prime_multif0(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
 int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips,
                             int fs, const mpx_prime_params* params, double* chroma_sums);
 
+/* ---- Iterative F0 (method 3): iterative_f0.py:21-33, periodicity.py:15-28 kwargs ----
+ * replaces iterative_f0.py:54-96 + periodicity.py:48-163: 70-channel resonator filterbank over the
+ * WHOLE signal (quirk A.1 kept), warped-FIR compression, full-wave rectifier, (y + LP(y, fc))/2,
+ * frames of `frame_size` (2048/4096/8192) x Hamming zero-padded to 2*frame_size, sum over channels of
+ * |FFT|^power, then the iterative period search / harmonic cancellation per frame.
+ * Long signals are filtered in 262144-sample chunks with a 65536-sample zero-state warm-up (every pole
+ * of the chain has decayed below 1e-30 by then), so chunks run in parallel and shard across GPUs. */
+typedef struct mpx_if0_params {
+    int frame_size;      /* default 8192 */
+    double power;        /* default 1.0 */
+    int channels;        /* default 70 */
+    double zeta0;        /* default 2.3 */
+    double zeta1;        /* default 0.39 */
+    int max_voices;      /* default 4 (<= 8) */
+    double tau_min;      /* default 1/2100 */
+    double tau_max;      /* default 1/40 */
+    double tau_prec;     /* default 1e-7 */
+    int Q;               /* default 20 (<= 32) */
+    int M;               /* default 20 (<= 64) */
+    double epsilon1;     /* default 20 */
+    double epsilon2;     /* default 320 */
+    double gamma;        /* default 0.66 */
+} mpx_if0_params;
+
+int mpx_iterative_f0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,
+                     double* chroma_frames /* [F,12] or NULL */, double* chroma_sum /* [12] */);
+
+int mpx_iterative_f0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
+                           const mpx_if0_params* params, double* chroma_sums /* [C,12] */);
+
+/* Debug tap: summary spectra Ut [F, 2*frame_size] (iterative_f0.py:80-85), host buffers. */
+int mpx_iterative_f0_spectra(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,
+                             double* ut);
+
 /* Debug taps for parity tests: per-frame intermediates of the ESACF chain,
  * host buffers, each [F, len]:
  *   MPX_STAGE_WFIR  len = frame            dsp/wfir.py:25-43

@@ -331,6 +331,25 @@ def main():
     pr["kwargs_h2_o3_e3_r3/sum"] = np.array([c[i] for i in range(12)])
     np.testing.assert_allclose(o_prime.prime_compute(clips["poly_seed1"], fs, 2, 3, 3, 3), pr["kwargs_h2_o3_e3_r3/sum"], rtol=1e-12)
     np.savez_compressed(os.path.join(HERE, "prime_multif0.npz"), **pr)
+
+    # ------------------------------------------------------ Iterative F0 (ref-code: only closed-form librosa helpers)
+    from oracle import iterative_f0 as o_if0
+    it = {"provenance": np.array("ref-code")}
+    for name in ("tone_E4", "tones_G2_B2_Gsharp3", "piano_like_Cmaj", "poly_seed1", "poly_seed2", "short_ragged"):
+        x = clips[name]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            obj = chord_detection.MultipitchIterativeF0(name)
+            total = obj.compute_pitches()
+            it[name + "/sum"] = np.array([total[i] for i in range(12)])
+            it[name + "/repr"] = np.array(repr(total))
+            it[name + "/key"] = np.array(total.key())
+            per, Ut = o_if0.iterative_f0_frames(x, fs)
+            np.testing.assert_allclose(per.sum(0), it[name + "/sum"], rtol=1e-12, atol=0)
+        # a thin slice of the summary spectrum of frame 0 (full rows are 16384 doubles each)
+        it[name + "/ut0_head"] = Ut[0][:512].copy()
+        it[name + "/frames"] = per
+    np.savez_compressed(os.path.join(HERE, "iterative_f0.npz"), **it)
     print("golden fixtures written to", HERE)
 
 

@@ -197,3 +197,21 @@ def test_prime_multif0(golden_dir, clips):
                                    d["kwargs_h2_o3_e3_r3/sum"], rtol=1e-12)
     ws = [w for _, w in o_prime.candidates(FS)]
     assert min(ws) == 357 and max(ws) == 1348 and len(ws) == 24
+
+
+def test_iterative_f0(golden_dir, clips):
+    """Method 3 (next-tier row f1): pinned by the reference's own code (only closed-form librosa helpers
+    stood in)."""
+    from oracle import iterative_f0 as o_if0
+    d = np.load(os.path.join(golden_dir, "iterative_f0.npz"))
+    assert str(d["provenance"]) == "ref-code"
+    for name in ("tone_E4", "short_ragged"):   # two clips keep the CPU suite short; the GPU suite covers all six
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            per, Ut = o_if0.iterative_f0_frames(clips[name], FS)
+        np.testing.assert_allclose(per, d[name + "/frames"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(per.sum(0), d[name + "/sum"], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(Ut[0][:512], d[name + "/ut0_head"], rtol=1e-12)
+        assert o_chroma.pack(per.sum(0)) == str(d[name + "/repr"])
+    fc = o_if0.channel_frequencies()
+    assert len(fc) == 70 and 64 < fc[0] < 65 and 5000 < fc[-1] < 5100
