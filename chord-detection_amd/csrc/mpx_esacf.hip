@@ -30,58 +30,101 @@ struct BandCoef {
 };
 
 // ------------------------------------------------------------------ kernel 1
+// One lane per frame runs the sample-serial IIR chain; a wave owns 64 consecutive frames.  Input and the
+// two outputs move through LDS tiles of 64 frames x 16 samples so that global traffic is row segments
+// (64 B in, 128 B out per frame and tile) instead of one isolated element per lane: lanes 16r..16r+15 of
+// a transfer instruction cover 16 consecutive samples of frame r.  Tile rows are padded to 17 elements:
+// conflict free both for the per-lane row walk and for the row-segment transfers.
+constexpr int BS_TILE = 16;
+
+template <bool XW>
 __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__ sig, long long n,
                                                        const FrameDesc* __restrict__ desc, long long frame0,
                                                        long long num_frames, int N, int hop, BandCoef k,
                                                        double* __restrict__ xlo, double* __restrict__ xhi,
                                                        double* __restrict__ xw) {
-    const long long lf = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // frame within this batch
-    if (lf >= num_frames) return;
-    const long long f = frame0 + lf;
-    long long start;
-    int valid;
-    if (desc) {
-        start = desc[f].start;
-        valid = desc[f].valid;
-    } else {
-        start = f * (long long)hop;
-        const long long left = n - start;
-        valid = left >= N ? N : (left > 0 ? (int)left : 0);
+    __shared__ float tin[64][BS_TILE + 1];
+    __shared__ double tlo[64][BS_TILE + 1];
+    __shared__ double thi[64][BS_TILE + 1];
+    __shared__ double twf[XW ? 64 : 1][BS_TILE + 1];
+    __shared__ long long row_start[64];
+    __shared__ int row_valid[64];
+    const int lane = threadIdx.x;
+    const long long lf0 = (long long)blockIdx.x * 64;  // first frame (within this batch) of the wave
+    {
+        const long long lf = lf0 + lane;
+        long long start = 0;
+        int valid = 0;
+        if (lf < num_frames) {
+            const long long f = frame0 + lf;
+            if (desc) {
+                start = desc[f].start;
+                valid = desc[f].valid;
+            } else {
+                start = f * (long long)hop;
+                const long long left = n - start;
+                valid = left >= N ? N : (left > 0 ? (int)left : 0);
+            }
+        }
+        row_start[lane] = start;
+        row_valid[lane] = valid;
     }
-    const float* __restrict__ x = sig + start;
+    __syncthreads();
     double z[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) z[i] = 0.0;
     double h1 = 0, h2 = 0, g1 = 0, g2 = 0, l1 = 0, l2 = 0;
-    const long long base = lf * (long long)N;
-    for (int t = 0; t < N; ++t) {
-        const double xt = t < valid ? (double)x[t] : 0.0;
-        // warped FIR: ys[i] = allpass(ys[i-1]); x_hat = c0*x + sum c[i+1]*ys[i]
-        double xhat = k.c[0] * xt;
-        double in = xt;
+    for (int t0 = 0; t0 < N; t0 += BS_TILE) {
+        // ---- stage in: 4 frame rows x 16 samples per instruction
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const double y = -k.a * in + z[i];  // b0*x + z
-            z[i] = in + k.a * y;                // b1*x - a1*y with b1 = 1, a1 = -a
-            in = y;
-            xhat += k.c[i + 1] * y;
+        for (int q = 0; q < BS_TILE; ++q) {
+            const int e = q * 64 + lane, r = e >> 4, c = e & 15;
+            const int t = t0 + c;
+            tin[r][c] = t < row_valid[r] ? sig[row_start[r] + t] : 0.f;
         }
-        const double r = xt - xhat;
-        // high-pass -> half-wave rectification -> low-pass
-        const double yh = k.hpb[0] * r + h1;
-        h1 = (h2 + k.hpb[1] * r) - k.hpa[1] * yh;
-        h2 = k.hpb[2] * r - k.hpa[2] * yh;
-        const double rect = yh < 0.0 ? 0.0 : yh;
-        const double yhl = k.lpb[0] * rect + g1;
-        g1 = (g2 + k.lpb[1] * rect) - k.lpa[1] * yhl;
-        g2 = k.lpb[2] * rect - k.lpa[2] * yhl;
-        // low-pass
-        const double yl = k.lpb[0] * r + l1;
-        l1 = (l2 + k.lpb[1] * r) - k.lpa[1] * yl;
-        l2 = k.lpb[2] * r - k.lpa[2] * yl;
-        xlo[base + t] = yl;
-        xhi[base + t] = yhl;
-        if (xw) xw[base + t] = r;
+        __syncthreads();
+        // ---- this lane's frame: BS_TILE samples of the chain
+#pragma unroll 4
+        for (int j = 0; j < BS_TILE; ++j) {
+            const double xt = (double)tin[lane][j];
+            double xhat = k.c[0] * xt;
+            double in = xt;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const double y = -k.a * in + z[i];  // b0*x + z
+                z[i] = in + k.a * y;                // b1*x - a1*y with b1 = 1, a1 = -a
+                in = y;
+                xhat += k.c[i + 1] * y;
+            }
+            const double r = xt - xhat;
+            const double yh = k.hpb[0] * r + h1;
+            h1 = (h2 + k.hpb[1] * r) - k.hpa[1] * yh;
+            h2 = k.hpb[2] * r - k.hpa[2] * yh;
+            const double rect = yh < 0.0 ? 0.0 : yh;
+            const double yhl = k.lpb[0] * rect + g1;
+            g1 = (g2 + k.lpb[1] * rect) - k.lpa[1] * yhl;
+            g2 = k.lpb[2] * rect - k.lpa[2] * yhl;
+            const double yl = k.lpb[0] * r + l1;
+            l1 = (l2 + k.lpb[1] * r) - k.lpa[1] * yl;
+            l2 = k.lpb[2] * r - k.lpa[2] * yl;
+            tlo[lane][j] = yl;
+            thi[lane][j] = yhl;
+            if (XW) twf[lane][j] = r;
+        }
+        __syncthreads();
+        // ---- stage out: 128-byte row segments
+#pragma unroll
+        for (int q = 0; q < BS_TILE; ++q) {
+            const int e = q * 64 + lane, r = e >> 4, c = e & 15;
+            const int t = t0 + c;
+            if (t < N && lf0 + r < num_frames) {
+                const long long o = (lf0 + r) * (long long)N + t;
+                xlo[o] = tlo[r][c];
+                xhi[o] = thi[r][c];
+                if (XW) xw[o] = twf[r][c];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1039,8 +1082,12 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     for (long long f0 = 0; f0 < num_frames; f0 += batch) {
         const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
         double* xw = (stage == MPX_STAGE_WFIR) ? d_stage_out + (size_t)f0 * N : nullptr;
-        hipLaunchKernelGGL(bandsplit_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
-                           (long long)n, d_desc, f0, nf, N, hop, coef, xlo, xhi, xw);
+        if (xw)
+            hipLaunchKernelGGL(bandsplit_kernel<true>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
+                               (long long)n, d_desc, f0, nf, N, hop, coef, xlo, xhi, xw);
+        else
+            hipLaunchKernelGGL(bandsplit_kernel<false>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
+                               (long long)n, d_desc, f0, nf, N, hop, coef, xlo, xhi, xw);
         MPX_HIP(ctx, hipGetLastError());
         if (stage == MPX_STAGE_XLO || stage == MPX_STAGE_XHI)
             MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * N, stage == MPX_STAGE_XLO ? xlo : xhi,
