@@ -40,6 +40,7 @@ struct If0Chunk {
     int clip_left;         // samples of the clip from sig_start on (>= len unless the clip ends inside)
     int warm;              // run-in samples before sig_start (0 at the start of a clip)
     int pad;
+    long long yc_row0;     // first row of this chunk in the [t][channel] output buffer
 };
 
 struct If0Wfir {
@@ -57,44 +58,84 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     const int ch = (int)(w - ck * channels);
     const If0Chunk c = chunks[ck];
     const If0ChanCoef k = coefs[ch];
+    // The chain is 17 filter stages deep (4 resonators, 12 all-passes, rectifier + low-pass).  Evaluated
+    // sample by sample it is ONE dependent chain of ~20 fp64 operations per step, and a lone wave pays the
+    // full FMA latency on each.  Software pipelining across samples removes that: in iteration tau stage j
+    // works on sample tau - j, reading what stage j-1 produced one iteration earlier.  All 17 stage updates
+    // of an iteration are then independent of each other (stages are walked in reverse so that an input is
+    // consumed before it is overwritten).  Every stage performs exactly the operations of the sequential
+    // form on exactly the same operands, so results are bit-identical; only the schedule changes.
     double a1 = 0, a2 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, d1 = 0, d2 = 0, l1 = 0, l2 = 0;
-    double z[12];
+    double z[12], pin[12], pso[12], pxh[12];   // all-pass state; pipeline registers feeding all-pass i
 #pragma unroll
-    for (int i = 0; i < 12; ++i) z[i] = 0.0;
+    for (int i = 0; i < 12; ++i) z[i] = pin[i] = pso[i] = pxh[i] = 0.0;
+    double qy = 0, qu = 0, qv = 0;             // inputs of resonator stages 1..3
+    double fso = 0, fxh = 0;                   // input of the final stage
+    constexpr int DEPTH = 16;                  // output of sample n appears in iteration n + DEPTH
     const float* __restrict__ x = sig + c.sig_start;
-    double* __restrict__ out = yc + (size_t)ck * IF0_CHUNK * channels + ch;
-    for (int t = -c.warm; t < c.len; ++t) {
-        const double xt = t < c.clip_left ? (double)x[t] : 0.0;
-        // resonator 1 twice (DF2T, like scipy.signal.lfilter)
-        double y = k.r1b0 * xt + a1;
-        a1 = a2 - k.r1a1 * y;               // b1 = 0
-        a2 = k.r1b2 * xt - k.r1a2 * y;
-        double u = k.r1b0 * y + b1;
-        b1 = b2 - k.r1a1 * u;
-        b2 = k.r1b2 * y - k.r1a2 * u;
-        // resonator 2 twice
-        double v = k.r2b0 * u + c1;
-        c1 = c2 - k.r2a1 * v;
-        c2 = -k.r2a2 * v;
-        double s = k.r2b0 * v + d1;
-        d1 = d2 - k.r2a1 * s;
-        d2 = -k.r2a2 * s;
-        // warped FIR residual (dsp/wfir.py:25-43)
-        double xhat = wf.c[0] * s;
-        double in = s;
+    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + ch;
+    constexpr int PF = 8;
+    for (int tb = -c.warm; tb < c.len + DEPTH; tb += PF) {
+        float xs[PF];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const double o = -wf.a * in + z[i];
-            z[i] = in + wf.a * o;
-            in = o;
-            xhat += wf.c[i + 1] * o;
+        for (int q = 0; q < PF; ++q) xs[q] = (tb + q < c.clip_left && tb + q < c.len) ? x[tb + q] : 0.f;
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int tau = tb + q;
+            // ---- final stage (sample tau-16): residual, full-wave rectifier, low-pass, average
+            {
+                double r = fso - fxh;
+                r = r < 0.0 ? -r : r;
+                const double lp = k.lpb0 * r + l1;
+                l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
+                l2 = k.lpb2 * r - k.lpa2 * lp;
+                const int t = tau - DEPTH;
+                if (t >= 0 && t < c.len) out[(size_t)t * channels] = (r + lp) / 2.0;
+            }
+            // ---- all-pass stages 11..0 (samples tau-15 .. tau-4), dsp/wfir.py:25-43
+            {
+                const double o = -wf.a * pin[11] + z[11];
+                z[11] = pin[11] + wf.a * o;
+                fso = pso[11];
+                fxh = pxh[11] + wf.c[12] * o;
+            }
+#pragma unroll
+            for (int i = 10; i >= 0; --i) {
+                const double o = -wf.a * pin[i] + z[i];
+                z[i] = pin[i] + wf.a * o;
+                pin[i + 1] = o;
+                pso[i + 1] = pso[i];
+                pxh[i + 1] = pxh[i] + wf.c[i + 1] * o;
+            }
+            // ---- resonator 2 twice, resonator 1 twice (samples tau-3 .. tau), DF2T like scipy.signal.lfilter
+            {
+                const double sres = k.r2b0 * qv + d1;
+                d1 = d2 - k.r2a1 * sres;
+                d2 = -k.r2a2 * sres;
+                pin[0] = sres;
+                pso[0] = sres;
+                pxh[0] = wf.c[0] * sres;
+            }
+            {
+                const double v = k.r2b0 * qu + c1;
+                c1 = c2 - k.r2a1 * v;
+                c2 = -k.r2a2 * v;
+                qv = v;
+            }
+            {
+                const double u = k.r1b0 * qy + b1;
+                b1 = b2 - k.r1a1 * u;
+                b2 = k.r1b2 * qy - k.r1a2 * u;
+                qu = u;
+            }
+            {
+                const double xt = (double)xs[q];
+                const double y = k.r1b0 * xt + a1;
+                a1 = a2 - k.r1a1 * y;
+                a2 = k.r1b2 * xt - k.r1a2 * y;
+                qy = y;
+            }
         }
-        double r = s - xhat;
-        r = r < 0.0 ? -r : r;               // full-wave rectification (iterative_f0.py:60)
-        const double lp = k.lpb0 * r + l1;
-        l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
-        l2 = k.lpb2 * r - k.lpa2 * lp;
-        if (t >= 0) out[(size_t)t * channels] = (r + lp) / 2.0;
     }
 }
 
@@ -451,6 +492,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     std::vector<If0Chunk> chunks;
     std::vector<If0Frame> frames;
     std::vector<long long> seg(1, 0);
+    long long yc_rows = 0;
     for (int c = 0; c < num_clips; ++c) {
         const int64_t len = offsets[c + 1] - offsets[c];
         if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
@@ -465,11 +507,12 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             ck.clip_left = (int)(left > IF0_CHUNK + IF0_WARMUP ? IF0_CHUNK + IF0_WARMUP : (left > 0 ? left : 0));
             ck.warm = (int)(t0 < IF0_WARMUP ? t0 : IF0_WARMUP);
             ck.pad = 0;
-            const long long chunk_id = (long long)chunks.size();
+            ck.yc_row0 = yc_rows;
+            yc_rows += ck.len;
             chunks.push_back(ck);
             for (int64_t fo = 0; fo < ck.len; fo += NF) {
                 If0Frame fr;
-                fr.yc_row = chunk_id * IF0_CHUNK + fo;
+                fr.yc_row = ck.yc_row0 + fo;
                 const int64_t fl = len - (t0 + fo);
                 fr.valid = (int)(fl >= NF ? NF : (fl > 0 ? fl : 0));
                 fr.clip = c;
@@ -486,7 +529,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         return MPX_OK;
     }
     // the [t][channel] buffer of the front end is the big one: 560 B per sample at 70 channels
-    const size_t yc_bytes = (size_t)nchunks * IF0_CHUNK * p.channels * sizeof(double);
+    const size_t yc_bytes = (size_t)yc_rows * p.channels * sizeof(double);
     if (yc_bytes > ((size_t)96 << 30))
         return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: %lld chunks need %zu GiB of workspace; split the call", nchunks,
                          yc_bytes >> 30);
