@@ -53,6 +53,7 @@ struct mpx_ctx {
     std::map<std::string, std::vector<void*>> misc_plans;
     // grow-only device workspaces
     mpx::DevBuf d_signal, d_frames_out, d_partials, d_sum, d_desc, d_offsets, d_ws0, d_ws1, d_ws2, d_ws3, d_counter;
+    std::map<std::string, std::vector<unsigned char>> host_blobs;  // host copies of plan records, per context
     std::map<std::string, int> occupancy;      // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answers
     std::map<int, std::vector<double>> remez;  // user-registered warped-FIR taps per sample rate
     std::vector<void*> owned;  // plan tables, freed in mpx_destroy

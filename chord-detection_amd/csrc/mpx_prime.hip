@@ -7,6 +7,7 @@
 // (prime_multif0.py:66-82).  Every item writes its <= runs (pitch class, value) pairs to a fixed slot;
 // one workgroup per clip adds them up in item order (deterministic).
 #include <cmath>
+#include <cstring>
 
 #include "mpx_fft.hpp"
 #include "mpx_internal.hpp"
@@ -167,16 +168,19 @@ struct PrimePlan {
     PrimeCand* d_cands = nullptr;
 };
 
-static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan*& out) {
-    static std::map<std::string, PrimePlan> plans;  // keyed per context below
-    const std::string key = std::to_string((uintptr_t)ctx) + "_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) +
-                            "_" + std::to_string(p.num_octave);
-    auto it = plans.find(key);
-    if (it != plans.end()) {
-        out = &it->second;
+// Plans live in the context (host copy of the candidate records in ctx->host_blobs, device tables in
+// ctx->owned) and die with it.
+static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan& plan) {
+    const std::string key = "prime_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
+                            std::to_string(p.num_octave);
+    auto bit = ctx->host_blobs.find(key);
+    if (bit != ctx->host_blobs.end()) {
+        const size_t cnt = bit->second.size() / sizeof(PrimeCand);
+        plan.cands.resize(cnt);
+        memcpy(plan.cands.data(), bit->second.data(), cnt * sizeof(PrimeCand));
+        plan.d_cands = (PrimeCand*)ctx->misc_plans[key][0];
         return MPX_OK;
     }
-    PrimePlan plan;
     const double c3 = 440.0 * std::pow(2.0, (48.0 - 69.0) / 12.0);
     std::map<int, void*> twl;
     for (int n = 0; n < 12; ++n) {
@@ -234,7 +238,10 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
     }
     plan.d_cands = (PrimeCand*)upload(ctx, plan.cands.data(), plan.cands.size() * sizeof(PrimeCand));
     if (!plan.d_cands) return MPX_ENOMEM;
-    out = &plans.emplace(key, plan).first->second;
+    std::vector<unsigned char> blob(plan.cands.size() * sizeof(PrimeCand));
+    memcpy(blob.data(), plan.cands.data(), blob.size());
+    ctx->host_blobs[key] = std::move(blob);
+    ctx->misc_plans[key] = {plan.d_cands};
     return MPX_OK;
 }
 
@@ -256,9 +263,10 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         p.harmonic_multiples_elim > 64 || p.harmonic_elim_runs < 0 || p.harmonic_elim_runs > PRIME_MAX_RUNS)
         return set_error(ctx, MPX_EINVAL, "bad prime-multiF0 params");
     if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
-    PrimePlan* plan = nullptr;
-    int rc = prime_plan(ctx, fs, p, plan);
+    PrimePlan plan_storage;
+    int rc = prime_plan(ctx, fs, p, plan_storage);
     if (rc) return rc;
+    PrimePlan* plan = &plan_storage;
     const int64_t total = offsets[num_clips];
     // items in the reference's loop order per clip: candidate-major, then frame
     std::vector<PrimeItem> items[3];
