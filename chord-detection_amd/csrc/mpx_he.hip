@@ -240,29 +240,34 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
             const cx<Real> X = cadd(E, mul_mi(cmul(a.twn[k], D)));
             mag[i] = sqrt(sqrt(X.x * X.x + X.y * X.y));
         }
-        __syncthreads();
-        // half-open window maxima (harmonic_energy.py:58-62)
-        for (int wi = tid; wi < a.nwin; wi += T) {
-            Real m = -INFINITY;
-            for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) {
-                const Real v = mag[k - a.kmin];
-                m = v > m ? v : m;
+        __syncthreads();  // mag[] complete, and nobody reads buf any more: the next frame may overwrite it
+        // Window maxima and pitch-class sums by wave 0 alone: its LDS traffic is ordered by the wave's own
+        // in-order LDS pipeline, so no further workgroup barrier is needed and waves 1..3 run ahead into the
+        // next frame (they meet wave 0 again at that frame's first barrier, before mag[] is rewritten).
+        if (tid < 64) {
+            for (int wi = tid; wi < a.nwin; wi += 64) {  // half-open window maxima (harmonic_energy.py:58-62)
+                Real m = -INFINITY;
+                for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) {
+                    const Real v = mag[k - a.kmin];
+                    m = v > m ? v : m;
+                }
+                winmax[wi] = m;
             }
-            winmax[wi] = m;
-        }
-        __syncthreads();
-        // chroma[n] = sum_octave ( sum_harmonic max/h ), same association as the reference
-        if (tid < 12) {
-            double chroma = 0.0;
-            const int base = tid * a.wins_per_note;
-            for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
-                double note_sum = 0.0;
-                for (int h = 0; h < a.num_harmonic; ++h)
-                    note_sum += (double)winmax[base + o + h] * (double)a.ww[base + o + h];
-                chroma += note_sum;
+            wave_lds_fence();
+            // chroma[n] = sum_octave ( sum_harmonic max/h ), same association as the reference
+            if (tid < 12) {
+                double chroma = 0.0;
+                const int base = tid * a.wins_per_note;
+                for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
+                    double note_sum = 0.0;
+                    for (int h = 0; h < a.num_harmonic; ++h)
+                        note_sum += (double)winmax[base + o + h] * (double)a.ww[base + o + h];
+                    chroma += note_sum;
+                }
+                if (a.out) a.out[f * 12 + tid] = chroma;
+                acc += chroma;
             }
-            if (a.out) a.out[f * 12 + tid] = chroma;
-            acc += chroma;
+            wave_lds_fence();
         }
         // the next iteration's first LDS write (pass 1) is ordered after this iteration's last
         // LDS read of buf by the two barriers above; winmax/mag are rewritten only after the
