@@ -173,19 +173,62 @@ __device__ __forceinline__ void dft_n(cx<double>* buf, const SacfArgs& a, cx<dou
     }
 }
 
-// Inclusive Hillis-Steele scans over T ints in LDS (T a power of two).
+// Inclusive scan (sum or max) over T ints, one per thread, by position `pos` (pos == tid, or
+// pos == T-1-tid for a scan that runs from the last thread to the first).  Wave-level shuffle scan +
+// one LDS hop across the T/64 waves: two workgroup barriers instead of the 3*log2(T) of a
+// Hillis-Steele scan in LDS.  On return sh[p] holds the inclusive result of position p for every p.
 template <int T, bool MAXOP>
-__device__ __forceinline__ int block_scan(int* sh, int v, int tid) {
-    sh[tid] = v;
-    __syncthreads();
-    for (int off = 1; off < T; off <<= 1) {
-        int o = tid >= off ? sh[tid - off] : (MAXOP ? -0x7fffffff : 0);
-        __syncthreads();
-        v = MAXOP ? (o > v ? o : v) : v + o;
-        sh[tid] = v;
-        __syncthreads();
+__device__ __forceinline__ int block_scan(int* sh, int v, int pos) {
+    __shared__ int wave_tot[T / 64 > 0 ? T / 64 : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool rev = pos != tid;            // uniform
+    const int ident = MAXOP ? -0x7fffffff : 0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = rev ? __shfl_down(v, off) : __shfl_up(v, off);
+        const bool ok = rev ? (lane + off < 64) : (lane >= off);
+        const int oo = ok ? o : ident;
+        v = MAXOP ? (oo > v ? oo : v) : v + oo;
     }
+    // the lane holding the wave's last position publishes the wave total
+    if ((!rev && lane == 63) || (rev && lane == 0)) wave_tot[wave] = v;
+    __syncthreads();
+    int carry = ident;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) {
+        const bool before = rev ? (w > wave) : (w < wave);  // waves holding smaller positions
+        const int t = wave_tot[w];
+        if (before) carry = MAXOP ? (t > carry ? t : carry) : carry + t;
+    }
+    v = MAXOP ? (carry > v ? carry : v) : v + carry;
+    sh[pos] = v;
+    __syncthreads();
     return v;
+}
+
+// workgroup max and min of one double per thread; result in every thread
+template <int T>
+__device__ __forceinline__ void block_minmax(double* sh, double& mx, double& mn) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double a = __shfl_xor(mx, off), b = __shfl_xor(mn, off);
+        mx = a > mx ? a : mx;
+        mn = b < mn ? b : mn;
+    }
+    if (lane == 0) {
+        sh[wave] = mx;
+        sh[T / 64 + wave] = mn;
+    }
+    __syncthreads();
+    mx = sh[0];
+    mn = sh[T / 64];
+#pragma unroll
+    for (int w = 1; w < T / 64; ++w) {
+        mx = sh[w] > mx ? sh[w] : mx;
+        mn = sh[T / 64 + w] < mn ? sh[T / 64 + w] : mn;
+    }
+    __syncthreads();
 }
 
 // peakutils.indexes(y, thres, min_dist) on the Mh values in yv (LDS) + publication of the kept peaks.
@@ -209,17 +252,8 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
         mx = v > mx ? v : mx;
         mn = v < mn ? v : mn;
     }
-    sh_red[tid] = mx;
-    sh_red[T + tid] = mn;
-    __syncthreads();
-    for (int s = T / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            sh_red[tid] = sh_red[tid] > sh_red[tid + s] ? sh_red[tid] : sh_red[tid + s];
-            sh_red[T + tid] = sh_red[T + tid] < sh_red[T + tid + s] ? sh_red[T + tid] : sh_red[T + tid + s];
-        }
-        __syncthreads();
-    }
-    const double thres = a.peak_thresh * (sh_red[0] - sh_red[T]) + sh_red[T];
+    block_minmax<T>(sh_red, mx, mn);
+    const double thres = a.peak_thresh * (mx - mn) + mn;
     for (int i = tid; i < D; i += T) dy[i] = yv[i + 1] - yv[i];
     __syncthreads();
     // nearest non-zero of dy to the left / right of every position (plateau rule)
