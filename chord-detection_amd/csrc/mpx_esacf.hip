@@ -16,7 +16,7 @@
 //                        (esacf.py:64-71).
 #include <cmath>
 
-#include "mpx_fft.hpp"
+#include "mpx_fft_dif.hpp"
 #include "mpx_internal.hpp"
 #include "mpx_lm.hpp"
 
@@ -153,23 +153,36 @@ struct SacfArgs {
 __device__ __forceinline__ cx<double> cconj(cx<double> a) { return {a.x, -a.y}; }
 __device__ __forceinline__ cx<double> cswap(cx<double> a) { return {a.y, a.x}; }
 
-// N-point forward DFT of buf[0..N) in place (LDS).  For BLUE the transform runs
-// as a length-L circular convolution with the chirp (L >= 2N-1).
-template <int L, int T, bool BLUE>
-__device__ __forceinline__ void dft_n(cx<double>* buf, const SacfArgs& a, cx<double>* regs, int tid) {
+// N-point forward DFT on the in-place DIF / inverse-DIT LDS engine (mpx_fft_dif.hpp), T = L/8
+// threads, 8 points per thread.  In: regs[r] = x[tid + r*T] (anything for indices >= N).
+//   BLUE:  Bluestein chirp-z as a length-L circular convolution (L >= 2N-1): chirp multiply ->
+//          DIF (spectrum stays in registers, digit-reversed) -> filter spectrum (stored in that same
+//          register order) -> inverse DIT -> chirp multiply.  Out: regs[r] = X[tid + r*T], natural.
+//          Two workgroup barriers in total (one per FFT).
+//   !BLUE: N == L, plain DIF.  Out: regs[e] = X[dif_freq(dif_last_pos(tid, e / RL, e % RL))].
+// Entry condition: no wave is still reading `buf`.
+template <int L, bool BLUE>
+__device__ __forceinline__ void dft_regs(cx<double>* buf, const DifTwiddles<L, double>& twd, const SacfArgs& a,
+                                         cx<double>* regs, int tid) {
+    constexpr int T = L / 8;
     if (BLUE) {
         const int N = a.N;
-        for (int n = tid; n < L; n += T) buf[lds_slot(n)] = n < N ? cmul(buf[lds_slot(n)], cconj(a.chirp[n])) : cx<double>{0.0, 0.0};
-        __syncthreads();
-        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
-        // multiply by the filter spectrum; swap re/im so that the next forward FFT is an inverse one
-        for (int k = tid; k < L; k += T) buf[lds_slot(k)] = cswap(cmul(buf[lds_slot(k)], a.bhat[k]));
-        __syncthreads();
-        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
-        for (int k = tid; k < N; k += T) buf[lds_slot(k)] = cmul(cswap(buf[lds_slot(k)]), cconj(a.chirp[k]));
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n = tid + r * T;
+            regs[r] = n < N ? cmulc(regs[r], a.chirp[n]) : cx<double>{0.0, 0.0};
+        }
+        dif_fft_keep_last<L, double>(buf, twd, regs, tid);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) regs[e] = cmul(regs[e], a.bhat[e * T + tid]);
+        idit_fft_from_last<L, double>(buf, twd, regs, tid);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int k = tid + r * T;
+            regs[r] = cmulc(regs[r], a.chirp[k < N ? k : 0]);
+        }
     } else {
-        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+        dif_fft_keep_last<L, double>(buf, twd, regs, tid);
     }
 }
 
@@ -242,7 +255,7 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     int* cand = rnz + Mh + 1;                              // Mh
     int* state = cand + Mh + 1;                            // Mh
     __shared__ int sh_scan[T];
-    __shared__ double sh_red[2 * T];
+    __shared__ double sh_red[2 * (T / 64)];
     __shared__ int sh_misc[4];
     // ---- peakutils.indexes(y, thres, min_dist)
     const int D = Mh - 1;  // len(dy)
@@ -381,39 +394,78 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     }
 }
 
-template <int L, int T, bool BLUE>
-__global__ __launch_bounds__(T) void sacf_kernel(SacfArgs a) {
+// |X|^0.67 of one band.  hypot/pow as in numpy (esacf.py:95-103); the spectra of audio-range input are
+// far from the overflow/underflow guards of hypot, so a plain sqrt of the squared magnitude is exact enough
+// (<= 1 ulp) and several times cheaper.
+__device__ __forceinline__ double mag067(double re, double im) { return pow(sqrt(re * re + im * im), 0.67); }
+
+template <int L, bool BLUE>
+__global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
+    constexpr int T = L / 8;
+    using PL = DifPlan<L>;
+    constexpr int RL = PL::radix(PL::n - 1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = a.N, Mh = a.Mh;
-    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                 // L complex
-    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));  // N + 2 doubles
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                      // L complex, slot sigma<L>(position)
+    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * L);      // Mh + 2 doubles
     const int tid = threadIdx.x;
     const long long f = blockIdx.x;
-    cx<double> regs[L / T];
+    const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(a.tw, tid);
+    cx<double> regs[8];
 
     // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N
     const double* lo = a.xlo + f * (long long)N;
     const double* hi = a.xhi + f * (long long)N;
-    for (int n = tid; n < N; n += T) buf[lds_slot(n)] = {lo[n], hi[n]};
-    __syncthreads();
-    dft_n<L, T, BLUE>(buf, a, regs, tid);
-    for (int k = tid; k < N; k += T) {
-        const cx<double> A = buf[lds_slot(k)];
-        const cx<double> B = cconj(buf[lds_slot(k == 0 ? 0 : N - k)]);
-        // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
-        const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
-        const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-        yv[k] = pow(hypot(lr, li), 0.67) + pow(hypot(hr, hm), 0.67);  // esacf.py:95-103, k fixed at 0.67
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = tid + r * T;
+        regs[r] = n < N ? cx<double>{lo[n], hi[n]} : cx<double>{0.0, 0.0};
+    }
+    dft_regs<L, BLUE>(buf, twd, a, regs, tid);
+    // every thread needs the mirror bin X[N-k] of each of its bins: exchange through LDS
+    int kk[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int pos;
+        if (BLUE) {
+            kk[e] = tid + e * T;
+            pos = kk[e];
+        } else {
+            pos = dif_last_pos<L>(tid, e / RL, e % RL);
+            kk[e] = dif_freq<L>(pos);
+        }
+        buf[sigma<L>(pos)] = regs[e];
     }
     __syncthreads();
-    for (int k = tid; k < N; k += T) buf[lds_slot(k)] = {yv[k], 0.0};
-    __syncthreads();
-    dft_n<L, T, BLUE>(buf, a, regs, tid);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kk[e];
+        double s = 0.0;
+        if (k < N) {
+            const int km = k == 0 ? 0 : N - k;
+            const cx<double> A = regs[e];
+            const cx<double> B = cconj(buf[sigma<L>(BLUE ? km : dif_pos<L>(km))]);
+            // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
+            const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+            const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+            s = mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
+        }
+        regs[e] = {s, 0.0};
+    }
+    __syncthreads();  // mirror reads done before the next transform writes
+    if (BLUE)
+        dft_regs<L, true>(buf, twd, a, regs, tid);
+    else
+        idit_fft_from_last<L, double>(buf, twd, regs, tid);  // S is real and even: its inverse DFT x N is its DFT
     const double inv_n = 1.0 / (double)N;
-    for (int n = tid; n < Mh; n += T) {
-        const double v = buf[lds_slot(n)].x * inv_n;
-        yv[n] = v;
-        if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = tid + r * T;
+        if (n < Mh) {
+            const double v = regs[r].x * inv_n;
+            yv[n] = v;
+            if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+        }
     }
     __syncthreads();  // buf is dead from here on; the peak-picking scratch aliases it
     if (a.defer_enhance) {  // phase-vocoder regime: pv_enhance_kernel + peakpick_kernel take over from the raw SACF
@@ -948,6 +1000,21 @@ static void host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, forward
     }
 }
 
+// frequency held by register e of thread t after dif_fft_keep_last<L>
+template <int L>
+static int dif_reg_freq_t(int t, int e) {
+    constexpr int RL = DifPlan<L>::radix(DifPlan<L>::n - 1);
+    return dif_freq<L>(dif_last_pos<L>(t, e / RL, e % RL));
+}
+static int dif_reg_freq(int L, int t, int e) {
+    switch (L) {
+        case 512: return dif_reg_freq_t<512>(t, e);
+        case 1024: return dif_reg_freq_t<1024>(t, e);
+        case 2048: return dif_reg_freq_t<2048>(t, e);
+        default: return dif_reg_freq_t<4096>(t, e);
+    }
+}
+
 struct EsacfPlan {
     cx<double>* tw = nullptr;
     cx<double>* chirp = nullptr;
@@ -994,8 +1061,13 @@ static int esacf_plan(mpx_ctx* ctx, int N, EsacfPlan& plan) {
             v.x /= L;
             v.y /= L;
         }
+        // the kernel multiplies the filter spectrum onto registers that hold the DIF output of thread tid,
+        // element e: store it in exactly that order ([e][tid], coalesced)
+        std::vector<cx<double>> filt_regs(L);
+        for (int t = 0; t < L / 8; ++t)
+            for (int e = 0; e < 8; ++e) filt_regs[(size_t)e * (L / 8) + t] = filt[dif_reg_freq(L, t, e)];
         plan.chirp = (cx<double>*)upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
-        plan.bhat = (cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
+        plan.bhat = (cx<double>*)upload(ctx, filt_regs.data(), filt_regs.size() * sizeof(cx<double>));
         if (!plan.chirp || !plan.bhat) return MPX_ENOMEM;
     }
     ctx->misc_plans[key] = {plan.tw, plan.chirp, plan.bhat};
@@ -1053,16 +1125,16 @@ static int band_coefs_rest(int fs, BandCoef& k) {
     return MPX_OK;
 }
 
-template <int L, int T, bool BLUE>
+template <int L, bool BLUE>
 static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStream_t st) {
-    const size_t lds = sizeof(cx<double>) * lds_slots(L) + sizeof(double) * (size_t)(a.N + 2);
+    const size_t lds = sizeof(cx<double>) * L + sizeof(double) * (size_t)(a.Mh + 2);
     const size_t alias = (size_t)(a.Mh + 1) * (sizeof(double) + 4 * sizeof(int));
     if (alias > sizeof(cx<double>) * L)
         return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", a.N);
-    auto kern = sacf_kernel<L, T, BLUE>;
+    auto kern = sacf_kernel<L, BLUE>;
     if (lds > 48 * 1024)
         MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)frames), dim3(T), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)frames), dim3(L / 8), lds, st, a);
     MPX_HIP(ctx, hipGetLastError());
     return MPX_OK;
 }
@@ -1149,15 +1221,15 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.total_peaks = total;
         a.worklist = worklist;
         if (plan.blue) {
-            if (plan.L == 512) rc = sacf_launch<512, 64, true>(ctx, a, nf, st);
-            else if (plan.L == 1024) rc = sacf_launch<1024, 64, true>(ctx, a, nf, st);
-            else if (plan.L == 2048) rc = sacf_launch<2048, 128, true>(ctx, a, nf, st);
-            else rc = sacf_launch<4096, 256, true>(ctx, a, nf, st);
+            if (plan.L == 512) rc = sacf_launch<512, true>(ctx, a, nf, st);
+            else if (plan.L == 1024) rc = sacf_launch<1024, true>(ctx, a, nf, st);
+            else if (plan.L == 2048) rc = sacf_launch<2048, true>(ctx, a, nf, st);
+            else rc = sacf_launch<4096, true>(ctx, a, nf, st);
         } else {
-            if (plan.L == 512) rc = sacf_launch<512, 64, false>(ctx, a, nf, st);
-            else if (plan.L == 1024) rc = sacf_launch<1024, 64, false>(ctx, a, nf, st);
-            else if (plan.L == 2048) rc = sacf_launch<2048, 128, false>(ctx, a, nf, st);
-            else rc = sacf_launch<4096, 256, false>(ctx, a, nf, st);
+            if (plan.L == 512) rc = sacf_launch<512, false>(ctx, a, nf, st);
+            else if (plan.L == 1024) rc = sacf_launch<1024, false>(ctx, a, nf, st);
+            else if (plan.L == 2048) rc = sacf_launch<2048, false>(ctx, a, nf, st);
+            else rc = sacf_launch<4096, false>(ctx, a, nf, st);
         }
         if (rc) return rc;
         if (pv) {

@@ -76,7 +76,7 @@ struct DifPlan {
 
 // LDS position (before sigma) of frequency k after the last pass (digit reversal).
 template <int M>
-__device__ __forceinline__ int dif_pos(int k) {
+__host__ __device__ __forceinline__ int dif_pos(int k) {
     using PL = DifPlan<M>;
     int pos = 0, remk = k;
 #pragma unroll
@@ -90,7 +90,7 @@ __device__ __forceinline__ int dif_pos(int k) {
 
 // Frequency held at LDS position pos after the last pass (inverse of dif_pos).
 template <int M>
-__device__ __forceinline__ int dif_freq(int pos) {
+__host__ __device__ __forceinline__ int dif_freq(int pos) {
     using PL = DifPlan<M>;
     int k = 0, mul = 1;
 #pragma unroll
@@ -167,7 +167,7 @@ __device__ __forceinline__ int dif_butterfly(cx<Real>* buf, const DifTwiddles<M,
 // Butterfly id of thread `tid` in pass I (h-th butterfly of the thread; h > 0 only when the last
 // radix is below 8).  The last pass uses a wave-local assignment.
 template <int M, int I>
-__device__ __forceinline__ int dif_bid(int tid, int h) {
+__host__ __device__ __forceinline__ int dif_bid(int tid, int h) {
     using PL = DifPlan<M>;
     constexpr int R = PL::radix(I);
     if (R == 8) return tid;
@@ -211,10 +211,83 @@ __device__ __forceinline__ void dif_fft_keep_last(cx<Real>* buf, const DifTwiddl
 }
 
 template <int M>
-__device__ __forceinline__ int dif_last_pos(int tid, int h, int q) {
+__host__ __device__ __forceinline__ int dif_last_pos(int tid, int h, int q) {
     using PL = DifPlan<M>;
     constexpr int RL = PL::radix(PL::n - 1);
     return dif_bid<M, PL::n - 1>(tid, h) * RL + q;
+}
+
+// ---------------------------------------------------------------- inverse (decimation in time)
+// The transpose of the network above, run backwards: digit-reversed input, natural output, same LDS
+// addresses pass by pass, so the wave-local property carries over -- the passes n-1 .. 1 stay inside
+// a wave's 512-point region and only pass 0 (last here) needs the workgroup barrier.  Each butterfly
+// undoes its forward twin: multiply by the CONJUGATE twiddles first, then the conjugate small DFT
+// (re/im swap in and out of SmallDft).  Unscaled: idit(dif(x)) = M x.
+template <typename Real>
+__device__ __forceinline__ cx<Real> cmulc(cx<Real> a, cx<Real> w) {  // a * conj(w)
+    return {a.x * w.x + a.y * w.y, a.y * w.x - a.x * w.y};
+}
+
+template <int M, int I, bool LOAD, bool STORE, typename Real>
+__device__ __forceinline__ void idit_butterfly(cx<Real>* buf, const DifTwiddles<M, Real>& twd, cx<Real>* v, int b) {
+    using PL = DifPlan<M>;
+    constexpr int R = PL::radix(I), L = PL::block(I), S = PL::stride(I);
+    const int blk = b / S, j = b & (S - 1);
+    const int base = blk * L + j;
+    const int sb = sigma<M>(base);
+    if (LOAD) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = buf[dif_addr<M, S>(sb, r)];
+    }
+    if (S > 1) {
+        cx<Real> w[R];
+        w[1] = twd.w[I < PL::n - 1 ? I : 0];
+        asm volatile("" : "+v"(w[1].x), "+v"(w[1].y));
+#pragma unroll
+        for (int q = 2; q < R; ++q) {
+            const int hb = 1 << (31 - __builtin_clz(q));
+            w[q] = (q == hb) ? cmul(w[q / 2], w[q / 2]) : cmul(w[hb], w[q - hb]);
+        }
+#pragma unroll
+        for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], w[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = {v[q].y, v[q].x};
+    SmallDft<R, Real>::run(v);
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = {v[q].y, v[q].x};
+    if (STORE) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) buf[dif_addr<M, S>(sb, q)] = v[q];
+    }
+}
+
+template <int M, int I, typename Real>
+__device__ __forceinline__ void idit_middle(cx<Real>* buf, const DifTwiddles<M, Real>& twd, cx<Real>* v, int tid) {
+    if constexpr (I >= 1) {
+        idit_butterfly<M, I, true, true, Real>(buf, twd, v, tid);
+        wave_lds_fence();
+        idit_middle<M, I - 1, Real>(buf, twd, v, tid);
+    }
+}
+
+// Unscaled inverse transform.  In: regs in the layout dif_fft_keep_last leaves (regs[h*R + q] =
+// spectrum value of LDS position dif_last_pos(tid, h, q), frequency dif_freq(position)).
+// Out: regs[r] = point tid + r*T (T = M/8), not stored.  One __syncthreads() inside; the caller
+// guarantees nobody else is still reading `buf` when a wave enters (only the wave's own 512-point
+// region is written before that barrier).
+template <int M, typename Real>
+__device__ __forceinline__ void idit_fft_from_last(cx<Real>* buf, const DifTwiddles<M, Real>& twd, cx<Real>* regs,
+                                                   int tid) {
+    using PL = DifPlan<M>;
+    constexpr int RL = PL::radix(PL::n - 1);
+#pragma unroll
+    for (int h = 0; h < 8 / RL; ++h)
+        idit_butterfly<M, PL::n - 1, false, true, Real>(buf, twd, regs + h * RL, dif_bid<M, PL::n - 1>(tid, h));
+    wave_lds_fence();
+    idit_middle<M, PL::n - 2, Real>(buf, twd, regs, tid);
+    __syncthreads();
+    idit_butterfly<M, 0, true, false, Real>(buf, twd, regs, tid);
 }
 
 }  // namespace mpx
