@@ -627,21 +627,39 @@ __global__ __launch_bounds__(T) void peakpick_kernel(SacfArgs a) {
 // Per trip of the main loop a lane runs at most one OUTER step (jacobian, pivoted Householder QR, Q^T f)
 // followed by one INNER step (lmpar, trial point, ratio test); both are straight-line code shared by all
 // lanes in that state.  Jacobian + samples are VGPRs, MINPACK's two m-vectors are LDS [row][lane].
+// The only per-fit vector that must survive between trips is MINPACK's fvec (LDS, [row][lane]); the 21 samples
+// are re-read from the ESACF row (L2) at the start of each step, the trial residuals and the copy of fvec
+// that the reflections turn into Q^T f are registers that share the space of the (by then dead) samples /
+// jacobian.  That keeps the kernel at <= 256 registers and 10.5 KB of LDS per wave: 2 waves per SIMD.
+// Divisions by a common denominator (forward-difference step, Householder norm, 2 dev^2) are one reciprocal
+// and multiplies: 1-2 ulp away from MINPACK's quotients, far inside what the forward-difference jacobian
+// (noise ~1e-8) and the tolerances (1.5e-8) resolve.
 constexpr int FIT_THREADS = 128;
+constexpr int FIT_WAVES_PER_SIMD = 2;
 enum { FIT_NEED_WORK = 0, FIT_OUTER = 1, FIT_INNER = 2, FIT_DONE = 3 };
 
-__global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restrict__ total_peaks, int* next_item,
-                                                              const int* __restrict__ worklist,
-                                                              const double* __restrict__ y, int Mh, int maxp,
-                                                              const int* __restrict__ peak_idx, double* center,
-                                                              int* ok) {
+struct GaussEval {
+    double ampl, mu, ninv;  // ninv = -1 / (2 dev^2 + eps)   (peakutils.gaussian)
+};
+__device__ __forceinline__ GaussEval gauss_prep(const double* p) {
+    return {p[0], p[1], -1.0 / (2.0 * p[2] * p[2] + lm::EPSMCH)};
+}
+__device__ __forceinline__ double gauss_resid(const GaussEval& g, double xi, double yi) {
+    const double d = xi - g.mu;
+    return g.ampl * exp((d * d) * g.ninv) - yi;
+}
+__device__ __forceinline__ void load_samples(const double* __restrict__ row, int m, double* ys) {
+#pragma unroll
+    for (int q = 0; q < lm::MAXM; ++q) ys[q] = q < m ? row[q] : 0.0;
+}
+
+__global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
+    const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
+    const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx, double* center, int* ok) {
     using namespace lm;
-    __shared__ double sh[2 * MAXM * FIT_THREADS];
+    __shared__ double sh[MAXM * FIT_THREADS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    LaneLds L;
-    L.fvec = sh + (size_t)wave * 2 * MAXM * 64;
-    L.wa4 = L.fvec + MAXM * 64;
-    L.lane = lane;
+    double* fvec = sh + (size_t)wave * MAXM * 64 + lane;  // element i at fvec[i * 64]
     const int total = *total_peaks;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const int maxfev = 200 * (NP + 1);
@@ -649,14 +667,12 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
 
     int phase = FIT_NEED_WORK;
     // per-fit state
-    double ys[MAXM];
+    const double* row = y;
     double x0 = 0.0, x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1}, qtf[NP] = {0, 0, 0}, r[NP * NP];
     double par = 0.0, delta = 0.0, xnorm = 0.0, fnorm = 0.0, gnorm = 0.0;
     int ipvt[NP] = {0, 1, 2};
     int m = 0, nfev = 0, it = 1;
     long long out = 0;
-#pragma unroll
-    for (int q = 0; q < MAXM; ++q) ys[q] = 0.0;
 #pragma unroll
     for (int q = 0; q < NP * NP; ++q) r[q] = 0.0;
 
@@ -684,9 +700,9 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
                 if (i < 10 || m < 3) {
                     ok[out] = 0;  // stays in NEED_WORK: fetches again on the next trip
                 } else {
-                    const double* row = y + f * (long long)Mh + (i - 10);
-#pragma unroll
-                    for (int q = 0; q < MAXM; ++q) ys[q] = q < m ? row[q] : 0.0;
+                    row = y + f * (long long)Mh + (i - 10);
+                    double ys[MAXM];
+                    load_samples(row, m, ys);
                     x0 = (double)(i - 10);
                     double ymax = ys[0];
 #pragma unroll
@@ -695,12 +711,13 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
                     x[0] = ymax;  // peakutils initial guess: [max(y), x[0], 5*(x[1]-x[0])]
                     x[1] = x0;
                     x[2] = 5.0;
+                    const GaussEval g = gauss_prep(x);
                     double s = 0.0;
 #pragma unroll
                     for (int q = 0; q < MAXM; ++q)
                         if (q < m) {
-                            const double rr = lane_resid(ys, x0, q, x);
-                            L.f(q) = rr;
+                            const double rr = gauss_resid(g, x0 + (double)q, ys[q]);
+                            fvec[q * 64] = rr;
                             s += rr * rr;
                         }
                     nfev = 1;
@@ -719,20 +736,30 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
         // ---------------- OUTER: jacobian, QR, Q^T f
         if (phase == FIT_OUTER) {
             double a[MAXM][NP];
+            {
+                double ys[MAXM];
+                load_samples(row, m, ys);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const double temp = x[j];
-                double h = eps * fabs(temp);
-                if (h == 0.0) h = eps;
-                x[j] = temp + h;
+                for (int j = 0; j < NP; ++j) {
+                    const double temp = x[j];
+                    double h = eps * fabs(temp);
+                    if (h == 0.0) h = eps;
+                    x[j] = temp + h;
+                    const GaussEval g = gauss_prep(x);
+                    const double inv_h = 1.0 / h;
 #pragma unroll
-                for (int i = 0; i < MAXM; ++i) a[i][j] = i < m ? (lane_resid(ys, x0, i, x) - L.f(i)) / h : 0.0;
-                x[j] = temp;
+                    for (int i = 0; i < MAXM; ++i)
+                        a[i][j] = i < m ? (gauss_resid(g, x0 + (double)i, ys[i]) - fvec[i * 64]) * inv_h : 0.0;
+                    x[j] = temp;
+                }
             }
             nfev += NP;
             ipvt[0] = 0;
             ipvt[1] = 1;
             ipvt[2] = 2;
+            double w[MAXM];  // becomes Q^T fvec
+#pragma unroll
+            for (int i = 0; i < MAXM; ++i) w[i] = i < m ? fvec[i * 64] : 0.0;
             double acnorm[NP], rdiag[NP], wa[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -773,15 +800,17 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
                 double ajnorm = sqrt(q);
                 if (ajnorm != 0.0) {
                     if (a[j][j] < 0.0) ajnorm = -ajnorm;
+                    const double inv_aj = 1.0 / ajnorm;
 #pragma unroll
-                    for (int i = j; i < MAXM; ++i) a[i][j] /= ajnorm;
+                    for (int i = j; i < MAXM; ++i) a[i][j] *= inv_aj;
                     a[j][j] += 1.0;
+                    const double inv_ajj = 1.0 / a[j][j];
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
                         double sum = 0.0;
 #pragma unroll
                         for (int i = j; i < MAXM; ++i) sum += a[i][j] * a[i][k];
-                        const double temp = sum / a[j][j];
+                        const double temp = sum * inv_ajj;
 #pragma unroll
                         for (int i = j; i < MAXM; ++i) a[i][k] -= temp * a[i][j];
                         if (rdiag[k] != 0.0) {
@@ -798,8 +827,19 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
                             }
                         }
                     }
+                    // the same reflection applied to the copy of fvec (MINPACK does this after qrfac; rows >= m
+                    // of both the vector and the column are zero)
+                    {
+                        double sum = 0.0;
+#pragma unroll
+                        for (int i = j; i < MAXM; ++i) sum += a[i][j] * w[i];
+                        const double temp = -sum * inv_ajj;
+#pragma unroll
+                        for (int i = j; i < MAXM; ++i) w[i] += a[i][j] * temp;
+                    }
                 }
                 rdiag[j] = -ajnorm;
+                qtf[j] = w[j];
             }
             if (it == 1) {
                 double wa3[NP];
@@ -813,27 +853,9 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
                 if (delta == 0.0) delta = factor;
             }
 #pragma unroll
-            for (int i = 0; i < MAXM; ++i)
-                if (i < m) L.w(i) = L.f(i);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                if (a[j][j] != 0.0) {
-                    double sum = 0.0;
-#pragma unroll
-                    for (int i = j; i < MAXM; ++i)
-                        if (i < m) sum += a[i][j] * L.w(i);
-                    const double temp = -sum / a[j][j];
-#pragma unroll
-                    for (int i = j; i < MAXM; ++i)
-                        if (i < m) L.w(i) += a[i][j] * temp;
-                }
-                a[j][j] = rdiag[j];
-                qtf[j] = L.w(j);
-            }
-#pragma unroll
             for (int i = 0; i < NP; ++i)
 #pragma unroll
-                for (int j = 0; j < NP; ++j) r[i * NP + j] = a[i][j];
+                for (int j = 0; j < NP; ++j) r[i * NP + j] = i == j ? rdiag[j] : a[i][j];
             gnorm = 0.0;
             if (fnorm != 0.0) {
 #pragma unroll
@@ -870,14 +892,18 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
             }
             const double pnorm = enorm3(wa3);
             if (it == 1) delta = delta < pnorm ? delta : pnorm;
+            double rn[MAXM];  // residuals at the trial point (MINPACK's wa4)
             double s1 = 0.0;
+            {
+                double ys[MAXM];
+                load_samples(row, m, ys);
+                const GaussEval g = gauss_prep(xnew);
 #pragma unroll
-            for (int i = 0; i < MAXM; ++i)
-                if (i < m) {
-                    const double rn = lane_resid(ys, x0, i, xnew);
-                    L.w(i) = rn;
-                    s1 += rn * rn;
+                for (int i = 0; i < MAXM; ++i) {
+                    rn[i] = i < m ? gauss_resid(g, x0 + (double)i, ys[i]) : 0.0;
+                    s1 += rn[i] * rn[i];
                 }
+            }
             ++nfev;
             const double fnorm1 = sqrt(s1);
             double actred = -1.0;
@@ -916,7 +942,7 @@ __global__ __launch_bounds__(FIT_THREADS) void peakfit_kernel(const int* __restr
                 }
 #pragma unroll
                 for (int i = 0; i < MAXM; ++i)
-                    if (i < m) L.f(i) = L.w(i);
+                    if (i < m) fvec[i * 64] = rn[i];
                 xnorm = enorm3(wa3);
                 fnorm = fnorm1;
                 ++it;
@@ -1262,9 +1288,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         if (stage >= 0) continue;
         const long long slots = nf * maxp;
         {
-            // persistent grid: 3 blocks of 2 waves per CU (LDS-limited); lanes pull peaks until the list is empty
+            // persistent grid filling every SIMD with FIT_WAVES_PER_SIMD waves; lanes pull peaks until the list is empty
             long long blocks = (slots + FIT_THREADS - 1) / FIT_THREADS;
-            const long long resident = (long long)ctx->num_cus * 3;
+            const long long resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));
             if (blocks > resident) blocks = resident;
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                y, Mh, maxp, peak_idx, center, okf);
