@@ -146,8 +146,9 @@ struct SacfArgs {
     double* y_out;      // [F,Mh] enhanced SACF
     int* peak_count;    // [F]
     int* peak_idx;      // [F,maxp]
-    int* total_peaks;   // one counter for the whole batch
-    int* worklist;      // [F*maxp] packed (frame << 12 | slot) -- filled through total_peaks
+    int* total_peaks;   // [0] long fits queued, [1] next work item (fit kernel), [2] other fits queued
+    int* worklist;      // [worklist_cap] packed (frame << 12 | slot): long fits from the front, others from the back
+    int worklist_cap;
 };
 
 __device__ __forceinline__ cx<double> cconj(cx<double> a) { return {a.x, -a.y}; }
@@ -381,15 +382,40 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
         for (int c = tid; c < ncand; c += T) state[c] = 1;
     }
     __syncthreads();
+    // Fits whose window maximum is not the peak sample itself (or whose window is cut by the end of the lag
+    // range) are the ones that run away and burn MINPACK's whole maxfev budget (measured: 93 % of the fits
+    // above 200 evaluations, 15 % of all fits).  They are queued at the FRONT of the work list so that the
+    // persistent fit kernel starts them first and does not end on a tail of stragglers.
+    for (int c = tid; c < ncand; c += T)
+        if (state[c] == 1) {
+            const int i = cand[c];
+            const int lo = i - 10 > 0 ? i - 10 : 0, hi = i + 11 < Mh ? i + 11 : Mh;
+            double mxw = yv[lo];
+            for (int n = lo + 1; n < hi; ++n) mxw = yv[n] > mxw ? yv[n] : mxw;
+            if (mxw > yv[i] || hi - lo < 21) state[c] = 3;
+        }
+    __syncthreads();
     if (tid == 0) {
-        int p = 0;
+        int p = 0, nlong = 0;
         int* out = a.peak_idx + f * (long long)a.maxp;
         for (int c = 0; c < ncand; ++c)
-            if (state[c] == 1 && p < a.maxp) out[p++] = cand[c];
+            if ((state[c] & 1) && p < a.maxp) {
+                out[p++] = cand[c];
+                nlong += state[c] == 3;
+            }
         a.peak_count[f] = p;
         if (p > 0) {
-            const int slot = atomicAdd(a.total_peaks, p);
-            for (int j = 0; j < p; ++j) a.worklist[slot + j] = (int)(f << 12) | j;
+            // long fits fill the list from the front, the others from the back
+            int front = nlong ? atomicAdd(a.total_peaks, nlong) : 0;
+            int back = p - nlong ? a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, p - nlong) : 0;
+            int j = 0;
+            for (int c = 0; c < ncand && j < p; ++c)
+                if (state[c] & 1) {
+                    const int item = (int)(f << 12) | j;
+                    if (state[c] == 3) a.worklist[front++] = item;
+                    else a.worklist[back--] = item;
+                    ++j;
+                }
         }
     }
 }
@@ -655,12 +681,13 @@ __device__ __forceinline__ void load_samples(const double* __restrict__ row, int
 
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
     const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
-    const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx, double* center, int* ok) {
+    int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
+    double* center, int* ok) {
     using namespace lm;
     __shared__ double sh[MAXM * FIT_THREADS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* fvec = sh + (size_t)wave * MAXM * 64 + lane;  // element i at fvec[i * 64]
-    const int total = *total_peaks;
+    const int n_long = total_peaks[0], total = n_long + total_peaks[2];
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const int maxfev = 200 * (NP + 1);
     const double eps = sqrt(EPSMCH);
@@ -689,7 +716,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             if (wi >= total) {
                 phase = FIT_DONE;
             } else {
-                const int item = worklist[wi];
+                const int item = worklist[wi < n_long ? wi : worklist_cap - 1 - (wi - n_long)];
                 const long long f = item >> 12;
                 const int j = item & 0xfff;
                 const int i = peak_idx[f * maxp + j];
@@ -1225,7 +1252,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * N, stage == MPX_STAGE_XLO ? xlo : xhi,
                                         (size_t)nf * N * 8, hipMemcpyDeviceToDevice, st));
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
-        MPX_HIP(ctx, hipMemsetAsync(total, 0, 2 * sizeof(int), st));  // [0] peaks found, [1] next work item
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, 3 * sizeof(int), st));  // see SacfArgs::total_peaks
         SacfArgs a;
         a.xlo = xlo;
         a.xhi = xhi;
@@ -1246,6 +1273,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.peak_idx = peak_idx;
         a.total_peaks = total;
         a.worklist = worklist;
+        a.worklist_cap = (int)(nf * maxp);
         if (plan.blue) {
             if (plan.L == 512) rc = sacf_launch<512, true>(ctx, a, nf, st);
             else if (plan.L == 1024) rc = sacf_launch<1024, true>(ctx, a, nf, st);
@@ -1293,7 +1321,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const long long resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));
             if (blocks > resident) blocks = resident;
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
-                               y, Mh, maxp, peak_idx, center, okf);
+                               (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf);
         }
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,
                            y, peak_count, peak_idx, center, okf, d_chroma_frames);
