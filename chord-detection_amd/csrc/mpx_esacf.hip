@@ -15,6 +15,7 @@
 //  4. scatter_kernel     one thread per frame: fs/tau -> pitch class -> 12 bins
 //                        (esacf.py:64-71).
 #include <cmath>
+#include <cstdlib>
 
 #include "mpx_fft_dif.hpp"
 #include "mpx_internal.hpp"
@@ -149,6 +150,7 @@ struct SacfArgs {
     int* total_peaks;   // [0] long fits queued, [1] next work item (fit kernel), [2] other fits queued
     int* worklist;      // [worklist_cap] packed (frame << 12 | slot): long fits from the front, others from the back
     int worklist_cap;
+    int ablate;         // profiling knob (env MPX_SACF_ABLATE): 1 no pow, 2 no peak picking, 4 no 2nd DFT, 8 no 1st DFT
 };
 
 __device__ __forceinline__ cx<double> cconj(cx<double> a) { return {a.x, -a.y}; }
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
         const int n = tid + r * T;
         regs[r] = n < N ? cx<double>{lo[n], hi[n]} : cx<double>{0.0, 0.0};
     }
-    dft_regs<L, BLUE>(buf, twd, a, regs, tid);
+    if (!(a.ablate & 8)) dft_regs<L, BLUE>(buf, twd, a, regs, tid);
     // every thread needs the mirror bin X[N-k] of each of its bins: exchange through LDS
     int kk[8];
 #pragma unroll
@@ -474,12 +476,13 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
             // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
             const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
             const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-            s = mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
+            s = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
         }
         regs[e] = {s, 0.0};
     }
     __syncthreads();  // mirror reads done before the next transform writes
-    if (BLUE)
+    if (a.ablate & 4) {
+    } else if (BLUE)
         dft_regs<L, true>(buf, twd, a, regs, tid);
     else
         idit_fft_from_last<L, double>(buf, twd, regs, tid);  // S is real and even: its inverse DFT x N is its DFT
@@ -516,6 +519,7 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     double* yrow = a.y_out + f * (long long)Mh;
     for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
 
+    if (a.ablate & 2) return;
     peak_pick<T>(a, f, yv, smem, tid);
 }
 
@@ -662,7 +666,7 @@ __global__ __launch_bounds__(T) void peakpick_kernel(SacfArgs a) {
 // (noise ~1e-8) and the tolerances (1.5e-8) resolve.
 constexpr int FIT_THREADS = 128;
 constexpr int FIT_WAVES_PER_SIMD = 2;
-enum { FIT_NEED_WORK = 0, FIT_OUTER = 1, FIT_INNER = 2, FIT_DONE = 3 };
+enum { FIT_NEED_WORK = 0, FIT_OUTER = 1, FIT_INNER = 2, FIT_DONE = 3, FIT_INIT = 4 };
 
 struct GaussEval {
     double ampl, mu, ninv;  // ninv = -1 / (2 dev^2 + eps)   (peakutils.gaussian)
@@ -728,32 +732,15 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     ok[out] = 0;  // stays in NEED_WORK: fetches again on the next trip
                 } else {
                     row = y + f * (long long)Mh + (i - 10);
-                    double ys[MAXM];
-                    load_samples(row, m, ys);
                     x0 = (double)(i - 10);
-                    double ymax = ys[0];
+                    double ymax = row[0];
 #pragma unroll
                     for (int q = 1; q < MAXM; ++q)
-                        if (q < m) ymax = ys[q] > ymax ? ys[q] : ymax;
+                        if (q < m) ymax = row[q] > ymax ? row[q] : ymax;
                     x[0] = ymax;  // peakutils initial guess: [max(y), x[0], 5*(x[1]-x[0])]
                     x[1] = x0;
                     x[2] = 5.0;
-                    const GaussEval g = gauss_prep(x);
-                    double s = 0.0;
-#pragma unroll
-                    for (int q = 0; q < MAXM; ++q)
-                        if (q < m) {
-                            const double rr = gauss_resid(g, x0 + (double)q, ys[q]);
-                            fvec[q * 64] = rr;
-                            s += rr * rr;
-                        }
-                    nfev = 1;
-                    fnorm = sqrt(s);
-                    par = 0.0;
-                    it = 1;
-                    diag[0] = diag[1] = diag[2] = 1.0;
-                    delta = xnorm = 0.0;
-                    phase = FIT_OUTER;
+                    phase = FIT_INIT;  // the residuals at the initial point come from the shared evaluation below
                 }
             }
         }
@@ -766,8 +753,24 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             {
                 double ys[MAXM];
                 load_samples(row, m, ys);
+                // column 0 (amplitude): ((A+h) e_i - y_i - f_i)/h with f_i = A e_i - y_i is e_i itself up to the
+                // rounding noise of the difference; e_i = (f_i + y_i)/A is read off the stored residuals instead
+                // of 21 more exponentials (exact path kept for A == 0)
+                if (x[0] != 0.0) {
+                    const double inv_a = 1.0 / x[0];
 #pragma unroll
-                for (int j = 0; j < NP; ++j) {
+                    for (int i = 0; i < MAXM; ++i) a[i][0] = i < m ? (fvec[i * 64] + ys[i]) * inv_a : 0.0;
+                } else {
+                    x[0] = eps;
+                    const GaussEval g = gauss_prep(x);
+                    const double inv_h = 1.0 / eps;
+#pragma unroll
+                    for (int i = 0; i < MAXM; ++i)
+                        a[i][0] = i < m ? (gauss_resid(g, x0 + (double)i, ys[i]) - fvec[i * 64]) * inv_h : 0.0;
+                    x[0] = 0.0;
+                }
+#pragma unroll
+                for (int j = 1; j < NP; ++j) {
                     const double temp = x[j];
                     double h = eps * fabs(temp);
                     if (h == 0.0) h = eps;
@@ -906,19 +909,25 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             }
         }
         // ---------------- INNER: one trust-region trial
-        if (phase == FIT_INNER && info == 0) {
-            double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
+        if ((phase == FIT_INNER && info == 0) || phase == FIT_INIT) {
+            const bool fresh = phase == FIT_INIT;
+            double p[NP] = {0.0, 0.0, 0.0}, xnew[NP], wa3[NP];
+            double pnorm = 0.0;
+            if (!fresh) {
+                double rr[NP * NP], sd[NP];
 #pragma unroll
-            for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
-            par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
+                for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
+                par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                p[j] = -p[j];
-                xnew[j] = x[j] + p[j];
-                wa3[j] = diag[j] * p[j];
+                for (int j = 0; j < NP; ++j) {
+                    p[j] = -p[j];
+                    wa3[j] = diag[j] * p[j];
+                }
+                pnorm = enorm3(wa3);
+                if (it == 1) delta = delta < pnorm ? delta : pnorm;
             }
-            const double pnorm = enorm3(wa3);
-            if (it == 1) delta = delta < pnorm ? delta : pnorm;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) xnew[j] = x[j] + p[j];
             double rn[MAXM];  // residuals at the trial point (MINPACK's wa4)
             double s1 = 0.0;
             {
@@ -931,6 +940,18 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     s1 += rn[i] * rn[i];
                 }
             }
+            if (fresh) {  // lmdif's prologue: fvec at the initial point
+#pragma unroll
+                for (int i = 0; i < MAXM; ++i)
+                    if (i < m) fvec[i * 64] = rn[i];
+                nfev = 1;
+                fnorm = sqrt(s1);
+                par = 0.0;
+                it = 1;
+                diag[0] = diag[1] = diag[2] = 1.0;
+                delta = xnorm = 0.0;
+                phase = FIT_OUTER;
+            } else {
             ++nfev;
             const double fnorm1 = sqrt(s1);
             double actred = -1.0;
@@ -985,6 +1006,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                 if (gnorm <= EPSMCH) info = 8;
             }
             if (info == 0 && ratio >= 1e-4) phase = FIT_OUTER;  // step accepted: new jacobian next trip
+            }
         }
         if (info != 0) {
             ok[out] = (info >= 1 && info <= 4) ? 1 : 0;
@@ -1220,7 +1242,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
 
     // frames are processed in batches that fit a fixed workspace budget
     const size_t per_frame = (size_t)N * 16 + (size_t)Mh * 8 + (size_t)maxp * 20 + 8;
-    long long batch = (long long)((size_t(6) << 30) / per_frame);
+    long long batch = (long long)((size_t(24) << 30) / per_frame);
     if (batch > num_frames) batch = num_frames;
     if (batch > (1 << 19)) batch = 1 << 19;  // (frame << 12 | slot) must fit an int
     if (batch < 1) batch = 1;
@@ -1274,6 +1296,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.total_peaks = total;
         a.worklist = worklist;
         a.worklist_cap = (int)(nf * maxp);
+        a.ablate = getenv("MPX_SACF_ABLATE") ? atoi(getenv("MPX_SACF_ABLATE")) : 0;
         if (plan.blue) {
             if (plan.L == 512) rc = sacf_launch<512, true>(ctx, a, nf, st);
             else if (plan.L == 1024) rc = sacf_launch<1024, true>(ctx, a, nf, st);
