@@ -422,10 +422,12 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     }
 }
 
-// |X|^0.67 of one band.  hypot/pow as in numpy (esacf.py:95-103); the spectra of audio-range input are
-// far from the overflow/underflow guards of hypot, so a plain sqrt of the squared magnitude is exact enough
-// (<= 1 ulp) and several times cheaper.
-__device__ __forceinline__ double mag067(double re, double im) { return pow(sqrt(re * re + im * im), 0.67); }
+// |X|^0.67 of one band (esacf.py:95-103: np.abs(X) ** 0.67) as exp(0.335 * log(|X|^2)): two short libm
+// polynomials instead of hypot + the general pow (a third of the kernel's time before).  The spectra of
+// audio-range input are far from the overflow/underflow guards of hypot; the result is within ~15 ulp of
+// numpy's (|0.335 ln q| <= 30 amplifies the rounding of log), two orders of magnitude below the rounding
+// noise the FFTs put on the SACF.  |X| = 0 gives exp(-inf) = 0 like 0 ** 0.67.
+__device__ __forceinline__ double mag067(double re, double im) { return exp(0.335 * log(re * re + im * im)); }
 
 template <int L, bool BLUE>
 __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
