@@ -189,39 +189,6 @@ __device__ __forceinline__ void dft_regs(cx<double>* buf, const DifTwiddles<L, d
     }
 }
 
-// Inclusive scan (sum or max) over T ints, one per thread, by position `pos` (pos == tid, or
-// pos == T-1-tid for a scan that runs from the last thread to the first).  Wave-level shuffle scan +
-// one LDS hop across the T/64 waves: two workgroup barriers instead of the 3*log2(T) of a
-// Hillis-Steele scan in LDS.  On return sh[p] holds the inclusive result of position p for every p.
-template <int T, bool MAXOP>
-__device__ __forceinline__ int block_scan(int* sh, int v, int pos) {
-    __shared__ int wave_tot[T / 64 > 0 ? T / 64 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool rev = pos != tid;            // uniform
-    const int ident = MAXOP ? -0x7fffffff : 0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = rev ? __shfl_down(v, off) : __shfl_up(v, off);
-        const bool ok = rev ? (lane + off < 64) : (lane >= off);
-        const int oo = ok ? o : ident;
-        v = MAXOP ? (oo > v ? oo : v) : v + oo;
-    }
-    // the lane holding the wave's last position publishes the wave total
-    if ((!rev && lane == 63) || (rev && lane == 0)) wave_tot[wave] = v;
-    __syncthreads();
-    int carry = ident;
-#pragma unroll
-    for (int w = 0; w < T / 64; ++w) {
-        const bool before = rev ? (w > wave) : (w < wave);  // waves holding smaller positions
-        const int t = wave_tot[w];
-        if (before) carry = MAXOP ? (t > carry ? t : carry) : carry + t;
-    }
-    v = MAXOP ? (carry > v ? carry : v) : v + carry;
-    sh[pos] = v;
-    __syncthreads();
-    return v;
-}
-
 // workgroup max and min of one double per thread; result in every thread
 template <int T>
 __device__ __forceinline__ void block_minmax(double* sh, double& mx, double& mn) {
@@ -248,20 +215,37 @@ __device__ __forceinline__ void block_minmax(double* sh, double& mx, double& mn)
 }
 
 // peakutils.indexes(y, thres, min_dist) on the Mh values in yv (LDS) + publication of the kept peaks.
-// `scratch` is >= (Mh+1)*(8+16) bytes of LDS that nobody else uses any more.
+// `scratch` is >= PEAK_WORDS*32 + (Mh/2 + 2)*8 bytes of LDS that nobody else uses any more.
+//
+// Everything is flag words: position i = tid + e*T of wave w is bit `lane` of word e*T/64 + w, so a
+// __ballot is one word.  "dy != 0" words give the nearest non-zero neighbour of a plateau position
+// with a clz/ffs (plateau rule); candidate words and kept words give compaction ranks with popcounts;
+// no scans, no serial loops.  min_dist suppression is a parallel fixed point of peakutils' greedy
+// rule: a candidate is kept iff no HIGHER candidate within min_dist is kept (height, then larger
+// index, decides "higher" -- the visiting order of peakutils), so a candidate can decide as soon as
+// all its higher neighbours have; every round decides at least the highest undecided one.
+constexpr int PEAK_WORDS = 40;  // >= (Mh + T) / 64 for Mh <= 2047, T <= 512
+__host__ __device__ inline size_t peak_scratch_bytes(int Mh) {
+    return ((size_t)PEAK_WORDS * 32 + (size_t)(Mh / 2 + 2) * 8 + 15) & ~(size_t)15;
+}
+
 template <int T>
 __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double* yv, char* scratch, int tid) {
-    const int Mh = a.Mh;
-    double* dy = reinterpret_cast<double*>(scratch);       // Mh
-    int* lnz = reinterpret_cast<int*>(dy + Mh + 1);        // Mh
-    int* rnz = lnz + Mh + 1;                               // Mh
-    int* cand = rnz + Mh + 1;                              // Mh
-    int* state = cand + Mh + 1;                            // Mh
-    __shared__ int sh_scan[T];
-    __shared__ double sh_red[2 * (T / 64)];
-    __shared__ int sh_misc[4];
-    // ---- peakutils.indexes(y, thres, min_dist)
-    const int D = Mh - 1;  // len(dy)
+    typedef unsigned long long u64;
+    constexpr int NW = T / 64;
+    const int Mh = a.Mh, D = Mh - 1;  // D = len(dy)
+    const int lane = tid & 63, wave = tid >> 6;
+    u64* nzw = reinterpret_cast<u64*>(scratch);
+    u64* candw = nzw + PEAK_WORDS;
+    u64* keptw = candw + PEAK_WORDS;
+    u64* longw = keptw + PEAK_WORDS;
+    int* cand = reinterpret_cast<int*>(longw + PEAK_WORDS);  // [Mh/2 + 2]
+    volatile int* state = cand + (Mh / 2 + 2);               // [Mh/2 + 2]: 0 undecided, 1 kept, 2 removed
+    __shared__ double sh_red[2 * NW];
+    __shared__ int sh_flag[3];
+    __shared__ int sh_base[2];
+    const u64 lt_mask = (1ull << lane) - 1ull;
+    // ---- threshold
     double mx = -INFINITY, mn = INFINITY;
     for (int n = tid; n < Mh; n += T) {
         const double v = yv[n];
@@ -270,154 +254,174 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     }
     block_minmax<T>(sh_red, mx, mn);
     const double thres = a.peak_thresh * (mx - mn) + mn;
-    for (int i = tid; i < D; i += T) dy[i] = yv[i + 1] - yv[i];
+    // ---- words of "dy[i] != 0"
+    const int E = (Mh + T - 1) / T, nwords = E * NW;
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + e * T;
+        const u64 b = __ballot(i < D && yv[i + 1] != yv[i]);
+        if (lane == 0) nzw[e * NW + wave] = b;
+    }
+    if (tid < 3) sh_flag[tid] = 0;
     __syncthreads();
-    // nearest non-zero of dy to the left / right of every position (plateau rule)
-    const int chunk = (D + T - 1) / T;
-    const int c0 = tid * chunk, c1 = (c0 + chunk < D) ? c0 + chunk : D;
-    int last = -1, first = D, nz = 0;
-    for (int i = c0; i < c1; ++i)
-        if (dy[i] != 0.0) {
-            last = i;
-            if (first == D) first = i;
-            ++nz;
-        }
-    const int tot_nz = block_scan<T, false>(sh_scan, nz, tid);
-    if (tid == T - 1) sh_misc[0] = tot_nz;
-    const int incl_last = block_scan<T, true>(sh_scan, last, tid);
-    int carry_l = tid > 0 ? sh_scan[tid - 1] : -1;
-    (void)incl_last;
-    __syncthreads();
-    // suffix minimum of `first`: scan the reversed sequence with max over negated values
-    const int incl_first_rev = block_scan<T, true>(sh_scan, -first, T - 1 - tid);
-    (void)incl_first_rev;
-    // sh_scan[j] now holds max_{t' >= T-1-j} (-first[t'])  =>  carry for tid is entry (T-2-tid)
-    int carry_r = tid < T - 1 ? -sh_scan[T - 2 - tid] : D;
-    __syncthreads();
-    if (sh_misc[0] == 0 || D <= 0) {  // totally flat signal: no peaks (peakutils returns [])
-        if (tid == 0) a.peak_count[f] = 0;
+    if (D <= 0 || !__any(lane < nwords && nzw[lane < nwords ? lane : 0] != 0)) {
+        if (tid == 0) a.peak_count[f] = 0;  // totally flat signal: no peaks (peakutils returns [])
         return;
     }
-    {
-        int run = carry_l;
-        for (int i = c0; i < c1; ++i) {
-            if (dy[i] != 0.0) run = i;
-            lnz[i] = run;
+    // sign of the plateau-filled dy[i]: a zero run takes the value right after it (leading run), before it
+    // (trailing run), or left / right of its median (interior run)
+    auto dsign = [&](int i) -> int {
+        double d = yv[i + 1] - yv[i];
+        if (!(d != 0.0) || !(yv[i + 1] != yv[i])) {
+            int w = i >> 6;
+            u64 m = nzw[w] & ((1ull << (i & 63)) - 1ull);
+            while (m == 0 && w > 0) m = nzw[--w];
+            const int l = m ? w * 64 + 63 - __clzll((long long)m) : -1;  // nearest non-zero on the left
+            w = i >> 6;
+            m = (i & 63) == 63 ? 0ull : nzw[w] & (~0ull << ((i & 63) + 1));
+            while (m == 0 && w < nwords - 1) m = nzw[++w];
+            const int r = m ? w * 64 + __ffsll((long long)m) - 1 : D;    // ... on the right
+            const int s0 = l + 1, e0 = r - 1;                            // the zero run containing i
+            const int src = s0 == 0 ? r : (e0 == D - 1 ? l : (2 * i < s0 + e0 ? l : r));
+            d = yv[src + 1] - yv[src];
         }
-        run = carry_r;
-        for (int i = c1 - 1; i >= c0; --i) {
-            if (dy[i] != 0.0) run = i;
-            rnz[i] = run;
+        return d > 0.0 ? 1 : (d < 0.0 ? -1 : 0);
+    };
+    // ---- candidates, ascending
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + e * T;
+        bool c = false;
+        if (i >= 1 && i <= Mh - 2 && yv[i] > thres) c = dsign(i - 1) > 0 && dsign(i) < 0;
+        const u64 b = __ballot(c);
+        if (lane == 0) candw[e * NW + wave] = b;
+    }
+    __syncthreads();
+    int ncand;
+    {
+        const int cnt = lane < nwords ? __popcll(candw[lane < nwords ? lane : 0]) : 0;
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        ncand = __shfl(incl, 63);
+        for (int e = 0; e < E; ++e) {
+            const int base = __shfl(incl - cnt, e * NW + wave);
+            const u64 b = candw[e * NW + wave];
+            if ((b >> lane) & 1ull) {
+                const int rank = base + __popcll(b & lt_mask);
+                cand[rank] = tid + e * T;
+                state[rank] = 0;
+            }
         }
     }
     __syncthreads();
-    for (int i = tid; i < D; i += T) {
-        if (dy[i] != 0.0) continue;
-        const int l = lnz[i], r = rnz[i];
-        const int s = l + 1, e = r - 1;  // the zero run containing i
-        double v;
-        if (s == 0)
-            v = dy[r];                   // leading plateau takes the value right after it
-        else if (e == D - 1)
-            v = dy[l];                   // trailing plateau takes the value before it
-        else
-            v = (2 * i < s + e) ? dy[l] : dy[r];  // i < median(run) ? left : right
-        // write after everyone has read: zero positions only read non-zero positions, so in place is safe
-        dy[i] = v;
-    }
-    __syncthreads();
-    // candidates, ascending
-    const int pchunk = (Mh + T - 1) / T;
-    const int p0 = tid * pchunk, p1 = (p0 + pchunk < Mh) ? p0 + pchunk : Mh;
-    int cnt = 0;
-    for (int i = p0; i < p1; ++i)
-        if (i >= 1 && i <= Mh - 2 && dy[i - 1] > 0.0 && dy[i] < 0.0 && yv[i] > thres) ++cnt;
-    const int incl = block_scan<T, false>(sh_scan, cnt, tid);
-    if (tid == T - 1) sh_misc[1] = incl;
-    __syncthreads();
-    const int ncand = sh_misc[1];
-    {
-        int o = incl - cnt;
-        for (int i = p0; i < p1; ++i)
-            if (i >= 1 && i <= Mh - 2 && dy[i - 1] > 0.0 && dy[i] < 0.0 && yv[i] > thres) cand[o++] = i;
-    }
-    for (int c = tid; c < ncand; c += T) state[c] = 0;
-    __syncthreads();
-    // minimum-distance suppression: visit by descending height; a kept peak removes neighbours within min_dist
-    if (ncand > 1 && a.peak_min_dist > 1) {
-        if (tid < 64) {
-            volatile int* vstate = state;
-            for (;;) {
-                double bv = -INFINITY;
-                int bc = -1;
-                for (int c = tid; c < ncand; c += 64)
-                    if (vstate[c] == 0) {
-                        const double v = yv[cand[c]];
-                        if (v > bv || (v == bv && c > bc)) {
-                            bv = v;
-                            bc = c;
+    // ---- minimum-distance suppression
+    const int Q = (ncand + T - 1) / T, md = a.peak_min_dist;
+    if (ncand > 1 && md > 1) {
+        for (int round = 0;; ++round) {
+            bool undecided = false;
+            for (int q = 0; q < Q; ++q) {
+                const int c = tid + q * T;
+                if (c < ncand && state[c] == 0) {
+                    const int pos = cand[c];
+                    const double v = yv[pos];
+                    bool any_kept = false, any_open = false;
+                    for (int c2 = c - 1; c2 >= 0; --c2) {
+                        const int p2 = cand[c2];
+                        if (pos - p2 > md) break;
+                        if (yv[p2] > v) {  // ties go to the larger index
+                            const int st = state[c2];
+                            any_kept |= st == 1;
+                            any_open |= st == 0;
                         }
                     }
-                for (int off = 32; off > 0; off >>= 1) {
-                    const double ov = __shfl_xor(bv, off);
-                    const int oc = __shfl_xor(bc, off);
-                    if (oc >= 0 && (bc < 0 || ov > bv || (ov == bv && oc > bc))) {
-                        bv = ov;
-                        bc = oc;
+                    for (int c2 = c + 1; c2 < ncand; ++c2) {
+                        const int p2 = cand[c2];
+                        if (p2 - pos > md) break;
+                        if (yv[p2] >= v) {
+                            const int st = state[c2];
+                            any_kept |= st == 1;
+                            any_open |= st == 0;
+                        }
                     }
+                    if (any_kept) state[c] = 2;
+                    else if (!any_open) state[c] = 1;
+                    else undecided = true;
                 }
-                if (bc < 0) break;
-                const int pos = cand[bc];
-                for (int c = tid; c < ncand; c += 64)
-                    if (vstate[c] == 0) {
-                        const int d = cand[c] - pos;
-                        if (c == bc)
-                            vstate[c] = 1;
-                        else if (d >= -a.peak_min_dist && d <= a.peak_min_dist)
-                            vstate[c] = 2;
-                    }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
             }
+            if (__any(undecided) && lane == 0) sh_flag[round % 3] = 1;
+            __syncthreads();
+            const int more = sh_flag[round % 3];
+            if (tid == 0) sh_flag[(round + 2) % 3] = 0;  // the flag of the round after next: nobody reads or sets it now
+            if (!more) break;
         }
     } else {
         for (int c = tid; c < ncand; c += T) state[c] = 1;
+        __syncthreads();
     }
-    __syncthreads();
-    // Fits whose window maximum is not the peak sample itself (or whose window is cut by the end of the lag
-    // range) are the ones that run away and burn MINPACK's whole maxfev budget (measured: 93 % of the fits
-    // above 200 evaluations, 15 % of all fits).  They are queued at the FRONT of the work list so that the
-    // persistent fit kernel starts them first and does not end on a tail of stragglers.
-    for (int c = tid; c < ncand; c += T)
-        if (state[c] == 1) {
+    // ---- kept peaks -> peak_idx / work list.  Fits whose window maximum is not the peak sample itself (or
+    // whose window is cut by the end of the lag range) are the ones that run away and burn MINPACK's whole
+    // maxfev budget (measured: 93 % of the fits above 200 evaluations, 15 % of all fits).  They are queued at
+    // the FRONT of the work list so that the persistent fit kernel starts them first and does not end on a
+    // tail of stragglers; the others fill the list from the back.
+    const int cwords = Q * NW;
+    for (int q = 0; q < Q; ++q) {
+        const int c = tid + q * T;
+        const bool kept = c < ncand && state[c] == 1;
+        bool lng = false;
+        if (kept) {
             const int i = cand[c];
             const int lo = i - 10 > 0 ? i - 10 : 0, hi = i + 11 < Mh ? i + 11 : Mh;
             double mxw = yv[lo];
             for (int n = lo + 1; n < hi; ++n) mxw = yv[n] > mxw ? yv[n] : mxw;
-            if (mxw > yv[i] || hi - lo < 21) state[c] = 3;
+            lng = mxw > yv[i] || hi - lo < 21;
         }
+        const u64 bk = __ballot(kept), bl = __ballot(lng);
+        if (lane == 0) {
+            keptw[q * NW + wave] = bk;
+            longw[q * NW + wave] = bl;
+        }
+    }
     __syncthreads();
+    const int cnt2 = lane < cwords ? __popcll(keptw[lane < cwords ? lane : 0]) | (__popcll(longw[lane < cwords ? lane : 0]) << 16) : 0;
+    int incl2 = cnt2;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl2, off);
+        if (lane >= off) incl2 += o;
+    }
+    const int tot = __shfl(incl2, 63);
+    int n_kept = tot & 0xffff;
+    const int n_long = tot >> 16;
+    int* out = a.peak_idx + f * (long long)a.maxp;
+    if (n_kept > a.maxp) {  // cannot happen for maxp as esacf_run sizes it; serial and unsorted if it ever does
+        if (tid == 0) {
+            int p = 0;
+            for (int c = 0; c < ncand && p < a.maxp; ++c)
+                if (state[c] == 1) out[p++] = cand[c];
+            a.peak_count[f] = p;
+            const int back = a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, p);
+            for (int j = 0; j < p; ++j) a.worklist[back - j] = (int)(f << 12) | j;
+        }
+        return;
+    }
     if (tid == 0) {
-        int p = 0, nlong = 0;
-        int* out = a.peak_idx + f * (long long)a.maxp;
-        for (int c = 0; c < ncand; ++c)
-            if ((state[c] & 1) && p < a.maxp) {
-                out[p++] = cand[c];
-                nlong += state[c] == 3;
-            }
-        a.peak_count[f] = p;
-        if (p > 0) {
-            // long fits fill the list from the front, the others from the back
-            int front = nlong ? atomicAdd(a.total_peaks, nlong) : 0;
-            int back = p - nlong ? a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, p - nlong) : 0;
-            int j = 0;
-            for (int c = 0; c < ncand && j < p; ++c)
-                if (state[c] & 1) {
-                    const int item = (int)(f << 12) | j;
-                    if (state[c] == 3) a.worklist[front++] = item;
-                    else a.worklist[back--] = item;
-                    ++j;
-                }
+        a.peak_count[f] = n_kept;
+        sh_base[0] = n_long ? atomicAdd(a.total_peaks, n_long) : 0;
+        sh_base[1] = n_kept - n_long ? a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, n_kept - n_long) : 0;
+    }
+    __syncthreads();
+    for (int q = 0; q < Q; ++q) {
+        const int base = __shfl(incl2 - cnt2, q * NW + wave);
+        const u64 bk = keptw[q * NW + wave], bl = longw[q * NW + wave];
+        if ((bk >> lane) & 1ull) {
+            const int p = (base & 0xffff) + __popcll(bk & lt_mask);
+            const int pl = (base >> 16) + __popcll(bl & lt_mask);
+            out[p] = cand[tid + q * T];
+            const int item = (int)(f << 12) | p;
+            if ((bl >> lane) & 1ull) a.worklist[sh_base[0] + pl] = item;
+            else a.worklist[sh_base[1] - (p - pl)] = item;
         }
     }
 }
@@ -640,8 +644,8 @@ __global__ __launch_bounds__(T) void peakpick_kernel(SacfArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Mh = a.Mh, tid = threadIdx.x;
     const long long f = blockIdx.x;
-    char* scratch = smem;                                                           // (Mh+1)*24 bytes
-    double* yv = reinterpret_cast<double*>(smem + (((size_t)(Mh + 1) * 24 + 15) & ~(size_t)15));
+    char* scratch = smem;
+    double* yv = reinterpret_cast<double*>(smem + peak_scratch_bytes(Mh));
     const double* row = a.y_out + f * (long long)Mh;
     for (int n = tid; n < Mh; n += T) yv[n] = row[n];
     __syncthreads();
@@ -1205,7 +1209,7 @@ static int band_coefs_rest(int fs, BandCoef& k) {
 template <int L, bool BLUE>
 static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStream_t st) {
     const size_t lds = sizeof(cx<double>) * L + sizeof(double) * (size_t)(a.Mh + 2);
-    const size_t alias = (size_t)(a.Mh + 1) * (sizeof(double) + 4 * sizeof(int));
+    const size_t alias = peak_scratch_bytes(a.Mh);
     if (alias > sizeof(cx<double>) * L)
         return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", a.N);
     auto kern = sacf_kernel<L, BLUE>;
@@ -1331,7 +1335,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const size_t pv_lds = sizeof(cx<double>) * (lds_slots(PV_NFFT) + 2 * PV_BINS) + sizeof(double) * (size_t)(PV_BINS + 1 + Mh + 2);
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)pv_enhance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_lds));
             hipLaunchKernelGGL(pv_enhance_kernel, dim3((unsigned)nf), dim3(PV_T), pv_lds, st, pa);
-            const size_t pk_lds = (((size_t)(Mh + 1) * 24 + 15) & ~(size_t)15) + sizeof(double) * (size_t)(Mh + 2);
+            const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
             hipLaunchKernelGGL(peakpick_kernel<256>, dim3((unsigned)nf), dim3(256), pk_lds, st, a);
             MPX_HIP(ctx, hipGetLastError());
         }
