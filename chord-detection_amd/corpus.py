@@ -1,0 +1,171 @@
+"""Corpus driver (BASELINE.json configs[3]): all four methods over a synthetic corpus of short clips,
+clip-sharded over the GPUs of one node, ONE gather of the per-clip 12-vectors at the end.
+
+The reference has no corpus runner -- its CLI handles one file (chord_detect.py:45-63) and its tests loop
+over a directory in Python (tests/test.py:18-33).  This is that loop, batched: every rank takes a
+contiguous block of clip ids (clip-granular block partition, no data-path
+collective), synthesises its clips chunk by chunk (never stored), runs the chunk through each method's
+``compute_batch`` (the batch entry points of the C ABI) and keeps one ``[12]`` vector per clip and method.
+Launch with ``python -m torch.distributed.run --nproc-per-node G scripts/run_corpus.py ...`` for G GPUs
+(backend nccl = RCCL), or plainly for one.
+"""
+import json
+import math
+import time
+
+import numpy as np
+
+from .chromagram import Chromagram
+from .multipitch import METHODS
+
+SEED = 20260102  # + clip id (SURVEY.md section 8d, M-ESACF / M-corpus)
+
+
+def partition(n_clips, world, rank):
+    """Contiguous block of clip ids owned by `rank`: [lo, hi).  Blocks differ by at most one clip."""
+    if not (0 <= rank < world):
+        raise ValueError("rank outside world")
+    base, rem = divmod(int(n_clips), int(world))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def clip_notes(clip_id):
+    """2-4 random MIDI pitches 36..84 with a phase each, seeded by the clip id."""
+    rng = np.random.default_rng(SEED + int(clip_id))
+    k = int(rng.integers(2, 5))
+    return [(int(rng.integers(36, 85)), float(rng.uniform(0.0, 2.0 * math.pi))) for _ in range(k)]
+
+
+def synth_chunk(clip_ids, fs, seconds, device=None):
+    """float32 [len(clip_ids), fs*seconds] polyphonic clips: every note has 8 harmonics decaying by 0.7,
+    white noise at 0.003, peak-normalised to 0.9.  Tones are summed in float64 with torch on `device`
+    (CPU when None); the noise stream is seeded by the first clip id of the chunk, so a corpus is
+    reproducible for a fixed chunking and device type."""
+    import torch
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    n = int(round(fs * seconds))
+    t = torch.arange(n, dtype=torch.float64, device=dev) / float(fs)
+    out = torch.zeros((len(clip_ids), n), dtype=torch.float64, device=dev)
+    # partial table [clips, 4 notes x 8 harmonics]: angular frequency, phase, amplitude (0 = unused slot)
+    tab = np.zeros((len(clip_ids), 32, 3))
+    for row, cid in enumerate(clip_ids):
+        for k, (midi, ph) in enumerate(clip_notes(cid)):
+            f0 = 440.0 * 2.0 ** ((midi - 69) / 12.0)
+            for h in range(1, 9):
+                if f0 * h < fs / 2:
+                    tab[row, k * 8 + h - 1] = (2.0 * math.pi * f0 * h, ph * h, 0.7 ** (h - 1))
+    tab_t = torch.from_numpy(tab).to(dev)
+    for r0 in range(0, len(clip_ids), 32):  # [32 clips, 32 partials, n] float64 at a time
+        w = tab_t[r0:r0 + 32]
+        out[r0:r0 + 32] = (w[:, :, 2:3] * torch.sin(w[:, :, 0:1] * t + w[:, :, 1:2])).sum(dim=1)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(SEED + int(clip_ids[0]) if len(clip_ids) else SEED)
+    out += 0.003 * torch.randn(out.shape, dtype=torch.float64, device=dev, generator=gen)
+    out *= 0.9 / out.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    return out.to(torch.float32)
+
+
+def _engine_compute(method, clips, fs, device):
+    return np.stack([c.as_array() for c in METHODS[method].compute_batch(clips, fs, device=device)])
+
+
+def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, device=0,
+               compute=None, synth_device=None):
+    """Process this rank's block.  Returns (lo, hi, chroma[hi-lo, len(methods), 12] float64, seconds per method).
+    `compute(method, clips, fs, device) -> [n,12]` defaults to the HIP engine's batch entry points; tests
+    substitute a CPU function to exercise the sharding logic without a GPU."""
+    compute = compute or _engine_compute
+    lo, hi = partition(n_clips, world, rank)
+    out = np.zeros((hi - lo, len(methods), 12), dtype=np.float64)
+    spent = [0.0] * len(methods)
+    for c0 in range(lo, hi, chunk):
+        ids = list(range(c0, min(c0 + chunk, hi)))
+        clips = synth_chunk(ids, fs, seconds, synth_device).cpu().numpy()
+        for mi, m in enumerate(methods):
+            t0 = time.perf_counter()
+            out[c0 - lo:c0 - lo + len(ids), mi] = compute(m, list(clips), fs, device)
+            spent[mi] += time.perf_counter() - t0
+    return lo, hi, out, spent
+
+
+def gather_blocks(block, n_clips, world, rank, device=None):
+    """The job's one collective: all_gather of the (padded) per-rank blocks -> [n_clips, M, 12] on every rank."""
+    if world == 1:
+        return block
+    import torch
+    import torch.distributed as dist
+    per = -(-int(n_clips) // world)  # ceil: blocks are padded to a common size
+    pad = np.zeros((per,) + block.shape[1:], dtype=np.float64)
+    pad[:block.shape[0]] = block
+    t = torch.from_numpy(pad)
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    rows = []
+    for r, p in enumerate(parts):
+        lo, hi = partition(n_clips, world, r)
+        rows.append(p[:hi - lo].cpu().numpy())
+    return np.concatenate(rows, axis=0)
+
+
+def summarise(chroma, methods, seconds_per_method, n_clips, wall):
+    res = {"clips": int(n_clips), "wall_seconds": wall, "clips_per_s": n_clips / wall if wall > 0 else None,
+           "methods": {}}
+    for mi, m in enumerate(methods):
+        keys = {}
+        for row in chroma[:, mi]:
+            k = Chromagram(row).key()
+            keys[k] = keys.get(k, 0) + 1
+        res["methods"][str(m)] = {
+            "name": METHODS[m].display_name(),
+            "seconds_rank_max": seconds_per_method[mi],
+            "mean_chroma": [float(v) for v in chroma[:, mi].mean(axis=0)],
+            "first_clip": repr(Chromagram(chroma[0, mi])) if len(chroma) else None,
+            "keys": dict(sorted(keys.items(), key=lambda kv: -kv[1])[:6]),
+        }
+    return res
+
+
+def main(argv=None):
+    import argparse
+    import os
+    ap = argparse.ArgumentParser(description="all four methods over a synthetic corpus, clip-sharded over the visible GPUs")
+    ap.add_argument("--clips", type=int, default=4096)
+    ap.add_argument("--methods", default="1,2,3,4")
+    ap.add_argument("--fs", type=int, default=22050)
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--chunk", type=int, default=1024)
+    ap.add_argument("--out", default=None, help="write per-clip chroma [clips, methods, 12] to this .npz")
+    args = ap.parse_args(argv)
+    methods = [int(m) for m in args.methods.split(",")]
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    t0 = time.perf_counter()
+    lo, hi, block, spent = run_corpus(args.clips, methods, args.fs, args.seconds, args.chunk, rank, world, local,
+                                      synth_device=dev)
+    chroma = gather_blocks(block, args.clips, world, rank, dev if world > 1 else None)
+    wall = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([wall] + spent, dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, spent = float(tt[0]), [float(v) for v in tt[1:]]
+    if rank == 0:
+        res = summarise(chroma, methods, spent, args.clips, wall)
+        res["n_gpus"] = world
+        if args.out:
+            np.savez_compressed(args.out, chroma=chroma, methods=np.array(methods))
+        print(json.dumps(res))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return 0
