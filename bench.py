@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FS, N_FFT, HOP, FRAMES = 44100, 4096, 1024, 8192
+F_ALG = int(2.5 * 4096 * 12 + 4096)  # 2.5 N log2 N + N at N = 4096
 B_ALG = 4 * HOP + 48          # compulsory HBM bytes per frame, overlapped-signal input
 HBM_PEAK = 8.0e12             # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -202,7 +203,15 @@ def main():
                          "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE(x1.99 calibrated)+WRITE_SIZE, profiles/r1/traffic_v2.txt; algorithmic = %d" % (B_ALG * FRAMES),
                          "kernel": "he_kernel<4096,256,%s>" % ("float" if args.f32 else "double"),
                          "kernel_ms": kern_ms, "bytes_per_frame": B_ALG, "frames_per_launch": FRAMES,
-                         "step_ms_hip_events": step_ms_events, "host_enqueue_ms_per_step": host_enqueue_ms},
+                         "step_ms_hip_events": step_ms_events, "host_enqueue_ms_per_step": host_enqueue_ms,
+                         # the binding roof of an fp64 LDS FFT is the vector ALU, not HBM: standard
+                         # real-FFT count 2.5 N log2 N + N window multiplies per frame against the fp64 vector
+                         # peak (half the 157.3 TFLOP/s FP32 vector rate of MI355X_MICROARCH.md)
+                         "secondary": {"bound": "valu_f32" if args.f32 else "valu_f64",
+                                       "achieved": FRAMES * F_ALG / (kern_ms * 1e-3) / 1e12,
+                                       "peak": 157.3 if args.f32 else 78.65, "unit": "TFLOP/s",
+                                       "frac": FRAMES * F_ALG / (kern_ms * 1e-3) / 1e12 / (157.3 if args.f32 else 78.65),
+                                       "flops_per_frame": F_ALG}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(x_host)
