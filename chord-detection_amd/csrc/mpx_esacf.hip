@@ -15,6 +15,7 @@
 //  4. scatter_kernel     one thread per frame: fs/tau -> pitch class -> 12 bins
 //                        (esacf.py:64-71).
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 
 #include "mpx_fft_dif.hpp"
@@ -715,10 +716,260 @@ __device__ __forceinline__ void load_samples(const double* __restrict__ row, int
     for (int q = 0; q < lm::MAXM; ++q) ys[q] = q < m ? row[q] : 0.0;
 }
 
+// MINPACK state of a fit at the top of lmdif's outer loop (fvec is recomputed from x: same function, same bits).
+struct ParkedFit {
+    long long out;      // slot in center[] / ok[]
+    long long row_off;  // first sample of the 21-sample window, relative to y
+    double x0;          // abscissa of that sample
+    double x[3], diag[3];
+    double par, delta, xnorm, fnorm;
+    int m, it, nfev, pad;
+};
+constexpr int PARK_NFEV = 100;
+
+__device__ __forceinline__ double grp32_sum(double v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    return v;
+}
+
+// Cooperative continuation of parked fits: one fit per 32 lanes, lane l holding sample l (lm::gaussian_fit_coop
+// restated from a resume point and with the same reciprocal / column-0 / exponential forms as peakfit_kernel).
+// The m-vectors of MINPACK are one register per lane, norms and dot products are xor-butterfly all-reduces that
+// leave identical bits in every lane of the group, so the group runs the 3x3 part redundantly and uniformly.  A
+// trip costs ~3 k instructions instead of ~8.5 k and, more to the point, every parked fit gets its own lanes
+// instead of waiting behind 63 finished ones.
+__global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
+                                                     int* next_parked, const double* __restrict__ y, double* center,
+                                                     int* ok, int maxfev) {
+    using namespace lm;
+    __shared__ double exp_tab[64];
+    exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+    const int l = threadIdx.x & 31;
+    const int total = *parked_count;
+    const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
+    const double eps = sqrt(EPSMCH);
+    for (;;) {
+        int idx = 0;
+        if (l == 0) idx = atomicAdd(next_parked, 1);
+        idx = __shfl(idx, 0, 32);
+        if (idx >= total) break;
+        const ParkedFit pf = parked[idx];
+        const bool on = l < pf.m;
+        const double px = pf.x0 + (double)l;
+        const double py = on ? y[pf.row_off + l] : 0.0;
+        double x[NP] = {pf.x[0], pf.x[1], pf.x[2]}, diag[NP] = {pf.diag[0], pf.diag[1], pf.diag[2]};
+        double par = pf.par, delta = pf.delta, xnorm = pf.xnorm, fnorm = pf.fnorm;
+        int it = pf.it, nfev = pf.nfev, info = 0;
+        double f = on ? gauss_resid(gauss_prep(x, exp_tab), px, py) : 0.0;
+        for (;;) {
+            // forward-difference jacobian: this lane's row
+            double J0, J1, J2;
+            {
+                if (x[0] != 0.0) {
+                    J0 = on ? (f + py) * (1.0 / x[0]) : 0.0;
+                } else {
+                    x[0] = eps;
+                    J0 = on ? (gauss_resid(gauss_prep(x, exp_tab), px, py) - f) * (1.0 / eps) : 0.0;
+                    x[0] = 0.0;
+                }
+                double jj[NP];
+#pragma unroll
+                for (int j = 1; j < NP; ++j) {
+                    const double temp = x[j];
+                    double h = eps * fabs(temp);
+                    if (h == 0.0) h = eps;
+                    x[j] = temp + h;
+                    const double w = on ? gauss_resid(gauss_prep(x, exp_tab), px, py) : 0.0;
+                    x[j] = temp;
+                    jj[j] = (w - f) * (1.0 / h);
+                }
+                J1 = jj[1];
+                J2 = jj[2];
+            }
+            nfev += NP;
+            int ipvt[NP] = {0, 1, 2};
+            double acnorm[NP], rdiag[NP], wa[NP];
+            acnorm[0] = sqrt(grp32_sum(J0 * J0));
+            acnorm[1] = sqrt(grp32_sum(J1 * J1));
+            acnorm[2] = sqrt(grp32_sum(J2 * J2));
+#pragma unroll
+            for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
+            double qtf[NP];
+            double w4 = f;  // becomes Q^T fvec
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                int kmax = j;
+                double rmax = rdiag[j];
+#pragma unroll
+                for (int k = j + 1; k < NP; ++k)
+                    if (rdiag[k] > rmax) {
+                        kmax = k;
+                        rmax = rdiag[k];
+                    }
+                if (kmax != j) {
+                    double& cjs = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                    double& cks = kmax == 1 ? J1 : J2;
+                    const double t0 = cjs;
+                    cjs = cks;
+                    cks = t0;
+                    put3(rdiag, kmax, rdiag[j]);
+                    put3(wa, kmax, wa[j]);
+                    const int t = ipvt[j];
+                    ipvt[j] = sel3(ipvt, kmax);
+                    put3(ipvt, kmax, t);
+                }
+                double& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                const bool below = l >= j;  // rows j..m-1
+                double ajnorm = sqrt(grp32_sum(below ? cj * cj : 0.0));
+                if (ajnorm != 0.0) {
+                    if (__shfl(cj, j, 32) < 0.0) ajnorm = -ajnorm;
+                    const double inv_aj = 1.0 / ajnorm;
+                    if (below) cj *= inv_aj;
+                    if (l == j) cj += 1.0;
+                    const double inv_ajj = 1.0 / __shfl(cj, j, 32);
+#pragma unroll
+                    for (int k = j + 1; k < NP; ++k) {
+                        double& ck = k == 1 ? J1 : J2;
+                        const double temp = grp32_sum(below ? cj * ck : 0.0) * inv_ajj;
+                        if (below) ck -= temp * cj;
+                        if (rdiag[k] != 0.0) {
+                            const double t = __shfl(ck, j, 32) / rdiag[k];
+                            const double u = 1.0 - t * t;
+                            rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
+                            const double q = rdiag[k] / wa[k];
+                            if (0.05 * q * q <= EPSMCH) {
+                                rdiag[k] = sqrt(grp32_sum(l > j ? ck * ck : 0.0));
+                                wa[k] = rdiag[k];
+                            }
+                        }
+                    }
+                    const double temp = -grp32_sum(below ? cj * w4 : 0.0) * inv_ajj;
+                    if (below) w4 += cj * temp;
+                }
+                rdiag[j] = -ajnorm;
+                qtf[j] = __shfl(w4, j, 32);
+            }
+            if (it == 1) {
+                double wa3[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    diag[j] = acnorm[j] != 0.0 ? acnorm[j] : 1.0;
+                    wa3[j] = diag[j] * x[j];
+                }
+                xnorm = enorm3(wa3);
+                delta = factor * xnorm;
+                if (delta == 0.0) delta = factor;
+            }
+            // replicate the 3x3 upper triangle R (row i lives in lane i; its diagonal is rdiag)
+            double r[NP * NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                r[i * NP + 0] = i == 0 ? rdiag[0] : __shfl(J0, i, 32);
+                r[i * NP + 1] = i == 1 ? rdiag[1] : __shfl(J1, i, 32);
+                r[i * NP + 2] = i == 2 ? rdiag[2] : __shfl(J2, i, 32);
+            }
+            double gnorm = 0.0;
+            if (fnorm != 0.0) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double an = sel3(acnorm, ipvt[j]);
+                    if (an != 0.0) {
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int i = 0; i <= j; ++i) s2 += r[i * NP + j] * (qtf[i] / fnorm);
+                        const double g = fabs(s2 / an);
+                        gnorm = g > gnorm ? g : gnorm;
+                    }
+                }
+            }
+            if (gnorm <= gtol) {
+                info = 4;
+                break;
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
+            for (;;) {
+                double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
+#pragma unroll
+                for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
+                par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    p[j] = -p[j];
+                    xnew[j] = x[j] + p[j];
+                    wa3[j] = diag[j] * p[j];
+                }
+                const double pnorm = enorm3(wa3);
+                if (it == 1) delta = delta < pnorm ? delta : pnorm;
+                const double fn = on ? gauss_resid(gauss_prep(xnew, exp_tab), px, py) : 0.0;
+                ++nfev;
+                const double fnorm1 = sqrt(grp32_sum(fn * fn));
+                double actred = -1.0;
+                if (0.1 * fnorm1 < fnorm) {
+                    const double q = fnorm1 / fnorm;
+                    actred = 1.0 - q * q;
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double temp = sel3(p, ipvt[j]);
+#pragma unroll
+                    for (int i = 0; i <= j; ++i) wa3[i] += r[i * NP + j] * temp;
+                }
+                const double temp1 = enorm3(wa3) / fnorm;
+                const double temp2 = (sqrt(par) * pnorm) / fnorm;
+                const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+                const double dirder = -(temp1 * temp1 + temp2 * temp2);
+                const double ratio = prered != 0.0 ? actred / prered : 0.0;
+                if (ratio <= 0.25) {
+                    double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+                    if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                    const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
+                    delta = temp * dm;
+                    par = par / temp;
+                } else if (par == 0.0 || ratio >= 0.75) {
+                    delta = pnorm / 0.5;
+                    par = 0.5 * par;
+                }
+                if (ratio >= 1e-4) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        x[j] = xnew[j];
+                        wa3[j] = diag[j] * x[j];
+                    }
+                    f = fn;
+                    xnorm = enorm3(wa3);
+                    fnorm = fnorm1;
+                    ++it;
+                }
+                const bool c1 = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+                if (c1) info = 1;
+                if (delta <= xtol * xnorm) info = 2;
+                if (c1 && info == 2) info = 3;
+                if (info != 0) break;
+                if (nfev >= maxfev) info = 5;
+                if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1.0) info = 6;
+                if (delta <= EPSMCH * xnorm) info = 7;
+                if (gnorm <= EPSMCH) info = 8;
+                if (info != 0) break;
+                if (ratio >= 1e-4) break;
+            }
+            if (info != 0) break;
+        }
+        if (l == 0) {
+            ok[pf.out] = (info >= 1 && info <= 4) ? 1 : 0;
+            center[pf.out] = x[1];
+        }
+    }
+}
+
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
     const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
     int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
-    double* center, int* ok) {
+    double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count) {
     using namespace lm;
     __shared__ double sh[MAXM * FIT_THREADS];
     __shared__ double exp_tab[64];
@@ -728,10 +979,10 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     double* fvec = sh + (size_t)wave * MAXM * 64 + lane;  // element i at fvec[i * 64]
     const int n_long = total_peaks[0], total = n_long + total_peaks[2];
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
-    const int maxfev = 200 * (NP + 1);
     const double eps = sqrt(EPSMCH);
 
     int phase = FIT_NEED_WORK;
+    bool drained = false;  // wave-uniform: some lane has found the work list empty
     // per-fit state
     const double* row = y;
     double x0 = 0.0, x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1}, qtf[NP] = {0, 0, 0}, r[NP * NP];
@@ -778,6 +1029,32 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     phase = FIT_INIT;  // the residuals at the initial point come from the shared evaluation below
                 }
             }
+        }
+        // End game: once the work list is empty, a fit that is already past PARK_NFEV evaluations (a runaway fit:
+        // the others need ~60) would keep this wave -- and the kernel -- alive for up to 200 more trips of
+        // ~45 us.  Its MINPACK state is handed to coopfit_kernel instead, which finishes all such fits at once
+        // with 32 lanes each.
+        drained = drained || __any(phase == FIT_DONE);
+        if (drained && phase == FIT_OUTER && nfev >= PARK_NFEV && parked) {
+            ParkedFit pf;
+            pf.out = out;
+            pf.row_off = row - y;
+            pf.x0 = x0;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                pf.x[j] = x[j];
+                pf.diag[j] = diag[j];
+            }
+            pf.par = par;
+            pf.delta = delta;
+            pf.xnorm = xnorm;
+            pf.fnorm = fnorm;
+            pf.m = m;
+            pf.it = it;
+            pf.nfev = nfev;
+            pf.pad = 0;
+            parked[atomicAdd(parked_count, 1)] = pf;
+            phase = FIT_DONE;
         }
         if (__all(phase == FIT_DONE)) break;
 
@@ -1283,7 +1560,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if (batch < 1) batch = 1;
     if ((rc = ensure(ctx, ctx->d_ws0, (size_t)batch * N * 16))) return rc;                   // x_lo | x_hi
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)batch * Mh * 8 + 64))) return rc;              // y
-    if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 128))) return rc;
+    const long long fit_resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));  // blocks
+    const size_t park_bytes = (size_t)fit_resident * FIT_THREADS * sizeof(ParkedFit);  // at most one parked fit per lane
+    if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 256 + park_bytes))) return rc;
     double* xlo = (double*)ctx->d_ws0.p;
     double* xhi = xlo + (size_t)batch * N;
     double* y = (double*)ctx->d_ws1.p;
@@ -1293,7 +1572,8 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     int* okf = peak_idx + (size_t)batch * maxp;
     int* worklist = okf + (size_t)batch * maxp;
     int* peak_count = worklist + (size_t)batch * maxp;
-    int* total = peak_count + batch;
+    int* total = peak_count + batch;  // 5 counters, see SacfArgs::total_peaks; [3] parked fits, [4] next parked fit
+    ParkedFit* parked = reinterpret_cast<ParkedFit*>(((uintptr_t)(total + 8) + 63) & ~(uintptr_t)63);
 
     for (long long f0 = 0; f0 < num_frames; f0 += batch) {
         const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
@@ -1309,7 +1589,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * N, stage == MPX_STAGE_XLO ? xlo : xhi,
                                         (size_t)nf * N * 8, hipMemcpyDeviceToDevice, st));
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
-        MPX_HIP(ctx, hipMemsetAsync(total, 0, 3 * sizeof(int), st));  // see SacfArgs::total_peaks
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, 5 * sizeof(int), st));  // see SacfArgs::total_peaks
         SacfArgs a;
         a.xlo = xlo;
         a.xhi = xhi;
@@ -1376,10 +1656,16 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         {
             // persistent grid filling every SIMD with FIT_WAVES_PER_SIMD waves; lanes pull peaks until the list is empty
             long long blocks = (slots + FIT_THREADS - 1) / FIT_THREADS;
-            const long long resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));
-            if (blocks > resident) blocks = resident;
+            if (blocks > fit_resident) blocks = fit_resident;
+            // MINPACK: maxfev = 200 (n + 1); the env knobs are for profiling
+            const int maxfev = getenv("MPX_FIT_MAXFEV") ? atoi(getenv("MPX_FIT_MAXFEV")) : 200 * (lm::NP + 1);
+            const bool park = !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
-                               (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf);
+                               (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
+                               total + 3);
+            if (park)  // the runaway fits still open when the list ran dry: 32 lanes each, all at once
+                hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 16)), dim3(64), 0, st, parked, total + 3,
+                                   total + 4, y, center, okf, maxfev);
         }
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,
                            y, peak_count, peak_idx, center, okf, d_chroma_frames);
