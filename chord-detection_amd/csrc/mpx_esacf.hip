@@ -681,23 +681,53 @@ enum { FIT_NEED_WORK = 0, FIT_OUTER = 1, FIT_INNER = 2, FIT_DONE = 3, FIT_INIT =
 // 19 VALU instructions + one LDS read instead of ~31.  The fused multiply-adds are spelled as v_fma_f64 so
 // that the compiler cannot turn them into a v_mov + v_fmac pair per coefficient (it does for libm's Horner
 // chain: 9 moves per exponential).
-__device__ __forceinline__ double fma_v(double a, double b, double c) {
+// (one SGPR-pair constant per instruction: the constant-bus limit of a gfx9 VOP3; constants passed as VGPR operands
+// got spilled to scratch and reloaded behind an s_waitcnt in front of every use)
+__device__ __forceinline__ double fma_vvv(double a, double b, double c) {
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+__device__ __forceinline__ double fma_vsv(double a, double k, double c) {  // a * k + c, k a constant
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double fma_vvs(double a, double b, double k) {  // a * b + k, k a constant
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(k));
+    return d;
+}
+__device__ __forceinline__ double mul_vs(double a, double k) {
+    double d;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+    return d;
+}
+__device__ __forceinline__ double add_vs(double a, double k) {
+    double d;
+    asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k));
+    return d;
+}
 __device__ __forceinline__ double exp_nonpos(double x, const double* __restrict__ tab) {
     const double xc = x < -750.0 ? -750.0 : x;  // exp(-750) = 0 in fp64; keeps the integer conversion in range
-    const double n = rint(xc * 92.33248261689366);                // 64 / ln 2
-    double r = fma_v(n, -0.01083042469326756, xc);                // ln2/64, high part (32 significant bits)
-    r = fma_v(n, -2.9815858269852933e-12, r);                     // ... low part
+    const double n = rint(mul_vs(xc, 92.33248261689366));         // 64 / ln 2
+    double r = fma_vsv(n, -0.01083042469326756, xc);              // ln2/64, high part (32 significant bits)
+    r = fma_vsv(n, -2.9815858269852933e-12, r);                   // ... low part
     const int ni = (int)n;
     const double t = tab[ni & 63];
-    double q = fma_v(r, 1.0 / 120.0, 1.0 / 24.0);
-    q = fma_v(r, q, 1.0 / 6.0);
-    q = fma_v(r, q, 0.5);
-    const double p = fma_v(r * r, q, r);                          // e^r - 1
-    return ldexp(fma_v(t, p, t), ni >> 6);
+    double q = add_vs(mul_vs(r, 1.0 / 120.0), 1.0 / 24.0);        // r/120 + 1/24
+    q = fma_vvs(r, q, 1.0 / 6.0);
+    q = fma_vvs(r, q, 0.5);
+    const double p = fma_vvv(r * r, q, r);                        // e^r - 1
+    return ldexp(fma_vvv(t, p, t), ni >> 6);
+}
+
+// c ? v : 0 with v evaluated unconditionally.  The 21 samples of a window are independent dependency chains
+// (an exponential each); behind per-sample `if (i < m)` branches they run one after the other, as selects the
+// scheduler interleaves them.  Rows >= m read stale LDS / compute on zero samples and are discarded here.
+__device__ __forceinline__ double keep_if(bool c, double v) {
+    asm volatile("" : "+v"(v));
+    return c ? v : 0.0;
 }
 
 struct GaussEval {
@@ -969,14 +999,16 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
     const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
     int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
-    double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count) {
+    double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev) {
     using namespace lm;
     __shared__ double sh[MAXM * FIT_THREADS];
+    __shared__ double sh_rq[9 * FIT_THREADS];
     __shared__ double exp_tab[64];
     if (threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* fvec = sh + (size_t)wave * MAXM * 64 + lane;  // element i at fvec[i * 64]
+    double* rq = sh_rq + (size_t)wave * 9 * 64 + lane;      // R (6) and Q^T f (3) between OUTER and INNER
     const int n_long = total_peaks[0], total = n_long + total_peaks[2];
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const double eps = sqrt(EPSMCH);
@@ -985,13 +1017,11 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     bool drained = false;  // wave-uniform: some lane has found the work list empty
     // per-fit state
     const double* row = y;
-    double x0 = 0.0, x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1}, qtf[NP] = {0, 0, 0}, r[NP * NP];
+    double x0 = 0.0, x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1};
     double par = 0.0, delta = 0.0, xnorm = 0.0, fnorm = 0.0, gnorm = 0.0;
     int ipvt[NP] = {0, 1, 2};
     int m = 0, nfev = 0, it = 1;
     long long out = 0;
-#pragma unroll
-    for (int q = 0; q < NP * NP; ++q) r[q] = 0.0;
 
     for (;;) {
         // ---------------- fetch
@@ -1035,7 +1065,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         // ~45 us.  Its MINPACK state is handed to coopfit_kernel instead, which finishes all such fits at once
         // with 32 lanes each.
         drained = drained || __any(phase == FIT_DONE);
-        if (drained && phase == FIT_OUTER && nfev >= PARK_NFEV && parked) {
+        if (drained && phase == FIT_OUTER && nfev >= park_nfev && parked) {
             ParkedFit pf;
             pf.out = out;
             pf.row_off = row - y;
@@ -1061,7 +1091,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         int info = 0;
         // ---------------- OUTER: jacobian, QR, Q^T f
         if (phase == FIT_OUTER) {
-            double a[MAXM][NP];
+            double a[MAXM][NP], r[NP * NP], qtf[NP];
             {
                 double ys[MAXM];
                 load_samples(row, m, ys);
@@ -1071,7 +1101,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                 if (x[0] != 0.0) {
                     const double inv_a = 1.0 / x[0];
 #pragma unroll
-                    for (int i = 0; i < MAXM; ++i) a[i][0] = i < m ? (fvec[i * 64] + ys[i]) * inv_a : 0.0;
+                    for (int i = 0; i < MAXM; ++i) a[i][0] = keep_if(i < m, (fvec[i * 64] + ys[i]) * inv_a);
                 } else {
                     x[0] = eps;
                     const GaussEval g = gauss_prep(x, exp_tab);
@@ -1091,7 +1121,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     const double inv_h = 1.0 / h;
 #pragma unroll
                     for (int i = 0; i < MAXM; ++i)
-                        a[i][j] = i < m ? (gauss_resid(g, x0 + (double)i, ys[i]) - fvec[i * 64]) * inv_h : 0.0;
+                        a[i][j] = keep_if(i < m, (gauss_resid(g, x0 + (double)i, ys[i]) - fvec[i * 64]) * inv_h);
                     x[j] = temp;
                 }
             }
@@ -1101,7 +1131,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             ipvt[2] = 2;
             double w[MAXM];  // becomes Q^T fvec
 #pragma unroll
-            for (int i = 0; i < MAXM; ++i) w[i] = i < m ? fvec[i * 64] : 0.0;
+            for (int i = 0; i < MAXM; ++i) w[i] = keep_if(i < m, fvec[i * 64]);
             double acnorm[NP], rdiag[NP], wa[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -1212,6 +1242,16 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     }
                 }
             }
+            // R's upper triangle and Q^T f wait in LDS for the INNER steps (they must survive the next OUTER section
+            // of lanes that only retry a step, and 9 more doubles in registers there are 9 spilled ones)
+            rq[0 * 64] = r[0];
+            rq[1 * 64] = r[1];
+            rq[2 * 64] = r[2];
+            rq[3 * 64] = r[4];
+            rq[4 * 64] = r[5];
+            rq[5 * 64] = r[8];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) rq[(6 + j) * 64] = qtf[j];
             if (gnorm <= gtol) {
                 info = 4;
             } else {
@@ -1225,6 +1265,16 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             const bool fresh = phase == FIT_INIT;
             double p[NP] = {0.0, 0.0, 0.0}, xnew[NP], wa3[NP];
             double pnorm = 0.0;
+            double r[NP * NP], qtf[NP];
+            r[0] = rq[0 * 64];
+            r[1] = rq[1 * 64];
+            r[2] = rq[2 * 64];
+            r[4] = rq[3 * 64];
+            r[5] = rq[4 * 64];
+            r[8] = rq[5 * 64];
+            r[3] = r[6] = r[7] = 0.0;  // below the diagonal: scratch of lmpar / qrsolv, never read
+#pragma unroll
+            for (int j = 0; j < NP; ++j) qtf[j] = rq[(6 + j) * 64];
             if (!fresh) {
                 double rr[NP * NP], sd[NP];
 #pragma unroll
@@ -1248,7 +1298,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                 const GaussEval g = gauss_prep(xnew, exp_tab);
 #pragma unroll
                 for (int i = 0; i < MAXM; ++i) {
-                    rn[i] = i < m ? gauss_resid(g, x0 + (double)i, ys[i]) : 0.0;
+                    rn[i] = keep_if(i < m, gauss_resid(g, x0 + (double)i, ys[i]));
                     s1 += rn[i] * rn[i];
                 }
             }
@@ -1662,7 +1712,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const bool park = !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
-                               total + 3);
+                               total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : PARK_NFEV);
             if (park)  // the runaway fits still open when the list ran dry: 32 lanes each, all at once
                 hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 16)), dim3(64), 0, st, parked, total + 3,
                                    total + 4, y, center, okf, maxfev);
