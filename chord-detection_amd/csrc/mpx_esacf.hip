@@ -39,11 +39,19 @@ struct BandCoef {
 // conflict free both for the per-lane row walk and for the row-segment transfers.
 constexpr int BS_TILE = 16;
 
+// Band-split output layout: kernel 1 writes whole LDS tiles (64 frames x 16 samples of (x_lo, x_hi) pairs,
+// 16 KB) back to back -- streaming writes instead of 128-byte pieces 16 KB apart, which held the kernel at
+// 1.8 TB/s -- and kernel 2 gathers a frame as 256-byte pieces.  Index of sample n of (batch-local) frame f:
+__host__ __device__ inline size_t band_index(long long f, int n, int N) {
+    const int ntiles = (N + BS_TILE - 1) / BS_TILE;
+    return (((size_t)(f >> 6) * ntiles + (n >> 4)) * 64 + (size_t)(f & 63)) * BS_TILE + (n & 15);
+}
+
 template <bool XW>
 __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__ sig, long long n,
                                                        const FrameDesc* __restrict__ desc, long long frame0,
                                                        long long num_frames, int N, int hop, BandCoef k,
-                                                       double* __restrict__ xlo, double* __restrict__ xhi,
+                                                       cx<double>* __restrict__ xb,
                                                        double* __restrict__ xw) {
     __shared__ float tin[64][BS_TILE + 1];
     __shared__ double tlo[64][BS_TILE + 1];
@@ -76,15 +84,28 @@ __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 12; ++i) z[i] = 0.0;
     double h1 = 0, h2 = 0, g1 = 0, g2 = 0, l1 = 0, l2 = 0;
-    for (int t0 = 0; t0 < N; t0 += BS_TILE) {
-        // ---- stage in: 4 frame rows x 16 samples per instruction
+    // The workgroup is ONE wave: its LDS operations execute in program order, so the tiles need no
+    // s_barrier -- and above all no __syncthreads(), whose release fence would make every tile wait for its
+    // own 16 KB of global stores to retire.  The input of tile t+1 is fetched into registers while tile t runs.
+    float nxt[BS_TILE];
+    auto fetch = [&](int t0) {
 #pragma unroll
         for (int q = 0; q < BS_TILE; ++q) {
             const int e = q * 64 + lane, r = e >> 4, c = e & 15;
             const int t = t0 + c;
-            tin[r][c] = t < row_valid[r] ? sig[row_start[r] + t] : 0.f;
+            nxt[q] = t < row_valid[r] ? sig[row_start[r] + t] : 0.f;
         }
-        __syncthreads();
+    };
+    fetch(0);
+    for (int t0 = 0; t0 < N; t0 += BS_TILE) {
+        // ---- stage in: 4 frame rows x 16 samples per instruction
+#pragma unroll
+        for (int q = 0; q < BS_TILE; ++q) {
+            const int e = q * 64 + lane;
+            tin[e >> 4][e & 15] = nxt[q];
+        }
+        wave_lds_fence();
+        if (t0 + BS_TILE < N) fetch(t0 + BS_TILE);
         // ---- this lane's frame: BS_TILE samples of the chain
 #pragma unroll 4
         for (int j = 0; j < BS_TILE; ++j) {
@@ -113,27 +134,38 @@ __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__
             thi[lane][j] = yhl;
             if (XW) twf[lane][j] = r;
         }
-        __syncthreads();
-        // ---- stage out: 128-byte row segments
+        wave_lds_fence();
+        // ---- stage out: the tile goes out exactly as it lies, (x_lo, x_hi) pairs, 16 KB contiguous per wave:
+        // band layout [block of 64 frames][tile of 16 samples][frame][sample] (band_index above)
+        {
+            cx<double>* dst = xb + ((size_t)blockIdx.x * ((N + BS_TILE - 1) / BS_TILE) + t0 / BS_TILE) * (64 * BS_TILE);
 #pragma unroll
-        for (int q = 0; q < BS_TILE; ++q) {
-            const int e = q * 64 + lane, r = e >> 4, c = e & 15;
-            const int t = t0 + c;
-            if (t < N && lf0 + r < num_frames) {
-                const long long o = (lf0 + r) * (long long)N + t;
-                xlo[o] = tlo[r][c];
-                xhi[o] = thi[r][c];
-                if (XW) xw[o] = twf[r][c];
+            for (int q = 0; q < BS_TILE; ++q) {
+                const int e = q * 64 + lane, r = e >> 4, c = e & 15;
+                dst[e] = {tlo[r][c], thi[r][c]};
+                if (XW) {
+                    const int t = t0 + c;
+                    if (t < N && lf0 + r < num_frames) xw[(lf0 + r) * (long long)N + t] = twf[r][c];
+                }
             }
         }
-        __syncthreads();
+        wave_lds_fence();
+    }
+}
+
+// debug taps (mpx_esacf_stage XLO / XHI): band layout -> [F,N] rows
+__global__ __launch_bounds__(256) void band_unpack_kernel(const cx<double>* __restrict__ xb, long long num_frames, int N,
+                                                          int which, double* __restrict__ out) {
+    const long long f = blockIdx.x;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const cx<double> v = xb[band_index(f, n, N)];
+        out[f * (long long)N + n] = which ? v.y : v.x;
     }
 }
 
 // ------------------------------------------------------------------ kernel 2
 struct SacfArgs {
-    const double* xlo;
-    const double* xhi;
+    const cx<double>* xb;  // (x_lo, x_hi), band layout
     int N, Mh;
     const cx<double>* tw;     // W_L
     const cx<double>* chirp;  // b[n] = exp(i*pi*n^2/N), n < N   (Bluestein only)
@@ -449,12 +481,11 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     cx<double> regs[8];
 
     // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N
-    const double* lo = a.xlo + f * (long long)N;
-    const double* hi = a.xhi + f * (long long)N;
+    const cx<double>* xin = a.xb + band_index(f, 0, N);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n = tid + r * T;
-        regs[r] = n < N ? cx<double>{lo[n], hi[n]} : cx<double>{0.0, 0.0};
+        regs[r] = n < N ? xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)] : cx<double>{0.0, 0.0};
     }
     if (!(a.ablate & 8)) dft_regs<L, BLUE>(buf, twd, a, regs, tid);
     // every thread needs the mirror bin X[N-k] of each of its bins: exchange through LDS
@@ -1603,18 +1634,18 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if (maxp > 4095) return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: too many peak slots");
 
     // frames are processed in batches that fit a fixed workspace budget
-    const size_t per_frame = (size_t)N * 16 + (size_t)Mh * 8 + (size_t)maxp * 20 + 8;
+    const size_t per_frame = (size_t)(N + BS_TILE) * 16 + (size_t)Mh * 8 + (size_t)maxp * 20 + 8;
     long long batch = (long long)((size_t(24) << 30) / per_frame);
     if (batch > num_frames) batch = num_frames;
     if (batch > (1 << 19)) batch = 1 << 19;  // (frame << 12 | slot) must fit an int
     if (batch < 1) batch = 1;
-    if ((rc = ensure(ctx, ctx->d_ws0, (size_t)batch * N * 16))) return rc;                   // x_lo | x_hi
+    // (x_lo, x_hi) in band layout: whole blocks of 64 frames x whole tiles of 16 samples
+    if ((rc = ensure(ctx, ctx->d_ws0, (size_t)((batch + 63) / 64) * ((N + BS_TILE - 1) / BS_TILE) * 64 * BS_TILE * 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)batch * Mh * 8 + 64))) return rc;              // y
     const long long fit_resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));  // blocks
     const size_t park_bytes = (size_t)fit_resident * FIT_THREADS * sizeof(ParkedFit);  // at most one parked fit per lane
     if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 256 + park_bytes))) return rc;
-    double* xlo = (double*)ctx->d_ws0.p;
-    double* xhi = xlo + (size_t)batch * N;
+    cx<double>* xb = (cx<double>*)ctx->d_ws0.p;
     double* y = (double*)ctx->d_ws1.p;
     char* w3 = (char*)ctx->d_ws3.p;
     double* center = (double*)w3;
@@ -1630,19 +1661,18 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         double* xw = (stage == MPX_STAGE_WFIR) ? d_stage_out + (size_t)f0 * N : nullptr;
         if (xw)
             hipLaunchKernelGGL(bandsplit_kernel<true>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
-                               (long long)n, d_desc, f0, nf, N, hop, coef, xlo, xhi, xw);
+                               (long long)n, d_desc, f0, nf, N, hop, coef, xb, xw);
         else
             hipLaunchKernelGGL(bandsplit_kernel<false>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
-                               (long long)n, d_desc, f0, nf, N, hop, coef, xlo, xhi, xw);
+                               (long long)n, d_desc, f0, nf, N, hop, coef, xb, xw);
         MPX_HIP(ctx, hipGetLastError());
         if (stage == MPX_STAGE_XLO || stage == MPX_STAGE_XHI)
-            MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * N, stage == MPX_STAGE_XLO ? xlo : xhi,
-                                        (size_t)nf * N * 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(band_unpack_kernel, dim3((unsigned)nf), dim3(256), 0, st, xb, nf, N, stage == MPX_STAGE_XHI ? 1 : 0,
+                               d_stage_out + (size_t)f0 * N);
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
         MPX_HIP(ctx, hipMemsetAsync(total, 0, 5 * sizeof(int), st));  // see SacfArgs::total_peaks
         SacfArgs a;
-        a.xlo = xlo;
-        a.xhi = xhi;
+        a.xb = xb;
         a.N = N;
         a.Mh = Mh;
         a.tw = plan.tw;
