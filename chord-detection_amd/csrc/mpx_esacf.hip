@@ -503,21 +503,37 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
         buf[sigma<L>(pos)] = regs[e];
     }
     __syncthreads();
+    // S[k] = |X_lo[k]|^0.67 + |X_hi[k]|^0.67 is even in k (the bands are real): the owner of k <= N/2 computes it
+    // for N-k as well (bit-identical: the mirror pair only swaps the operands of commutative adds and flips signs
+    // that the squares drop), so the two exp/log per bin run on half the bins.
+    double sv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int k = kk[e];
-        double s = 0.0;
-        if (k < N) {
+        sv[e] = 0.0;
+        if (2 * k <= N) {
             const int km = k == 0 ? 0 : N - k;
             const cx<double> A = regs[e];
             const cx<double> B = cconj(buf[sigma<L>(BLUE ? km : dif_pos<L>(km))]);
             // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
             const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
             const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-            s = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
+            sv[e] = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
         }
-        regs[e] = {s, 0.0};
     }
+    __syncthreads();  // mirror reads done; buf becomes the S exchange (N doubles)
+    double* sd = reinterpret_cast<double*>(buf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kk[e];
+        if (2 * k <= N) {
+            sd[k] = sv[e];
+            if (k != 0) sd[N - k] = sv[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) regs[e] = {kk[e] < N ? sd[kk[e]] : 0.0, 0.0};
     __syncthreads();  // mirror reads done before the next transform writes
     if (a.ablate & 4) {
     } else if (BLUE)
