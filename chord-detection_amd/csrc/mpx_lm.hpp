@@ -132,16 +132,15 @@ MPX_HD inline void qrsolv(double* r, const int* ipvt, const double* diag, const 
 #pragma unroll
             for (int k = j; k < NP; ++k) {
                 if (sdiag[k] != 0.0) {
-                    double sn, cs;
-                    if (fabs(r[k * NP + k]) < fabs(sdiag[k])) {
-                        const double cotan = r[k * NP + k] / sdiag[k];
-                        sn = 0.5 / sqrt(0.25 + 0.25 * cotan * cotan);
-                        cs = sn * cotan;
-                    } else {
-                        const double tn = sdiag[k] / r[k * NP + k];
-                        cs = 0.5 / sqrt(0.25 + 0.25 * tn * tn);
-                        sn = cs * tn;
-                    }
+                    // MINPACK's two cases (cotangent when |r_kk| < |sdiag_k|, tangent otherwise) as ONE instruction
+                    // stream with the operands selected: the same operations per case, but a wave whose lanes
+                    // disagree no longer runs both (2 divisions + 1 square root each)
+                    const double rkk = r[k * NP + k], sk = sdiag[k];
+                    const bool small = fabs(rkk) < fabs(sk);
+                    const double t = (small ? rkk : sk) / (small ? sk : rkk);
+                    const double c0 = 0.5 / sqrt(0.25 + 0.25 * t * t);
+                    const double c1 = c0 * t;
+                    const double sn = small ? c0 : c1, cs = small ? c1 : c0;
                     r[k * NP + k] = cs * r[k * NP + k] + sn * sdiag[k];
                     const double temp = cs * wa[k] + sn * qtbpj;
                     qtbpj = -sn * wa[k] + cs * qtbpj;
