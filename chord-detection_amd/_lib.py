@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libmpx_hip.so")
 
 MPX_OK, MPX_EINVAL, MPX_ENOMEM, MPX_EHIP, MPX_EUNSUPPORTED = 0, -1, -2, -3, -4
 MPX_FLAG_F32 = 0x1
+MPX_FLAG_DETERMINISTIC = 0x2
 MPX_ENHANCE_LIBROSA010, MPX_ENHANCE_NOOP = 0, 1
 STAGES = {"wfir": 0, "x_lo": 1, "x_hi": 2, "sacf": 3, "esacf": 4}
 

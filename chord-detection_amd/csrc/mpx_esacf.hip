@@ -573,7 +573,7 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     double* yrow = a.y_out + f * (long long)Mh;
     for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
 
-    if (a.ablate & 2) return;
+    if (a.ablate & (2 | 16)) return;  // 16: peak picking runs as its own one-wave-per-frame kernel
     peak_pick<T>(a, f, yv, smem, tid);
 }
 
@@ -1744,6 +1744,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             hipLaunchKernelGGL(peakpick_kernel<256>, dim3((unsigned)nf), dim3(256), pk_lds, st, a);
             MPX_HIP(ctx, hipGetLastError());
         }
+        if (!pv && (a.ablate & 16)) {
+            const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
+            hipLaunchKernelGGL(peakpick_kernel<64>, dim3((unsigned)nf), dim3(64), pk_lds, st, a);
+        }
         if (stage == MPX_STAGE_ESACF)
             MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * Mh, y, (size_t)nf * Mh * 8,
                                         hipMemcpyDeviceToDevice, st));
@@ -1755,7 +1759,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             if (blocks > fit_resident) blocks = fit_resident;
             // MINPACK: maxfev = 200 (n + 1); the env knobs are for profiling
             const int maxfev = getenv("MPX_FIT_MAXFEV") ? atoi(getenv("MPX_FIT_MAXFEV")) : 200 * (lm::NP + 1);
-            const bool park = !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
+            const bool park = !(ctx->flags & MPX_FLAG_DETERMINISTIC) && !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : PARK_NFEV);

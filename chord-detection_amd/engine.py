@@ -20,11 +20,12 @@ class MpxError(RuntimeError):
 
 
 class Engine:
-    def __init__(self, device=0, f32=False):
+    def __init__(self, device=0, f32=False, deterministic=False):
         self.lib = _lib.load()
         self.device = device
         self.f32 = bool(f32)
-        self.ctx = self.lib.mpx_create(device, _lib.MPX_FLAG_F32 if f32 else 0)
+        self.ctx = self.lib.mpx_create(device, (_lib.MPX_FLAG_F32 if f32 else 0) |
+                                       (_lib.MPX_FLAG_DETERMINISTIC if deterministic else 0))
         if not self.ctx:
             msg = self.lib.mpx_last_error(None)
             raise MpxError("mpx_create(device=%d) failed: %s" % (device, (msg or b"?").decode()))

@@ -12,8 +12,22 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "coop_endgame: run the ESACF fit kernel with its default cooperative end game")
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def lane_mode_fits(monkeypatch, request):
+    """Parity tests run the ESACF fit kernel in its bit-reproducible mode (every gaussian fit finishes on the lane
+    that started it -- what MPX_FLAG_DETERMINISTIC selects; MPX_FIT_NOPARK is the per-call override of the same
+    switch).  The default end game hands the last runaway fits to a cooperative kernel with another summation
+    order, which flips ~3 frames in 100 000 on which the reference's own fit is ill-conditioned; tests marked
+    `coop_endgame` run with the default and bound exactly that."""
+    if request.node.get_closest_marker("coop_endgame"):
+        monkeypatch.delenv("MPX_FIT_NOPARK", raising=False)
+    else:
+        monkeypatch.setenv("MPX_FIT_NOPARK", "1")
