@@ -183,6 +183,8 @@ struct SacfArgs {
     int* total_peaks;   // [0] long fits queued, [1] next work item (fit kernel), [2] other fits queued
     int* worklist;      // [worklist_cap] packed (frame << 12 | slot): long fits from the front, others from the back
     int worklist_cap;
+    long long num_frames;  // frames in this launch
+    int pair;              // 1: a workgroup takes two frames and shares the second DFT between them
     int ablate;         // profiling knob (env MPX_SACF_ABLATE): 1 no pow, 2 no peak picking, 4 no 2nd DFT, 8 no 1st DFT
 };
 
@@ -476,105 +478,132 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                      // L complex, slot sigma<L>(position)
     double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * L);      // Mh + 2 doubles
     const int tid = threadIdx.x;
-    const long long f = blockIdx.x;
     const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(a.tw, tid);
     cx<double> regs[8];
 
-    // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N
-    const cx<double>* xin = a.xb + band_index(f, 0, N);
+    // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N.
+    // With a.pair (experimental, off by default: see esacf_run) a workgroup takes TWO frames: S is real and even, so DFT_N(S) is real, and one complex transform of
+    // S_a + i S_b returns the lags of frame a in its real part and those of frame b in its imaginary part
+    // (the cross-talk is the rounding-level imaginary part of a real-even DFT): 3 DFTs per 2 frames instead of 4.
+    const long long fa = a.pair ? 2 * (long long)blockIdx.x : (long long)blockIdx.x;
+    const bool have_b = a.pair && fa + 1 < a.num_frames;
+    double* sa_half = yv;                       // S_a[0 .. N/2] waits here while frame b's spectrum is computed
+    double* sd = reinterpret_cast<double*>(buf);  // S of the frame in flight, all N bins (aliases buf)
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !have_b) break;
+        // (an opaque copy of the thread id per trip: everything below depends only on the thread, and a compiler
+        //  that hoists all of it out of this two-trip loop runs out of registers and spills)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        int kk[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int n = tid + r * T;
-        regs[r] = n < N ? xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)] : cx<double>{0.0, 0.0};
-    }
-    if (!(a.ablate & 8)) dft_regs<L, BLUE>(buf, twd, a, regs, tid);
-    // every thread needs the mirror bin X[N-k] of each of its bins: exchange through LDS
-    int kk[8];
+        for (int e = 0; e < 8; ++e) kk[e] = BLUE ? tid + e * T : dif_freq<L>(dif_last_pos<L>(tid, e / RL, e % RL));
+        const cx<double>* xin = a.xb + band_index(fa + h, 0, N);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        int pos;
-        if (BLUE) {
-            kk[e] = tid + e * T;
-            pos = kk[e];
+        for (int r = 0; r < 8; ++r) {
+            const int n = tid + r * T;
+            regs[r] = n < N ? xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)] : cx<double>{0.0, 0.0};
+        }
+        if (!(a.ablate & 8)) dft_regs<L, BLUE>(buf, twd, a, regs, tid);
+        // every thread needs the mirror bin X[N-k] of each of its bins: exchange through LDS
+#pragma unroll
+        for (int e = 0; e < 8; ++e) buf[sigma<L>(BLUE ? kk[e] : dif_last_pos<L>(tid, e / RL, e % RL))] = regs[e];
+        __syncthreads();
+        // S[k] = |X_lo[k]|^0.67 + |X_hi[k]|^0.67 is even in k (the bands are real): the owner of k <= N/2 computes
+        // it for N-k as well (bit-identical: the mirror pair only swaps the operands of commutative adds and flips
+        // signs that the squares drop), so the two exp/log per bin run on half the bins.
+        double sv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kk[e];
+            sv[e] = 0.0;
+            if (2 * k <= N) {
+                const int km = k == 0 ? 0 : N - k;
+                const cx<double> A = regs[e];
+                const cx<double> B = cconj(buf[sigma<L>(BLUE ? km : dif_pos<L>(km))]);
+                // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
+                const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+                const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+                sv[e] = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
+            }
+        }
+        __syncthreads();  // mirror reads done: buf is free
+        if (h == 0 && have_b) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (2 * kk[e] <= N) sa_half[kk[e]] = sv[e];
         } else {
-            pos = dif_last_pos<L>(tid, e / RL, e % RL);
-            kk[e] = dif_freq<L>(pos);
-        }
-        buf[sigma<L>(pos)] = regs[e];
-    }
-    __syncthreads();
-    // S[k] = |X_lo[k]|^0.67 + |X_hi[k]|^0.67 is even in k (the bands are real): the owner of k <= N/2 computes it
-    // for N-k as well (bit-identical: the mirror pair only swaps the operands of commutative adds and flips signs
-    // that the squares drop), so the two exp/log per bin run on half the bins.
-    double sv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = kk[e];
-        sv[e] = 0.0;
-        if (2 * k <= N) {
-            const int km = k == 0 ? 0 : N - k;
-            const cx<double> A = regs[e];
-            const cx<double> B = cconj(buf[sigma<L>(BLUE ? km : dif_pos<L>(km))]);
-            // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
-            const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
-            const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-            sv[e] = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
+            for (int e = 0; e < 8; ++e) {
+                const int k = kk[e];
+                if (2 * k <= N) {
+                    sd[k] = sv[e];
+                    if (k != 0) sd[N - k] = sv[e];
+                }
+            }
         }
-    }
-    __syncthreads();  // mirror reads done; buf becomes the S exchange (N doubles)
-    double* sd = reinterpret_cast<double*>(buf);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = kk[e];
-        if (2 * k <= N) {
-            sd[k] = sv[e];
-            if (k != 0) sd[N - k] = sv[e];
-        }
+        // (the next writers of buf are this loop's second DFT or the transform below, both behind a barrier)
     }
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 8; ++e) regs[e] = {kk[e] < N ? sd[kk[e]] : 0.0, 0.0};
-    __syncthreads();  // mirror reads done before the next transform writes
+    for (int e = 0; e < 8; ++e) {
+        const int k = BLUE ? tid + e * T : dif_freq<L>(dif_last_pos<L>(tid, e / RL, e % RL));
+        if (k >= N) regs[e] = {0.0, 0.0};
+        else if (have_b) regs[e] = {sa_half[2 * k <= N ? k : N - k], sd[k]};
+        else regs[e] = {sd[k], 0.0};
+    }
+    __syncthreads();  // S reads done before the transform writes buf
     if (a.ablate & 4) {
     } else if (BLUE)
         dft_regs<L, true>(buf, twd, a, regs, tid);
     else
         idit_fft_from_last<L, double>(buf, twd, regs, tid);  // S is real and even: its inverse DFT x N is its DFT
+    __syncthreads();  // buf is dead from here on: frame b's lags and the peak-picking scratch alias it
+    double* yvb = reinterpret_cast<double*>(smem + sizeof(cx<double>) * (L / 2));
     const double inv_n = 1.0 / (double)N;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int n = tid + r * T;
         if (n < Mh) {
-            const double v = regs[r].x * inv_n;
-            yv[n] = v;
-            if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+            const double va = regs[r].x * inv_n, vb = regs[r].y * inv_n;
+            yv[n] = va;
+            yvb[n] = vb;
+            if (a.sacf_out) {
+                a.sacf_out[fa * (long long)Mh + n] = va;
+                if (have_b) a.sacf_out[(fa + 1) * (long long)Mh + n] = vb;
+            }
         }
     }
-    __syncthreads();  // buf is dead from here on; the peak-picking scratch aliases it
-    if (a.defer_enhance) {  // phase-vocoder regime: pv_enhance_kernel + peakpick_kernel take over from the raw SACF
-        double* yrow0 = a.y_out + f * (long long)Mh;
-        for (int n = tid; n < Mh; n += T) yrow0[n] = yv[n];
-        return;
-    }
-
-    // ---- enhancement (esacf.py:108-129)
-    for (int r = 2; r <= a.n_peaks_elim; ++r) {
-        int cut = 0;
-        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-        for (int n = tid; n < Mh; n += T) {
-            double v = yv[n];
-            v = v < 0.0 ? 0.0 : v;          // clip
-            if (n < cut) v = v - v;         // minus the "stretched" copy (== itself for a <=2-frame STFT)
-            v = v < 0.0 ? 0.0 : v;          // clip
-            yv[n] = v;
+    __syncthreads();
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !have_b) break;
+        const long long f = fa + h;
+        double* yh = h ? yvb : yv;
+        double* yrow = a.y_out + f * (long long)Mh;
+        if (a.defer_enhance) {  // phase-vocoder regime: pv_enhance_kernel + peakpick_kernel take over from the raw SACF
+            for (int n = tid; n < Mh; n += T) yrow[n] = yh[n];
+            continue;
         }
-        __syncthreads();
+        // ---- enhancement (esacf.py:108-129)
+        for (int r = 2; r <= a.n_peaks_elim; ++r) {
+            int cut = 0;
+            if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+            for (int n = tid; n < Mh; n += T) {
+                double v = yh[n];
+                v = v < 0.0 ? 0.0 : v;          // clip
+                if (n < cut) v = v - v;         // minus the "stretched" copy (== itself for a <=2-frame STFT)
+                v = v < 0.0 ? 0.0 : v;          // clip
+                yh[n] = v;
+            }
+            __syncthreads();
+        }
+        for (int n = tid; n < Mh; n += T) yrow[n] = yh[n];
+        if (a.ablate & (2 | 16)) continue;  // 16: peak picking runs as its own one-wave-per-frame kernel
+        peak_pick<T>(a, f, yh, smem, tid);
+        __syncthreads();  // frame a's scratch is dead before frame b's
     }
-    double* yrow = a.y_out + f * (long long)Mh;
-    for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
-
-    if (a.ablate & (2 | 16)) return;  // 16: peak picking runs as its own one-wave-per-frame kernel
-    peak_pick<T>(a, f, yv, smem, tid);
 }
 
 // ------------------------------------------------------------------ kernel 2b / 2c
@@ -1618,7 +1647,7 @@ static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStr
     auto kern = sacf_kernel<L, BLUE>;
     if (lds > 48 * 1024)
         MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)frames), dim3(L / 8), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.pair ? (frames + 1) / 2 : frames)), dim3(L / 8), lds, st, a);
     MPX_HIP(ctx, hipGetLastError());
     return MPX_OK;
 }
@@ -1627,6 +1656,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
               int fs, const mpx_esacf_params* params, int frame, int hop, double* d_chroma_frames, int stage,
               double* d_stage_out, hipStream_t st) {
     mpx_esacf_params p = params ? *params : mpx_esacf_params{6, 0.1, 10, MPX_ENHANCE_LIBROSA010};
+    // bit-reproducible mode (MPX_FLAG_DETERMINISTIC; MPX_DETERMINISTIC=1 overrides per call): every gaussian fit is
+    // finished on the lane that started it
+    const bool deterministic = (ctx->flags & MPX_FLAG_DETERMINISTIC) || (getenv("MPX_DETERMINISTIC") && atoi(getenv("MPX_DETERMINISTIC")));
     const int N = frame, Mh = (N - 1) / 2;
     if (N < 64 || N > 4096)
         return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: frame length %d outside [64, 4096]", N);
@@ -1707,6 +1739,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.total_peaks = total;
         a.worklist = worklist;
         a.worklist_cap = (int)(nf * maxp);
+        a.num_frames = nf;
+        // measured, not adopted: pairing saves 0.85 ms per 176 k frames, but the rounding-level cross-talk between the
+        // two frames makes results depend on the batch neighbour and flips 0.075 % of the frames (ill-conditioned fits)
+        a.pair = !deterministic && getenv("MPX_SACF_PAIR") && atoi(getenv("MPX_SACF_PAIR")) ? 1 : 0;
         a.ablate = getenv("MPX_SACF_ABLATE") ? atoi(getenv("MPX_SACF_ABLATE")) : 0;
         if (plan.blue) {
             if (plan.L == 512) rc = sacf_launch<512, true>(ctx, a, nf, st);
@@ -1759,7 +1795,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             if (blocks > fit_resident) blocks = fit_resident;
             // MINPACK: maxfev = 200 (n + 1); the env knobs are for profiling
             const int maxfev = getenv("MPX_FIT_MAXFEV") ? atoi(getenv("MPX_FIT_MAXFEV")) : 200 * (lm::NP + 1);
-            const bool park = !(ctx->flags & MPX_FLAG_DETERMINISTIC) && !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
+            const bool park = !deterministic && !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : PARK_NFEV);

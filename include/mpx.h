@@ -44,10 +44,11 @@ typedef enum mpx_status {
 
 /* mpx_create flags */
 #define MPX_FLAG_F32 0x1    /* opt-in fp32 arithmetic (default: fp64, the reference's dtype) */
-#define MPX_FLAG_DETERMINISTIC 0x2 /* ESACF: finish every gaussian fit on the lane that started it.  By default the
-                                      runaway fits still open when the work list runs dry are finished cooperatively
-                                      (different summation order): bit-identical runs for all but ~3 frames in 100 000,
-                                      those on which the reference's own fit is ill-conditioned. */
+#define MPX_FLAG_DETERMINISTIC 0x2 /* ESACF: bit-reproducible runs (every gaussian fit finished on the lane that started
+                                      it; ~3 ms per 176 k frames slower).  By default the runaway fits still open when
+                                      the work list runs dry are finished cooperatively (other summation order): 3-5
+                                      frames in 176 573 -- ones on which the reference's own fit is ill-conditioned
+                                       -- can differ from run to run. */
 
 typedef struct mpx_ctx mpx_ctx;
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ESACF end-game evidence at BASELINE configs[2] size (4096 clips, 176 573 frames): rows that differ between two
-default runs, between the default (cooperative finish of the last runaway fits) and MPX_FIT_NOPARK=1 (every fit
-finishes on its lane, bit-reproducible), and whether the reference algorithm itself is ill-conditioned on the
+default runs, between the default (cooperative finish of the last runaway fits) and MPX_DETERMINISTIC=1 (one frame per SACF
+workgroup, every fit finishes on its lane: bit-reproducible), and whether the reference algorithm itself is ill-conditioned on the
 differing frames (oracle.esacf.frame_fragility: a 1e-12 relative perturbation of the ESACF row changes its chroma)."""
 import os
 import sys
@@ -33,15 +33,15 @@ def run():
 
 
 a, b = run(), run()
-os.environ["MPX_FIT_NOPARK"] = "1"
+os.environ["MPX_DETERMINISTIC"] = "1"
 c, c2 = run(), run()
-del os.environ["MPX_FIT_NOPARK"]
+del os.environ["MPX_DETERMINISTIC"]
 rows_ab = np.flatnonzero((a != b).any(axis=1))
-rows_ac = np.flatnonzero((a != c).any(axis=1))
+rows_ac = np.flatnonzero((~np.isclose(a, c, rtol=1e-9, atol=1e-12)).any(axis=1))
 print("frames", nf)
 print("default vs default, differing rows:", len(rows_ab))
 print("lane mode vs lane mode, differing rows:", int((c != c2).any(axis=1).sum()))
-print("default vs lane mode, differing rows:", len(rows_ac))
+print("default vs deterministic mode, rows differing beyond 1e-9:", len(rows_ac), " max |rel| elsewhere: %.1e" % float(np.max(np.abs(a - c)[np.isclose(a, c, rtol=1e-9, atol=1e-12)] / np.maximum(np.abs(c)[np.isclose(a, c, rtol=1e-9, atol=1e-12)], 1e-300))))
 xh = x.cpu().numpy()
 frag = 0
 with warnings.catch_warnings():

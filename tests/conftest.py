@@ -22,12 +22,11 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def lane_mode_fits(monkeypatch, request):
-    """Parity tests run the ESACF fit kernel in its bit-reproducible mode (every gaussian fit finishes on the lane
-    that started it -- what MPX_FLAG_DETERMINISTIC selects; MPX_FIT_NOPARK is the per-call override of the same
-    switch).  The default end game hands the last runaway fits to a cooperative kernel with another summation
-    order, which flips ~3 frames in 100 000 on which the reference's own fit is ill-conditioned; tests marked
-    `coop_endgame` run with the default and bound exactly that."""
+    """Parity tests run ESACF in its bit-reproducible mode (what MPX_FLAG_DETERMINISTIC selects; MPX_DETERMINISTIC=1
+    is the per-call override of the same switch).  The default hands the last runaway gaussian fits to a
+    cooperative kernel with another summation order, which flips ~3 frames in 100 000 on which the reference's own
+    fit is ill-conditioned; tests marked `coop_endgame` run with the default and bound exactly that."""
     if request.node.get_closest_marker("coop_endgame"):
-        monkeypatch.delenv("MPX_FIT_NOPARK", raising=False)
+        monkeypatch.delenv("MPX_DETERMINISTIC", raising=False)
     else:
-        monkeypatch.setenv("MPX_FIT_NOPARK", "1")
+        monkeypatch.setenv("MPX_DETERMINISTIC", "1")

@@ -235,7 +235,7 @@ def test_many_clips_properties(eng, det_eng):
     # summation order).  Only fits on which the reference itself is ill-conditioned can come out differently:
     # measured 5 frames in 176 573.
     d = fast_eng.esacf_batch(clips, 44100, 2046)
-    assert int((d != a).any(axis=1).sum()) <= 1
+    assert int((~np.isclose(d, a, rtol=1e-9, atol=1e-12)).any(axis=1).sum()) <= 1
 
 
 @pytest.mark.coop_endgame
@@ -261,5 +261,5 @@ def test_cooperative_finish_agrees_with_lane_mode(eng, det_eng):
     a2, fa2 = det_eng.esacf(x, 44100, 2046, return_frames=True)
     assert fa.shape == (64 * 44, 12)
     np.testing.assert_array_equal(fa, fa2)
-    assert int((fa != fb).any(axis=1).sum()) <= 2          # expectation ~0.1 frame
+    assert int((~np.isclose(fa, fb, rtol=1e-9, atol=1e-12)).any(axis=1).sum()) <= 2   # expectation ~0.1 frame
     np.testing.assert_allclose(b, a, rtol=1e-2)                # a differing frame moves one peak height between bins
