@@ -833,10 +833,37 @@ struct ParkedFit {
 };
 constexpr int PARK_NFEV = 100;
 
+// Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
+// (~100 cycles through the LDS crossbar): the all-reduce over a 32-lane group is four mirror / quad-permute
+// steps inside the 16-lane rows plus one ds_swizzle across the two rows.  Every step pairs lanes symmetrically
+// (i <-> partner(i)), so both partners add the same two numbers and all 32 lanes end with identical bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int PATTERN>
+__device__ __forceinline__ double swz_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, PATTERN);
+    hi = __builtin_amdgcn_ds_swizzle(hi, PATTERN);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double grp32_sum(double v) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    v += dpp_f64<0x140>(v);   // row_mirror
+    v += swz_f64<0x401F>(v);  // lane ^ 16 inside each group of 32
     return v;
+}
+// value of lane J of the caller's 32-lane group (bit-mask swizzle: and 0, or J, xor 0)
+template <int J>
+__device__ __forceinline__ double grp32_bcast(double v) { return swz_f64<(J << 5)>(v); }
+__device__ __forceinline__ double bcast_j(double v, int j) {  // j in 0..2, a constant after unrolling
+    return j == 0 ? grp32_bcast<0>(v) : (j == 1 ? grp32_bcast<1>(v) : grp32_bcast<2>(v));
 }
 
 // Cooperative continuation of parked fits: one fit per 32 lanes, lane l holding sample l (lm::gaussian_fit_coop
@@ -930,18 +957,18 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                 const bool below = l >= j;  // rows j..m-1
                 double ajnorm = sqrt(grp32_sum(below ? cj * cj : 0.0));
                 if (ajnorm != 0.0) {
-                    if (__shfl(cj, j, 32) < 0.0) ajnorm = -ajnorm;
+                    if (bcast_j(cj, j) < 0.0) ajnorm = -ajnorm;
                     const double inv_aj = 1.0 / ajnorm;
                     if (below) cj *= inv_aj;
                     if (l == j) cj += 1.0;
-                    const double inv_ajj = 1.0 / __shfl(cj, j, 32);
+                    const double inv_ajj = 1.0 / bcast_j(cj, j);
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
                         double& ck = k == 1 ? J1 : J2;
                         const double temp = grp32_sum(below ? cj * ck : 0.0) * inv_ajj;
                         if (below) ck -= temp * cj;
                         if (rdiag[k] != 0.0) {
-                            const double t = __shfl(ck, j, 32) / rdiag[k];
+                            const double t = bcast_j(ck, j) / rdiag[k];
                             const double u = 1.0 - t * t;
                             rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
                             const double q = rdiag[k] / wa[k];
@@ -955,7 +982,7 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                     if (below) w4 += cj * temp;
                 }
                 rdiag[j] = -ajnorm;
-                qtf[j] = __shfl(w4, j, 32);
+                qtf[j] = bcast_j(w4, j);
             }
             if (it == 1) {
                 double wa3[NP];
@@ -972,9 +999,9 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
             double r[NP * NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                r[i * NP + 0] = i == 0 ? rdiag[0] : __shfl(J0, i, 32);
-                r[i * NP + 1] = i == 1 ? rdiag[1] : __shfl(J1, i, 32);
-                r[i * NP + 2] = i == 2 ? rdiag[2] : __shfl(J2, i, 32);
+                r[i * NP + 0] = i == 0 ? rdiag[0] : bcast_j(J0, i);
+                r[i * NP + 1] = i == 1 ? rdiag[1] : bcast_j(J1, i);
+                r[i * NP + 2] = i == 2 ? rdiag[2] : bcast_j(J2, i);
             }
             double gnorm = 0.0;
             if (fnorm != 0.0) {
