@@ -627,16 +627,21 @@ __device__ __forceinline__ double pv_hann(const cx<double>* __restrict__ tw, int
     return 0.5 - 0.5 * tw[n & (PV_NFFT - 1)].x;  // periodic Hann: cos(2 pi n / 2048) = Re W_2048^n
 }
 
-__global__ __launch_bounds__(PV_T) void pv_enhance_kernel(PvArgs a) {
+__global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                       // 2048 complex (padded)
-    cx<double>* dout = buf + lds_slots(PV_NFFT);                                  // [2][PV_BINS] synthesis spectra
-    double* phase = reinterpret_cast<double*>(dout + 2 * PV_BINS);                // [PV_BINS] phase accumulator
-    double* x = phase + PV_BINS + 1;                                              // [Mh] working copy of the SACF
+    double* x = reinterpret_cast<double*>(buf + lds_slots(PV_NFFT));             // [Mh] working copy of the SACF
     const int tid = threadIdx.x, Mh = a.Mh;
     const long long f = blockIdx.x;
     double* row = a.y + f * (long long)Mh;
     cx<double> regs[PV_NFFT / PV_T];
+    // A thread always owns the rfft bins k = tid + 256 j (j < 5; bin 1024 is thread 0's fifth): the phase
+    // accumulator and the synthesis spectra of both output frames stay in its registers, and it writes bin k AND
+    // its Hermitian mirror 2048-k of the packed inverse transform itself.  LDS is the FFT buffer + the row: 51 KB,
+    // two workgroups per CU (the spectra in LDS made it 92 KB and one).
+    constexpr int NB = (PV_BINS + PV_T - 1) / PV_T;  // 5
+    double phase[NB];
+    cx<double> d0[NB], d1[NB];
     for (int n = tid; n < Mh; n += PV_T) x[n] = row[n];
     __syncthreads();
     const int n_frames = 1 + Mh / PV_HOP;  // centered STFT of Mh samples
@@ -645,6 +650,8 @@ __global__ __launch_bounds__(PV_T) void pv_enhance_kernel(PvArgs a) {
         __syncthreads();
         const int len_out = (int)nearbyint((double)Mh / (double)r);          // int(round(len/rate)), half-to-even
         const int nsteps = (n_frames + r - 1) / r;                            // len(arange(0, n_frames, r)) <= 2
+#pragma unroll
+        for (int j = 0; j < NB; ++j) d1[j] = {0.0, 0.0};
         for (int t = 0; t < nsteps; ++t) {
             const int c0 = t * r, c1 = c0 + 1;                                // STFT columns int(step), int(step)+1
             // analysis: frame c covers xpad[c*512 + n], xpad = [1024 zeros | x | 1024 zeros]
@@ -657,34 +664,40 @@ __global__ __launch_bounds__(PV_T) void pv_enhance_kernel(PvArgs a) {
             }
             __syncthreads();
             fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
-            for (int k = tid; k < PV_BINS; k += PV_T) {
-                const cx<double> Z = buf[lds_slot(k & (PV_NFFT - 1))];
-                const cx<double> Zc = cconj(buf[lds_slot((PV_NFFT - k) & (PV_NFFT - 1))]);
-                const cx<double> A = {0.5 * (Z.x + Zc.x), 0.5 * (Z.y + Zc.y)};   // rfft of column c0
-                const cx<double> B = {0.5 * (Z.y - Zc.y), -0.5 * (Z.x - Zc.x)};  // rfft of column c1
-                const double ang0 = atan2(A.y, A.x), ang1 = atan2(B.y, B.x);
-                double pacc = t == 0 ? ang0 : phase[k];                           // phase_acc = angle(D[:, 0])
-                const double mag = hypot(A.x, A.y);                               // alpha = 0: |column c0|
-                dout[t * PV_BINS + k] = {mag * cos(pacc), mag * sin(pacc)};
-                const double phi = M_PI * (double)PV_HOP * (double)k / (double)(PV_BINS - 1);  // linspace(0, pi*hop, 1025)
-                double dphase = ang1 - ang0 - phi;
-                dphase = dphase - 2.0 * M_PI * nearbyint(dphase / (2.0 * M_PI));
-                phase[k] = pacc + (phi + dphase);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int k = tid + j * PV_T;
+                if (k < PV_BINS) {
+                    const cx<double> Z = buf[lds_slot(k & (PV_NFFT - 1))];
+                    const cx<double> Zc = cconj(buf[lds_slot((PV_NFFT - k) & (PV_NFFT - 1))]);
+                    const cx<double> A = {0.5 * (Z.x + Zc.x), 0.5 * (Z.y + Zc.y)};   // rfft of column c0
+                    const cx<double> B = {0.5 * (Z.y - Zc.y), -0.5 * (Z.x - Zc.x)};  // rfft of column c1
+                    const double ang0 = atan2(A.y, A.x), ang1 = atan2(B.y, B.x);
+                    const double pacc = t == 0 ? ang0 : phase[j];                     // phase_acc = angle(D[:, 0])
+                    const double mag = hypot(A.x, A.y);                               // alpha = 0: |column c0|
+                    const cx<double> d = {mag * cos(pacc), mag * sin(pacc)};
+                    if (t == 0) d0[j] = d;
+                    else d1[j] = d;
+                    const double phi = M_PI * (double)PV_HOP * (double)k / (double)(PV_BINS - 1);  // linspace(0, pi*hop, 1025)
+                    double dphase = ang1 - ang0 - phi;
+                    dphase = dphase - 2.0 * M_PI * nearbyint(dphase / (2.0 * M_PI));
+                    phase[j] = pacc + (phi + dphase);
+                }
             }
             __syncthreads();
         }
-        // synthesis: irfft of both output frames through one complex inverse FFT (swap trick)
-        for (int k = tid; k < PV_NFFT; k += PV_T) {
-            const int kk = k <= PV_NFFT / 2 ? k : PV_NFFT - k;
-            cx<double> d0 = dout[kk];
-            cx<double> d1 = nsteps > 1 ? dout[PV_BINS + kk] : cx<double>{0.0, 0.0};
-            if (kk == 0 || kk == PV_NFFT / 2) d0.y = d1.y = 0.0;   // irfft ignores the imaginary part there
-            if (k > PV_NFFT / 2) {                                  // Hermitian extension
-                d0.y = -d0.y;
-                d1.y = -d1.y;
+        // synthesis: irfft of both output frames through one complex inverse FFT (swap trick); every thread
+        // writes its bins and their Hermitian mirrors
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int k = tid + j * PV_T;
+            if (k < PV_BINS) {
+                cx<double> e0 = d0[j], e1 = d1[j];
+                if (k == 0 || k == PV_NFFT / 2) e0.y = e1.y = 0.0;    // irfft ignores the imaginary part there
+                buf[lds_slot(k & (PV_NFFT - 1))] = cswap(cx<double>{e0.x - e1.y, e0.y + e1.x});  // D0 + i*D1
+                if (k != 0 && k != PV_NFFT / 2)                         // conj(D0) + i*conj(D1) at 2048-k
+                    buf[lds_slot(PV_NFFT - k)] = cswap(cx<double>{e0.x + e1.y, -e0.y + e1.x});
             }
-            const cx<double> u = {d0.x - d1.y, d0.y + d1.x};       // D0 + i*D1
-            buf[lds_slot(k)] = cswap(u);
         }
         __syncthreads();
         fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
@@ -1800,7 +1813,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             pa.Mh = Mh;
             pa.n_peaks_elim = p.n_peaks_elim;
             pa.tw = (const cx<double>*)pit->second[0];
-            const size_t pv_lds = sizeof(cx<double>) * (lds_slots(PV_NFFT) + 2 * PV_BINS) + sizeof(double) * (size_t)(PV_BINS + 1 + Mh + 2);
+            const size_t pv_lds = sizeof(cx<double>) * lds_slots(PV_NFFT) + sizeof(double) * (size_t)(Mh + 2);
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)pv_enhance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_lds));
             hipLaunchKernelGGL(pv_enhance_kernel, dim3((unsigned)nf), dim3(PV_T), pv_lds, st, pa);
             const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
