@@ -16,6 +16,7 @@
 //                        (esacf.py:64-71).
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "mpx_fft_dif.hpp"
@@ -847,9 +848,9 @@ struct ParkedFit {
 constexpr int PARK_NFEV = 100;
 
 // Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
-// (~100 cycles through the LDS crossbar): the all-reduce over a 32-lane group is four mirror / quad-permute
-// steps inside the 16-lane rows plus one ds_swizzle across the two rows.  Every step pairs lanes symmetrically
-// (i <-> partner(i)), so both partners add the same two numbers and all 32 lanes end with identical bits.
+// (~100 cycles through the LDS crossbar): a fit owns one 16-lane DPP row, so its all-reduce is four mirror /
+// quad-permute steps.  Every step pairs lanes symmetrically (i <-> partner(i)), so both partners add the same
+// two numbers and all 16 lanes end with identical bits.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -857,34 +858,34 @@ __device__ __forceinline__ double dpp_f64(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-template <int PATTERN>
-__device__ __forceinline__ double swz_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_swizzle(lo, PATTERN);
-    hi = __builtin_amdgcn_ds_swizzle(hi, PATTERN);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double grp32_sum(double v) {
+__device__ __forceinline__ double row_sum(double v) {
     v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
     v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
     v += dpp_f64<0x141>(v);   // row_half_mirror
     v += dpp_f64<0x140>(v);   // row_mirror
-    v += swz_f64<0x401F>(v);  // lane ^ 16 inside each group of 32
     return v;
 }
-// value of lane J of the caller's 32-lane group (bit-mask swizzle: and 0, or J, xor 0)
+// value of lane J of the caller's 16-lane row (ds_swizzle, bit-mask mode: lane' = (lane & 0x10) | J)
 template <int J>
-__device__ __forceinline__ double grp32_bcast(double v) { return swz_f64<(J << 5)>(v); }
-__device__ __forceinline__ double bcast_j(double v, int j) {  // j in 0..2, a constant after unrolling
-    return j == 0 ? grp32_bcast<0>(v) : (j == 1 ? grp32_bcast<1>(v) : grp32_bcast<2>(v));
+__device__ __forceinline__ double row_bcast_c(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_swizzle(lo, 0x10 | (J << 5));
+    hi = __builtin_amdgcn_ds_swizzle(hi, 0x10 | (J << 5));
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double row_bcast(double v, int j) {  // j in 0..2, a constant after unrolling
+    return j == 0 ? row_bcast_c<0>(v) : (j == 1 ? row_bcast_c<1>(v) : row_bcast_c<2>(v));
+}
+struct D2 {  // this lane's two samples: rows l and l + 16 of the m <= 21 rows
+    double a, b;
+};
 
-// Cooperative continuation of parked fits: one fit per 32 lanes, lane l holding sample l (lm::gaussian_fit_coop
-// restated from a resume point and with the same reciprocal / column-0 / exponential forms as peakfit_kernel).
-// The m-vectors of MINPACK are one register per lane, norms and dot products are xor-butterfly all-reduces that
-// leave identical bits in every lane of the group, so the group runs the 3x3 part redundantly and uniformly.  A
-// trip costs ~3 k instructions instead of ~8.5 k and, more to the point, every parked fit gets its own lanes
-// instead of waiting behind 63 finished ones.
+// Cooperative continuation of parked fits: one fit per 16-lane row (4 per wave), lane l holding samples l and
+// l + 16 (lm::gaussian_fit_coop restated from a resume point and with the same reciprocal / column-0 / exponential
+// forms as peakfit_kernel).  The m-vectors of MINPACK are two registers per lane, norms and dot products are
+// all-reduces that leave identical bits in every lane of the row, so the row runs the 3x3 part redundantly and
+// uniformly.  A trip costs ~3.3 k instructions per FOUR fits instead of ~8.5 k and, more to the point, every
+// parked fit gets its own lanes instead of waiting behind 63 finished ones.
 __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
                                                      int* next_parked, const double* __restrict__ y, double* center,
                                                      int* ok, int maxfev) {
@@ -892,44 +893,52 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
     __shared__ double exp_tab[64];
     exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
     __syncthreads();
-    const int l = threadIdx.x & 31;
+    const int l = threadIdx.x & 15;
     const int total = *parked_count;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const double eps = sqrt(EPSMCH);
     for (;;) {
         int idx = 0;
         if (l == 0) idx = atomicAdd(next_parked, 1);
-        idx = __shfl(idx, 0, 32);
+        idx = __shfl(idx, 0, 16);
         if (idx >= total) break;
         const ParkedFit pf = parked[idx];
-        const bool on = l < pf.m;
-        const double px = pf.x0 + (double)l;
-        const double py = on ? y[pf.row_off + l] : 0.0;
+        const bool ona = l < pf.m, onb = l + 16 < pf.m;
+        const D2 px = {pf.x0 + (double)l, pf.x0 + (double)(l + 16)};
+        const D2 py = {ona ? y[pf.row_off + l] : 0.0, onb ? y[pf.row_off + l + 16] : 0.0};
         double x[NP] = {pf.x[0], pf.x[1], pf.x[2]}, diag[NP] = {pf.diag[0], pf.diag[1], pf.diag[2]};
         double par = pf.par, delta = pf.delta, xnorm = pf.xnorm, fnorm = pf.fnorm;
         int it = pf.it, nfev = pf.nfev, info = 0;
-        double f = on ? gauss_resid(gauss_prep(x, exp_tab), px, py) : 0.0;
+        auto resid = [&](const double* p) -> D2 {
+            const GaussEval g = gauss_prep(p, exp_tab);
+            const double ra = gauss_resid(g, px.a, py.a), rb = gauss_resid(g, px.b, py.b);
+            return {ona ? ra : 0.0, onb ? rb : 0.0};
+        };
+        D2 f = resid(x);
         for (;;) {
-            // forward-difference jacobian: this lane's row
-            double J0, J1, J2;
+            // forward-difference jacobian: this lane's two rows
+            D2 J0, J1, J2;
             {
                 if (x[0] != 0.0) {
-                    J0 = on ? (f + py) * (1.0 / x[0]) : 0.0;
+                    const double inv_a = 1.0 / x[0];
+                    J0 = {ona ? (f.a + py.a) * inv_a : 0.0, onb ? (f.b + py.b) * inv_a : 0.0};
                 } else {
                     x[0] = eps;
-                    J0 = on ? (gauss_resid(gauss_prep(x, exp_tab), px, py) - f) * (1.0 / eps) : 0.0;
+                    const D2 w = resid(x);
+                    J0 = {(w.a - f.a) * (1.0 / eps), (w.b - f.b) * (1.0 / eps)};
                     x[0] = 0.0;
                 }
-                double jj[NP];
+                D2 jj[NP];
 #pragma unroll
                 for (int j = 1; j < NP; ++j) {
                     const double temp = x[j];
                     double h = eps * fabs(temp);
                     if (h == 0.0) h = eps;
                     x[j] = temp + h;
-                    const double w = on ? gauss_resid(gauss_prep(x, exp_tab), px, py) : 0.0;
+                    const D2 w = resid(x);
                     x[j] = temp;
-                    jj[j] = (w - f) * (1.0 / h);
+                    const double inv_h = 1.0 / h;
+                    jj[j] = {(w.a - f.a) * inv_h, (w.b - f.b) * inv_h};
                 }
                 J1 = jj[1];
                 J2 = jj[2];
@@ -937,13 +946,13 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
             nfev += NP;
             int ipvt[NP] = {0, 1, 2};
             double acnorm[NP], rdiag[NP], wa[NP];
-            acnorm[0] = sqrt(grp32_sum(J0 * J0));
-            acnorm[1] = sqrt(grp32_sum(J1 * J1));
-            acnorm[2] = sqrt(grp32_sum(J2 * J2));
+            acnorm[0] = sqrt(row_sum(J0.a * J0.a + J0.b * J0.b));
+            acnorm[1] = sqrt(row_sum(J1.a * J1.a + J1.b * J1.b));
+            acnorm[2] = sqrt(row_sum(J2.a * J2.a + J2.b * J2.b));
 #pragma unroll
             for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
             double qtf[NP];
-            double w4 = f;  // becomes Q^T fvec
+            D2 w4 = f;  // becomes Q^T fvec
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 int kmax = j;
@@ -955,9 +964,9 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                         rmax = rdiag[k];
                     }
                 if (kmax != j) {
-                    double& cjs = j == 0 ? J0 : (j == 1 ? J1 : J2);
-                    double& cks = kmax == 1 ? J1 : J2;
-                    const double t0 = cjs;
+                    D2& cjs = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                    D2& cks = kmax == 1 ? J1 : J2;
+                    const D2 t0 = cjs;
                     cjs = cks;
                     cks = t0;
                     put3(rdiag, kmax, rdiag[j]);
@@ -966,36 +975,39 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                     ipvt[j] = sel3(ipvt, kmax);
                     put3(ipvt, kmax, t);
                 }
-                double& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
-                const bool below = l >= j;  // rows j..m-1
-                double ajnorm = sqrt(grp32_sum(below ? cj * cj : 0.0));
+                D2& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                const bool below = l >= j;  // rows j..15 of the first slot; the second slot (rows 16..) is always below
+                double ajnorm = sqrt(row_sum((below ? cj.a * cj.a : 0.0) + cj.b * cj.b));
                 if (ajnorm != 0.0) {
-                    if (bcast_j(cj, j) < 0.0) ajnorm = -ajnorm;
+                    if (row_bcast(cj.a, j) < 0.0) ajnorm = -ajnorm;
                     const double inv_aj = 1.0 / ajnorm;
-                    if (below) cj *= inv_aj;
-                    if (l == j) cj += 1.0;
-                    const double inv_ajj = 1.0 / bcast_j(cj, j);
+                    if (below) cj.a *= inv_aj;
+                    cj.b *= inv_aj;
+                    if (l == j) cj.a += 1.0;
+                    const double inv_ajj = 1.0 / row_bcast(cj.a, j);
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
-                        double& ck = k == 1 ? J1 : J2;
-                        const double temp = grp32_sum(below ? cj * ck : 0.0) * inv_ajj;
-                        if (below) ck -= temp * cj;
+                        D2& ck = k == 1 ? J1 : J2;
+                        const double temp = row_sum((below ? cj.a * ck.a : 0.0) + cj.b * ck.b) * inv_ajj;
+                        if (below) ck.a -= temp * cj.a;
+                        ck.b -= temp * cj.b;
                         if (rdiag[k] != 0.0) {
-                            const double t = bcast_j(ck, j) / rdiag[k];
+                            const double t = row_bcast(ck.a, j) / rdiag[k];
                             const double u = 1.0 - t * t;
                             rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
                             const double q = rdiag[k] / wa[k];
                             if (0.05 * q * q <= EPSMCH) {
-                                rdiag[k] = sqrt(grp32_sum(l > j ? ck * ck : 0.0));
+                                rdiag[k] = sqrt(row_sum((l > j ? ck.a * ck.a : 0.0) + ck.b * ck.b));
                                 wa[k] = rdiag[k];
                             }
                         }
                     }
-                    const double temp = -grp32_sum(below ? cj * w4 : 0.0) * inv_ajj;
-                    if (below) w4 += cj * temp;
+                    const double temp = -row_sum((below ? cj.a * w4.a : 0.0) + cj.b * w4.b) * inv_ajj;
+                    if (below) w4.a += cj.a * temp;
+                    w4.b += cj.b * temp;
                 }
                 rdiag[j] = -ajnorm;
-                qtf[j] = bcast_j(w4, j);
+                qtf[j] = row_bcast(w4.a, j);
             }
             if (it == 1) {
                 double wa3[NP];
@@ -1008,13 +1020,13 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                 delta = factor * xnorm;
                 if (delta == 0.0) delta = factor;
             }
-            // replicate the 3x3 upper triangle R (row i lives in lane i; its diagonal is rdiag)
+            // replicate the 3x3 upper triangle R (row i lives in lane i, first slot; its diagonal is rdiag)
             double r[NP * NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                r[i * NP + 0] = i == 0 ? rdiag[0] : bcast_j(J0, i);
-                r[i * NP + 1] = i == 1 ? rdiag[1] : bcast_j(J1, i);
-                r[i * NP + 2] = i == 2 ? rdiag[2] : bcast_j(J2, i);
+                r[i * NP + 0] = i == 0 ? rdiag[0] : row_bcast(J0.a, i);
+                r[i * NP + 1] = i == 1 ? rdiag[1] : row_bcast(J1.a, i);
+                r[i * NP + 2] = i == 2 ? rdiag[2] : row_bcast(J2.a, i);
             }
             double gnorm = 0.0;
             if (fnorm != 0.0) {
@@ -1049,9 +1061,9 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                 }
                 const double pnorm = enorm3(wa3);
                 if (it == 1) delta = delta < pnorm ? delta : pnorm;
-                const double fn = on ? gauss_resid(gauss_prep(xnew, exp_tab), px, py) : 0.0;
+                const D2 fn = resid(xnew);
                 ++nfev;
-                const double fnorm1 = sqrt(grp32_sum(fn * fn));
+                const double fnorm1 = sqrt(row_sum(fn.a * fn.a + fn.b * fn.b));
                 double actred = -1.0;
                 if (0.1 * fnorm1 < fnorm) {
                     const double q = fnorm1 / fnorm;
@@ -1179,7 +1191,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         // End game: once the work list is empty, a fit that is already past PARK_NFEV evaluations (a runaway fit:
         // the others need ~60) would keep this wave -- and the kernel -- alive for up to 200 more trips of
         // ~45 us.  Its MINPACK state is handed to coopfit_kernel instead, which finishes all such fits at once
-        // with 32 lanes each.
+        // with 16 lanes each.
         drained = drained || __any(phase == FIT_DONE);
         if (drained && phase == FIT_OUTER && nfev >= park_nfev && parked) {
             ParkedFit pf;
@@ -1839,9 +1851,15 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : PARK_NFEV);
-            if (park)  // the runaway fits still open when the list ran dry: 32 lanes each, all at once
-                hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 16)), dim3(64), 0, st, parked, total + 3,
+            if (park)  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
+                hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 12)), dim3(64), 0, st, parked, total + 3,
                                    total + 4, y, center, okf, maxfev);
+        }
+        if (getenv("MPX_DEBUG_FITS")) {  // profiling aid: work-list counters of this batch
+            int h[5];
+            MPX_HIP(ctx, hipMemcpyAsync(h, total, sizeof(h), hipMemcpyDeviceToHost, st));
+            MPX_HIP(ctx, hipStreamSynchronize(st));
+            fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d\n", nf, h[0] + h[2], h[0], h[3]);
         }
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,
                            y, peak_count, peak_idx, center, okf, d_chroma_frames);
