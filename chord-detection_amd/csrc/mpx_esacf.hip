@@ -607,6 +607,87 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     }
 }
 
+// Frames whose Bluestein length exceeds the 4096 points of the in-place engine (non-power-of-two N above 2048:
+// e.g. the reference's default 46.4 ms frame at 48 kHz, N = 2227 -> L = 8192): the same pipeline on the
+// padded Stockham engine of mpx_fft.hpp, one 512-thread workgroup per frame and per CU (139 KB of LDS).
+// Correct and complete, not tuned: ~4x the time per frame of the in-place kernel.
+template <int L, int T>
+__device__ __forceinline__ void dft_n_stockham(cx<double>* buf, const SacfArgs& a, cx<double>* regs, int tid) {
+    const int N = a.N;
+    for (int n = tid; n < L; n += T) buf[lds_slot(n)] = n < N ? cmulc(buf[lds_slot(n)], a.chirp[n]) : cx<double>{0.0, 0.0};
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+    // multiply by the filter spectrum; swap re/im so that the next forward FFT is an inverse one
+    for (int k = tid; k < L; k += T) buf[lds_slot(k)] = cswap(cmul(buf[lds_slot(k)], a.bhat[k]));
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+    for (int k = tid; k < N; k += T) buf[lds_slot(k)] = cmulc(cswap(buf[lds_slot(k)]), a.chirp[k]);
+    __syncthreads();
+}
+
+template <int L, int T>
+__global__ __launch_bounds__(T) void sacf_big_kernel(SacfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, Mh = a.Mh;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                                  // L complex, padded
+    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));       // Mh + 2 doubles
+    const int tid = threadIdx.x;
+    const long long f = blockIdx.x;
+    cx<double> regs[L / T];
+    const cx<double>* xin = a.xb + band_index(f, 0, N);
+    for (int n = tid; n < N; n += T) buf[lds_slot(n)] = xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)];
+    __syncthreads();
+    dft_n_stockham<L, T>(buf, a, regs, tid);
+    constexpr int PER = 4096 / T;  // N <= 4096 bins, this thread's share
+    double sv[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int k = tid + e * T;
+        sv[e] = 0.0;
+        if (k < N) {
+            const cx<double> A = buf[lds_slot(k)];
+            const cx<double> B = cconj(buf[lds_slot(k == 0 ? 0 : N - k)]);
+            const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+            const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+            sv[e] = mag067(lr, li) + mag067(hr, hm);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int k = tid + e * T;
+        if (k < N) buf[lds_slot(k)] = {sv[e], 0.0};
+    }
+    __syncthreads();
+    dft_n_stockham<L, T>(buf, a, regs, tid);
+    const double inv_n = 1.0 / (double)N;
+    for (int n = tid; n < Mh; n += T) {
+        const double v = buf[lds_slot(n)].x * inv_n;
+        yv[n] = v;
+        if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+    }
+    __syncthreads();  // buf is dead from here on; the peak-picking scratch aliases it
+    double* yrow = a.y_out + f * (long long)Mh;
+    if (a.defer_enhance) {
+        for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+        return;
+    }
+    for (int r = 2; r <= a.n_peaks_elim; ++r) {
+        int cut = 0;
+        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+        for (int n = tid; n < Mh; n += T) {
+            double v = yv[n];
+            v = v < 0.0 ? 0.0 : v;
+            if (n < cut) v = v - v;
+            v = v < 0.0 ? 0.0 : v;
+            yv[n] = v;
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+    peak_pick<T>(a, f, yv, smem, tid);
+}
+
 // ------------------------------------------------------------------ kernel 2b / 2c
 // Enhancement when librosa.effects.time_stretch is a REAL phase vocoder, i.e. when the STFT of the
 // Mh-lag SACF has more than two frames (Mh >= 1024: ESACF frames above 2048 samples).  Per rate r
@@ -1629,8 +1710,11 @@ static int esacf_plan(mpx_ctx* ctx, int N, EsacfPlan& plan) {
         // the kernel multiplies the filter spectrum onto registers that hold the DIF output of thread tid,
         // element e: store it in exactly that order ([e][tid], coalesced)
         std::vector<cx<double>> filt_regs(L);
-        for (int t = 0; t < L / 8; ++t)
-            for (int e = 0; e < 8; ++e) filt_regs[(size_t)e * (L / 8) + t] = filt[dif_reg_freq(L, t, e)];
+        if (L > 4096)
+            filt_regs = filt;  // sacf_big_kernel (Stockham engine) multiplies in natural order
+        else
+            for (int t = 0; t < L / 8; ++t)
+                for (int e = 0; e < 8; ++e) filt_regs[(size_t)e * (L / 8) + t] = filt[dif_reg_freq(L, t, e)];
         plan.chirp = (cx<double>*)upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
         plan.bhat = (cx<double>*)upload(ctx, filt_regs.data(), filt_regs.size() * sizeof(cx<double>));
         if (!plan.chirp || !plan.bhat) return MPX_ENOMEM;
@@ -1728,8 +1812,8 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if (rc) return rc;
     EsacfPlan plan;
     if ((rc = esacf_plan(ctx, N, plan))) return rc;
-    if (plan.L > 4096)
-        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: non power-of-two frame %d needs a %d-point FFT (> 4096)", N, plan.L);
+    if (plan.L > 8192)
+        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: non power-of-two frame %d needs a %d-point FFT (> 8192)", N, plan.L);
     const int maxp = p.peak_min_dist > 1 ? Mh / (p.peak_min_dist + 1) + 2 : Mh / 2 + 2;
     if (maxp > 4095) return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: too many peak slots");
 
@@ -1796,7 +1880,13 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         // two frames makes results depend on the batch neighbour and flips 0.075 % of the frames (ill-conditioned fits)
         a.pair = !deterministic && getenv("MPX_SACF_PAIR") && atoi(getenv("MPX_SACF_PAIR")) ? 1 : 0;
         a.ablate = getenv("MPX_SACF_ABLATE") ? atoi(getenv("MPX_SACF_ABLATE")) : 0;
-        if (plan.blue) {
+        if (plan.L == 8192) {
+            const size_t lds = sizeof(cx<double>) * lds_slots(8192) + sizeof(double) * (size_t)(Mh + 2);
+            auto kern = sacf_big_kernel<8192, 512>;
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(512), lds, st, a);
+            MPX_HIP(ctx, hipGetLastError());
+        } else if (plan.blue) {
             if (plan.L == 512) rc = sacf_launch<512, true>(ctx, a, nf, st);
             else if (plan.L == 1024) rc = sacf_launch<1024, true>(ctx, a, nf, st);
             else if (plan.L == 2048) rc = sacf_launch<2048, true>(ctx, a, nf, st);

@@ -154,6 +154,30 @@ def test_parameters_and_44100_default_frame(eng):
     _check_clip(eng, x[:8000], 16000, 742)
 
 
+def test_48k_default_frame_8192_point_bluestein(eng):
+    """The reference's default 46.4 ms frame at 48 kHz is 2227 samples: non-power-of-two above 2048, so the
+    chirp-z length is 8192 (sacf_big_kernel on the Stockham engine) and the SACF (1113 lags) is in the real
+    phase-vocoder regime.  Also 3000 and 4095 samples (largest supported)."""
+    from oracle import esacf as o_esacf
+    rng = np.random.default_rng(48)
+    n = 3 * 2227 + 500
+    t = np.arange(n) / 48000.0
+    x = np.zeros(n)
+    for f0 in (220.0, 277.18, 329.63):
+        for h in range(1, 6):
+            x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+    x = (0.3 * x + 0.005 * rng.standard_normal(n)).astype(np.float32)
+    assert o_esacf.ham_samples(48000) == 2227
+    got = eng.esacf_stage("sacf", x, 48000, 2227)
+    frames = np.zeros((4, 2227))
+    frames.reshape(-1)[:n] = x
+    _, lo, hi = o_esacf.band_split(frames, 48000)
+    np.testing.assert_allclose(got, o_esacf.sacf(lo, hi), rtol=0, atol=1e-10 * np.abs(got).max())
+    _check_clip(eng, x, 48000, 2227)
+    _check_clip(eng, x, 48000, 3000, enhance_mode="noop")
+    _check_clip(eng, x[:2 * 4095], 48000, 4095, enhance_mode="noop")
+
+
 def test_phase_vocoder_enhancement_4096_frames(eng):
     """ESACF frames above 2048 samples: librosa.effects.time_stretch is a real phase vocoder
     (STFT of the 2047-lag SACF has 4 frames).  BASELINE's 4096/hop-1024 ESACF variant."""
