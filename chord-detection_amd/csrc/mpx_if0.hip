@@ -18,7 +18,7 @@
 #include <cmath>
 #include <cstring>
 
-#include "mpx_fft.hpp"
+#include "mpx_fft_dif.hpp"
 #include "mpx_internal.hpp"
 
 namespace mpx {
@@ -40,7 +40,7 @@ struct If0Chunk {
     int clip_left;         // samples of the clip from sig_start on (>= len unless the clip ends inside)
     int warm;              // run-in samples before sig_start (0 at the start of a clip)
     int pad;
-    long long yc_row0;     // first row of this chunk in the [t][channel] output buffer
+    long long yc_row0;     // the chunk's block of the output buffer starts at yc_row0 * channels; inside: [channel][len]
 };
 
 struct If0Wfir {
@@ -49,13 +49,19 @@ struct If0Wfir {
 };
 
 __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
-                                                          long long num_items, int channels,
+                                                          long long num_chunks, int channels,
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc) {
-    const long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= num_items) return;
-    const long long ck = w / channels;
-    const int ch = (int)(w - ck * channels);
+    // one wave per (chunk, group of 64 channels): all lanes share the chunk's loop bounds, and the outputs go
+    // through an LDS tile [channel][16 samples] so that the buffer can be [chunk][channel][t] -- every channel's
+    // samples contiguous for the spectrum kernel -- with 128-byte row segments per store instead of 8-byte ones
+    __shared__ double tile[64][17];
+    const int groups = (channels + 63) / 64;
+    const long long ck = blockIdx.x / groups;
+    const int ch0 = (int)(blockIdx.x % groups) * 64, lane = threadIdx.x;
+    const int nch = channels - ch0 < 64 ? channels - ch0 : 64;
+    const int ch = ch0 + (lane < nch ? lane : 0);   // idle lanes shadow channel ch0 (results discarded)
+    if (ck >= num_chunks) return;
     const If0Chunk c = chunks[ck];
     const If0ChanCoef k = coefs[ch];
     // The chain is 17 filter stages deep (4 resonators, 12 all-passes, rectifier + low-pass).  Evaluated
@@ -73,8 +79,8 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     double fso = 0, fxh = 0;                   // input of the final stage
     constexpr int DEPTH = 16;                  // output of sample n appears in iteration n + DEPTH
     const float* __restrict__ x = sig + c.sig_start;
-    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + ch;
-    constexpr int PF = 8;
+    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + (size_t)ch0 * c.len;  // [channel - ch0][len]
+    constexpr int PF = 16;                     // = the tile width = DEPTH: block tb produces outputs tb-16 .. tb-1
     // the samples of block tb + PF are fetched while block tb runs: a chunk's lanes are often alone on their SIMD
     // (256 two-second clips x 70 channels are 280 waves on 1024 SIMDs), so nothing else hides the load latency
     float nx[PF];
@@ -98,8 +104,7 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                 const double lp = k.lpb0 * r + l1;
                 l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
                 l2 = k.lpb2 * r - k.lpa2 * lp;
-                const int t = tau - DEPTH;
-                if (t >= 0 && t < c.len) out[(size_t)t * channels] = (r + lp) / 2.0;
+                tile[lane][q] = (r + lp) / 2.0;   // output sample tau - DEPTH = tb - 16 + q
             }
             // ---- all-pass stages 11..0 (samples tau-15 .. tau-4), dsp/wfir.py:25-43
             {
@@ -145,14 +150,26 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                 qy = y;
             }
         }
+        const int t0 = tb - DEPTH;
+        if (t0 >= 0 && t0 < c.len) {   // uniform: warm-up and length are multiples of 16
+            wave_lds_fence();
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int e = q * 64 + lane, r = e >> 4, cc = e & 15;
+                if (r < nch) out[(size_t)r * c.len + t0 + cc] = tile[r][cc];
+            }
+            wave_lds_fence();
+        }
     }
 }
 
 // ------------------------------------------------------------------ spectrum
 struct If0Frame {
-    long long yc_row;   // row (sample index) of the frame's first sample in yc
+    long long yc_base;  // index in yc of the frame's first sample of channel 0
     int valid;          // samples of the frame that exist (tail of a clip is zero padded)
     int clip;
+    int ch_stride;      // distance between channels (= the chunk's length)
+    int pad;
 };
 
 template <int NF, int T>   // NF = frame size = complex FFT length (2*NF real points, upper half zero)
@@ -179,8 +196,8 @@ __global__ __launch_bounds__(T) void if0_spectrum_kernel(const double* __restric
             const int s = 2 * p;
             double x0 = 0.0, x1 = 0.0;
             if (s < NF) {  // the second half of the 2*NF-point frame is the zero padding
-                if (s < fr.valid) x0 = yc[(size_t)(fr.yc_row + s) * channels + ch] * window[s];
-                if (s + 1 < fr.valid) x1 = yc[(size_t)(fr.yc_row + s + 1) * channels + ch] * window[s + 1];
+                if (s < fr.valid) x0 = yc[fr.yc_base + (size_t)ch * fr.ch_stride + s] * window[s];
+                if (s + 1 < fr.valid) x1 = yc[fr.yc_base + (size_t)ch * fr.ch_stride + s + 1] * window[s + 1];
             }
             regs[e] = {x0, x1};
         }
@@ -521,7 +538,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             chunks.push_back(ck);
             for (int64_t fo = 0; fo < ck.len; fo += NF) {
                 If0Frame fr;
-                fr.yc_row = ck.yc_row0 + fo;
+                fr.yc_base = ck.yc_row0 * p.channels + fo;
+                fr.ch_stride = ck.len;
+                fr.pad = 0;
                 const int64_t fl = len - (t0 + fo);
                 fr.valid = (int)(fl >= NF ? NF : (fl > 0 ? fl : 0));
                 fr.clip = c;
@@ -559,9 +578,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     double* ut = (double*)ctx->d_ws1.p;
     double* ur = ut + (size_t)nframes * n2;
     double* ud = ur + (size_t)nframes * n2;
-    const long long items = nchunks * p.channels;
-    hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, st, (const float*)ctx->d_signal.p,
-                       d_chunks, items, p.channels, plan.d_coefs, plan.wf, yc);
+    hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * ((p.channels + 63) / 64))), dim3(64), 0, st,
+                       (const float*)ctx->d_signal.p, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc);
     MPX_HIP(ctx, hipGetLastError());
     if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
