@@ -24,7 +24,8 @@
 namespace mpx {
 
 constexpr int IF0_MAXCH = 128;
-constexpr long long IF0_CHUNK = 262144;   // samples per front-end chunk (multiple of every frame size)
+constexpr long long IF0_CHUNK = 262144;   // largest front-end chunk (samples; multiple of every frame size)
+constexpr long long IF0_CHUNK_MIN = 16384;
 constexpr long long IF0_WARMUP = 65536;   // zero-state run-in before a chunk that does not start a clip
 
 struct If0ChanCoef {   // per channel, built on the host in double
@@ -519,18 +520,31 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     std::vector<If0Frame> frames;
     std::vector<long long> seg(1, 0);
     long long yc_rows = 0;
+    // Chunk length: a chunk is a serial chain per channel, so a long stream cut into few chunks leaves the GPU empty
+    // (600 s in 262144-sample chunks: 51 chunks = 102 waves on 1024 SIMDs).  Halve the chunk -- at the price of one
+    // 65536-sample run-in per chunk -- until there is a wave for every SIMD or the minimum is reached.
+    long long chunk = IF0_CHUNK;
+    for (;;) {
+        long long waves = 0;
+        for (int c = 0; c < num_clips; ++c) {
+            const int64_t len = offsets[c + 1] - offsets[c];
+            if (len > 0) waves += ((len + chunk - 1) / chunk) * ((p.channels + 63) / 64);
+        }
+        if (waves >= 4LL * ctx->num_cus || chunk <= IF0_CHUNK_MIN) break;
+        chunk >>= 1;
+    }
     for (int c = 0; c < num_clips; ++c) {
         const int64_t len = offsets[c + 1] - offsets[c];
         if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
         const int64_t nfr = len <= 0 ? 0 : (len + NF - 1) / NF;
-        for (int64_t t0 = 0; t0 < nfr * NF; t0 += IF0_CHUNK) {
+        for (int64_t t0 = 0; t0 < nfr * NF; t0 += chunk) {
             If0Chunk ck;
             ck.sig_start = offsets[c] + t0;
             ck.clip_start = offsets[c];
             const int64_t want = nfr * NF - t0;            // produce whole frames (zero input beyond the clip)
-            ck.len = (int)(want < IF0_CHUNK ? want : IF0_CHUNK);
+            ck.len = (int)(want < chunk ? want : chunk);
             const int64_t left = len - t0;
-            ck.clip_left = (int)(left > IF0_CHUNK + IF0_WARMUP ? IF0_CHUNK + IF0_WARMUP : (left > 0 ? left : 0));
+            ck.clip_left = (int)(left > chunk + IF0_WARMUP ? chunk + IF0_WARMUP : (left > 0 ? left : 0));
             ck.warm = (int)(t0 < IF0_WARMUP ? t0 : IF0_WARMUP);
             ck.pad = 0;
             ck.yc_row0 = yc_rows;
