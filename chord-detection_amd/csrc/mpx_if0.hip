@@ -16,6 +16,7 @@
 //                           search (one wave per harmonic m for the range maxima), harmonic
 //                           cancellation, pitch-class scatter (quirks A.10-A.13, A.18).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "mpx_fft_dif.hpp"
@@ -482,15 +483,118 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
     return MPX_OK;
 }
 
+// The same spectrum on the in-place DIF engine (mpx_fft_dif.hpp).  The 2*NF-point frame is zero in its upper
+// half, so the NF-point complex sequence z[m] = x[2m] + i x[2m+1] is zero for m >= NF/2 and its DFT splits
+// without arithmetic: Z[2j] = DFT_H(z)[j], Z[2j+1] = DFT_H(z W_NF^m)[j], H = NF/2 -- two H-point transforms
+// (H <= 4096: wave-local passes, one barrier each) instead of one padded NF-point Stockham transform, 64 KB of LDS
+// instead of 139 KB (two workgroups per CU).  Outputs stay digit-reversed in registers: |X|^power is summed over
+// the channels per bin, and a sum does not care which register holds which bin.
+template <int NF, int P>   // P = 0: even bins 2j (and bin NF), P = 1: odd bins 2j + 1
+__device__ __forceinline__ void if0_half_spectrum(cx<double>* buf, const DifTwiddles<NF / 2, double>& twd, const double* __restrict__ src,
+                                                  int valid, const double* __restrict__ window,
+                                                  const cx<double>* __restrict__ twNF, const cx<double>* __restrict__ twn,
+                                                  double power, double* acc, double& acc_nyq) {
+    constexpr int H = NF / 2, T = H / 8;
+    using PL = DifPlan<H>;
+    constexpr int RL = PL::radix(PL::n - 1);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // nothing below may be hoisted out of the caller's channel loop (registers)
+    cx<double> regs[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int m = tid + r * T, s0 = 2 * m;
+        double x0 = 0.0, x1 = 0.0;
+        if (s0 + 1 < valid) {
+            const cx<double> v = *reinterpret_cast<const cx<double>*>(src + s0);
+            const cx<double> w = *reinterpret_cast<const cx<double>*>(window + s0);
+            x0 = v.x * w.x;
+            x1 = v.y * w.y;
+        } else if (s0 < valid) {
+            x0 = src[s0] * window[s0];
+        }
+        regs[r] = {x0, x1};
+        if (P) regs[r] = cmul(regs[r], twNF[m]);
+    }
+    dif_fft_keep_last<H, double>(buf, twd, regs, tid);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) buf[sigma<H>(dif_last_pos<H>(tid, e / RL, e % RL))] = regs[e];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = dif_freq<H>(dif_last_pos<H>(tid, e / RL, e % RL));
+        const int jm = P ? H - 1 - j : (H - j) & (H - 1);   // Z[NF - k] lives in the same half-transform
+        const cx<double> A = regs[e];
+        cx<double> B = buf[sigma<H>(dif_pos<H>(jm))];
+        B.y = -B.y;
+        const cx<double> E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
+        const cx<double> D = {0.5 * (A.x - B.x), 0.5 * (A.y - B.y)};
+        const cx<double> X = cadd(E, mul_mi(cmul(twn[2 * j + P], D)));
+        const double mag = sqrt(X.x * X.x + X.y * X.y);  // |X| of audio-range data: no need for hypot's scaling
+        acc[e] += power == 1.0 ? mag : pow(mag, power);
+        if (!P && j == 0) {  // bin NF pairs Z[0] with itself
+            const cx<double> Xn = cadd(E, mul_mi(cmul(twn[NF], D)));
+            const double mn = sqrt(Xn.x * Xn.x + Xn.y * Xn.y);
+            acc_nyq += power == 1.0 ? mn : pow(mn, power);
+        }
+    }
+    __syncthreads();  // the mirror reads are done before the next transform writes buf
+}
+
+template <int NF>
+__global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_dif_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
+                                                                     int channels, double power, const double* __restrict__ window,
+                                                                     const cx<double>* __restrict__ twNF,  // W_NF^j, j < NF
+                                                                     const cx<double>* __restrict__ twn,   // W_{2NF}^k, k <= NF
+                                                                     double* __restrict__ ut) {            // [F, 2*NF]
+    constexpr int H = NF / 2;
+    using PL = DifPlan<H>;
+    constexpr int RL = PL::radix(PL::n - 1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    const int tid = threadIdx.x;
+    const If0Frame fr = frames[blockIdx.x];
+    DifTwiddles<H, double> twd;
+#pragma unroll
+    for (int i = 0; i < PL::n - 1; ++i) twd.w[i] = twNF[2 * ((tid & (PL::stride(i) - 1)) * (H / PL::block(i)))];  // W_H = W_NF^2
+    double acc_e[8], acc_o[8], acc_nyq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc_e[e] = acc_o[e] = 0.0;
+    for (int ch = 0; ch < channels; ++ch) {
+        const double* src = yc + fr.yc_base + (size_t)ch * fr.ch_stride;
+        if0_half_spectrum<NF, 0>(buf, twd, src, fr.valid, window, twNF, twn, power, acc_e, acc_nyq);
+        if0_half_spectrum<NF, 1>(buf, twd, src, fr.valid, window, twNF, twn, power, acc_o, acc_nyq);
+    }
+    double* row = ut + (size_t)blockIdx.x * 2 * NF;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = dif_freq<H>(dif_last_pos<H>(tid, e / RL, e % RL));
+        const int k0 = 2 * j, k1 = 2 * j + 1;
+        row[k0] = acc_e[e];
+        if (k0 > 0) row[2 * NF - k0] = acc_e[e];  // |X[N-k]| = |X[k]| for a real frame
+        row[k1] = acc_o[e];
+        row[2 * NF - k1] = acc_o[e];
+        if (j == 0) row[NF] = acc_nyq;
+    }
+}
+
 template <int NF, int T>
 static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int channels,
                                double power, const If0Plan& plan, double* ut, hipStream_t st) {
-    const size_t lds = sizeof(cx<double>) * lds_slots(NF);
-    auto kern = if0_spectrum_kernel<NF, T>;
-    if (lds > 48 * 1024)
-        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, channels, power, plan.d_window, plan.d_tw,
-                       plan.d_twn, ut);
+    if (getenv("MPX_IF0_STOCKHAM")) {  // profiling knob: the padded NF-point Stockham transform
+        const size_t lds = sizeof(cx<double>) * lds_slots(NF);
+        auto kern = if0_spectrum_kernel<NF, T>;
+        if (lds > 48 * 1024)
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, channels, power, plan.d_window, plan.d_tw,
+                           plan.d_twn, ut);
+    } else {
+        const size_t lds = sizeof(cx<double>) * (NF / 2);
+        auto kern = if0_spectrum_dif_kernel<NF>;
+        if (lds > 48 * 1024)
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(NF / 16), lds, st, yc, frames, channels, power, plan.d_window,
+                           plan.d_tw, plan.d_twn, ut);
+    }
     MPX_HIP(ctx, hipGetLastError());
     return MPX_OK;
 }
