@@ -248,12 +248,27 @@ constexpr int PER_T = 256;
 __constant__ double IF0_HAMMING9[9] = {0.0011244659258033, 0.11559343551383, 0.42817348241183, 0.81822361914331, 1.0,
                                        0.81822361914331, 0.42817348241183, 0.11559343551383, 0.0011244659258033};
 
-// max over ur[lo..hi] by ONE wave (no workgroup barrier)
-__device__ __forceinline__ double wave_range_max(const double* __restrict__ ur, int lo, int hi, int lane) {
+// max over ur[lo..hi] by ONE wave (no workgroup barrier).  Wide ranges (the first interval-halving steps span
+// thousands of bins) take the maxima of whole 64-bin blocks from `bmax` (LDS, rebuilt whenever ur changes) and
+// read only the two ragged ends from memory; a maximum does not depend on the order, so the result is identical.
+__device__ __forceinline__ double wave_range_max(const double* __restrict__ ur, const double* bmax, int lo, int hi, int lane) {
     double m = -INFINITY;
-    for (int i = lo + lane; i <= hi; i += 64) {
-        const double v = ur[i];
-        m = v > m ? v : m;
+    if (hi - lo < 192) {
+        for (int i = lo + lane; i <= hi; i += 64) {
+            const double v = ur[i];
+            m = v > m ? v : m;
+        }
+    } else {
+        const int b0 = (lo + 63) >> 6, b1 = (hi + 1) >> 6;  // whole blocks [b0, b1)
+        if (lo + lane < b0 * 64) m = ur[lo + lane];
+        if (b1 * 64 + lane <= hi) {
+            const double v = ur[b1 * 64 + lane];
+            m = v > m ? v : m;
+        }
+        for (int b = b0 + lane; b < b1; b += 64) {
+            const double v = bmax[b];
+            m = v > m ? v : m;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -266,18 +281,32 @@ __device__ __forceinline__ double wave_range_max(const double* __restrict__ ur, 
 __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     __shared__ double tau_low[32], tau_up[32], smax[32];
     __shared__ double umax[64];
+    __shared__ double bmax[256];  // maxima of the 64-bin blocks of ur (n <= 16384)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long f = blockIdx.x;
     const int n = a.n;
     const double* __restrict__ uk = a.ut + f * (long long)n;
     double* __restrict__ ur = a.ur + f * (long long)n;
     double* __restrict__ ud = a.ud + f * (long long)n;
+    auto build_bmax = [&]() {  // after ur has been (re)written and made visible
+        for (int b = wave; b < (n >> 6); b += PER_T / 64) {
+            double m = ur[b * 64 + lane];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(m, off);
+                m = o > m ? o : m;
+            }
+            if (lane == 0) bmax[b] = m;
+        }
+        __syncthreads();
+    };
     for (int i = tid; i < n; i += PER_T) {
         ur[i] = uk[i];
         ud[i] = 0.0;
     }
     __syncthreads();
     __threadfence_block();
+    build_bmax();
 
     // periodicity.py:144-163; executed by every thread with identical (uniform) results
     auto smax_fn = [&](int q) -> double {
@@ -289,7 +318,7 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
             const int lowk = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
             int highk = (int)(m * a.K / (tau - 0.5 * deltatau) + 0.5);
             if (highk > n - 1) highk = n - 1;  // numpy slicing clips silently
-            const double mx = wave_range_max(ur, lowk, highk, lane);
+            const double mx = wave_range_max(ur, bmax, lowk, highk, lane);
             if (lane == 0) umax[m] = mx;
         }
         __syncthreads();
@@ -384,6 +413,7 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
         }
         __syncthreads();
         __threadfence_block();
+        build_bmax();
     }
     if (tid == 0) {
         double chroma[12];
