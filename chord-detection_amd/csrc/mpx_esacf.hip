@@ -927,6 +927,8 @@ struct ParkedFit {
     int m, it, nfev, pad;
 };
 constexpr int PARK_NFEV = 100;
+constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinished fits ...
+constexpr int PARK_CAP = 8192;  // ... or while fewer fits than this are parked (what coopfit_kernel holds at once)
 
 // Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
 // (~100 cycles through the LDS crossbar): a fit owns one 16-lane DPP row, so its all-reduce is four mirror /
@@ -1208,7 +1210,7 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
     const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
     int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
-    double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev) {
+    double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev, int park_live, int park_cap) {
     using namespace lm;
     __shared__ double sh[MAXM * FIT_THREADS];
     __shared__ double sh_rq[9 * FIT_THREADS];
@@ -1274,7 +1276,10 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         // ~45 us.  Its MINPACK state is handed to coopfit_kernel instead, which finishes all such fits at once
         // with 16 lanes each.
         drained = drained || __any(phase == FIT_DONE);
-        if (drained && phase == FIT_OUTER && nfev >= park_nfev && parked) {
+        // ... but only once the wave has thinned out: a wave that still holds many runaway fits (short frames: 11 % of
+        // the fits at N = 1023) runs them at good lane utilisation, far cheaper than 16 lanes per fit
+        const int live = __popcll(__ballot(phase != FIT_DONE));
+        if (drained && (live <= park_live || *(volatile int*)parked_count < park_cap) && phase == FIT_OUTER && nfev >= park_nfev && parked) {
             ParkedFit pf;
             pf.out = out;
             pf.row_off = row - y;
@@ -1940,7 +1945,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const bool park = !deterministic && !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
-                               total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : PARK_NFEV);
+                               total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : PARK_NFEV,
+                               getenv("MPX_FIT_PARK_LIVE") ? atoi(getenv("MPX_FIT_PARK_LIVE")) : PARK_LIVE,
+                               getenv("MPX_FIT_PARK_CAP") ? atoi(getenv("MPX_FIT_PARK_CAP")) : PARK_CAP);
             if (park)  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
                 hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 12)), dim3(64), 0, st, parked, total + 3,
                                    total + 4, y, center, okf, maxfev);
