@@ -109,6 +109,17 @@ def frame_fragility(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, eps=1e-12, t
     return False
 
 
+def frame_has_runaway_fit(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, width=10):
+    """Test helper: True when an ACCEPTED gaussian fit of this frame put its centre outside the 21-sample window
+    it was fitted on (MINPACK "converged" somewhere along a flat valley: the reference keeps such a centre, and its
+    value -- hence the pitch class -- moves with the last bits of the arithmetic even when a 1e-12 perturbation of
+    the input happens not to flip it), or when a fit failed, which shifts the index/lag pairing (quirk A.8)."""
+    _, peaks, interp = frame_chroma(x_esacf, fs, peak_thresh, peak_min_dist, detail=True)
+    if len(interp) != len(peaks):
+        return True
+    return bool(np.any(np.abs(np.asarray(interp) - np.asarray(peaks, dtype=np.float64)) > width + 0.5))
+
+
 def esacf_frames(x, fs, frame_size=None, hop=None, n_peaks_elim=6, peak_thresh=0.1,
                  peak_min_dist=10, enhance_mode="librosa010"):
     if frame_size is None:

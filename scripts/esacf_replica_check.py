@@ -48,7 +48,7 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for f in sorted(set(rows_ab.tolist() + rows_ac.tolist()))[:16]:
         y = eng.esacf_stage("esacf", xh[f * B.N:(f + 1) * B.N], B.FS, B.N)[0]
-        fr = o_esacf.frame_fragility(y, B.FS)
+        fr = o_esacf.frame_fragility(y, B.FS) or o_esacf.frame_has_runaway_fit(y, B.FS)
         frag += bool(fr)
-        print("  frame", f, "reference ill-conditioned:", bool(fr))
+        print("  frame", f, "reference ill-conditioned (perturbation test or runaway fit):", bool(fr))
 print("ill-conditioned among the differing frames checked:", frag)
