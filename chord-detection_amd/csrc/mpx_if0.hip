@@ -15,6 +15,7 @@
 //  3. if0_periodicity_kernel one workgroup per frame: periodicity.py:48-163 -- interval-halving period
 //                           search (one wave per harmonic m for the range maxima), harmonic
 //                           cancellation, pitch-class scatter (quirks A.10-A.13, A.18).
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -656,15 +657,24 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     long long yc_rows = 0;
     // Chunk length: a chunk is a serial chain per channel, so a long stream cut into few chunks leaves the GPU empty
     // (600 s in 262144-sample chunks: 51 chunks = 102 waves on 1024 SIMDs).  Halve the chunk -- at the price of one
-    // 65536-sample run-in per chunk -- until there is a wave for every SIMD or the minimum is reached.
+    // 65536-sample run-in per chunk -- while the machine is not full AND the longest lane gets shorter by it (a clip
+    // below 65536 samples gains nothing: its later chunks would re-run it from the start).
+    int64_t longest = 0;
+    for (int c = 0; c < num_clips; ++c) longest = std::max<int64_t>(longest, offsets[c + 1] - offsets[c]);
+    auto lane_steps = [&](long long chunk) {  // samples the busiest lane of the longest clip walks through
+        long long worst = 0;
+        for (int64_t t0 = 0; t0 < longest; t0 += chunk)
+            worst = std::max<long long>(worst, std::min<long long>(t0, IF0_WARMUP) + std::min<long long>(chunk, longest - t0));
+        return worst;
+    };
     long long chunk = IF0_CHUNK;
-    for (;;) {
+    while (chunk > IF0_CHUNK_MIN) {
         long long waves = 0;
         for (int c = 0; c < num_clips; ++c) {
             const int64_t len = offsets[c + 1] - offsets[c];
             if (len > 0) waves += ((len + chunk - 1) / chunk) * ((p.channels + 63) / 64);
         }
-        if (waves >= 4LL * ctx->num_cus || chunk <= IF0_CHUNK_MIN) break;
+        if (waves >= 4LL * ctx->num_cus || 10 * lane_steps(chunk / 2) > 9 * lane_steps(chunk)) break;
         chunk >>= 1;
     }
     for (int c = 0; c < num_clips; ++c) {
