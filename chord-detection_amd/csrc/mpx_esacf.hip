@@ -829,7 +829,7 @@ __global__ __launch_bounds__(T) void peakpick_kernel(SacfArgs a) {
 // MINPACK's iteration count is data dependent (typically ~50 function evaluations, but 1-2 % of the
 // peaks -- runaway fits near the end of the lag range -- burn the full maxfev = 800).  With a static
 // "lane w fits peak w" mapping nearly every wave contains such a straggler and waits for it (measured:
-// 2.6 M VALU instructions per wave instead of ~0.1 M).  Here lm::gaussian_fit_lane is unrolled into a
+// 2.6 M VALU instructions per wave instead of ~0.1 M).  Here lm::gaussian_fit (mpx_lm.hpp) is unrolled into a
 // resumable state machine: a lane that finishes its peak pulls the next one from a global counter
 // (wave-aggregated atomic), so stragglers only delay themselves.
 // Per trip of the main loop a lane runs at most one OUTER step (jacobian, pivoted Householder QR, Q^T f)
@@ -964,7 +964,7 @@ struct D2 {  // this lane's two samples: rows l and l + 16 of the m <= 21 rows
 };
 
 // Cooperative continuation of parked fits: one fit per 16-lane row (4 per wave), lane l holding samples l and
-// l + 16 (lm::gaussian_fit_coop restated from a resume point and with the same reciprocal / column-0 / exponential
+// l + 16 (lm::gaussian_fit restated from a resume point, m-vectors across lanes, with the same reciprocal / column-0 / exponential
 // forms as peakfit_kernel).  The m-vectors of MINPACK are two registers per lane, norms and dot products are
 // all-reduces that leave identical bits in every lane of the row, so the row runs the 3x3 part redundantly and
 // uniformly.  A trip costs ~3.3 k instructions per FOUR fits instead of ~8.5 k and, more to the point, every

@@ -410,533 +410,5 @@ MPX_HD inline int gaussian_fit(const Problem& pr, double* center) {
     return info;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Cooperative form of the same algorithm: one fit per group of 32 lanes, lane l holding data point l
-// (l < m <= 21).  The m-long vectors of MINPACK (fvec, the jacobian rows, Q^T f) become one register
-// per lane; their norms and dot products are xor-butterfly all-reduces, which leave bit-identical sums
-// in every lane, so all 32 lanes take the same branches and run the 3x3 part (lmpar / qrsolv)
-// redundantly.  Compared with one fit per lane this removes the per-lane scratch arrays and the
-// 64-way divergence of data-dependent iteration counts (a wave now waits for the slower of 2 fits).
-// Sums are added in tree order instead of left to right: trajectories agree with the serial code to
-// rounding, and both stop on the same 1.49e-8 tolerances.
-#if defined(__HIPCC__)
-__device__ __forceinline__ double grp_sum(double v) {
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-    return v;
-}
-__device__ __forceinline__ double grp_bcast(double v, int src) { return __shfl(v, src, 32); }
-
-struct CoopPoint {
-    double x, y;
-    bool on;  // lane < m
-};
-
-__device__ __forceinline__ double coop_residual(const CoopPoint& pt, const double* p) {
-    const double den = 2.0 * p[2] * p[2] + EPSMCH;
-    const double d = pt.x - p[1];
-    const double r = p[0] * exp(-(d * d) / den) - pt.y;
-    return pt.on ? r : 0.0;
-}
-
-__device__ __forceinline__ void swap_d(double& a, double& b) {
-    const double t = a;
-    a = b;
-    b = t;
-}
-
-// lane = index within the 32-lane group.  Returns MINPACK's info; *center valid in every lane.
-__device__ inline int gaussian_fit_coop(const CoopPoint& pt, int lane, double ymax, double x0, double dx,
-                                        double* center) {
-    const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
-    const int maxfev = 200 * (NP + 1);
-    double x[NP] = {ymax, x0, dx * 5.0};
-    double f = coop_residual(pt, x);
-    int nfev = 1;
-    double fnorm = sqrt(grp_sum(f * f));
-    double par = 0.0;
-    int it = 1, info = 0;
-    const double eps = sqrt(EPSMCH);
-    double diag[NP] = {1.0, 1.0, 1.0};
-    double delta = 0.0, xnorm = 0.0;
-    for (;;) {
-        // forward-difference jacobian: this lane's row
-        double J0, J1, J2;
-        {
-            double jj[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const double temp = x[j];
-                double h = eps * fabs(temp);
-                if (h == 0.0) h = eps;
-                x[j] = temp + h;
-                const double w = coop_residual(pt, x);
-                x[j] = temp;
-                jj[j] = (w - f) / h;
-            }
-            J0 = jj[0];
-            J1 = jj[1];
-            J2 = jj[2];
-        }
-        nfev += NP;
-        // ---- qrfac with column pivoting; columns live in J0,J1,J2 (physical order = pivoted order)
-        int ipvt[NP] = {0, 1, 2};
-        double acnorm[NP], rdiag[NP], wa[NP];
-        acnorm[0] = sqrt(grp_sum(J0 * J0));
-        acnorm[1] = sqrt(grp_sum(J1 * J1));
-        acnorm[2] = sqrt(grp_sum(J2 * J2));
-#pragma unroll
-        for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            int kmax = j;
-            double rmax = rdiag[j];
-#pragma unroll
-            for (int k = j + 1; k < NP; ++k)
-                if (rdiag[k] > rmax) {
-                    kmax = k;
-                    rmax = rdiag[k];
-                }
-            if (kmax != j) {
-                // swap physical columns j and kmax (j is a compile-time index after unrolling)
-                double& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
-                if (kmax == 1) swap_d(cj, J1);
-                else swap_d(cj, J2);
-                put3(rdiag, kmax, rdiag[j]);
-                put3(wa, kmax, wa[j]);
-                const int t = ipvt[j];
-                ipvt[j] = sel3(ipvt, kmax);
-                put3(ipvt, kmax, t);
-            }
-            double& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
-            const bool below = lane >= j;  // rows j..m-1
-            double ajnorm = sqrt(grp_sum(below ? cj * cj : 0.0));
-            if (ajnorm != 0.0) {
-                double ajj = grp_bcast(cj, j);
-                if (ajj < 0.0) ajnorm = -ajnorm;
-                if (below) cj /= ajnorm;
-                if (lane == j) cj += 1.0;
-                ajj = grp_bcast(cj, j);
-#pragma unroll
-                for (int k = j + 1; k < NP; ++k) {
-                    double& ck = k == 1 ? J1 : J2;
-                    const double sum = grp_sum(below ? cj * ck : 0.0);
-                    const double temp = sum / ajj;
-                    if (below) ck -= temp * cj;
-                    if (rdiag[k] != 0.0) {
-                        const double t = grp_bcast(ck, j) / rdiag[k];
-                        const double u = 1.0 - t * t;
-                        rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
-                        const double q = rdiag[k] / wa[k];
-                        if (0.05 * q * q <= EPSMCH) {
-                            rdiag[k] = sqrt(grp_sum(lane > j ? ck * ck : 0.0));
-                            wa[k] = rdiag[k];
-                        }
-                    }
-                }
-            }
-            rdiag[j] = -ajnorm;
-        }
-        if (it == 1) {
-            double wa3[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                diag[j] = acnorm[j] != 0.0 ? acnorm[j] : 1.0;
-                wa3[j] = diag[j] * x[j];
-            }
-            xnorm = enorm(wa3, NP);
-            delta = factor * xnorm;
-            if (delta == 0.0) delta = factor;
-        }
-        // ---- Q^T f, first three components; R's diagonal goes back into the matrix
-        double qtf[NP];
-        {
-            double w4 = f;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                double& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
-                const bool below = lane >= j;
-                const double ajj = grp_bcast(cj, j);
-                if (ajj != 0.0) {
-                    const double sum = grp_sum(below ? cj * w4 : 0.0);
-                    const double temp = -sum / ajj;
-                    if (below) w4 += cj * temp;
-                }
-                if (lane == j) cj = rdiag[j];
-                qtf[j] = grp_bcast(w4, j);
-            }
-        }
-        // ---- replicate the 3x3 upper triangle R (row i lives in lane i)
-        double r[NP * NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            r[i * NP + 0] = grp_bcast(J0, i);
-            r[i * NP + 1] = grp_bcast(J1, i);
-            r[i * NP + 2] = grp_bcast(J2, i);
-        }
-        double gnorm = 0.0;
-        if (fnorm != 0.0) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int l = ipvt[j];
-                const double an = l == 0 ? acnorm[0] : (l == 1 ? acnorm[1] : acnorm[2]);
-                if (an != 0.0) {
-                    double s2 = 0.0;
-#pragma unroll
-                    for (int i = 0; i <= j; ++i) s2 += r[i * NP + j] * (qtf[i] / fnorm);
-                    const double g = fabs(s2 / an);
-                    gnorm = g > gnorm ? g : gnorm;
-                }
-            }
-        }
-        if (gnorm <= gtol) {
-            info = 4;
-            break;
-        }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
-        for (;;) {
-            double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
-#pragma unroll
-            for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
-            par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                p[j] = -p[j];
-                xnew[j] = x[j] + p[j];
-                wa3[j] = diag[j] * p[j];
-            }
-            const double pnorm = enorm(wa3, NP);
-            if (it == 1) delta = delta < pnorm ? delta : pnorm;
-            const double fn = coop_residual(pt, xnew);
-            ++nfev;
-            const double fnorm1 = sqrt(grp_sum(fn * fn));
-            double actred = -1.0;
-            if (0.1 * fnorm1 < fnorm) {
-                const double q = fnorm1 / fnorm;
-                actred = 1.0 - q * q;
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const int l = ipvt[j];
-                const double temp = l == 0 ? p[0] : (l == 1 ? p[1] : p[2]);
-#pragma unroll
-                for (int i = 0; i <= j; ++i) wa3[i] += r[i * NP + j] * temp;
-            }
-            const double temp1 = enorm(wa3, NP) / fnorm;
-            const double temp2 = (sqrt(par) * pnorm) / fnorm;
-            const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-            const double dirder = -(temp1 * temp1 + temp2 * temp2);
-            const double ratio = prered != 0.0 ? actred / prered : 0.0;
-            if (ratio <= 0.25) {
-                double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
-                if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
-                delta = temp * dm;
-                par = par / temp;
-            } else if (par == 0.0 || ratio >= 0.75) {
-                delta = pnorm / 0.5;
-                par = 0.5 * par;
-            }
-            if (ratio >= 1e-4) {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    x[j] = xnew[j];
-                    wa3[j] = diag[j] * x[j];
-                }
-                f = fn;
-                xnorm = enorm(wa3, NP);
-                fnorm = fnorm1;
-                ++it;
-            }
-            const bool c1 = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
-            if (c1) info = 1;
-            if (delta <= xtol * xnorm) info = 2;
-            if (c1 && info == 2) info = 3;
-            if (info != 0) break;
-            if (nfev >= maxfev) info = 5;
-            if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1.0) info = 6;
-            if (delta <= EPSMCH * xnorm) info = 7;
-            if (gnorm <= EPSMCH) info = 8;
-            if (info != 0) break;
-            if (ratio >= 1e-4) break;
-        }
-        if (info != 0) break;
-    }
-    *center = x[1];
-    return info;
-}
-// ------------------------------------------------------------------------------------------------
-// Lane-per-fit form for the GPU: 64 fits per wave, every lane runs the serial algorithm above on its own
-// peak.  The 3x3 algebra (lmpar/qrsolv: ~70 % of MINPACK's work at n = 3) is then useful work in every
-// lane instead of being replicated 32 times as in gaussian_fit_coop.  To stay out of scratch memory the
-// jacobian (21x3) and the samples (21) live in VGPRs behind fully unrolled, predicated loops, and the two
-// m-vectors (fvec, wa4/fnew) live in LDS as [row][lane] (conflict free).
-struct LaneLds {
-    double* fvec;  // [MAXM][64] of this wave
-    double* wa4;   // [MAXM][64] of this wave
-    int lane;
-    __device__ __forceinline__ double& f(int i) const { return fvec[i * 64 + lane]; }
-    __device__ __forceinline__ double& w(int i) const { return wa4[i * 64 + lane]; }
-};
-
-__device__ __forceinline__ double lane_resid(const double* ys, double x0, int i, const double* p) {
-    const double den = 2.0 * p[2] * p[2] + EPSMCH;
-    const double d = (x0 + (double)i) - p[1];
-    return p[0] * exp(-(d * d) / den) - ys[i];
-}
-
-// ys[MAXM] samples (registers), x0 = abscissa of ys[0], m points.  Returns MINPACK's info.
-__device__ inline int gaussian_fit_lane(const double* ys, double x0, int m, const LaneLds& L, double* center) {
-    const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
-    const int maxfev = 200 * (NP + 1);
-    double x[NP];
-    double ymax = ys[0];
-#pragma unroll
-    for (int i = 1; i < MAXM; ++i)
-        if (i < m) ymax = ys[i] > ymax ? ys[i] : ymax;
-    x[0] = ymax;
-    x[1] = x0;
-    x[2] = 5.0;
-    double s = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXM; ++i)
-        if (i < m) {
-            const double r = lane_resid(ys, x0, i, x);
-            L.f(i) = r;
-            s += r * r;
-        }
-    int nfev = 1;
-    double fnorm = sqrt(s);
-    double par = 0.0;
-    int it = 1, info = 0;
-    const double eps = sqrt(EPSMCH);
-    double diag[NP] = {1.0, 1.0, 1.0};
-    double delta = 0.0, xnorm = 0.0;
-    double a[MAXM][NP];  // jacobian / Householder vectors: registers (static indices only)
-    for (;;) {
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const double temp = x[j];
-            double h = eps * fabs(temp);
-            if (h == 0.0) h = eps;
-            x[j] = temp + h;
-#pragma unroll
-            for (int i = 0; i < MAXM; ++i)
-                a[i][j] = i < m ? (lane_resid(ys, x0, i, x) - L.f(i)) / h : 0.0;
-            x[j] = temp;
-        }
-        nfev += NP;
-        // ---- qrfac (column pivoting)
-        int ipvt[NP] = {0, 1, 2};
-        double acnorm[NP], rdiag[NP], wa[NP];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            double q = 0.0;
-#pragma unroll
-            for (int i = 0; i < MAXM; ++i) q += a[i][j] * a[i][j];  // rows >= m hold zeros
-            acnorm[j] = sqrt(q);
-            rdiag[j] = wa[j] = acnorm[j];
-        }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            int kmax = j;
-            double rmax = rdiag[j];
-#pragma unroll
-            for (int k = j + 1; k < NP; ++k)
-                if (rdiag[k] > rmax) {
-                    kmax = k;
-                    rmax = rdiag[k];
-                }
-            if (kmax != j) {
-#pragma unroll
-                for (int i = 0; i < MAXM; ++i) {
-                    const double t = a[i][j];
-                    const double o = kmax == 1 ? a[i][1] : a[i][2];
-                    a[i][j] = o;
-                    if (kmax == 1) a[i][1] = t;
-                    else a[i][2] = t;
-                }
-                put3(rdiag, kmax, rdiag[j]);
-                put3(wa, kmax, wa[j]);
-                const int t = ipvt[j];
-                ipvt[j] = sel3(ipvt, kmax);
-                put3(ipvt, kmax, t);
-            }
-            double q = 0.0;
-#pragma unroll
-            for (int i = j; i < MAXM; ++i) q += a[i][j] * a[i][j];
-            double ajnorm = sqrt(q);
-            if (ajnorm != 0.0) {
-                if (a[j][j] < 0.0) ajnorm = -ajnorm;
-#pragma unroll
-                for (int i = j; i < MAXM; ++i) a[i][j] /= ajnorm;
-                a[j][j] += 1.0;
-#pragma unroll
-                for (int k = j + 1; k < NP; ++k) {
-                    double sum = 0.0;
-#pragma unroll
-                    for (int i = j; i < MAXM; ++i) sum += a[i][j] * a[i][k];
-                    const double temp = sum / a[j][j];
-#pragma unroll
-                    for (int i = j; i < MAXM; ++i) a[i][k] -= temp * a[i][j];
-                    if (rdiag[k] != 0.0) {
-                        const double t = a[j][k] / rdiag[k];
-                        const double u = 1.0 - t * t;
-                        rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
-                        const double qq = rdiag[k] / wa[k];
-                        if (0.05 * qq * qq <= EPSMCH) {
-                            double s2 = 0.0;
-#pragma unroll
-                            for (int i = j + 1; i < MAXM; ++i) s2 += a[i][k] * a[i][k];
-                            rdiag[k] = sqrt(s2);
-                            wa[k] = rdiag[k];
-                        }
-                    }
-                }
-            }
-            rdiag[j] = -ajnorm;
-        }
-        if (it == 1) {
-            double wa3[NP];
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                diag[j] = acnorm[j] != 0.0 ? acnorm[j] : 1.0;
-                wa3[j] = diag[j] * x[j];
-            }
-            xnorm = enorm3(wa3);
-            delta = factor * xnorm;
-            if (delta == 0.0) delta = factor;
-        }
-        // ---- Q^T fvec (first three components)
-        double qtf[NP];
-#pragma unroll
-        for (int i = 0; i < MAXM; ++i)
-            if (i < m) L.w(i) = L.f(i);
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            if (a[j][j] != 0.0) {
-                double sum = 0.0;
-#pragma unroll
-                for (int i = j; i < MAXM; ++i)
-                    if (i < m) sum += a[i][j] * L.w(i);
-                const double temp = -sum / a[j][j];
-#pragma unroll
-                for (int i = j; i < MAXM; ++i)
-                    if (i < m) L.w(i) += a[i][j] * temp;
-            }
-            a[j][j] = rdiag[j];
-            qtf[j] = L.w(j);
-        }
-        double r[NP * NP];
-#pragma unroll
-        for (int i = 0; i < NP; ++i)
-#pragma unroll
-            for (int j = 0; j < NP; ++j) r[i * NP + j] = a[i][j];
-        double gnorm = 0.0;
-        if (fnorm != 0.0) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const double an = sel3(acnorm, ipvt[j]);
-                if (an != 0.0) {
-                    double s2 = 0.0;
-#pragma unroll
-                    for (int i = 0; i <= j; ++i) s2 += r[i * NP + j] * (qtf[i] / fnorm);
-                    const double g = fabs(s2 / an);
-                    gnorm = g > gnorm ? g : gnorm;
-                }
-            }
-        }
-        if (gnorm <= gtol) {
-            info = 4;
-            break;
-        }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
-        for (;;) {
-            double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
-#pragma unroll
-            for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
-            par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                p[j] = -p[j];
-                xnew[j] = x[j] + p[j];
-                wa3[j] = diag[j] * p[j];
-            }
-            const double pnorm = enorm3(wa3);
-            if (it == 1) delta = delta < pnorm ? delta : pnorm;
-            double s1 = 0.0;
-#pragma unroll
-            for (int i = 0; i < MAXM; ++i)
-                if (i < m) {
-                    const double rn = lane_resid(ys, x0, i, xnew);
-                    L.w(i) = rn;  // fnew shares wa4's storage
-                    s1 += rn * rn;
-                }
-            ++nfev;
-            const double fnorm1 = sqrt(s1);
-            double actred = -1.0;
-            if (0.1 * fnorm1 < fnorm) {
-                const double q = fnorm1 / fnorm;
-                actred = 1.0 - q * q;
-            }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
-#pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                const double temp = sel3(p, ipvt[j]);
-#pragma unroll
-                for (int i = 0; i <= j; ++i) wa3[i] += r[i * NP + j] * temp;
-            }
-            const double temp1 = enorm3(wa3) / fnorm;
-            const double temp2 = (sqrt(par) * pnorm) / fnorm;
-            const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-            const double dirder = -(temp1 * temp1 + temp2 * temp2);
-            const double ratio = prered != 0.0 ? actred / prered : 0.0;
-            if (ratio <= 0.25) {
-                double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
-                if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
-                delta = temp * dm;
-                par = par / temp;
-            } else if (par == 0.0 || ratio >= 0.75) {
-                delta = pnorm / 0.5;
-                par = 0.5 * par;
-            }
-            if (ratio >= 1e-4) {
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    x[j] = xnew[j];
-                    wa3[j] = diag[j] * x[j];
-                }
-#pragma unroll
-                for (int i = 0; i < MAXM; ++i)
-                    if (i < m) L.f(i) = L.w(i);
-                xnorm = enorm3(wa3);
-                fnorm = fnorm1;
-                ++it;
-            }
-            const bool c1 = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
-            if (c1) info = 1;
-            if (delta <= xtol * xnorm) info = 2;
-            if (c1 && info == 2) info = 3;
-            if (info != 0) break;
-            if (nfev >= maxfev) info = 5;
-            if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1.0) info = 6;
-            if (delta <= EPSMCH * xnorm) info = 7;
-            if (gnorm <= EPSMCH) info = 8;
-            if (info != 0) break;
-            if (ratio >= 1e-4) break;
-        }
-        if (info != 0) break;
-    }
-    *center = x[1];
-    return info;
-}
-#endif  // __HIPCC__
-
 }  // namespace lm
 }  // namespace mpx
