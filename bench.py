@@ -85,8 +85,10 @@ def cpu_baseline(x, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: 0.15 s of GPU work.  The device needs on the order of 0.05 s under load to reach its sustained clock; a
+    # 20 + 200-step run (15 ms) times the ramp and reports the kernel 10 % slower than it runs a moment later.
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--f32", action="store_true", help="opt-in fp32 engine (not the headline)")
     args = ap.parse_args()
