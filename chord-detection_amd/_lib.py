@@ -74,10 +74,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """torch ships its own libamdhip64 with the same SONAME as the system one.  Two HIP runtimes in a process do not
+    both see the GPU, so if torch is installed but not imported yet, its copy is loaded first (a few ms, no
+    `import torch`): our library then binds to it, and a later `import torch` finds it already there."""
+    import sys
+    if "torch" in sys.modules or os.environ.get("MPX_NO_TORCH_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
-    """Load libmpx_hip.so (once).  If torch is going to be used in this process
-    it must be imported BEFORE this call: torch ships its own libamdhip64 with
-    the same SONAME and the loader then shares that one runtime between us."""
+    """Load libmpx_hip.so (once), sharing torch's HIP runtime when torch is installed (see above)."""
     global _lib
     if _lib is not None:
         return _lib
@@ -85,6 +102,7 @@ def load():
         raise RuntimeError(
             "chord_detection_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
