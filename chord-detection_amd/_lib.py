@@ -8,7 +8,7 @@ import os
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmpx_hip.so")
+LIB_PATH = os.environ.get("MPX_LIB_PATH") or os.path.join(_PKG, "libmpx_hip.so")  # env override: A/B builds
 
 MPX_OK, MPX_EINVAL, MPX_ENOMEM, MPX_EHIP, MPX_EUNSUPPORTED = 0, -1, -2, -3, -4
 MPX_FLAG_F32 = 0x1

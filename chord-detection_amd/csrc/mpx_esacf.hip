@@ -278,7 +278,6 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     int* cand = reinterpret_cast<int*>(longw + PEAK_WORDS);  // [Mh/2 + 2]
     volatile int* state = cand + (Mh / 2 + 2);               // [Mh/2 + 2]: 0 undecided, 1 kept, 2 removed
     __shared__ double sh_red[2 * NW];
-    __shared__ int sh_flag[3];
     __shared__ int sh_base[2];
     const u64 lt_mask = (1ull << lane) - 1ull;
     // ---- threshold
@@ -297,7 +296,6 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
         const u64 b = __ballot(i < D && yv[i + 1] != yv[i]);
         if (lane == 0) nzw[e * NW + wave] = b;
     }
-    if (tid < 3) sh_flag[tid] = 0;
     __syncthreads();
     if (D <= 0 || !__any(lane < nwords && nzw[lane < nwords ? lane : 0] != 0)) {
         if (tid == 0) a.peak_count[f] = 0;  // totally flat signal: no peaks (peakutils returns [])
@@ -355,43 +353,46 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     // ---- minimum-distance suppression
     const int Q = (ncand + T - 1) / T, md = a.peak_min_dist;
     if (ncand > 1 && md > 1) {
-        for (int round = 0;; ++round) {
-            bool undecided = false;
-            for (int q = 0; q < Q; ++q) {
-                const int c = tid + q * T;
-                if (c < ncand && state[c] == 0) {
-                    const int pos = cand[c];
-                    const double v = yv[pos];
-                    bool any_kept = false, any_open = false;
-                    for (int c2 = c - 1; c2 >= 0; --c2) {
-                        const int p2 = cand[c2];
-                        if (pos - p2 > md) break;
-                        if (yv[p2] > v) {  // ties go to the larger index
-                            const int st = state[c2];
-                            any_kept |= st == 1;
-                            any_open |= st == 0;
+        // a frame has a few dozen candidates: wave 0 runs the rounds alone, ordered by its own in-order LDS queue
+        // instead of a workgroup barrier per round
+        if (wave == 0) {
+            const int Q0 = (ncand + 63) / 64;
+            for (;;) {
+                bool undecided = false;
+                for (int q = 0; q < Q0; ++q) {
+                    const int c = lane + q * 64;
+                    if (c < ncand && state[c] == 0) {
+                        const int pos = cand[c];
+                        const double v = yv[pos];
+                        bool any_kept = false, any_open = false;
+                        for (int c2 = c - 1; c2 >= 0; --c2) {
+                            const int p2 = cand[c2];
+                            if (pos - p2 > md) break;
+                            if (yv[p2] > v) {  // ties go to the larger index
+                                const int st = state[c2];
+                                any_kept |= st == 1;
+                                any_open |= st == 0;
+                            }
                         }
-                    }
-                    for (int c2 = c + 1; c2 < ncand; ++c2) {
-                        const int p2 = cand[c2];
-                        if (p2 - pos > md) break;
-                        if (yv[p2] >= v) {
-                            const int st = state[c2];
-                            any_kept |= st == 1;
-                            any_open |= st == 0;
+                        for (int c2 = c + 1; c2 < ncand; ++c2) {
+                            const int p2 = cand[c2];
+                            if (p2 - pos > md) break;
+                            if (yv[p2] >= v) {
+                                const int st = state[c2];
+                                any_kept |= st == 1;
+                                any_open |= st == 0;
+                            }
                         }
+                        if (any_kept) state[c] = 2;
+                        else if (!any_open) state[c] = 1;
+                        else undecided = true;
                     }
-                    if (any_kept) state[c] = 2;
-                    else if (!any_open) state[c] = 1;
-                    else undecided = true;
                 }
+                wave_lds_fence();
+                if (!__any(undecided)) break;
             }
-            if (__any(undecided) && lane == 0) sh_flag[round % 3] = 1;
-            __syncthreads();
-            const int more = sh_flag[round % 3];
-            if (tid == 0) sh_flag[(round + 2) % 3] = 0;  // the flag of the round after next: nobody reads or sets it now
-            if (!more) break;
         }
+        __syncthreads();
     } else {
         for (int c = tid; c < ncand; c += T) state[c] = 1;
         __syncthreads();
