@@ -75,11 +75,16 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     // consumed before it is overwritten).  Every stage performs exactly the operations of the sequential
     // form on exactly the same operands, so results are bit-identical; only the schedule changes.
     double a1 = 0, a2 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, d1 = 0, d2 = 0, l1 = 0, l2 = 0;
-    double z[12], pin[12], pso[12], pxh[12];   // all-pass state; pipeline registers feeding all-pass i
+    double z[12], pin[12], pxh[12];   // all-pass state; pipeline registers feeding all-pass i
 #pragma unroll
-    for (int i = 0; i < 12; ++i) z[i] = pin[i] = pso[i] = pxh[i] = 0.0;
+    for (int i = 0; i < 12; ++i) z[i] = pin[i] = pxh[i] = 0.0;
+    // the wfir input sample only has to WAIT 13 steps for its residual: a 16-slot ring indexed by the (unrolled,
+    // compile-time) step number instead of a 12-register shift chain
+    double sob[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sob[i] = 0.0;
     double qy = 0, qu = 0, qv = 0;             // inputs of resonator stages 1..3
-    double fso = 0, fxh = 0;                   // input of the final stage
+    double fxh = 0;                            // x_hat input of the final stage
     constexpr int DEPTH = 16;                  // output of sample n appears in iteration n + DEPTH
     const float* __restrict__ x = sig + c.sig_start;
     double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + (size_t)ch0 * c.len;  // [channel - ch0][len]
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
             const int tau = tb + q;
             // ---- final stage (sample tau-16): residual, full-wave rectifier, low-pass, average
             {
-                double r = fso - fxh;
+                double r = sob[(q + 3) & 15] - fxh;   // written 13 steps ago
                 r = r < 0.0 ? -r : r;
                 const double lp = k.lpb0 * r + l1;
                 l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
@@ -113,7 +118,6 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
             {
                 const double o = -wf.a * pin[11] + z[11];
                 z[11] = pin[11] + wf.a * o;
-                fso = pso[11];
                 fxh = pxh[11] + wf.c[12] * o;
             }
 #pragma unroll
@@ -121,7 +125,6 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                 const double o = -wf.a * pin[i] + z[i];
                 z[i] = pin[i] + wf.a * o;
                 pin[i + 1] = o;
-                pso[i + 1] = pso[i];
                 pxh[i + 1] = pxh[i] + wf.c[i + 1] * o;
             }
             // ---- resonator 2 twice, resonator 1 twice (samples tau-3 .. tau), DF2T like scipy.signal.lfilter
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                 d1 = d2 - k.r2a1 * sres;
                 d2 = -k.r2a2 * sres;
                 pin[0] = sres;
-                pso[0] = sres;
+                sob[q] = sres;
                 pxh[0] = wf.c[0] * sres;
             }
             {
