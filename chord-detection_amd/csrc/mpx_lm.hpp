@@ -138,7 +138,17 @@ MPX_HD inline void qrsolv(double* r, const int* ipvt, const double* diag, const 
                     const double rkk = r[k * NP + k], sk = sdiag[k];
                     const bool small = fabs(rkk) < fabs(sk);
                     const double t = (small ? rkk : sk) / (small ? sk : rkk);
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // |t| <= 1, so the radicand lies in [0.25, 0.5]: no range scaling needed, and the hardware
+                    // reciprocal square root + two Newton steps (~1 ulp) replaces a full sqrt and a full division
+                    const double wq = fma(0.25 * t, t, 0.25);
+                    double yq = __builtin_amdgcn_rsq(wq);
+                    yq = fma(0.5 * yq, fma(-wq * yq, yq, 1.0), yq);
+                    yq = fma(0.5 * yq, fma(-wq * yq, yq, 1.0), yq);
+                    const double c0 = 0.5 * yq;
+#else
                     const double c0 = 0.5 / sqrt(0.25 + 0.25 * t * t);
+#endif
                     const double c1 = c0 * t;
                     const double sn = small ? c0 : c1, cs = small ? c1 : c0;
                     r[k * NP + k] = cs * r[k * NP + k] + sn * sdiag[k];
