@@ -218,10 +218,19 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
     if (fp <= 0.1 * delta) return 0.0;
     double parl = 0.0;
     if (nsing >= NP) {
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const double inv_dx = 1.0 / dxnorm;  // one division for the three quotients (1 ulp apart)
+#endif
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int l = ipvt[j];
-            wa1[j] = sel3(diag, l) * (sel3(wa2, l) / dxnorm);
+            for (int j = 0; j < NP; ++j) {
+                const int l = ipvt[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+                wa1[j] = sel3(diag, l) * (sel3(wa2, l) * inv_dx);
+#else
+                wa1[j] = sel3(diag, l) * (sel3(wa2, l) / dxnorm);
+#endif
+            }
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -231,7 +240,11 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
             wa1[j] = (wa1[j] - s) / r[j * NP + j];
         }
         const double temp = enorm3(wa1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        parl = fp / (delta * temp * temp);
+#else
         parl = ((fp / delta) / temp) / temp;
+#endif
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -259,10 +272,19 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
         temp = fp;
         fp = dxnorm - delta;
         if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || it == 10) break;
+        {
+#if defined(__HIP_DEVICE_COMPILE__)
+            const double inv_dx = 1.0 / dxnorm;  // one division for the three quotients (1 ulp apart)
+#endif
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const int l = ipvt[j];
-            wa1[j] = sel3(diag, l) * (sel3(wa2, l) / dxnorm);
+            for (int j = 0; j < NP; ++j) {
+                const int l = ipvt[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+                wa1[j] = sel3(diag, l) * (sel3(wa2, l) * inv_dx);
+#else
+                wa1[j] = sel3(diag, l) * (sel3(wa2, l) / dxnorm);
+#endif
+            }
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -272,7 +294,11 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
             for (int i = j + 1; i < NP; ++i) wa1[i] -= r[i * NP + j] * t;
         }
         temp = enorm3(wa1);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double parc = fp / (delta * temp * temp);
+#else
         const double parc = ((fp / delta) / temp) / temp;
+#endif
         if (fp > 0.0) parl = parl > par ? parl : par;
         if (fp < 0.0) paru = paru < par ? paru : par;
         par = parl > par + parc ? parl : par + parc;
