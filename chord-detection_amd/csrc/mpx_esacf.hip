@@ -929,7 +929,7 @@ struct ParkedFit {
 };
 constexpr int PARK_NFEV = 100;
 constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinished fits ...
-constexpr int PARK_CAP = 8192;  // ... or while fewer fits than this are parked (what coopfit_kernel holds at once)
+constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
 // Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
 // (~100 cycles through the LDS crossbar): a fit owns one 16-lane DPP row, so its all-reduce is four mirror /
@@ -1227,6 +1227,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 
     int phase = FIT_NEED_WORK;
     bool drained = false;  // wave-uniform: some lane has found the work list empty
+    bool cap_hit = false;  // wave-uniform: the cooperative kernel is full, park only from a thinned-out wave
     // per-fit state
     const double* row = y;
     double x0 = 0.0, x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1};
@@ -1277,10 +1278,17 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         // ~45 us.  Its MINPACK state is handed to coopfit_kernel instead, which finishes all such fits at once
         // with 16 lanes each.
         drained = drained || __any(phase == FIT_DONE);
-        // ... but only once the wave has thinned out: a wave that still holds many runaway fits (short frames: 11 % of
-        // the fits at N = 1023) runs them at good lane utilisation, far cheaper than 16 lanes per fit
+        // ... as long as coopfit_kernel can hold them all at once (park_cap), and beyond that only from waves that
+        // have thinned out: a wave that still holds many runaway fits (short frames: 11 % of the fits at N = 1023)
+        // runs them at good lane utilisation, far cheaper than 16 lanes per fit.  The cap is enforced with the return
+        // value of an atomic on its own counter (reading the hot parked counter every trip stalled every wave).
         const int live = __popcll(__ballot(phase != FIT_DONE));
-        if (drained && (live <= park_live || *(volatile int*)parked_count < park_cap) && phase == FIT_OUTER && nfev >= park_nfev && parked) {
+        bool may_park = drained && phase == FIT_OUTER && nfev >= park_nfev && parked != nullptr;
+        if (may_park && live > park_live) {
+            may_park = !cap_hit && atomicAdd(parked_count + 2, 1) < park_cap;
+            cap_hit = cap_hit || __any(!may_park);
+        }
+        if (may_park) {
             ParkedFit pf;
             pf.out = out;
             pf.row_off = row - y;
@@ -1860,7 +1868,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             hipLaunchKernelGGL(band_unpack_kernel, dim3((unsigned)nf), dim3(256), 0, st, xb, nf, N, stage == MPX_STAGE_XHI ? 1 : 0,
                                d_stage_out + (size_t)f0 * N);
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
-        MPX_HIP(ctx, hipMemsetAsync(total, 0, 5 * sizeof(int), st));  // see SacfArgs::total_peaks
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, 6 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts
         SacfArgs a;
         a.xb = xb;
         a.N = N;
