@@ -12,6 +12,7 @@
 // Output: [F,12] doubles.  Nothing else touches HBM: the N-point real FFT is an
 // N/2-point complex FFT held entirely in LDS (mpx_fft.hpp) followed by the
 // real-split butterfly evaluated only for the bins the 48 windows look at.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <type_traits>
@@ -33,8 +34,10 @@ struct HeArgs {
     const cx<Real>* woffs;  // [EPT] (cos, sin)(2*pi*o_e/(N-1)), o_e = 2*e*T: staged in LDS by the kernel
     const cx<Real>* tw;     // [M]
     const cx<Real>* twn;    // [M+1]
-    const int* wk0;
+    const int* wk0;   // windows as index ranges into bins[]
     const int* wk1;
+    const int* bins;  // the spectrum bins some window looks at, ascending
+    int nb;
     const Real* ww;
     int nwin, wins_per_note, num_harmonic;
     int kmin, kmax;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     constexpr bool DIF = he_uses_dif<N, T>();
     cx<Real>* buf = reinterpret_cast<cx<Real>*>(smem);
     Real* mag = reinterpret_cast<Real*>(smem + sizeof(cx<Real>) * he_buf_slots<N, T>());
-    const int nmag = a.kmax - a.kmin;
+    const int nmag = a.nb;  // magnitudes are computed for the bins the windows touch only (compact, window order)
     Real* winmax = mag + nmag;
     // [flag: 16 B][window offset angles: EPT complex] live behind winmax, 16-byte aligned
     char* tail = reinterpret_cast<char*>(winmax + a.nwin);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
 
         // real-split: X[k] = E + (-i) W_N^k D, E=(Z[k]+conj Z[M-k])/2, D=(Z[k]-conj Z[M-k])/2
         for (int i = ot; i < nmag; i += T) {
-            const int k = a.kmin + i;
+            const int k = a.bins[i];
             const int ka = k & (M - 1), kb = (M - k) & (M - 1);
             int sa, sb;
             if constexpr (DIF) {
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
             for (int wi = tid; wi < a.nwin; wi += 64) {  // half-open window maxima (harmonic_energy.py:58-62)
                 Real m = -INFINITY;
                 for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) {
-                    const Real v = mag[k - a.kmin];
+                    const Real v = mag[k];
                     m = v > m ? v : m;
                 }
                 winmax[wi] = m;
@@ -489,6 +492,22 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
     plan.window = upload(ctx, wang.data(), wang.size() * sizeof(cx<Real>));
     plan.tw = upload(ctx, tw.data(), tw.size() * sizeof(cx<Real>));
     plan.twn = upload(ctx, twn.data(), twn.size() * sizeof(cx<Real>));
+    // the bins some window touches, ascending; a window is a run of consecutive bins, hence a run of this list
+    std::vector<int> bins;
+    for (size_t w = 0; w < k0.size(); ++w)
+        for (int k = k0[w]; k < k1[w]; ++k) bins.push_back(k);
+    std::sort(bins.begin(), bins.end());
+    bins.erase(std::unique(bins.begin(), bins.end()), bins.end());
+    for (size_t w = 0; w < k0.size(); ++w) {
+        const int len = k1[w] > k0[w] ? k1[w] - k0[w] : 0;
+        const int c0 = (int)(std::lower_bound(bins.begin(), bins.end(), k0[w]) - bins.begin());
+        k0[w] = c0;
+        k1[w] = c0 + len;
+    }
+    if (bins.empty()) bins.push_back(0);
+    plan.nb = (int)bins.size();
+    plan.bins = (int*)upload(ctx, bins.data(), bins.size() * sizeof(int));
+    if (!plan.bins) return MPX_ENOMEM;
     plan.wk0 = (int*)upload(ctx, k0.data(), k0.size() * sizeof(int));
     plan.wk1 = (int*)upload(ctx, k1.data(), k1.size() * sizeof(int));
     plan.ww = upload(ctx, ww.data(), ww.size() * sizeof(Real));
@@ -530,6 +549,8 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.twn = (const cx<Real>*)plan.twn;
     a.wk0 = plan.wk0;
     a.wk1 = plan.wk1;
+    a.bins = plan.bins;
+    a.nb = plan.nb;
     a.ww = (const Real*)plan.ww;
     a.nwin = plan.nwin;
     a.wins_per_note = plan.wins_per_note;
@@ -540,7 +561,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.partial = nullptr;
     a.sum = nullptr;
     a.counter = nullptr;
-    const size_t lds = sizeof(cx<Real>) * he_buf_slots<N, T>() + sizeof(Real) * (size_t)(plan.kmax - plan.kmin + plan.nwin) + 48 + sizeof(cx<Real>) * (N / 2 / T);
+    const size_t lds = sizeof(cx<Real>) * he_buf_slots<N, T>() + sizeof(Real) * (size_t)(plan.nb + plan.nwin) + 48 + sizeof(cx<Real>) * (N / 2 / T);
     if (lds > 160 * 1024)
         return set_error(ctx, MPX_EUNSUPPORTED, "frame %d needs %zu B of LDS (> 160 KiB)", N, lds);
     auto kern = he_kernel<N, T, Real>;

@@ -31,8 +31,10 @@ struct HePlan {
     void* window = nullptr;  // cx[N]     (cos, sin)(2 pi s/(N-1)): symmetric Hamming angles (harmonic_energy.py:42)
     void* tw = nullptr;      // cx[M]     W_M^j, M = N/2
     void* twn = nullptr;     // cx[M+1]   W_N^k (real-FFT split)
-    int* wk0 = nullptr;      // [nwin] window start bin
-    int* wk1 = nullptr;      // [nwin] window end bin (exclusive, harmonic_energy.py:58)
+    int* wk0 = nullptr;      // [nwin] window start (index into `bins`)
+    int* wk1 = nullptr;      // [nwin] window end (exclusive, harmonic_energy.py:58)
+    int* bins = nullptr;     // [nb] the bins some window looks at, ascending
+    int nb = 0;
     void* ww = nullptr;      // Real[nwin] 1/harmonic
     int nwin = 0;            // 12 * num_octave * num_harmonic
     int wins_per_note = 0;
