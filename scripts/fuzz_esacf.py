@@ -19,7 +19,7 @@ bad = frag = frames = 0
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for case in range(cases):
-        fs = int(rng.choice([16000, 22050, 44100]))
+        fs = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
         N = int(rng.choice([64, 100, 255, 256, 511, 512, 742, 1000, 1023, 1024, 1500, 2046, 2047, 2048, 2049, 2227, 3000, 4095, 4096]))
         nfr = int(rng.integers(1, 5))
         n = nfr * N - int(rng.integers(0, N // 2))
