@@ -84,7 +84,7 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
         clips = synth_chunk(ids, fs, seconds, synth_device).cpu().numpy()
         for mi, m in enumerate(methods):
             t0 = time.perf_counter()
-            out[c0 - lo:c0 - lo + len(ids), mi] = compute(m, list(clips), fs, device)
+            out[c0 - lo:c0 - lo + len(ids), mi] = compute(m, clips, fs, device)   # [n, L] array: packed as it is
             spent[mi] += time.perf_counter() - t0
     return lo, hi, out, spent
 

@@ -649,6 +649,31 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if ((p.M - 1) * ((double)NF / fs) / p.tau_min + 1.5 >= n2)
         return set_error(ctx, MPX_EINVAL, "iterative F0: harmonic %d of tau_min falls outside the %d-bin spectrum (the "
                          "reference raises ValueError on the empty slice)", p.M - 1, n2);
+    // The front-end output is 8 * channels bytes per sample (560 B at 70 channels): keep the workspace of one pass
+    // below 8 GiB by halving the clip list (1024 two-second clips would ask for 28 GB, and allocating that costs a
+    // second); a pass of a few hundred clips already fills the machine.
+    {
+        size_t rows = 0, rows_first = 0;
+        const int mid = num_clips / 2;
+        for (int c = 0; c < num_clips; ++c) {
+            const int64_t len = offsets[c + 1] - offsets[c];
+            if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
+            const size_t r = len <= 0 ? 0 : (size_t)((len + NF - 1) / NF) * NF;
+            rows += r;
+            if (c < mid) rows_first += r;
+        }
+        if (num_clips > 1 && rows * p.channels * sizeof(double) > ((size_t)8 << 30)) {
+            std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
+            for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
+            const size_t frames_first = rows_first / NF;
+            int rc1 = if0_run_host(ctx, signals, offsets, mid, fs, &p, chroma_frames, chroma_sums, ut_out);
+            if (rc1) return rc1;
+            return if0_run_host(ctx, signals + (offsets[mid] - offsets[0]), off2.data(), num_clips - mid, fs, &p,
+                                chroma_frames ? chroma_frames + frames_first * 12 : nullptr,
+                                chroma_sums ? chroma_sums + (size_t)mid * 12 : nullptr,
+                                ut_out ? ut_out + frames_first * n2 : nullptr);
+        }
+    }
     If0Plan plan;
     int rc = if0_plan(ctx, fs, p, plan);
     if (rc) return rc;

@@ -63,6 +63,10 @@ class Engine:
 
     @staticmethod
     def _pack(clips):
+        if isinstance(clips, np.ndarray) and clips.ndim == 2:
+            # [C, L] array of equal-length clips: already packed back to back, no copy if float32 C-contiguous
+            flat = np.ascontiguousarray(clips, dtype=np.float32).reshape(-1)
+            return flat, np.arange(clips.shape[0] + 1, dtype=np.int64) * clips.shape[1]
         arrs = [Engine._sig(c) for c in clips]
         offsets = np.zeros(len(arrs) + 1, dtype=np.int64)
         for i, a in enumerate(arrs):

@@ -81,3 +81,25 @@ def test_chunked_front_end_matches_sequential_filtering(eng):
     assert ut.shape == Ut.shape
     # frames 32.. live in the second chunk
     np.testing.assert_allclose(ut[30:], Ut[30:], rtol=1e-9, atol=1e-9 * np.abs(Ut).max())
+
+
+def test_large_batch_is_split_without_changing_results(eng):
+    """More clips than fit one 8 GiB front-end workspace (27.5 MB per 2 s clip at 70 channels): the clip list is
+    halved internally; every clip must come out exactly as on its own."""
+    rng = np.random.default_rng(3)
+    t = np.arange(44100) / FS
+    base = []
+    for _ in range(6):
+        x = np.zeros(44100)
+        for _ in range(3):
+            f0 = 440.0 * 2.0 ** ((int(rng.integers(40, 80)) - 69) / 12.0)
+            for h in range(1, 5):
+                x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+        base.append((0.2 * x).astype(np.float32))
+    batch = np.stack([base[i % 6] for i in range(340)])          # [340, 44100]: the packed fast path as well
+    got = eng.iterative_f0_batch(batch, FS)
+    assert got.shape == (340, 12)
+    singles = [eng.iterative_f0(b, FS) for b in base]
+    for i in (0, 1, 169, 170, 171, 338, 339):
+        np.testing.assert_allclose(got[i], singles[i % 6], rtol=1e-12, atol=0)
+    np.testing.assert_array_equal(got[:6], got[6:12])
