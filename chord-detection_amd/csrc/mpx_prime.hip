@@ -39,7 +39,9 @@ __global__ __launch_bounds__(T) void prime_kernel(const float* __restrict__ sig,
                                                   int* out_pc, double* out_val) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
-    double* mag = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));
+    // the magnitudes (half <= N/2 + 1 <= L/4 + 1 doubles) go into the upper half of the FFT buffer: they are computed
+    // from slots below 4.25 L bytes, so nothing they overwrite is still needed -- and the 8192-point class fits
+    double* mag = reinterpret_cast<double*>(smem + 8 * (size_t)L);
     __shared__ double red_v[T];
     __shared__ int red_i[T];
     const int tid = threadIdx.x;
@@ -189,12 +191,12 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
             for (int h = 1; h <= p.num_harmonic; ++h) {
                 const double f = note * oct * h;
                 const int N = (int)((8 / f) * fs);  // prime_multif0.py:53
-                if (N < 2 || N > 2048)
+                if (N < 2 || N > 4096)
                     return set_error(ctx, MPX_EUNSUPPORTED,
-                                     "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..2048)", N, f);
+                                     "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..4096)", N, f);
                 PrimeCand c;
                 c.N = N;
-                c.L = N <= 512 ? 1024 : (N <= 1024 ? 2048 : 4096);
+                c.L = N <= 512 ? 1024 : (N <= 1024 ? 2048 : (N <= 2048 ? 4096 : 8192));
                 c.half = (N / 2 + 1) / 2;
                 c.val = 1.0 / (N * (1.0 / fs));
                 std::vector<double> win(N);
@@ -249,7 +251,7 @@ template <int L, int T>
 static void prime_launch(const float* d_sig, const PrimeItem* d_items, size_t count, const PrimeCand* d_cands, int runs,
                          int elim, int* d_pc, double* d_val, hipStream_t st) {
     if (!count) return;
-    const size_t lds = sizeof(cx<double>) * lds_slots(L) + sizeof(double) * (L / 4 + 8);
+    const size_t lds = sizeof(cx<double>) * lds_slots(L);  // the magnitudes alias the upper half of the buffer
     auto kern = prime_kernel<L, T>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, st, d_sig, d_items, d_cands, runs, elim, d_pc, d_val);
@@ -269,7 +271,7 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     PrimePlan* plan = &plan_storage;
     const int64_t total = offsets[num_clips];
     // items in the reference's loop order per clip: candidate-major, then frame
-    std::vector<PrimeItem> items[3];
+    std::vector<PrimeItem> items[4];
     std::vector<long long> seg(1, 0);
     long long slot = 0;
     for (int cidx = 0; cidx < num_clips; ++cidx) {
@@ -285,7 +287,7 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
                 it.valid = (int)(left >= c.N ? c.N : left);
                 it.cand = (int)k;
                 it.slot = slot++;
-                items[c.L == 1024 ? 0 : (c.L == 2048 ? 1 : 2)].push_back(it);
+                items[c.L == 1024 ? 0 : (c.L == 2048 ? 1 : (c.L == 4096 ? 2 : 3))].push_back(it);
             }
         }
         seg.push_back(slot);
@@ -305,13 +307,14 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     int* d_pc = (int*)(d_val + (nitems + 1) * PRIME_MAX_RUNS);
     char* d_items = (char*)ctx->d_desc.p;
     size_t off = 0;
-    for (int cls = 0; cls < 3; ++cls) {
+    for (int cls = 0; cls < 4; ++cls) {
         const size_t bytes = items[cls].size() * sizeof(PrimeItem);
         if (bytes) MPX_HIP(ctx, hipMemcpyAsync(d_items + off, items[cls].data(), bytes, hipMemcpyHostToDevice, st));
         const PrimeItem* di = (const PrimeItem*)(d_items + off);
         if (cls == 0) prime_launch<1024, 64>((const float*)ctx->d_signal.p, di, items[cls].size(), plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st);
         if (cls == 1) prime_launch<2048, 128>((const float*)ctx->d_signal.p, di, items[cls].size(), plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st);
         if (cls == 2) prime_launch<4096, 256>((const float*)ctx->d_signal.p, di, items[cls].size(), plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st);
+        if (cls == 3) prime_launch<8192, 512>((const float*)ctx->d_signal.p, di, items[cls].size(), plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st);
         off += bytes;
     }
     if (num_clips)

@@ -58,7 +58,16 @@ def test_batch_edge_cases_vs_oracle(eng, clips):
         np.testing.assert_allclose(got[i], want, rtol=RTOL, atol=1e-7)
     again = eng.prime_multif0_batch(batch[::-1], FS)[::-1]
     assert np.array_equal(got, again)                      # deterministic, independent of batch position
+    # 44.1 kHz: the low candidates need frames of 2049..2696 samples -> the 8192-point chirp-z class
+    rng = np.random.default_rng(44)
+    t = np.arange(60000) / 44100.0
+    x44 = (0.2 * sum(0.5 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6)) for f0 in (220.0, 330.0) for h in (1, 2, 3))
+           + 1e-3 * rng.standard_normal(t.shape[0])).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(eng.prime_multif0(x44, 44100), o_prime.prime_compute(x44.astype(np.float64), 44100),
+                                   rtol=RTOL, atol=1e-7)
     with pytest.raises(NotImplementedError):
-        eng.prime_multif0(np.zeros(100, dtype=np.float32), 44100)   # 8/f*fs > 2048 samples for the low candidates
+        eng.prime_multif0(np.zeros(100, dtype=np.float32), 96000)   # 8/f*fs > 4096 samples for the low candidates
     with pytest.raises(ValueError):
         eng.prime_multif0(np.zeros((2, 2), dtype=np.float32), FS)
