@@ -14,6 +14,9 @@
 // real-split butterfly evaluated only for the bins the 48 windows look at.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <string>
+#include <cstring>
 #include <cstdarg>
 #include <type_traits>
 
@@ -615,6 +618,229 @@ static int he_dispatch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, 
     }
 }
 
+// ------------------------------------------------------------------ arbitrary frame lengths
+// Frame sizes that are not a power of two in [1024, 16384] (the reference takes any `frame_size`): the N-point DFT of
+// the windowed frame as a chirp-z transform on the padded Stockham engine, one workgroup per frame, then the same
+// window maxima / pitch-class sums.  Complete and exact, not tuned (the power-of-two kernel above is the fast path).
+struct HeBlueArgs {
+    const float* sig;
+    long long n;
+    const FrameDesc* desc;
+    long long num_frames;
+    int N, hop;
+    const double* win;       // [N] symmetric Hamming (scipy.signal.hamming, harmonic_energy.py:42)
+    const cx<double>* chirp; // [N] exp(i pi n^2 / N)
+    const cx<double>* bhat;  // [L] FFT_L(chirp filter) / L
+    const cx<double>* tw;    // [L] W_L
+    const int* bins;         // [nb]
+    const int* wk0;
+    const int* wk1;
+    const double* ww;
+    int nb, nwin, wins_per_note, num_harmonic;
+    double* out;             // [F, 12]
+};
+
+template <int L, int T>
+__global__ __launch_bounds__(T) void he_blue_kernel(HeBlueArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    double* mag = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));  // [nb] then winmax [nwin]
+    double* winmax = mag + a.nb;
+    const int tid = threadIdx.x, N = a.N;
+    const long long f = blockIdx.x;
+    long long start;
+    int valid;
+    if (a.desc) {
+        start = a.desc[f].start;
+        valid = a.desc[f].valid;
+    } else {
+        start = f * (long long)a.hop;
+        const long long left = a.n - start;
+        valid = left >= N ? N : (left > 0 ? (int)left : 0);
+    }
+    const float* __restrict__ x = a.sig + start;
+    cx<double> regs[L / T];
+    for (int n = tid; n < L; n += T) {
+        cx<double> v = {0.0, 0.0};
+        if (n < N) {
+            const double s = (n < valid ? (double)x[n] : 0.0) * a.win[n];
+            const cx<double> ch = a.chirp[n];
+            v = {s * ch.x, -s * ch.y};  // s * conj(chirp)
+        }
+        buf[lds_slot(n)] = v;
+    }
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+    for (int k = tid; k < L; k += T) {
+        const cx<double> p = cmul(buf[lds_slot(k)], a.bhat[k]);
+        buf[lds_slot(k)] = {p.y, p.x};  // swapped: the next forward FFT acts as the inverse
+    }
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+    for (int i = tid; i < a.nb; i += T) {
+        const int k = a.bins[i];  // k <= N/2
+        const cx<double> b = buf[lds_slot(k)];
+        const cx<double> ch = a.chirp[k < N ? k : 0];
+        const cx<double> z = cmul(cx<double>{b.y, b.x}, cx<double>{ch.x, -ch.y});
+        mag[i] = sqrt(sqrt(z.x * z.x + z.y * z.y));  // sqrt(|rfft|), harmonic_energy.py:43
+    }
+    __syncthreads();
+    for (int wi = tid; wi < a.nwin; wi += T) {
+        double m = -INFINITY;
+        for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) m = mag[k] > m ? mag[k] : m;
+        winmax[wi] = m;
+    }
+    __syncthreads();
+    if (tid < 12) {
+        double chroma = 0.0;
+        const int base = tid * a.wins_per_note;
+        for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
+            double note_sum = 0.0;
+            for (int h = 0; h < a.num_harmonic; ++h) note_sum += winmax[base + o + h] * a.ww[base + o + h];
+            chroma += note_sum;
+        }
+        a.out[f * 12 + tid] = chroma;
+    }
+}
+
+static void he_host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, forward; plan tables only
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const long double ang = -2.0L * M_PIl / (long double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const cx<double> w = {(double)cosl(ang * k), (double)sinl(ang * k)};
+                const cx<double> t = a[i + k + len / 2];
+                const cx<double> u = a[i + k], v = {t.x * w.x - t.y * w.y, t.x * w.y + t.y * w.x};
+                a[i + k] = {u.x + v.x, u.y + v.y};
+                a[i + k + len / 2] = {u.x - v.x, u.y - v.y};
+            }
+    }
+}
+
+static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames, int fs,
+                       const mpx_he_params& p, int N, int hop, double* d_rows, double* d_sum, hipStream_t stream) {
+    int L = 1024;
+    while (L < 2 * N - 1) L <<= 1;
+    char keyb[128];
+    snprintf(keyb, sizeof keyb, "he_blue_%d_%d_%d_%d_%d", fs, N, p.num_harmonic, p.num_octave, p.num_bins);
+    const std::string key = keyb;
+    auto it = ctx->misc_plans.find(key);
+    if (it == ctx->misc_plans.end()) {
+        const double c3 = 440.0 * std::pow(2.0, (48.0 - 69.0) / 12.0);
+        const double divisor_ratio = (fs / 4.0) / N;  // harmonic_energy.py:35 (quirk A.2)
+        std::vector<int> k0, k1, bins;
+        std::vector<double> ww;
+        for (int nn = 0; nn < 12; ++nn) {
+            const double note = c3 * std::pow(2.0, nn / 12.0);
+            for (int oct = 1; oct <= p.num_octave; ++oct)
+                for (int h = 1; h <= p.num_harmonic; ++h) {
+                    const double kp = he_round_half_even((note * oct * h) / divisor_ratio);
+                    const int a0 = (int)(kp - p.num_bins * h), b0 = (int)(kp + p.num_bins * h);
+                    if (b0 > a0 && (a0 < 0 || b0 > N / 2 + 1))
+                        return set_error(ctx, MPX_EINVAL, "harmonic-energy window [%d,%d) outside the %d-bin spectrum (the "
+                                         "reference raises IndexError / wraps here)", a0, b0, N / 2 + 1);
+                    k0.push_back(a0);
+                    k1.push_back(b0);
+                    ww.push_back(1.0 / h);
+                    for (int k = a0; k < b0; ++k) bins.push_back(k);
+                }
+        }
+        std::sort(bins.begin(), bins.end());
+        bins.erase(std::unique(bins.begin(), bins.end()), bins.end());
+        for (size_t w = 0; w < k0.size(); ++w) {
+            const int len = k1[w] > k0[w] ? k1[w] - k0[w] : 0;
+            const int c0 = (int)(std::lower_bound(bins.begin(), bins.end(), k0[w]) - bins.begin());
+            k0[w] = c0;
+            k1[w] = c0 + len;
+        }
+        if (bins.empty()) bins.push_back(0);
+        std::vector<double> win(N);
+        for (int i = 0; i < N; ++i) win[i] = N == 1 ? 1.0 : 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (double)(N - 1));
+        std::vector<cx<double>> chirp(N), filt(L, cx<double>{0.0, 0.0}), tw(L);
+        for (long long i = 0; i < N; ++i) {
+            const long long q = (i * i) % (2LL * N);
+            const long double ang = M_PIl * (long double)q / (long double)N;
+            chirp[i] = {(double)cosl(ang), (double)sinl(ang)};
+        }
+        filt[0] = chirp[0];
+        for (int m = 1; m < N; ++m) filt[m] = filt[L - m] = chirp[m];
+        he_host_fft(filt);
+        for (auto& v : filt) {
+            v.x /= L;
+            v.y /= L;
+        }
+        for (int j = 0; j < L; ++j) {
+            const long double ang = -2.0L * M_PIl * j / (long double)L;
+            tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+        }
+        std::vector<int> meta = {(int)bins.size(), (int)k0.size(), p.num_octave * p.num_harmonic, p.num_harmonic};
+        std::vector<void*> d = {upload(ctx, win.data(), win.size() * sizeof(double)),
+                                upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>)),
+                                upload(ctx, filt.data(), filt.size() * sizeof(cx<double>)),
+                                upload(ctx, tw.data(), tw.size() * sizeof(cx<double>)),
+                                upload(ctx, bins.data(), bins.size() * sizeof(int)),
+                                upload(ctx, k0.data(), k0.size() * sizeof(int)),
+                                upload(ctx, k1.data(), k1.size() * sizeof(int)),
+                                upload(ctx, ww.data(), ww.size() * sizeof(double))};
+        for (void* q : d)
+            if (!q) return MPX_ENOMEM;
+        std::vector<unsigned char> blob(meta.size() * sizeof(int));
+        std::memcpy(blob.data(), meta.data(), blob.size());
+        ctx->host_blobs[key] = std::move(blob);
+        it = ctx->misc_plans.emplace(key, d).first;
+    }
+    const int* meta = reinterpret_cast<const int*>(ctx->host_blobs[key].data());
+    double* rows = d_rows;
+    if (!rows) {
+        int rc = ensure(ctx, ctx->d_frames_out, (size_t)(num_frames ? num_frames : 1) * 12 * sizeof(double));
+        if (rc) return rc;
+        rows = (double*)ctx->d_frames_out.p;
+    }
+    HeBlueArgs a;
+    a.sig = d_signal;
+    a.n = n;
+    a.desc = d_desc;
+    a.num_frames = num_frames;
+    a.N = N;
+    a.hop = hop;
+    a.win = (const double*)it->second[0];
+    a.chirp = (const cx<double>*)it->second[1];
+    a.bhat = (const cx<double>*)it->second[2];
+    a.tw = (const cx<double>*)it->second[3];
+    a.bins = (const int*)it->second[4];
+    a.wk0 = (const int*)it->second[5];
+    a.wk1 = (const int*)it->second[6];
+    a.ww = (const double*)it->second[7];
+    a.nb = meta[0];
+    a.nwin = meta[1];
+    a.wins_per_note = meta[2];
+    a.num_harmonic = meta[3];
+    a.out = rows;
+    const size_t extra = sizeof(double) * (size_t)(a.nb + a.nwin + 2);
+    auto launch = [&](auto kern, int T, size_t lds) -> int {
+        if (lds > 160 * 1024) return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame %d needs %zu B of LDS", N, lds);
+        if (lds > 48 * 1024) MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)num_frames), dim3(T), lds, stream, a);
+        MPX_HIP(ctx, hipGetLastError());
+        return MPX_OK;
+    };
+    int rc;
+    if (L == 1024) rc = launch(he_blue_kernel<1024, 64>, 64, sizeof(cx<double>) * lds_slots(1024) + extra);
+    else if (L == 2048) rc = launch(he_blue_kernel<2048, 128>, 128, sizeof(cx<double>) * lds_slots(2048) + extra);
+    else if (L == 4096) rc = launch(he_blue_kernel<4096, 256>, 256, sizeof(cx<double>) * lds_slots(4096) + extra);
+    else rc = launch(he_blue_kernel<8192, 512>, 512, sizeof(cx<double>) * lds_slots(8192) + extra);
+    if (rc) return rc;
+    if (d_sum) return segment_sum(ctx, rows, nullptr, 1, num_frames, d_sum, stream);
+    return MPX_OK;
+}
+
 int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
            int fs, const mpx_he_params* params, int frame, int hop, double* d_chroma_frames,
            double* d_chroma_sum, hipStream_t stream) {
@@ -623,10 +849,13 @@ int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_de
         return set_error(ctx, MPX_EINVAL, "bad harmonic-energy params (%d,%d,%d)", p.num_harmonic,
                          p.num_octave, p.num_bins);
     if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
-    if (frame < 1024 || frame > 16384 || (frame & (frame - 1)))
-        return set_error(ctx, MPX_EUNSUPPORTED,
-                         "harmonic energy: frame size %d is not a power of two in [1024, 16384]", frame);
     if (num_frames == 0) return MPX_OK;
+    if (frame < 1024 || frame > 16384 || (frame & (frame - 1))) {
+        if (frame < 2 || frame > 4096)
+            return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d (supported: powers of two in "
+                             "[1024, 16384] and any size in [2, 4096])", frame);
+        return he_blue_run(ctx, d_signal, n, d_desc, num_frames, fs, p, frame, hop, d_chroma_frames, d_chroma_sum, stream);
+    }
     const bool f32 = ctx->flags & MPX_FLAG_F32;
     auto key = std::make_tuple(fs, frame, p.num_harmonic, p.num_octave, p.num_bins);
     auto it = ctx->he_plans.find(key);

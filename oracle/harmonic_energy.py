@@ -46,12 +46,12 @@ def he_chroma_from_spectrum(x_dft, fs, frame_size, num_harmonic=2, num_octave=2,
     for n in range(12):
         for j in range(k0.shape[1]):
             a, b = int(k0[n, j]), int(k1[n, j])
-            if a < 0 or b > nbins:
-                raise IndexError("harmonic-energy window [%d,%d) outside spectrum of %d bins" % (a, b, nbins))
             if b <= a:
-                # empty python range: the -inf sentinel survives (harmonic_energy.py:49)
+                # empty python range: nothing is indexed, the -inf sentinel survives (harmonic_energy.py:49,57)
                 out[:, n] += -np.inf * w[n, j]
                 continue
+            if a < 0 or b > nbins:
+                raise IndexError("harmonic-energy window [%d,%d) outside spectrum of %d bins" % (a, b, nbins))
             out[:, n] += x_dft[:, a:b].max(axis=-1) * w[n, j]
     return out
 
