@@ -639,8 +639,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                  const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out) {
     mpx_if0_params p = params ? *params
                               : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66};
-    if (p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192)
-        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: 2048, 4096, 8192)", p.frame_size);
+    if (p.frame_size != 1024 && p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192)
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: 1024, 2048, 4096, 8192)", p.frame_size);
     if (p.channels < 1 || p.channels > IF0_MAXCH || p.max_voices < 1 || p.max_voices > 8 || p.Q < 2 || p.Q > 32 || p.M < 2 ||
         p.M > 64 || !(p.tau_min > 0) || !(p.tau_max > p.tau_min) || fs <= 0)
         return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
@@ -767,7 +767,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * ((p.channels + 63) / 64))), dim3(64), 0, st,
                        (const float*)ctx->d_signal.p, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc);
     MPX_HIP(ctx, hipGetLastError());
-    if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
+    if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
+    else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     else rc = if0_spectrum_launch<8192, 512>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     if (rc) return rc;

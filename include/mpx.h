@@ -148,7 +148,7 @@ int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* o
 /* ---- Iterative F0 (method 3): iterative_f0.py:21-33, periodicity.py:15-28 kwargs ----
  * replaces iterative_f0.py:54-96 + periodicity.py:48-163: 70-channel resonator filterbank over the
  * WHOLE signal (quirk A.1 kept), warped-FIR compression, full-wave rectifier, (y + LP(y, fc))/2,
- * frames of `frame_size` (2048/4096/8192) x Hamming zero-padded to 2*frame_size, sum over channels of
+ * frames of `frame_size` (1024/2048/4096/8192) x Hamming zero-padded to 2*frame_size, sum over channels of
  * |FFT|^power, then the iterative period search / harmonic cancellation per frame.
  * Long signals are filtered in 262144-sample chunks with a 65536-sample zero-state warm-up (every pole
  * of the chain has decayed below 1e-30 by then), so chunks run in parallel and shard across GPUs. */

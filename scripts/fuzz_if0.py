@@ -16,7 +16,7 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for case in range(cases):
         fs = 22050
-        NF = int(rng.choice([2048, 4096, 8192]))
+        NF = int(rng.choice([1024, 2048, 4096, 8192]))
         ch = int(rng.choice([5, 31, 64, 65, 70]))
         power = float(rng.choice([1.0, 0.5, 2.0]))
         n = int(rng.choice([NF // 2, NF, NF + 1, 2 * NF + 17, 16384 + 100, 3 * NF - 1, 40000, 70001, 140000, 300000]))
