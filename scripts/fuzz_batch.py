@@ -31,6 +31,8 @@ for r in range(rounds):
     checks = {
         "he": (lambda cs: eng.harmonic_energy_batch(cs, fs, 8192), lambda c: eng.harmonic_energy(c, fs, 8192)),
         "he4096/1024": (lambda cs: eng.harmonic_energy_batch(cs, fs, 4096, 1024), lambda c: eng.harmonic_energy(c, fs, 4096, 1024)),
+        "he1000/300": (lambda cs: eng.harmonic_energy_batch(cs, fs, 1000, 300), lambda c: eng.harmonic_energy(c, fs, 1000, 300)),
+        "esacf2227": (lambda cs: eng.esacf_batch(cs, 48000, 2227), lambda c: eng.esacf(c, 48000, 2227)),
         "esacf": (lambda cs: eng.esacf_batch(cs, fs, 1023), lambda c: eng.esacf(c, fs, 1023)),
         "if0": (lambda cs: eng.iterative_f0_batch(cs, fs), lambda c: eng.iterative_f0(c, fs)),
         "prime": (lambda cs: eng.prime_multif0_batch(cs, fs), lambda c: eng.prime_multif0(c, fs)),
