@@ -589,19 +589,20 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
             continue;
         }
         // ---- enhancement (esacf.py:108-129)
-        for (int r = 2; r <= a.n_peaks_elim; ++r) {
-            int cut = 0;
-            if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-            for (int n = tid; n < Mh; n += T) {
-                double v = yh[n];
+        // (every lag is touched by one thread only, the same one in every pass: registers, one store, one barrier)
+        for (int n = tid; n < Mh; n += T) {
+            double v = yh[n];
+            for (int r = 2; r <= a.n_peaks_elim; ++r) {
+                int cut = 0;
+                if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
                 v = v < 0.0 ? 0.0 : v;          // clip
                 if (n < cut) v = v - v;         // minus the "stretched" copy (== itself for a <=2-frame STFT)
                 v = v < 0.0 ? 0.0 : v;          // clip
-                yh[n] = v;
             }
-            __syncthreads();
+            yh[n] = v;
+            yrow[n] = v;
         }
-        for (int n = tid; n < Mh; n += T) yrow[n] = yh[n];
+        __syncthreads();
         if (a.ablate & (2 | 16)) continue;  // 16: peak picking runs as its own one-wave-per-frame kernel
         peak_pick<T>(a, f, yh, smem, tid);
         __syncthreads();  // frame a's scratch is dead before frame b's
