@@ -202,24 +202,23 @@ __device__ __forceinline__ cx<double> cswap(cx<double> a) { return {a.y, a.x}; }
 // Entry condition: no wave is still reading `buf`.
 template <int L, bool BLUE>
 __device__ __forceinline__ void dft_regs(cx<double>* buf, const DifTwiddles<L, double>& twd, const SacfArgs& a,
-                                         cx<double>* regs, int tid) {
+                                         cx<double>* regs, int tid, const cx<double>* chv) {
     constexpr int T = L / 8;
     if (BLUE) {
         const int N = a.N;
+        // N <= L/2 = 4T: only registers r < 4 hold input or output bins, and both chirp multiplications of both
+        // transforms of a frame use the same four chirp values chv[r] = chirp[tid + r*T] (loaded once per frame)
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int n = tid + r * T;
-            regs[r] = n < N ? cmulc(regs[r], a.chirp[n]) : cx<double>{0.0, 0.0};
+            regs[r] = (r < 4 && n < N) ? cmulc(regs[r], chv[r & 3]) : cx<double>{0.0, 0.0};
         }
         dif_fft_keep_last<L, double>(buf, twd, regs, tid);
 #pragma unroll
         for (int e = 0; e < 8; ++e) regs[e] = cmul(regs[e], a.bhat[e * T + tid]);
         idit_fft_from_last<L, double>(buf, twd, regs, tid);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int k = tid + r * T;
-            regs[r] = cmulc(regs[r], a.chirp[k < N ? k : 0]);
-        }
+        for (int r = 0; r < 4; ++r) regs[r] = cmulc(regs[r], chv[r]);
     } else {
         dif_fft_keep_last<L, double>(buf, twd, regs, tid);
     }
@@ -482,6 +481,9 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     const int tid = threadIdx.x;
     const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(a.tw, tid);
     cx<double> regs[8];
+    cx<double> chv[4];  // this thread's chirp values (Bluestein)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) chv[r] = BLUE ? a.chirp[(tid + r * (L / 8)) < N ? tid + r * (L / 8) : 0] : cx<double>{1.0, 0.0};
 
     // ---- SACF: DFT_N(x_lo + i x_hi) -> S -> DFT_N(S) -> first Mh lags / N.
     // With a.pair (experimental, off by default: see esacf_run) a workgroup takes TWO frames: S is real and even, so DFT_N(S) is real, and one complex transform of
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
             const int n = tid + r * T;
             regs[r] = n < N ? xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)] : cx<double>{0.0, 0.0};
         }
-        if (!(a.ablate & 8)) dft_regs<L, BLUE>(buf, twd, a, regs, tid);
+        if (!(a.ablate & 8)) dft_regs<L, BLUE>(buf, twd, a, regs, tid, chv);
         // every thread needs the mirror bin X[N-k] of each of its bins: exchange through LDS
 #pragma unroll
         for (int e = 0; e < 8; ++e) buf[sigma<L>(BLUE ? kk[e] : dif_last_pos<L>(tid, e / RL, e % RL))] = regs[e];
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     __syncthreads();  // S reads done before the transform writes buf
     if (a.ablate & 4) {
     } else if (BLUE)
-        dft_regs<L, true>(buf, twd, a, regs, tid);
+        dft_regs<L, true>(buf, twd, a, regs, tid, chv);
     else
         idit_fft_from_last<L, double>(buf, twd, regs, tid);  // S is real and even: its inverse DFT x N is its DFT
     __syncthreads();  // buf is dead from here on: frame b's lags and the peak-picking scratch alias it
