@@ -40,6 +40,7 @@ struct HeArgs {
     const int* wk0;   // windows as index ranges into bins[]
     const int* wk1;
     const int* bins;  // the spectrum bins some window looks at, ascending
+    const cx<Real>* twnb;  // W_N^k at bins[i], indexed like bins
     int nb;
     const Real* ww;
     int nwin, wins_per_note, num_harmonic;
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
             B.y = -B.y;
             const cx<Real> E = {(Real)0.5 * (A.x + B.x), (Real)0.5 * (A.y + B.y)};
             const cx<Real> D = {(Real)0.5 * (A.x - B.x), (Real)0.5 * (A.y - B.y)};
-            const cx<Real> X = cadd(E, mul_mi(cmul(a.twn[k], D)));
+            const cx<Real> X = cadd(E, mul_mi(cmul(a.twnb[i], D)));
             mag[i] = sqrt(sqrt(X.x * X.x + X.y * X.y));
         }
         __syncthreads();  // mag[] complete, and nobody reads buf any more: the next frame may overwrite it
@@ -510,7 +511,10 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
     if (bins.empty()) bins.push_back(0);
     plan.nb = (int)bins.size();
     plan.bins = (int*)upload(ctx, bins.data(), bins.size() * sizeof(int));
-    if (!plan.bins) return MPX_ENOMEM;
+    std::vector<cx<Real>> twnb(bins.size());
+    for (size_t i = 0; i < bins.size(); ++i) twnb[i] = twn[bins[i] <= M ? bins[i] : 0];
+    plan.twnb = upload(ctx, twnb.data(), twnb.size() * sizeof(cx<Real>));
+    if (!plan.bins || !plan.twnb) return MPX_ENOMEM;
     plan.wk0 = (int*)upload(ctx, k0.data(), k0.size() * sizeof(int));
     plan.wk1 = (int*)upload(ctx, k1.data(), k1.size() * sizeof(int));
     plan.ww = upload(ctx, ww.data(), ww.size() * sizeof(Real));
@@ -553,6 +557,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.wk0 = plan.wk0;
     a.wk1 = plan.wk1;
     a.bins = plan.bins;
+    a.twnb = (const cx<Real>*)plan.twnb;
     a.nb = plan.nb;
     a.ww = (const Real*)plan.ww;
     a.nwin = plan.nwin;

@@ -34,6 +34,7 @@ struct HePlan {
     int* wk0 = nullptr;      // [nwin] window start (index into `bins`)
     int* wk1 = nullptr;      // [nwin] window end (exclusive, harmonic_energy.py:58)
     int* bins = nullptr;     // [nb] the bins some window looks at, ascending
+    void* twnb = nullptr;    // cx[nb] W_N^k at those bins (so that the load does not wait for bins[i])
     int nb = 0;
     void* ww = nullptr;      // Real[nwin] 1/harmonic
     int nwin = 0;            // 12 * num_octave * num_harmonic
