@@ -112,7 +112,7 @@ struct SmallDft<16, T> {
 // fp64: every lane of a ds_write_b128 group on the same banks); the pad turns
 // that stride into R+1 (R=16) / R+0.5 slots and spreads the group over distinct
 // 16-byte bank slots.  Reads (lane stride 1) stay contiguous.
-__device__ __forceinline__ constexpr int lds_slot(int i) { return i + (i >> 4); }
+__host__ __device__ __forceinline__ constexpr int lds_slot(int i) { return i + (i >> 4); }
 constexpr int lds_slots(int m) { return m + (m >> 4); }
 
 // ---------------------------------------------------------------- radix plans

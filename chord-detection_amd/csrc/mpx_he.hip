@@ -39,7 +39,7 @@ struct HeArgs {
     const cx<Real>* twn;    // [M+1]
     const int* wk0;   // windows as index ranges into bins[]
     const int* wk1;
-    const int* bins;  // the spectrum bins some window looks at, ascending
+    const unsigned* slots;  // per window bin k: LDS slot of Z[k] | slot of Z[M-k] << 16
     const cx<Real>* twnb;  // W_N^k at bins[i], indexed like bins
     int nb;
     const Real* ww;
@@ -228,24 +228,17 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
         __syncthreads();
 
         // real-split: X[k] = E + (-i) W_N^k D, E=(Z[k]+conj Z[M-k])/2, D=(Z[k]-conj Z[M-k])/2
+        // (LDS slots of Z[k] and Z[M-k] come from a table built with the plan: no index arithmetic here.)  mag[]
+        // holds |X|^2: the fourth root is monotone, so it is taken of the 48 window maxima only, not of every bin.
         for (int i = ot; i < nmag; i += T) {
-            const int k = a.bins[i];
-            const int ka = k & (M - 1), kb = (M - k) & (M - 1);
-            int sa, sb;
-            if constexpr (DIF) {
-                sa = sigma<M>(dif_pos<M>(ka));
-                sb = sigma<M>(dif_pos<M>(kb));
-            } else {
-                sa = lds_slot(ka);
-                sb = lds_slot(kb);
-            }
-            const cx<Real> A = buf[sa];
-            cx<Real> B = buf[sb];
+            const unsigned s = a.slots[i];
+            const cx<Real> A = buf[s & 0xffffu];
+            cx<Real> B = buf[s >> 16];
             B.y = -B.y;
             const cx<Real> E = {(Real)0.5 * (A.x + B.x), (Real)0.5 * (A.y + B.y)};
             const cx<Real> D = {(Real)0.5 * (A.x - B.x), (Real)0.5 * (A.y - B.y)};
             const cx<Real> X = cadd(E, mul_mi(cmul(a.twnb[i], D)));
-            mag[i] = sqrt(sqrt(X.x * X.x + X.y * X.y));
+            mag[i] = X.x * X.x + X.y * X.y;
         }
         __syncthreads();  // mag[] complete, and nobody reads buf any more: the next frame may overwrite it
         // Window maxima and pitch-class sums by wave 0 alone: its LDS traffic is ordered by the wave's own
@@ -258,7 +251,8 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
                     const Real v = mag[k];
                     m = v > m ? v : m;
                 }
-                winmax[wi] = m;
+                // sqrt(|X|) = (|X|^2)^(1/4) of the maximum (harmonic_energy.py:43); an empty window keeps -inf
+                winmax[wi] = m < (Real)0 ? m : sqrt(sqrt(m));
             }
             wave_lds_fence();
             // chroma[n] = sum_octave ( sum_harmonic max/h ), same association as the reference
@@ -510,11 +504,11 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
     }
     if (bins.empty()) bins.push_back(0);
     plan.nb = (int)bins.size();
-    plan.bins = (int*)upload(ctx, bins.data(), bins.size() * sizeof(int));
+    plan.h_bins = bins;
     std::vector<cx<Real>> twnb(bins.size());
     for (size_t i = 0; i < bins.size(); ++i) twnb[i] = twn[bins[i] <= M ? bins[i] : 0];
     plan.twnb = upload(ctx, twnb.data(), twnb.size() * sizeof(cx<Real>));
-    if (!plan.bins || !plan.twnb) return MPX_ENOMEM;
+    if (!plan.twnb) return MPX_ENOMEM;
     plan.wk0 = (int*)upload(ctx, k0.data(), k0.size() * sizeof(int));
     plan.wk1 = (int*)upload(ctx, k1.data(), k1.size() * sizeof(int));
     plan.ww = upload(ctx, ww.data(), ww.size() * sizeof(Real));
@@ -556,7 +550,26 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.twn = (const cx<Real>*)plan.twn;
     a.wk0 = plan.wk0;
     a.wk1 = plan.wk1;
-    a.bins = plan.bins;
+    if (!plan.slots) {
+        constexpr int M_ = N / 2;
+        std::vector<unsigned> sl(plan.h_bins.size());
+        for (size_t i = 0; i < sl.size(); ++i) {
+            const int k = plan.h_bins[i];
+            const int ka = k & (M_ - 1), kb = (M_ - k) & (M_ - 1);
+            unsigned sa, sb;
+            if constexpr (he_uses_dif<N, T>()) {
+                sa = (unsigned)sigma<M_>(dif_pos<M_>(ka));
+                sb = (unsigned)sigma<M_>(dif_pos<M_>(kb));
+            } else {
+                sa = (unsigned)lds_slot(ka);
+                sb = (unsigned)lds_slot(kb);
+            }
+            sl[i] = sa | (sb << 16);
+        }
+        plan.slots = (unsigned*)upload(ctx, sl.data(), sl.size() * sizeof(unsigned));
+        if (!plan.slots) return MPX_ENOMEM;
+    }
+    a.slots = plan.slots;
     a.twnb = (const cx<Real>*)plan.twnb;
     a.nb = plan.nb;
     a.ww = (const Real*)plan.ww;

@@ -33,7 +33,8 @@ struct HePlan {
     void* twn = nullptr;     // cx[M+1]   W_N^k (real-FFT split)
     int* wk0 = nullptr;      // [nwin] window start (index into `bins`)
     int* wk1 = nullptr;      // [nwin] window end (exclusive, harmonic_energy.py:58)
-    int* bins = nullptr;     // [nb] the bins some window looks at, ascending
+    std::vector<int> h_bins;  // [nb] the bins some window looks at, ascending (host)
+    mutable unsigned* slots = nullptr;  // [nb] LDS slots of Z[k], Z[M-k] for the engine of this frame size (he_launch)
     void* twnb = nullptr;    // cx[nb] W_N^k at those bins (so that the load does not wait for bins[i])
     int nb = 0;
     void* ww = nullptr;      // Real[nwin] 1/harmonic
