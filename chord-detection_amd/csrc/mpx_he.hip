@@ -111,13 +111,12 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool DIF = he_uses_dif<N, T>();
     cx<Real>* buf = reinterpret_cast<cx<Real>*>(smem);
-    Real* mag = reinterpret_cast<Real*>(smem + sizeof(cx<Real>) * he_buf_slots<N, T>());
+    // behind the FFT buffer, at compile-time offsets: [window offset angles: EPT complex][flag: 16 B], then mag / winmax
+    cx<Real>* woffs_lds = buf + he_buf_slots<N, T>();
+    char* tail = reinterpret_cast<char*>(woffs_lds + EPT);
+    Real* mag = reinterpret_cast<Real*>(tail + 16);
     const int nmag = a.nb;  // magnitudes are computed for the bins the windows touch only (compact, window order)
     Real* winmax = mag + nmag;
-    // [flag: 16 B][window offset angles: EPT complex] live behind winmax, 16-byte aligned
-    char* tail = reinterpret_cast<char*>(winmax + a.nwin);
-    tail += (16 - (reinterpret_cast<uintptr_t>(tail) & 15)) & 15;
-    cx<Real>* woffs_lds = reinterpret_cast<cx<Real>*>(tail + 16);
 
     const int tid = threadIdx.x;
     if (tid < EPT) woffs_lds[tid] = a.woffs[tid];
