@@ -209,11 +209,23 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
             long long start;
             int valid;
             frame_span(f + 1 < f1 ? f + 1 : f, start, valid);
-            load_frame<EPT, FSTRIDE, FAST>(raw, a.sig + start, ot, valid);
+            load_frame<EPT, FSTRIDE, FAST>(raw, a.sig + start, tid, valid);
         }
         // FFT; the last pass keeps its outputs in registers and only the bins the windows look at are stored
         if constexpr (DIF) {
-            dif_fft_keep_last<M, Real>(buf, twd, regs, ot);
+            {
+                // dif_fft_keep_last, spelled out so that the first pass and the prefetch use the real thread id (their
+                // two address registers stay live across frames) while the later passes rebuild theirs from `ot`:
+                // hoisting those as well overflows the 128-register budget of 4 waves/SIMD into scratch
+                using PL = DifPlan<M>;
+                dif_butterfly<M, 0, false, true, Real>(buf, twd, regs, tid);
+                __syncthreads();
+                dif_middle<M, 1, Real>(buf, twd, regs, ot);
+                constexpr int RLAST = PL::radix(PL::n - 1);
+#pragma unroll
+                for (int h = 0; h < 8 / RLAST; ++h)
+                    dif_butterfly<M, PL::n - 1, true, false, Real>(buf, twd, regs + h * RLAST, dif_bid<M, PL::n - 1>(ot, h));
+            }
             constexpr int RL = DifPlan<M>::radix(DifPlan<M>::n - 1);
 #pragma unroll
             for (int e = 0; e < EPT; ++e)

@@ -3,7 +3,7 @@
 @44.1 kHz, reference default frame (int(44100*46.4/1000) = 2046 samples, non-overlapping).
 Device-resident input; prints frames/s and per-launch time.  Not the headline metric."""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 import chord_detection_amd as cd

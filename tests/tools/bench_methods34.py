@@ -5,7 +5,7 @@
   * Iterative-F0 on one long stream @22050 Hz (x real time).
 Each result is spot-checked against the oracle."""
 import argparse, json, os, sys, time, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import chord_detection_amd as cd
 

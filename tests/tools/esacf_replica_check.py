@@ -6,9 +6,9 @@ differing frames (oracle.esacf.frame_fragility: a 1e-12 relative perturbation of
 import os
 import sys
 import warnings
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import numpy as np
 import torch
 import chord_detection_amd as cd

@@ -3,7 +3,7 @@
 frame / chunk -- every method's batch entry point must return exactly what the single-clip entry point returns for
 each clip up to the order of the final sum over frames (1e-12; ESACF in deterministic mode)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["MPX_DETERMINISTIC"] = "1"
 import numpy as np
 import chord_detection_amd as cd

@@ -3,9 +3,9 @@
 peak parameters and signals with silences / hard clipping (plateaus in the SACF).  Frames that differ end to end are accepted only if they agree on identical
 inputs (the oracle fed the GPU's ESACF row) or the oracle flags them as ill-conditioned (perturbation test, or an
 accepted gaussian fit whose centre left its 21-sample window).  Not part of the test suite
-(minutes of NumPy); run on the GPU box:  python scripts/fuzz_esacf.py [cases] [seed]"""
+(minutes of NumPy); run on the GPU box:  python tests/tools/fuzz_esacf.py [cases] [seed]"""
 import os, sys, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 if os.environ.get("FUZZ_DEFAULT_MODE") != "1":   # FUZZ_DEFAULT_MODE=1: the library's default (cooperative end game)
     os.environ["MPX_DETERMINISTIC"] = "1"

@@ -3,7 +3,7 @@
 and Prime-multiF0 (parameters, lengths) against the oracle.  HE per-frame rows to 1e-9 (frame sizes: the five powers of two and
 arbitrary sizes up to 4096), Prime sums to 1e-7."""
 import os, sys, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import chord_detection_amd as cd
 from oracle import harmonic_energy as o_he, prime_multif0 as o_pr

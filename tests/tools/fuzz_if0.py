@@ -3,7 +3,7 @@
 (incl. > 64: two front-end waves, and < 64), powers, clip lengths around chunk / frame boundaries; summary spectra to
 1e-9, per-frame chroma to 1e-5.  Not part of the suite (the oracle's 70-channel filterbank is seconds per clip)."""
 import os, sys, warnings
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import chord_detection_amd as cd
 from oracle import iterative_f0 as o
