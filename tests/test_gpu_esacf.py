@@ -296,7 +296,7 @@ def test_full_size_batch_is_periodic_in_the_clips(eng, det_eng):
     sits in the batch -- bit-exactly with MPX_FLAG_DETERMINISTIC, and for all but a handful of clips (the
     cooperative end game of the fit kernel) by default."""
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import bench_esacf as B
     uniq = B.synth_clips()
     clips = [uniq[c % 64] for c in range(4096)]
