@@ -1,0 +1,160 @@
+"""Long-stream driver (BASELINE.json configs[4]): Iterative-F0 over one long signal, time-sharded over the
+GPUs of a node, ONE gather of the per-frame 12-vectors at the end.
+
+The reference filters the whole signal sequentially through its 70-channel filterbank and then treats every
+frame on its own (iterative_f0.py:54-96).  Every filter stage is stable with pole radius <= 0.999, so a rank can
+start `WARMUP` samples before its first frame from zero state and lands on the sequential result to fp64
+rounding (0.999^65536 ~ 3e-29) -- the same argument the front-end kernel uses for its own chunks
+(csrc/mpx_if0.hip).  Frames are block-partitioned over the ranks (contiguous ranges with
+a sample halo, no device-to-device exchange); the job's only collective is the all_gather of `[frames, 12]`.
+Launch with ``python -m torch.distributed.run --nproc-per-node G scripts/run_stream.py ...`` (backend nccl =
+RCCL), or plainly for one GPU.
+"""
+import json
+import math
+import time
+
+import numpy as np
+
+from .chromagram import Chromagram
+from .corpus import gather_blocks, partition
+
+WARMUP = 65536  # samples; a multiple of every Iterative-F0 frame size (1024 ... 8192)
+SEED = 20260103  # + segment id
+SEGMENT_SECONDS = 0.5
+
+
+def num_frames(n, frame_size):
+    """frame_cutter's count (dsp/frame.py:5-14): ceil(n / frame_size), the tail frame zero-padded."""
+    return -(-int(n) // int(frame_size)) if n > 0 else 0
+
+
+def shard_window(n, frame_size, world, rank):
+    """(f0, f1, s0, s1, skip): this rank owns frames [f0, f1) of the stream, computes on samples [s0, s1)
+    and drops the first `skip` frames of what it computed (the warm-up)."""
+    if WARMUP % int(frame_size):
+        raise ValueError("frame size must divide the %d-sample warm-up" % WARMUP)
+    f0, f1 = partition(num_frames(n, frame_size), world, rank)
+    if f1 == f0:
+        return f0, f1, 0, 0, 0
+    s0 = max(0, f0 * frame_size - WARMUP)
+    s1 = min(int(n), f1 * frame_size)
+    return f0, f1, s0, s1, (f0 * frame_size - s0) // frame_size
+
+
+def _engine_frames(x, fs, frame_size, device, **kw):
+    from .engine import get_engine
+    return get_engine(device).iterative_f0(x, fs, return_frames=True, frame_size=frame_size, **kw)[1]
+
+
+def run_stream_shard(read, n, fs, rank=0, world=1, frame_size=8192, device=0, compute=None, **kw):
+    """`read(s0, s1) -> float32[s1-s0]` hands out samples of the stream (a slice of an array, a memmap, a
+    generator seeded by position).  Returns (f0, f1, frames[f1-f0, 12] float64) for this rank's frames.
+    `compute(x, fs, frame_size, device, **kw) -> [F,12]` defaults to the HIP engine; tests substitute the CPU
+    checker to exercise the halo logic without a GPU."""
+    compute = compute or _engine_frames
+    f0, f1, s0, s1, skip = shard_window(n, frame_size, world, rank)
+    if f1 == f0:
+        return f0, f1, np.zeros((0, 12), dtype=np.float64)
+    x = np.ascontiguousarray(read(s0, s1), dtype=np.float32)
+    if x.shape[0] != s1 - s0:
+        raise ValueError("read(%d, %d) returned %d samples" % (s0, s1, x.shape[0]))
+    frames = np.asarray(compute(x, fs, frame_size, device, **kw), dtype=np.float64)
+    return f0, f1, frames[skip:skip + (f1 - f0)]
+
+
+def gather_frames(block, total_frames, world, rank, device=None):
+    """all_gather of the per-rank `[frames, 12]` blocks -> `[total_frames, 12]` on every rank."""
+    return gather_blocks(block[:, None, :], total_frames, world, rank, device)[:, 0, :]
+
+
+def chroma_of(frames):
+    """The reference's accumulation (iterative_f0.py:87-96 via Chromagram.__add__): frame by frame, in order."""
+    acc = np.zeros(12, dtype=np.float64)
+    for row in frames:
+        acc = acc + row
+    return Chromagram(acc)
+
+
+# ------------------------------------------------------------------ synthetic stream (SURVEY.md 8d, M-stream)
+def segment_notes(seg):
+    rng = np.random.default_rng(SEED + int(seg))
+    k = int(rng.integers(3, 7))
+    return [(int(rng.integers(36, 85)), float(rng.uniform(0.0, 2.0 * math.pi))) for _ in range(k)]
+
+
+def synth_stream(s0, s1, fs, device=None):
+    """Samples [s0, s1) of an endless stream: every 0.5 s segment holds 3-6 notes (8 harmonics decaying by 0.7)
+    at MIDI pitches 36..84 plus white noise at -40 dBFS, scaled by a fixed 0.05.  A function of the sample
+    position only (segment id -> seed), so every rank synthesises exactly its own window."""
+    import torch
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    seg_len = int(round(SEGMENT_SECONDS * fs))
+    out = torch.empty(int(s1 - s0), dtype=torch.float32, device=dev)
+    for seg in range(int(s0) // seg_len, (int(s1) + seg_len - 1) // seg_len):
+        a, b = max(int(s0), seg * seg_len), min(int(s1), (seg + 1) * seg_len)
+        t = torch.arange(a, b, dtype=torch.float64, device=dev) / float(fs)
+        y = torch.zeros(b - a, dtype=torch.float64, device=dev)
+        for midi, ph in segment_notes(seg):
+            f0 = 440.0 * 2.0 ** ((midi - 69) / 12.0)
+            for h in range(1, 9):
+                if f0 * h < fs / 2:
+                    y += (0.7 ** (h - 1)) * torch.sin(2.0 * math.pi * f0 * h * t + ph * h)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(SEED + 7919 * seg)
+        noise = torch.randn(seg_len, generator=g, dtype=torch.float64)[a - seg * seg_len:b - seg * seg_len].to(dev)
+        out[a - int(s0):b - int(s0)] = (0.05 * y + 0.003 * noise).to(torch.float32)
+    return out
+
+
+def main(argv=None):
+    import argparse
+    import os
+    ap = argparse.ArgumentParser(description="Iterative-F0 over one long synthetic stream, time-sharded over the GPUs of a node")
+    ap.add_argument("--seconds", type=float, default=3600.0)
+    ap.add_argument("--fs", type=int, default=44100)
+    ap.add_argument("--frame-size", type=int, default=8192)
+    args = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    import torch
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    n = int(round(args.seconds * args.fs))
+    total_frames = num_frames(n, args.frame_size)
+
+    def read(s0, s1):
+        return synth_stream(s0, s1, args.fs, dev).cpu().numpy()
+
+    _engine_frames(read(0, min(n, 4 * args.frame_size)), args.fs, args.frame_size, local)  # plans, tables, clocks
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f0, f1, s0, s1, _ = shard_window(n, args.frame_size, world, rank)
+    x = read(s0, s1)
+    t1 = time.perf_counter()
+    _, _, block = run_stream_shard(lambda a, b: x, n, args.fs, rank, world, args.frame_size, local)
+    t2 = time.perf_counter()
+    frames = gather_frames(block, total_frames, world, rank, dev if world > 1 else None)
+    spent = torch.tensor([t1 - t0, t2 - t1, time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(spent, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        c = chroma_of(frames)
+        synth_s, compute_s, wall = (float(v) for v in spent.cpu())
+        print(json.dumps({"workload": "Iterative-F0, %.0f s stream @%d Hz (BASELINE configs[4])" % (args.seconds, args.fs),
+                          "n_gpus": world, "frames": total_frames, "frames_per_rank": f1 - f0,
+                          "synthesis_seconds_rank_max": synth_s, "compute_seconds_rank_max": compute_s,
+                          "x_realtime_compute": args.seconds / compute_s if compute_s > 0 else None,
+                          "wall_seconds": wall, "chroma": repr(c), "key": c.key()}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""Long-stream driver (BASELINE configs[4]): frame partition with a sample halo, the world-size-2 gloo path on
+CPU with the checker standing in for the engine (which also proves the warm-up argument on the restated
+reference itself), and -- on the GPU -- the sharded job against the unsharded one and the oracle."""
+import os
+import socket
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import chord_detection_amd  # noqa: E402,F401
+from chord_detection_amd import stream  # noqa: E402
+
+FS = 22050
+FRAME = 8192
+
+
+def test_shard_windows_tile_the_stream():
+    for n in (0, 1, FRAME, 20 * FRAME + 17, 158760000):
+        nf = stream.num_frames(n, FRAME)
+        for world in (1, 2, 3, 8):
+            wins = [stream.shard_window(n, FRAME, world, r) for r in range(world)]
+            assert wins[0][0] == 0 and wins[-1][1] == nf
+            for (f0, f1, s0, s1, skip), nxt in zip(wins, wins[1:] + [None]):
+                if nxt is not None:
+                    assert f1 == nxt[0]
+                if f1 > f0:
+                    assert s1 == min(n, f1 * FRAME) and s0 == max(0, f0 * FRAME - stream.WARMUP)
+                    assert s0 % FRAME == 0 and skip == (f0 * FRAME - s0) // FRAME and skip <= stream.WARMUP // FRAME
+    with pytest.raises(ValueError):
+        stream.shard_window(10 * 3000, 3000, 2, 0)      # the warm-up must be whole frames
+
+
+def test_synthetic_stream_is_a_function_of_the_position():
+    a = stream.synth_stream(0, 30000, FS)
+    b = stream.synth_stream(9000, 26000, FS)
+    assert a.dtype == torch.float32 and a.shape == (30000,)
+    assert torch.equal(a[9000:26000], b)                 # a rank synthesises exactly its own window
+    assert 0.02 < float(a.abs().max()) < 1.0
+    assert stream.segment_notes(3) == stream.segment_notes(3) != stream.segment_notes(4)
+
+
+def _oracle_frames(x, fs, frame_size, device, **kw):
+    from oracle import iterative_f0 as o_if0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return o_if0.iterative_f0_frames(np.asarray(x, dtype=np.float32), fs, frame_size=frame_size)[0]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+N_CPU = 21 * FRAME + 1234   # 22 frames: rank 1 owns 11..21 and starts 8 frames (65536 samples) early, at frame 3
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = stream.synth_stream(0, N_CPU, FS).numpy()
+    f0, f1, block = stream.run_stream_shard(lambda a, b: x[a:b], N_CPU, FS, rank, world, FRAME, compute=_oracle_frames)
+    frames = stream.gather_frames(block, stream.num_frames(N_CPU, FRAME), world, rank)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), f0=f0, f1=f1, block=block, frames=frames)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_the_stream_and_gather(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert (int(r0["f0"]), int(r0["f1"]), int(r1["f0"]), int(r1["f1"])) == (0, 11, 11, 22)
+    np.testing.assert_array_equal(r0["frames"], r1["frames"])
+    assert r0["frames"].shape == (22, 12)
+    np.testing.assert_array_equal(r0["frames"][:11], r0["block"])
+    np.testing.assert_array_equal(r0["frames"][11:], r1["block"])
+    # the sharded job equals the sequential one: rank 1 started from zero state 65536 samples before its frames
+    x = stream.synth_stream(0, N_CPU, FS).numpy()
+    whole = _oracle_frames(x, FS, FRAME, None)
+    assert whole.shape == (22, 12) and np.abs(whole).sum() > 0
+    np.testing.assert_allclose(r0["frames"], whole, rtol=1e-9, atol=1e-12)
+    assert repr(stream.chroma_of(r0["frames"])) == repr(stream.chroma_of(whole))
+
+
+@pytest.mark.gpu
+def test_sharded_stream_matches_the_whole_stream_on_gpu():
+    import chord_detection_amd as cd
+    n = 60 * FRAME + 4321
+    x = stream.synth_stream(0, n, FS, "cuda:0").cpu().numpy()
+    eng = cd.get_engine(0)
+    total, whole = eng.iterative_f0(x, FS, return_frames=True)
+    assert whole.shape == (61, 12)
+    for world in (2, 3, 8):
+        blocks = [stream.run_stream_shard(lambda a, b: x[a:b], n, FS, r, world, FRAME)[2] for r in range(world)]
+        got = np.concatenate(blocks, axis=0)
+        np.testing.assert_allclose(got, whole, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(stream.chroma_of(whole).as_array(), total, rtol=1e-9)
+    want = _oracle_frames(x[:12 * FRAME], FS, FRAME, None)
+    np.testing.assert_allclose(whole[:12], want, rtol=1e-9, atol=1e-12)
+    # other frame sizes divide the warm-up as well
+    f0, f1, blk = stream.run_stream_shard(lambda a, b: x[a:b], 90 * 2048, FS, 1, 2, 2048)
+    _, ref = eng.iterative_f0(x[:90 * 2048], FS, return_frames=True, frame_size=2048)
+    np.testing.assert_allclose(blk, ref[f0:f1], rtol=1e-9, atol=1e-12)

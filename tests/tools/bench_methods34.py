@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--clips", type=int, default=256)
     ap.add_argument("--stream-seconds", type=int, default=600)
+    ap.add_argument("--stream-fs", type=int, default=FS, help="sample rate of the long stream (BASELINE configs[4]: 44100, 3600 s)")
     args = ap.parse_args()
     eng = cd.get_engine(0)
     uniq = [clip(20260102 + i) for i in range(16)]
@@ -45,15 +46,16 @@ def main():
         ok = bool(np.allclose(res[3], ofn(batch[3], FS), rtol=1e-5, atol=1e-7))
         out[name] = {"clips": args.clips, "seconds": dt, "clips_per_s": args.clips / dt, "oracle_spot_check": ok}
     # long stream through method 3 (chunked front end)
-    n = args.stream_seconds * FS
+    sfs = args.stream_fs
+    n = args.stream_seconds * sfs
     reps = (n + 44099) // 44100
-    stream = np.concatenate([uniq[i % 16] for i in range(reps)])[:n]
-    eng.iterative_f0(stream[:50000], FS)
+    stream = np.concatenate([uniq[i % 16] for i in range(reps)])[:n]   # the 22.05 kHz clips, read at the stream's rate
+    eng.iterative_f0(stream[:50000], sfs)
     t0 = time.perf_counter()
-    total, frames = eng.iterative_f0(stream, FS, return_frames=True)
+    total, frames = eng.iterative_f0(stream, sfs, return_frames=True)
     dt = time.perf_counter() - t0
-    want = o_if0.iterative_f0_frames(stream[:3 * 8192], FS)[0]
-    out["iterative_f0_stream"] = {"seconds_of_audio": args.stream_seconds, "seconds": dt,
+    want = o_if0.iterative_f0_frames(stream[:3 * 8192], sfs)[0]
+    out["iterative_f0_stream"] = {"seconds_of_audio": args.stream_seconds, "fs": sfs, "seconds": dt,
                                   "x_realtime": args.stream_seconds / dt, "frames": int(frames.shape[0]),
                                   "oracle_spot_check": bool(np.allclose(frames[:3], want, rtol=1e-5))}
     print(json.dumps(out))
