@@ -136,6 +136,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     f0, f1, s0, s1, _ = shard_window(n, args.frame_size, world, rank)
     x = read(s0, s1)
+    torch.cuda.empty_cache()  # the synthesis' cached blocks: with them in place the engine's first hipMalloc of its workspace takes ~1 s
     t1 = time.perf_counter()
     _, _, block = run_stream_shard(lambda a, b: x, n, args.fs, rank, world, args.frame_size, local)
     t2 = time.perf_counter()
