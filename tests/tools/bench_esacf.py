@@ -11,7 +11,10 @@ import chord_detection_amd as cd
 FS, N, CLIP = 44100, 2046, 88200
 
 
-def synth_clips(n_unique=64):
+def synth_clips(n_unique=64, fs=None):
+    global FS, N, CLIP
+    if fs is not None and fs != FS:   # e.g. 22050: the reference's own rate, 1023-sample frames
+        FS, N, CLIP = int(fs), int(fs * 46.4 / 1000), 2 * int(fs)
     out = np.zeros((n_unique, CLIP), dtype=np.float32)
     t = np.arange(CLIP) / FS
     for c in range(n_unique):
@@ -84,13 +87,14 @@ def main():
     ap.add_argument("--mode", default="librosa010")
     ap.add_argument("--stft", action="store_true",
                     help="north-star variant: ONE signal, 8192 overlapping frames, N=4096, hop 1024 (like bench.py)")
+    ap.add_argument("--fs", type=int, default=FS, help="sample rate of the clips; the frame is the reference's 46.4 ms")
     ap.add_argument("--contexts", type=int, default=1, help="--stft only: batches in flight (one context/stream each)")
     args = ap.parse_args()
     if args.stft:
         return stft_variant(args)
     eng = cd.Engine(0)
     dev = torch.device("cuda", 0)
-    uniq = torch.from_numpy(synth_clips()).to(dev)
+    uniq = torch.from_numpy(synth_clips(fs=args.fs)).to(dev)
     x = uniq.repeat((args.clips + 63) // 64, 1)[:args.clips].reshape(-1).contiguous()
     n = x.numel()
     nf = eng.num_frames(n, N, N)
@@ -111,7 +115,7 @@ def main():
         want = o_esacf.esacf_frames(xs, FS, enhance_mode=args.mode)
     got = d_frames[:6].cpu().numpy()
     ok = bool(np.allclose(got, want, rtol=1e-5, atol=1e-12))
-    print(json.dumps({"metric": "frames/s ESACF (N=2046, hop=N, 44.1 kHz)", "value": nf / (ms * 1e-3), "frames": nf,
+    print(json.dumps({"metric": "frames/s ESACF (N=%d, hop=N, %d Hz)" % (N, FS), "value": nf / (ms * 1e-3), "frames": nf,
                       "clips": args.clips, "ms_per_launch": ms, "dtype": "f64", "oracle_spot_check": ok,
                       "alg_bytes_per_frame": 4 * N + 48,
                       "hbm_frac": nf / (ms * 1e-3) * (4 * N + 48) / 8.0e12}))
