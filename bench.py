@@ -205,7 +205,7 @@ def main():
                        "sharding": "frames per rank, no data-path collective; one RCCL all_gather of 12-vectors at the end"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
-                         "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE(x1.99 calibrated)+WRITE_SIZE, profiles/r1/traffic_v2.txt; algorithmic = %d" % (B_ALG * FRAMES),
+                         "traffic_note": "bytes/launch, rocprofv3 FETCH_SIZE(x1.99 calibrated)+WRITE_SIZE, profiles/r1/traffic_v5.txt; algorithmic = %d" % (B_ALG * FRAMES),
                          "kernel": "he_kernel<4096,256,%s>" % ("float" if args.f32 else "double"),
                          "kernel_ms": kern_ms, "bytes_per_frame": B_ALG, "frames_per_launch": FRAMES,
                          "step_ms_hip_events": step_ms_events, "host_enqueue_ms_per_step": host_enqueue_ms,
