@@ -117,9 +117,18 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     Real* mag = reinterpret_cast<Real*>(tail + 16);
     const int nmag = a.nb;  // magnitudes are computed for the bins the windows touch only (compact, window order)
     Real* winmax = mag + nmag;
+    // the window table (index ranges into mag[], 1/harmonic weights) behind winmax: wave 0 walks it every frame, and
+    // from global memory each dependent step of that walk costs an L2 round trip
+    Real* ww_lds = winmax + a.nwin;
+    int* wk_lds = reinterpret_cast<int*>(ww_lds + a.nwin);
 
     const int tid = threadIdx.x;
     if (tid < EPT) woffs_lds[tid] = a.woffs[tid];
+    for (int i = tid; i < a.nwin; i += T) {
+        ww_lds[i] = a.ww[i];
+        wk_lds[2 * i] = a.wk0[i];
+        wk_lds[2 * i + 1] = a.wk1[i];
+    }
     __syncthreads();
     const long long w = xcd_contiguous(blockIdx.x, gridDim.x);
     const long long per = (a.num_frames + gridDim.x - 1) / gridDim.x;
@@ -258,9 +267,16 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
         if (tid < 64) {
             for (int wi = tid; wi < a.nwin; wi += 64) {  // half-open window maxima (harmonic_energy.py:58-62)
                 Real m = -INFINITY;
-                for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) {
-                    const Real v = mag[k];
-                    m = v > m ? v : m;
+                const int k1 = wk_lds[2 * wi + 1], kl = k1 - 1;
+                for (int k = wk_lds[2 * wi]; k < k1; k += 4) {
+                    // four independent LDS reads per round (indices clamped to the window's last bin: seeing a bin
+                    // twice does not change a maximum), compared in bin order like the reference's loop
+                    const Real v0 = mag[k], v1 = mag[k + 1 < kl ? k + 1 : kl], v2 = mag[k + 2 < kl ? k + 2 : kl],
+                               v3 = mag[k + 3 < kl ? k + 3 : kl];
+                    m = v0 > m ? v0 : m;
+                    m = v1 > m ? v1 : m;
+                    m = v2 > m ? v2 : m;
+                    m = v3 > m ? v3 : m;
                 }
                 // sqrt(|X|) = (|X|^2)^(1/4) of the maximum (harmonic_energy.py:43); an empty window keeps -inf
                 winmax[wi] = m < (Real)0 ? m : sqrt(sqrt(m));
@@ -273,7 +289,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
                 for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
                     double note_sum = 0.0;
                     for (int h = 0; h < a.num_harmonic; ++h)
-                        note_sum += (double)winmax[base + o + h] * (double)a.ww[base + o + h];
+                        note_sum += (double)winmax[base + o + h] * (double)ww_lds[base + o + h];
                     chroma += note_sum;
                 }
                 if (a.out) a.out[f * 12 + tid] = chroma;
@@ -593,7 +609,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.partial = nullptr;
     a.sum = nullptr;
     a.counter = nullptr;
-    const size_t lds = sizeof(cx<Real>) * he_buf_slots<N, T>() + sizeof(Real) * (size_t)(plan.nb + plan.nwin) + 48 + sizeof(cx<Real>) * (N / 2 / T);
+    const size_t lds = sizeof(cx<Real>) * he_buf_slots<N, T>() + sizeof(Real) * (size_t)(plan.nb + 2 * plan.nwin) + 8 * (size_t)plan.nwin + 48 + sizeof(cx<Real>) * (N / 2 / T);
     if (lds > 160 * 1024)
         return set_error(ctx, MPX_EUNSUPPORTED, "frame %d needs %zu B of LDS (> 160 KiB)", N, lds);
     auto kern = he_kernel<N, T, Real>;
