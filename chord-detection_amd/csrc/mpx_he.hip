@@ -121,6 +121,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     // from global memory each dependent step of that walk costs an L2 round trip
     Real* ww_lds = winmax + a.nwin;
     int* wk_lds = reinterpret_cast<int*>(ww_lds + a.nwin);
+    unsigned* slots_lds = reinterpret_cast<unsigned*>(wk_lds + 2 * a.nwin);  // [nb] see HeArgs::slots
 
     const int tid = threadIdx.x;
     if (tid < EPT) woffs_lds[tid] = a.woffs[tid];
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
         wk_lds[2 * i] = a.wk0[i];
         wk_lds[2 * i + 1] = a.wk1[i];
     }
+    for (int i = tid; i < a.nb; i += T) slots_lds[i] = a.slots[i];
     __syncthreads();
     const long long w = xcd_contiguous(blockIdx.x, gridDim.x);
     const long long per = (a.num_frames + gridDim.x - 1) / gridDim.x;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
     // twiddle bases of the DIF passes: loop invariant, 1 complex per pass
     DifTwiddles<DIF ? M : 512, Real> twd;
     if constexpr (DIF) twd = dif_load_twiddles<M, Real>(a.tw, tid);
-    double acc = 0.0;  // chroma bin `tid` summed over this workgroup's frames (tid < 12)
+    double acc = 0.0;  // chroma bin `wl` summed over this workgroup's frames, in lane wl < 12 of the LAST wave
 
     // Every frame of this workgroup full-length and 8-byte aligned (true for all but the workgroup holding
     // the ragged tail of a signal, and for packed clips of odd length)?  Then the frame loop is instantiated
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
         // (LDS slots of Z[k] and Z[M-k] come from a table built with the plan: no index arithmetic here.)  mag[]
         // holds |X|^2: the fourth root is monotone, so it is taken of the 48 window maxima only, not of every bin.
         for (int i = ot; i < nmag; i += T) {
-            const unsigned s = a.slots[i];
+            const unsigned s = slots_lds[i];
             const cx<Real> A = buf[s & 0xffffu];
             cx<Real> B = buf[s >> 16];
             B.y = -B.y;
@@ -261,11 +263,14 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
             mag[i] = X.x * X.x + X.y * X.y;
         }
         __syncthreads();  // mag[] complete, and nobody reads buf any more: the next frame may overwrite it
-        // Window maxima and pitch-class sums by wave 0 alone: its LDS traffic is ordered by the wave's own
-        // in-order LDS pipeline, so no further workgroup barrier is needed and waves 1..3 run ahead into the
-        // next frame (they meet wave 0 again at that frame's first barrier, before mag[] is rewritten).
-        if (tid < 64) {
-            for (int wi = tid; wi < a.nwin; wi += 64) {  // half-open window maxima (harmonic_energy.py:58-62)
+        // Window maxima and pitch-class sums by the LAST wave alone (the first ones also take the second round of
+        // the split loop above when nb > T): its LDS traffic is ordered by the wave's own in-order LDS pipeline, so
+        // no further workgroup barrier is needed and the other waves run ahead into the next frame (they meet this
+        // wave again at that frame's first barrier, before mag[] is rewritten).  Everything on this path is a
+        // serial chain on the workgroup's critical path, hence tables in LDS and independent loads.
+        const int wl = ot - (T - 64);  // lane of the last wave (rebuilt from the opaque id: one register less across the FFT)
+        if (wl >= 0) {
+            for (int wi = wl; wi < a.nwin; wi += 64) {  // half-open window maxima (harmonic_energy.py:58-62)
                 Real m = -INFINITY;
                 const int k1 = wk_lds[2 * wi + 1], kl = k1 - 1;
                 for (int k = wk_lds[2 * wi]; k < k1; k += 4) {
@@ -283,16 +288,28 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
             }
             wave_lds_fence();
             // chroma[n] = sum_octave ( sum_harmonic max/h ), same association as the reference
-            if (tid < 12) {
+            if (wl < 12) {
                 double chroma = 0.0;
-                const int base = tid * a.wins_per_note;
-                for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
-                    double note_sum = 0.0;
-                    for (int h = 0; h < a.num_harmonic; ++h)
-                        note_sum += (double)winmax[base + o + h] * (double)ww_lds[base + o + h];
-                    chroma += note_sum;
+                const int base = wl * a.wins_per_note;
+                if (a.wins_per_note == 4 && a.num_harmonic == 2) {  // the reference's defaults: all eight reads at once
+                    const double m0 = winmax[base], m1 = winmax[base + 1], m2 = winmax[base + 2], m3 = winmax[base + 3];
+                    const double w0 = ww_lds[base], w1 = ww_lds[base + 1], w2 = ww_lds[base + 2], w3 = ww_lds[base + 3];
+                    double n0 = 0.0, n1 = 0.0;
+                    n0 += m0 * w0;
+                    n0 += m1 * w1;
+                    n1 += m2 * w2;
+                    n1 += m3 * w3;
+                    chroma += n0;
+                    chroma += n1;
+                } else {
+                    for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
+                        double note_sum = 0.0;
+                        for (int h = 0; h < a.num_harmonic; ++h)
+                            note_sum += (double)winmax[base + o + h] * (double)ww_lds[base + o + h];
+                        chroma += note_sum;
+                    }
                 }
-                if (a.out) a.out[f * 12 + tid] = chroma;
+                if (a.out) a.out[f * 12 + wl] = chroma;
                 acc += chroma;
             }
             wave_lds_fence();
@@ -324,6 +341,12 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
         const long long grp_first = grp * GROUP;
         const long long grp_size = (g - grp_first) < GROUP ? (g - grp_first) : GROUP;
         double* sh = reinterpret_cast<double*>(smem);  // buf is dead
+        if (T > 64) {  // the publishing lanes below are tid < 12: hand them the sums of the last wave's lanes
+            if (tid >= T - 64 && tid < T - 52) sh[tid - (T - 64)] = acc;
+            __syncthreads();
+            if (tid < 12) acc = sh[tid];
+            __syncthreads();
+        }
 
         // sum `count` rows starting at `first`: 12 bins x up to 21 strided sub-sums, all loads in flight at once
         auto sum_rows = [&](long long first, long long count) -> double {
@@ -609,7 +632,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
     a.partial = nullptr;
     a.sum = nullptr;
     a.counter = nullptr;
-    const size_t lds = sizeof(cx<Real>) * he_buf_slots<N, T>() + sizeof(Real) * (size_t)(plan.nb + 2 * plan.nwin) + 8 * (size_t)plan.nwin + 48 + sizeof(cx<Real>) * (N / 2 / T);
+    const size_t lds = sizeof(cx<Real>) * he_buf_slots<N, T>() + sizeof(Real) * (size_t)(plan.nb + 2 * plan.nwin) + 8 * (size_t)plan.nwin + 4 * (size_t)plan.nb + 48 + sizeof(cx<Real>) * (N / 2 / T);
     if (lds > 160 * 1024)
         return set_error(ctx, MPX_EUNSUPPORTED, "frame %d needs %zu B of LDS (> 160 KiB)", N, lds);
     auto kern = he_kernel<N, T, Real>;
