@@ -247,21 +247,26 @@ __global__ __launch_bounds__(T, (he_waves_per_simd<N, T, Real>())) void he_kerne
             for (int e = 0; e < EPT; ++e)
                 if (need & (1u << e)) buf[lds_slot(last_pass_index<M, T>(tid, e))] = regs[e];
         }
+        // W_N^k of this thread's first window bin: the load is issued before the barrier, its L2 latency passes
+        // while the workgroup gathers (entry 0 always exists)
+        const cx<Real> tw_first = a.twnb[ot < nmag ? ot : 0];
         __syncthreads();
 
         // real-split: X[k] = E + (-i) W_N^k D, E=(Z[k]+conj Z[M-k])/2, D=(Z[k]-conj Z[M-k])/2
         // (LDS slots of Z[k] and Z[M-k] come from a table built with the plan: no index arithmetic here.)  mag[]
         // holds |X|^2: the fourth root is monotone, so it is taken of the 48 window maxima only, not of every bin.
-        for (int i = ot; i < nmag; i += T) {
+        auto split_bin = [&](int i, cx<Real> twk) {
             const unsigned s = slots_lds[i];
             const cx<Real> A = buf[s & 0xffffu];
             cx<Real> B = buf[s >> 16];
             B.y = -B.y;
             const cx<Real> E = {(Real)0.5 * (A.x + B.x), (Real)0.5 * (A.y + B.y)};
             const cx<Real> D = {(Real)0.5 * (A.x - B.x), (Real)0.5 * (A.y - B.y)};
-            const cx<Real> X = cadd(E, mul_mi(cmul(a.twnb[i], D)));
+            const cx<Real> X = cadd(E, mul_mi(cmul(twk, D)));
             mag[i] = X.x * X.x + X.y * X.y;
-        }
+        };
+        if (ot < nmag) split_bin(ot, tw_first);
+        for (int i = ot + T; i < nmag; i += T) split_bin(i, a.twnb[i]);
         __syncthreads();  // mag[] complete, and nobody reads buf any more: the next frame may overwrite it
         // Window maxima and pitch-class sums by the LAST wave alone (the first ones also take the second round of
         // the split loop above when nb > T): its LDS traffic is ordered by the wave's own in-order LDS pipeline, so
