@@ -81,7 +81,10 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
     spent = [0.0] * len(methods)
     for c0 in range(lo, hi, chunk):
         ids = list(range(c0, min(c0 + chunk, hi)))
-        clips = synth_chunk(ids, fs, seconds, synth_device).cpu().numpy()
+        clips = synth_chunk(ids, fs, seconds, synth_device)
+        # synthesised on the GPU and consumed by the engine: the chunk stays in HBM (include/mpx.h, "where the samples
+        # live"); a substituted compute function and a CPU synthesis get a host array
+        clips = clips if (clips.is_cuda and compute is _engine_compute) else clips.cpu().numpy()
         for mi, m in enumerate(methods):
             t0 = time.perf_counter()
             out[c0 - lo:c0 - lo + len(ids), mi] = compute(m, clips, fs, device)   # [n, L] array: packed as it is

@@ -244,7 +244,7 @@ static int method_host(mpx_ctx* ctx, run_fn run, const float* signal, int64_t n,
     if ((rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
-    if (n) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (n) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyDefault, ctx->stream));
     rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
                     chroma_frames ? (double*)ctx->d_frames_out.p : nullptr, (double*)ctx->d_sum.p, ctx->stream);
     if (rc) return rc;
@@ -278,7 +278,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
     hipStream_t st = ctx->stream;
-    if (total) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyHostToDevice, st));
+    if (total) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyDefault, st));
     if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     bool did_sum = false;
@@ -416,7 +416,7 @@ int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int
     if ((rc = ensure(ctx, ctx->d_signal, (size_t)n * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nf * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws2, (size_t)nf * len * sizeof(double) + 16))) return rc;
-    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyDefault, ctx->stream));
     if ((rc = esacf_run(ctx, (const float*)ctx->d_signal.p, n, nullptr, nf, fs, params, frame, hop,
                         (double*)ctx->d_frames_out.p, stage, (double*)ctx->d_ws2.p, ctx->stream)))
         return rc;

@@ -19,6 +19,17 @@ class MpxError(RuntimeError):
     pass
 
 
+class _DevFlat:
+    """A device tensor dressed like the packed numpy array the batch entry points take (`.ctypes.data_as`)."""
+
+    def __init__(self, t):
+        self._t = t  # keeps the memory alive for the duration of the call
+        self.ctypes = self
+
+    def data_as(self, typ):
+        return C.cast(C.c_void_p(self._t.data_ptr()), typ)
+
+
 class Engine:
     def __init__(self, device=0, f32=False, deterministic=False):
         self.lib = _lib.load()
@@ -63,6 +74,14 @@ class Engine:
 
     @staticmethod
     def _pack(clips):
+        if hasattr(clips, "is_cuda") and clips.is_cuda:
+            # [C, L] float32 tensor already on the device (e.g. a synthesised corpus chunk): handed over in place, the
+            # library copies inside HBM (include/mpx.h, "where the samples live") instead of device -> host -> device
+            import torch
+            if clips.dim() != 2 or clips.dtype != torch.float32 or not clips.is_contiguous():
+                raise ValueError("device clips must be a contiguous float32 [clips, samples] tensor")
+            torch.cuda.current_stream(clips.device).synchronize()   # complete before the library's stream reads it
+            return _DevFlat(clips), np.arange(clips.shape[0] + 1, dtype=np.int64) * clips.shape[1]
         if isinstance(clips, np.ndarray) and clips.ndim == 2:
             # [C, L] array of equal-length clips: already packed back to back, no copy if float32 C-contiguous
             flat = np.ascontiguousarray(clips, dtype=np.float32).reshape(-1)

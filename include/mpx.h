@@ -64,6 +64,13 @@ int mpx_synchronize(mpx_ctx* ctx);
  * own work after ours. */
 void* mpx_stream(mpx_ctx* ctx);
 
+/* ---- where the samples live -------------------------------------------------
+ * `signal` / `signals` of the entry points below (all but the *_dev ones, which run in place) may point to host
+ * memory or to memory of the context's device: the library copies it into its staging buffer with
+ * hipMemcpyDefault, i.e. over PCIe for a host buffer and inside HBM for a device buffer (a corpus synthesised or
+ * decoded on the GPU need not travel to the host and back).  A device buffer must be complete when the call is
+ * made: the copy runs on the context's stream, not on the producer's.  offsets and all outputs are host memory. */
+
 /* ---- framing: dsp/frame.py:5-14 ------------------------------------------
  * Number of frames cut from n samples: ceil(n/frame) when hop == frame (the
  * reference's only mode); for hop < frame, frames start every `hop` samples

@@ -101,3 +101,20 @@ def test_corpus_driver_matches_oracle_on_gpu():
             x = clips[j].astype(np.float64)
             np.testing.assert_allclose(block[cid, 0], o_he.he_compute(x, 22050), rtol=1e-9, atol=1e-12)
             np.testing.assert_allclose(block[cid, 1], o_pr.prime_compute(x, 22050), rtol=1e-7, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_device_resident_clips_equal_host_clips():
+    """The batch entry points take the packed clips from host or device memory (include/mpx.h): same bits either way."""
+    import chord_detection_amd as cd
+    eng = cd.get_engine(0)
+    dev_clips = corpus.synth_chunk(list(range(9)), 22050, 0.75, "cuda:0")
+    host_clips = dev_clips.cpu().numpy()
+    for fn, kw in ((eng.harmonic_energy_batch, {}), (eng.prime_multif0_batch, {}), (eng.iterative_f0_batch, {}),
+                   (eng.esacf_batch, {"frame": 1023})):
+        a = fn(host_clips, 22050, **kw)
+        b = fn(dev_clips, 22050, **kw)
+        assert a.shape == (9, 12) and np.abs(a).sum() > 0
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        eng.harmonic_energy_batch(dev_clips.double(), 22050)
