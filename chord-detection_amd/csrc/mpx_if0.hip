@@ -650,8 +650,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         return set_error(ctx, MPX_EINVAL, "iterative F0: harmonic %d of tau_min falls outside the %d-bin spectrum (the "
                          "reference raises ValueError on the empty slice)", p.M - 1, n2);
     // The front-end output is 8 * channels bytes per sample (560 B at 70 channels): keep the workspace of one pass
-    // below 8 GiB by halving the clip list (1024 two-second clips would ask for 28 GB, and allocating that costs a
-    // second); a pass of a few hundred clips already fills the machine.
+    // below 32 GiB of the 288 GB (env MPX_IF0_WS_GIB) by halving the clip list.  A clip is one serial chain per
+    // channel, so a pass wants thousands of clips in flight: 4096 two-second clips take 0.38 s in passes of 256
+    // (8 GiB), 0.29 s in passes of 1024.
     {
         size_t rows = 0, rows_first = 0;
         const int mid = num_clips / 2;
@@ -662,7 +663,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             rows += r;
             if (c < mid) rows_first += r;
         }
-        if (num_clips > 1 && rows * p.channels * sizeof(double) > ((size_t)8 << 30)) {
+        const size_t ws_cap = (size_t)(getenv("MPX_IF0_WS_GIB") ? atoi(getenv("MPX_IF0_WS_GIB")) : 32) << 30;
+        if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap) {
             std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
             for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
             const size_t frames_first = rows_first / NF;

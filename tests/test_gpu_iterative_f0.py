@@ -83,9 +83,11 @@ def test_chunked_front_end_matches_sequential_filtering(eng):
     np.testing.assert_allclose(ut[30:], Ut[30:], rtol=1e-9, atol=1e-9 * np.abs(Ut).max())
 
 
-def test_large_batch_is_split_without_changing_results(eng):
-    """More clips than fit one 8 GiB front-end workspace (27.5 MB per 2 s clip at 70 channels): the clip list is
-    halved internally; every clip must come out exactly as on its own."""
+def test_large_batch_is_split_without_changing_results(eng, monkeypatch):
+    """More clips than fit one front-end workspace (27.5 MB per 2 s clip at 70 channels; the cap is 32 GiB by
+    default, 8 GiB here through the per-call knob): the clip list is halved internally; every clip must come out
+    exactly as on its own."""
+    monkeypatch.setenv("MPX_IF0_WS_GIB", "8")
     rng = np.random.default_rng(3)
     t = np.arange(44100) / FS
     base = []
