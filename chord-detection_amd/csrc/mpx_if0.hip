@@ -51,22 +51,41 @@ struct If0Wfir {
     double c[13];
 };
 
+struct If0TailGroup {   // chunks with the same (warm, len) whose leftover channels (channels % 64) share one wave
+    int first, count;   // tail_list[first .. first + count)
+};
+
 __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                           long long num_chunks, int channels,
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
-                                                          double* __restrict__ yc) {
-    // one wave per (chunk, group of 64 channels): all lanes share the chunk's loop bounds, and the outputs go
-    // through an LDS tile [channel][16 samples] so that the buffer can be [chunk][channel][t] -- every channel's
+                                                          double* __restrict__ yc, const int* __restrict__ tail_list,
+                                                          const If0TailGroup* __restrict__ tail_groups) {
+    // One wave per (chunk, group of 64 channels), one lane per channel; the channels % 64 left over (6 of the default
+    // 70) would fill a wave to 9 %, so the leftovers of up to 64 / (channels % 64) chunks of equal length and run-in
+    // share one: lane -> (chunk, channel).  All lanes of a wave share the loop bounds, and the outputs go
+    // through an LDS tile [lane][16 samples] so that the buffer can be [chunk][channel][t] -- every channel's
     // samples contiguous for the spectrum kernel -- with 128-byte row segments per store instead of 8-byte ones
     __shared__ double tile[64][17];
-    const int groups = (channels + 63) / 64;
-    const long long ck = blockIdx.x / groups;
-    const int ch0 = (int)(blockIdx.x % groups) * 64, lane = threadIdx.x;
-    const int nch = channels - ch0 < 64 ? channels - ch0 : 64;
-    const int ch = ch0 + (lane < nch ? lane : 0);   // idle lanes shadow channel ch0 (results discarded)
-    if (ck >= num_chunks) return;
+    __shared__ long long rowbase[64];   // per lane: index in yc of its output row, -1 for an idle lane
+    const int lane = threadIdx.x;
+    const int full = channels >> 6, nt = channels & 63;
+    long long ck;
+    int ch;
+    bool active = true;
+    if ((long long)blockIdx.x < num_chunks * full) {
+        ck = blockIdx.x / full;
+        ch = (int)(blockIdx.x % full) * 64 + lane;
+    } else {
+        const If0TailGroup g = tail_groups[blockIdx.x - num_chunks * full];
+        const int sub = lane / nt;
+        active = sub < g.count;
+        ck = tail_list[g.first + (active ? sub : 0)];   // idle lanes shadow the first chunk (results discarded)
+        ch = 64 * full + lane % nt;
+    }
     const If0Chunk c = chunks[ck];
+    const int c_warm = __builtin_amdgcn_readfirstlane(c.warm), c_len = __builtin_amdgcn_readfirstlane(c.len);
     const If0ChanCoef k = coefs[ch];
+    rowbase[lane] = active ? c.yc_row0 * channels + (long long)ch * c_len : -1;
     // The chain is 17 filter stages deep (4 resonators, 12 all-passes, rectifier + low-pass).  Evaluated
     // sample by sample it is ONE dependent chain of ~20 fp64 operations per step, and a lone wave pays the
     // full FMA latency on each.  Software pipelining across samples removes that: in iteration tau stage j
@@ -86,18 +105,17 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     double qy = 0, qu = 0, qv = 0;             // inputs of resonator stages 1..3
     double fxh = 0;                            // x_hat input of the final stage
     constexpr int DEPTH = 16;                  // output of sample n appears in iteration n + DEPTH
-    const float* __restrict__ x = sig + c.sig_start;
-    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + (size_t)ch0 * c.len;  // [channel - ch0][len]
+    const float* __restrict__ x = sig + c.sig_start;   // per lane in a wave of leftovers
     constexpr int PF = 16;                     // = the tile width = DEPTH: block tb produces outputs tb-16 .. tb-1
     // the samples of block tb + PF are fetched while block tb runs: a chunk's lanes are often alone on their SIMD
     // (256 two-second clips x 70 channels are 280 waves on 1024 SIMDs), so nothing else hides the load latency
     float nx[PF];
     auto fetch = [&](int tb) {
 #pragma unroll
-        for (int q = 0; q < PF; ++q) nx[q] = (tb + q < c.clip_left && tb + q < c.len) ? x[tb + q] : 0.f;
+        for (int q = 0; q < PF; ++q) nx[q] = (tb + q < c.clip_left && tb + q < c_len) ? x[tb + q] : 0.f;
     };
-    fetch(-c.warm);
-    for (int tb = -c.warm; tb < c.len + DEPTH; tb += PF) {
+    fetch(-c_warm);
+    for (int tb = -c_warm; tb < c_len + DEPTH; tb += PF) {
         float xs[PF];
 #pragma unroll
         for (int q = 0; q < PF; ++q) xs[q] = nx[q];
@@ -157,12 +175,13 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
             }
         }
         const int t0 = tb - DEPTH;
-        if (t0 >= 0 && t0 < c.len) {   // uniform: warm-up and length are multiples of 16
+        if (t0 >= 0 && t0 < c_len) {   // uniform: warm-up and length are multiples of 16
             wave_lds_fence();
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 const int e = q * 64 + lane, r = e >> 4, cc = e & 15;
-                if (r < nch) out[(size_t)r * c.len + t0 + cc] = tile[r][cc];
+                const long long rb = rowbase[r];
+                if (rb >= 0) yc[rb + t0 + cc] = tile[r][cc];
             }
             wave_lds_fence();
         }
@@ -702,7 +721,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         long long waves = 0;
         for (int c = 0; c < num_clips; ++c) {
             const int64_t len = offsets[c + 1] - offsets[c];
-            if (len > 0) waves += ((len + chunk - 1) / chunk) * ((p.channels + 63) / 64);
+            if (len > 0) waves += ((len + chunk - 1) / chunk) * ((p.channels + 63) / 64);  // (before leftovers are packed)
         }
         if (waves >= 4LL * ctx->num_cus || 10 * lane_steps(chunk / 2) > 9 * lane_steps(chunk)) break;
         chunk >>= 1;
@@ -738,6 +757,21 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         seg.push_back((long long)frames.size());
     }
     const long long nframes = (long long)frames.size(), nchunks = (long long)chunks.size();
+    // leftover channels (channels % 64): consecutive chunks of equal length and run-in share a wave
+    std::vector<int> tail_list;
+    std::vector<If0TailGroup> tail_groups;
+    const int full_groups = p.channels / 64, nt = p.channels % 64;
+    if (nt) {
+        const int per_wave = 64 / nt;
+        for (long long i = 0; i < nchunks; ++i) {
+            if (tail_groups.empty() || tail_groups.back().count == per_wave ||
+                chunks[(size_t)tail_list[(size_t)tail_groups.back().first]].len != chunks[(size_t)i].len ||
+                chunks[(size_t)tail_list[(size_t)tail_groups.back().first]].warm != chunks[(size_t)i].warm)
+                tail_groups.push_back({(int)tail_list.size(), 0});
+            tail_list.push_back((int)i);
+            ++tail_groups.back().count;
+        }
+    }
     const int64_t total = offsets[num_clips];
     hipStream_t st = ctx->stream;
     if (nframes == 0) {
@@ -752,22 +786,30 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + IF0_WARMUP * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)nframes * n2 * sizeof(double) * 3))) return rc;   // ut | ur | ud
-    if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + frames.size() * sizeof(If0Frame) + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
+                                       tail_groups.size() * sizeof(If0TailGroup) + 128))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
     If0Chunk* d_chunks = (If0Chunk*)ctx->d_desc.p;
     If0Frame* d_frames = (If0Frame*)((char*)ctx->d_desc.p + ((chunks.size() * sizeof(If0Chunk) + 15) & ~(size_t)15));
+    If0TailGroup* d_tail_groups = (If0TailGroup*)((char*)d_frames + ((frames.size() * sizeof(If0Frame) + 15) & ~(size_t)15));
+    int* d_tail_list = (int*)((char*)d_tail_groups + ((tail_groups.size() * sizeof(If0TailGroup) + 15) & ~(size_t)15));
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyDefault, st));
     MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(d_frames, frames.data(), frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
+    if (nt) {
+        MPX_HIP(ctx, hipMemcpyAsync(d_tail_groups, tail_groups.data(), tail_groups.size() * sizeof(If0TailGroup), hipMemcpyHostToDevice, st));
+        MPX_HIP(ctx, hipMemcpyAsync(d_tail_list, tail_list.data(), tail_list.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    }
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     double* yc = (double*)ctx->d_ws0.p;
     double* ut = (double*)ctx->d_ws1.p;
     double* ur = ut + (size_t)nframes * n2;
     double* ud = ur + (size_t)nframes * n2;
-    hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * ((p.channels + 63) / 64))), dim3(64), 0, st,
-                       (const float*)ctx->d_signal.p, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc);
+    hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
+                       (const float*)ctx->d_signal.p, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
+                       d_tail_groups);
     MPX_HIP(ctx, hipGetLastError());
     if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
