@@ -25,6 +25,7 @@ class _DevFlat:
     def __init__(self, t):
         self._t = t  # keeps the memory alive for the duration of the call
         self.ctypes = self
+        self.shape = (t.numel(),)
 
     def data_as(self, typ):
         return C.cast(C.c_void_p(self._t.data_ptr()), typ)
@@ -67,6 +68,12 @@ class Engine:
 
     @staticmethod
     def _sig(x):
+        if hasattr(x, "is_cuda") and x.is_cuda:   # 1-D float32 tensor on the device: handed over in place (include/mpx.h)
+            import torch
+            if x.dim() != 1 or x.dtype != torch.float32 or not x.is_contiguous():
+                raise ValueError("a device signal must be a contiguous 1-D float32 tensor")
+            torch.cuda.current_stream(x.device).synchronize()
+            return _DevFlat(x)
         x = np.asarray(x)
         if x.ndim != 1:
             raise ValueError("Only 1D numpy ndarrays are supported")  # dsp/frame.py:6-7
@@ -87,6 +94,8 @@ class Engine:
             flat = np.ascontiguousarray(clips, dtype=np.float32).reshape(-1)
             return flat, np.arange(clips.shape[0] + 1, dtype=np.int64) * clips.shape[1]
         arrs = [Engine._sig(c) for c in clips]
+        if any(isinstance(a, _DevFlat) for a in arrs):
+            raise ValueError("a list of device tensors cannot be packed: stack equal-length clips into one [clips, samples] tensor")
         offsets = np.zeros(len(arrs) + 1, dtype=np.int64)
         for i, a in enumerate(arrs):
             offsets[i + 1] = offsets[i] + a.shape[0]

@@ -118,3 +118,11 @@ def test_device_resident_clips_equal_host_clips():
         np.testing.assert_array_equal(a, b)
     with pytest.raises(ValueError):
         eng.harmonic_energy_batch(dev_clips.double(), 22050)
+    with pytest.raises(ValueError):
+        eng.harmonic_energy_batch([dev_clips[0], dev_clips[1]], 22050)
+    # single signals as well
+    x_dev, x_host = dev_clips[3], host_clips[3]
+    np.testing.assert_array_equal(eng.harmonic_energy(x_dev, 22050), eng.harmonic_energy(x_host, 22050))
+    np.testing.assert_array_equal(eng.iterative_f0(x_dev, 22050), eng.iterative_f0(x_host, 22050))
+    np.testing.assert_array_equal(eng.prime_multif0(x_dev, 22050), eng.prime_multif0(x_host, 22050))
+    np.testing.assert_array_equal(eng.esacf(x_dev, 22050, 1023), eng.esacf(x_host, 22050, 1023))
