@@ -726,7 +726,6 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a) {
     // its Hermitian mirror 2048-k of the packed inverse transform itself.  LDS is the FFT buffer + the row: 51 KB,
     // two workgroups per CU (the spectra in LDS made it 92 KB and one).
     constexpr int NB = (PV_BINS + PV_T - 1) / PV_T;  // 5
-    double phase[NB];
     cx<double> d0[NB], d1[NB];
     for (int n = tid; n < Mh; n += PV_T) x[n] = row[n];
     __syncthreads();
@@ -736,8 +735,6 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a) {
         __syncthreads();
         const int len_out = (int)nearbyint((double)Mh / (double)r);          // int(round(len/rate)), half-to-even
         const int nsteps = (n_frames + r - 1) / r;                            // len(arange(0, n_frames, r)) <= 2
-#pragma unroll
-        for (int j = 0; j < NB; ++j) d1[j] = {0.0, 0.0};
         for (int t = 0; t < nsteps; ++t) {
             const int c0 = t * r, c1 = c0 + 1;                                // STFT columns int(step), int(step)+1
             // analysis: frame c covers xpad[c*512 + n], xpad = [1024 zeros | x | 1024 zeros]
@@ -758,19 +755,29 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a) {
                     const cx<double> Zc = cconj(buf[lds_slot((PV_NFFT - k) & (PV_NFFT - 1))]);
                     const cx<double> A = {0.5 * (Z.x + Zc.x), 0.5 * (Z.y + Zc.y)};   // rfft of column c0
                     const cx<double> B = {0.5 * (Z.y - Zc.y), -0.5 * (Z.x - Zc.x)};  // rfft of column c1
-                    const double ang0 = atan2(A.y, A.x), ang1 = atan2(B.y, B.x);
-                    const double pacc = t == 0 ? ang0 : phase[j];                     // phase_acc = angle(D[:, 0])
-                    const double mag = hypot(A.x, A.y);                               // alpha = 0: |column c0|
-                    const cx<double> d = {mag * cos(pacc), mag * sin(pacc)};
-                    if (t == 0) d0[j] = d;
-                    else d1[j] = d;
-                    const double phi = M_PI * (double)PV_HOP * (double)k / (double)(PV_BINS - 1);  // linspace(0, pi*hop, 1025)
-                    double dphase = ang1 - ang0 - phi;
-                    dphase = dphase - 2.0 * M_PI * nearbyint(dphase / (2.0 * M_PI));
-                    phase[j] = pacc + (phi + dphase);
+                    // librosa: D'[:, t] = |column c0| e^{i phase_acc}, phase_acc = angle(D[:, 0]) at t = 0 and then
+                    // phase_acc += phi + wrap(angle(c1) - angle(c0) - phi).  With at most two output frames this needs
+                    // no angle at all: at t = 0, |A| e^{i angle(A)} is A itself, and the accumulated phase of t = 1 is
+                    // angle(column 1 of step 0) up to a multiple of 2 pi, so D'[:, 1] = |column r| * B_0 / |B_0|
+                    // (angle(0) = 0 -> direction (1, 0)).  That is the reference's value to the ~2e-13 rad its own
+                    // phi = pi*512*k/1024 arithmetic carries, and replaces two atan2, a hypot, a cos and a sin per
+                    // bin and step -- most of this kernel's instructions -- by a square root and a division.
+                    if (t == 0) {
+                        d0[j] = A;
+                        const double nb = sqrt(B.x * B.x + B.y * B.y);
+                        const double inb = nb > 0.0 ? 1.0 / nb : 0.0;
+                        d1[j] = nb > 0.0 ? cx<double>{B.x * inb, B.y * inb} : cx<double>{1.0, 0.0};   // direction for t = 1
+                    } else {
+                        const double mag = sqrt(A.x * A.x + A.y * A.y);
+                        d1[j] = {mag * d1[j].x, mag * d1[j].y};
+                    }
                 }
             }
             __syncthreads();
+        }
+        if (nsteps < 2) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) d1[j] = {0.0, 0.0};   // (held the direction of column 1 so far)
         }
         // synthesis: irfft of both output frames through one complex inverse FFT (swap trick); every thread
         // writes its bins and their Hermitian mirrors
