@@ -70,8 +70,19 @@ def _engine_compute(method, clips, fs, device):
     return np.stack([c.as_array() for c in METHODS[method].compute_batch(clips, fs, device=device)])
 
 
+_SECOND_ENGINE = {}
+
+
+def _second_engine(device):
+    """A second context (own stream, own workspaces) on the same GPU: Iterative-F0 runs there next to the other methods."""
+    from .engine import Engine
+    if device not in _SECOND_ENGINE:
+        _SECOND_ENGINE[device] = Engine(device)
+    return _SECOND_ENGINE[device]
+
+
 def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, device=0,
-               compute=None, synth_device=None):
+               compute=None, synth_device=None, overlap=True):
     """Process this rank's block.  Returns (lo, hi, chroma[hi-lo, len(methods), 12] float64, seconds per method).
     `compute(method, clips, fs, device) -> [n,12]` defaults to the HIP engine's batch entry points; tests
     substitute a CPU function to exercise the sharding logic without a GPU."""
@@ -85,10 +96,28 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
         # synthesised on the GPU and consumed by the engine: the chunk stays in HBM (include/mpx.h, "where the samples
         # live"); a substituted compute function and a CPU synthesis get a host array
         clips = clips if (clips.is_cuda and compute is _engine_compute) else clips.cpu().numpy()
-        for mi, m in enumerate(methods):
+        rows = slice(c0 - lo, c0 - lo + len(ids))
+
+        def run(mi, m, fn):
             t0 = time.perf_counter()
-            out[c0 - lo:c0 - lo + len(ids), mi] = compute(m, clips, fs, device)   # [n, L] array: packed as it is
+            out[rows, mi] = fn()   # [n, L] array: packed as it is
             spent[mi] += time.perf_counter() - t0
+
+        side = None
+        if overlap and compute is _engine_compute and 3 in methods and len(methods) > 1:
+            # Iterative-F0's front end is one serial chain per lane and leaves most issue slots of a SIMD free: it runs on
+            # a second context and stream (ctypes releases the GIL) while the other methods go through the first one
+            import threading
+            mi3 = list(methods).index(3)
+            eng2 = _second_engine(device)
+            side = threading.Thread(target=run, args=(mi3, 3, lambda: eng2.iterative_f0_batch(clips, fs)))
+            side.start()
+        for mi, m in enumerate(methods):
+            if side is not None and m == 3:
+                continue
+            run(mi, m, lambda m=m: compute(m, clips, fs, device))
+        if side is not None:
+            side.join()
     return lo, hi, out, spent
 
 
@@ -141,6 +170,7 @@ def main(argv=None):
     ap.add_argument("--seconds", type=float, default=2.0)
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--out", default=None, help="write per-clip chroma [clips, methods, 12] to this .npz")
+    ap.add_argument("--no-overlap", action="store_true", help="run Iterative-F0 after the other methods instead of next to them")
     args = ap.parse_args(argv)
     methods = [int(m) for m in args.methods.split(",")]
     rank = int(os.environ.get("RANK", "0"))
@@ -154,7 +184,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=dev)
     t0 = time.perf_counter()
     lo, hi, block, spent = run_corpus(args.clips, methods, args.fs, args.seconds, args.chunk, rank, world, local,
-                                      synth_device=dev)
+                                      synth_device=dev, overlap=not args.no_overlap)
     chroma = gather_blocks(block, args.clips, world, rank, dev if world > 1 else None)
     wall = time.perf_counter() - t0
     if world > 1:
