@@ -105,3 +105,24 @@ def test_large_batch_is_split_without_changing_results(eng, monkeypatch):
     for i in (0, 1, 169, 170, 171, 338, 339):
         np.testing.assert_allclose(got[i], singles[i % 6], rtol=1e-12, atol=0)
     np.testing.assert_array_equal(got[:6], got[6:12])
+
+
+@pytest.mark.parametrize("channels", [5, 33, 64, 70, 80])
+def test_channel_counts_and_packed_leftover_waves(eng, clips, channels):
+    """channels % 64 leftover channels of several chunks share one front-end wave (lane -> (chunk, channel)): every
+    grouping -- all leftovers (5, 33), none (64), the default 64 + 6, four leftover sets per wave (64 + 16) -- against the
+    oracle's summary spectra, for a batch whose clips differ in length (chunks of unequal length never share a wave)."""
+    from oracle import iterative_f0 as o_if0
+    batch = [clips["poly_seed1"][:20000], clips["poly_seed2"][:20000], clips["poly_seed1"][:20000], clips["tone_E4"][:9000],
+             clips["poly_seed2"][:20000]]
+    got = eng.iterative_f0_batch(batch, FS, channels=channels)
+    for i in (0, 1, 3):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            per, Ut = o_if0.iterative_f0_frames(batch[i], FS, channels=channels)
+        ut = eng.iterative_f0_spectra(batch[i], FS, channels=channels)
+        np.testing.assert_allclose(ut, Ut, rtol=1e-9, atol=1e-9 * np.abs(Ut).max())
+        np.testing.assert_allclose(got[i], per.sum(0), rtol=1e-5)
+    np.testing.assert_array_equal(got[0], got[2])
+    np.testing.assert_array_equal(got[1], got[4])
+    np.testing.assert_array_equal(got[0], eng.iterative_f0(batch[0], FS, channels=channels))
