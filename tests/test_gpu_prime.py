@@ -71,3 +71,20 @@ def test_batch_edge_cases_vs_oracle(eng, clips):
         eng.prime_multif0(np.zeros(100, dtype=np.float32), 96000)   # 8/f*fs > 4096 samples for the low candidates
     with pytest.raises(ValueError):
         eng.prime_multif0(np.zeros((2, 2), dtype=np.float32), FS)
+
+
+def test_equal_length_clips_share_one_item_list(eng, clips):
+    """A batch of equal-length clips takes the path where the host builds ONE clip's item list and the kernel derives
+    the others: every clip must come out exactly as on its own, and as in a ragged batch (the general path)."""
+    names = ["poly_seed1", "poly_seed2", "tone_E4", "piano_like_Cmaj", "poly_seed1"]
+    same = np.stack([clips[n][:30000] for n in names])
+    got = eng.prime_multif0_batch(same, FS)
+    assert got.shape == (5, 12) and np.abs(got).sum() > 0
+    for i in range(5):
+        np.testing.assert_array_equal(got[i], eng.prime_multif0(same[i], FS))
+    ragged = eng.prime_multif0_batch([same[0], same[1][:29999], same[2]], FS)
+    np.testing.assert_array_equal(ragged[0], got[0])
+    np.testing.assert_array_equal(ragged[2], got[2])
+    np.testing.assert_array_equal(got[0], got[4])
+    two = eng.prime_multif0_batch(np.zeros((3, 0), dtype=np.float32), FS)      # equal length zero
+    assert two.shape == (3, 12) and np.all(two == 0)
