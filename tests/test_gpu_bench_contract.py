@@ -33,7 +33,10 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
     assert r["achieved"] == pytest.approx(4144 * 8192 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)   # algorithmic bytes / kernel time
-    assert 0.0 < r["kernel_ms"] <= d["ms_per_step"] * 1.05                                       # the kernel is inside the step
+    assert 0.0 < r["kernel_ms"] <= r["step_ms_hip_events"] * 1.05     # the kernel is inside the (one-at-a-time) step
+    assert d["config"]["batches_in_flight"] == 2 and r["in_flight"]["batches"] == 2
+    assert d["ms_per_step"] <= r["step_ms_hip_events"] * 1.05         # two batches in flight are not slower than one
+    assert r["in_flight"]["frac"] == pytest.approx(4144 * 8192 / (d["ms_per_step"] * 1e-3) / 8.0e12, rel=1e-6)
     assert r["traffic"] is None or r["traffic"] >= 0.9 * 4144 * 8192
     assert r["secondary"]["bound"] == "valu_f64" and 0.0 < r["secondary"]["frac"] < 1.0
     c = d["cpu_baseline"]
@@ -42,7 +45,8 @@ def test_bench_line_has_the_contract_fields():
 
 
 def test_bench_without_cpu_leg_and_smoke():
-    d = _run_bench("--no-cpu-baseline")
+    d = _run_bench("--no-cpu-baseline", "--streams", "1")
+    assert d["config"]["batches_in_flight"] == 1
     assert "roofline" in d and d.get("cpu_baseline") in (None, {}) or "cpu_baseline" not in d
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
