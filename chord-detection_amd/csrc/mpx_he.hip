@@ -654,7 +654,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
         oit = ctx->occupancy.emplace(okey, o < 1 ? 1 : o).first;
     }
     const int occ = oit->second;
-    long long g = (long long)occ * ctx->num_cus;
+    long long g = (long long)occ * ctx->num_cus * (getenv("MPX_HE_OVERSUB") ? atoi(getenv("MPX_HE_OVERSUB")) : 1);
     if (g > num_frames) g = num_frames;
     const long long per = (num_frames + g - 1) / g;
     g = (num_frames + per - 1) / per;
