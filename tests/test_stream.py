@@ -112,3 +112,20 @@ def test_sharded_stream_matches_the_whole_stream_on_gpu():
     f0, f1, blk = stream.run_stream_shard(lambda a, b: x[a:b], 90 * 2048, FS, 1, 2, 2048)
     _, ref = eng.iterative_f0(x[:90 * 2048], FS, return_frames=True, frame_size=2048)
     np.testing.assert_allclose(blk, ref[f0:f1], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_time_shards_in_flight_on_one_gpu():
+    """run_stream_rank: a rank's frames as two time shards on two contexts at once == the unsharded run."""
+    import chord_detection_amd as cd
+    n = 50 * FRAME + 999
+    x_dev = stream.synth_stream(0, n, FS, "cuda:0")
+    x = x_dev.cpu().numpy()
+    _, whole = cd.get_engine(0).iterative_f0(x, FS, return_frames=True)
+    for world, sub in ((1, 2), (2, 2), (1, 3)):
+        rows = []
+        for r in range(world):
+            f0, f1, blk = stream.run_stream_rank(lambda a, b: x_dev[a:b], n, FS, r, world, FRAME, 0, sub=sub)
+            assert (f0, f1) == stream.shard_window(n, FRAME, world, r)[:2]
+            rows.append(blk)
+        np.testing.assert_allclose(np.concatenate(rows), whole, rtol=1e-9, atol=1e-12)
