@@ -90,19 +90,28 @@ def _engine_frames_on(j):
     return compute
 
 
-def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=2, **kw):
+PIECE_BYTES = 32 << 30   # front-end output of one piece (560 B per sample at 70 channels): bounds the contexts' workspaces
+
+
+def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=2, channels=70, **kw):
     """This rank's frames, computed as `sub` time shards IN FLIGHT on the same GPU (one context and one host thread
     each; ctypes releases the GIL): the front end of one shard runs next to the spectra and the period search of the
     other.  Same halo logic as between ranks: the rank's block of frames is partitioned once more.
     Returns (f0, f1, frames[f1-f0, 12])."""
     import threading
-    parts = [None] * sub
     F0, F1 = partition(num_frames(n, frame_size), world, rank)
+    # pieces: a multiple of `sub`, each small enough for PIECE_BYTES of front-end output (a two-hour stream would
+    # otherwise ask one context for 180 GB, and the library refuses beyond 96 GiB per call)
+    per_frame = int(frame_size) * int(channels) * 8
+    rounds = max(1, -(-((F1 - F0) * per_frame) // (sub * PIECE_BYTES)))
+    pieces = sub * rounds
+    parts = [None] * pieces
 
-    def work(j):
-        a, b = partition(F1 - F0, sub, j)
-        parts[j] = run_stream_shard(read, n, fs, rank, world, frame_size, device, compute=_engine_frames_on(j),
-                                    frames=(F0 + a, F0 + b), **kw)
+    def work(j):   # context j takes pieces j, j + sub, j + 2 sub, ...
+        for q in range(j, pieces, sub):
+            a, b = partition(F1 - F0, pieces, q)
+            parts[q] = run_stream_shard(read, n, fs, rank, world, frame_size, device, compute=_engine_frames_on(j),
+                                        frames=(F0 + a, F0 + b), channels=channels, **kw)
 
     threads = [threading.Thread(target=work, args=(j,)) for j in range(1, sub)]
     for t in threads:
