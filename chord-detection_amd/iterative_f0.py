@@ -44,6 +44,16 @@ class MultipitchIterativeF0(Multipitch):
         return 3
 
     def compute_pitches(self, display_plot_frame=-1):
+        from . import stream
+        if (stream.WARMUP % int(self.frame_size) == 0
+                and self.x.shape[0] * int(self.num_channels) * 8 > stream.PIECE_BYTES):
+            # hours of audio: the front-end output of one call would be tens of GB (the library refuses beyond
+            # 96 GiB): time shards with a halo, two in flight (stream.py), summed like the reference sums its frames
+            x, n = self.x, self.x.shape[0]
+            _, _, frames = stream.run_stream_rank(lambda a, b: x[a:b], n, self.fs, 0, 1, self.frame_size, self.device,
+                                                  sub=2, channels=self.num_channels, power=self.power,
+                                                  zeta0=self.zeta0, zeta1=self.zeta1)
+            return stream.chroma_of(frames)
         total = get_engine(self.device).iterative_f0(
             self.x, self.fs, frame_size=self.frame_size, power=self.power, channels=self.num_channels,
             zeta0=self.zeta0, zeta1=self.zeta1)

@@ -129,3 +129,17 @@ def test_time_shards_in_flight_on_one_gpu():
             assert (f0, f1) == stream.shard_window(n, FRAME, world, r)[:2]
             rows.append(blk)
         np.testing.assert_allclose(np.concatenate(rows), whole, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_drop_in_class_takes_the_sharded_route_for_long_audio(monkeypatch):
+    """MultipitchIterativeF0.compute_pitches on audio whose front-end output exceeds one piece (forced here by a small
+    piece size) goes through the time shards and returns what the single call returns."""
+    import chord_detection_amd as cd
+    n = 30 * FRAME + 77
+    x = stream.synth_stream(0, n, FS, "cuda:0").cpu().numpy()
+    want = cd.MultipitchIterativeF0((x, FS)).compute_pitches()
+    monkeypatch.setattr(stream, "PIECE_BYTES", 4 * FRAME * 70 * 8)      # 4 frames per piece
+    got = cd.MultipitchIterativeF0((x, FS)).compute_pitches()
+    np.testing.assert_allclose(got.as_array(), want.as_array(), rtol=1e-9)
+    assert repr(got) == repr(want)
