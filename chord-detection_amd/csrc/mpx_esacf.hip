@@ -937,7 +937,7 @@ struct ParkedFit {
     double par, delta, xnorm, fnorm;
     int m, it, nfev, pad;
 };
-constexpr int PARK_NFEV = 100;
+constexpr int PARK_NFEV = 160;   // (swept 60 ... 550 on three workloads: 130-180 is the flat optimum)
 constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinished fits ...
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
