@@ -55,37 +55,43 @@ struct If0TailGroup {   // chunks with the same (warm, len) whose leftover chann
     int first, count;   // tail_list[first .. first + count)
 };
 
-__global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
-                                                          long long num_chunks, int channels,
-                                                          const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
-                                                          double* __restrict__ yc, const int* __restrict__ tail_list,
-                                                          const If0TailGroup* __restrict__ tail_groups) {
+// TAIL = false: a wave of 64 channels of ONE chunk -- chunk, input pointer and output rows are wave-uniform (scalar
+// loads, plain pointer arithmetic).  TAIL = true: a wave of leftover channels of several chunks -- per-lane chunk,
+// input pointer and an LDS table of output rows.  (One body for both had cost the common case 16 % of its speed.)
+template <bool TAIL>
+__device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
+                                                  long long num_chunks, int channels,
+                                                  const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
+                                                  double* __restrict__ yc, const int* __restrict__ tail_list,
+                                                  const If0TailGroup* __restrict__ tail_groups,
+                                                  double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
+                                                  int nch_u, const If0TailGroup g) {
     // One wave per (chunk, group of 64 channels), one lane per channel; the channels % 64 left over (6 of the default
     // 70) would fill a wave to 9 %, so the leftovers of up to 64 / (channels % 64) chunks of equal length and run-in
     // share one: lane -> (chunk, channel).  All lanes of a wave share the loop bounds, and the outputs go
     // through an LDS tile [lane][16 samples] so that the buffer can be [chunk][channel][t] -- every channel's
     // samples contiguous for the spectrum kernel -- with 128-byte row segments per store instead of 8-byte ones
-    __shared__ double tile[64][17];
-    __shared__ long long rowbase[64];   // per lane: index in yc of its output row, -1 for an idle lane
     const int lane = threadIdx.x;
     const int full = channels >> 6, nt = channels & 63;
     long long ck;
-    int ch;
+    int ch, ch0 = 0;
     bool active = true;
-    if ((long long)blockIdx.x < num_chunks * full) {
-        ck = blockIdx.x / full;
-        ch = (int)(blockIdx.x % full) * 64 + lane;
+    if (!TAIL) {
+        ck = ck_u;
+        ch0 = ch0_u;
+        ch = ch0 + (lane < nch_u ? lane : 0);   // idle lanes shadow channel ch0 (results discarded)
     } else {
-        const If0TailGroup g = tail_groups[blockIdx.x - num_chunks * full];
         const int sub = lane / nt;
         active = sub < g.count;
         ck = tail_list[g.first + (active ? sub : 0)];   // idle lanes shadow the first chunk (results discarded)
         ch = 64 * full + lane % nt;
     }
     const If0Chunk c = chunks[ck];
-    const int c_warm = __builtin_amdgcn_readfirstlane(c.warm), c_len = __builtin_amdgcn_readfirstlane(c.len);
+    const int c_warm = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
+    const int c_len = TAIL ? __builtin_amdgcn_readfirstlane(c.len) : c.len;
     const If0ChanCoef k = coefs[ch];
-    rowbase[lane] = active ? c.yc_row0 * channels + (long long)ch * c_len : -1;
+    if (TAIL) rowbase[lane] = active ? c.yc_row0 * channels + (long long)ch * c_len : -1;
+    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + (size_t)ch0 * c_len;  // !TAIL: [channel - ch0][len]
     // The chain is 17 filter stages deep (4 resonators, 12 all-passes, rectifier + low-pass).  Evaluated
     // sample by sample it is ONE dependent chain of ~20 fp64 operations per step, and a lone wave pays the
     // full FMA latency on each.  Software pipelining across samples removes that: in iteration tau stage j
@@ -180,12 +186,39 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 const int e = q * 64 + lane, r = e >> 4, cc = e & 15;
-                const long long rb = rowbase[r];
-                if (rb >= 0) yc[rb + t0 + cc] = tile[r][cc];
+                if (TAIL) {
+                    const long long rb = rowbase[r];
+                    if (rb >= 0) yc[rb + t0 + cc] = tile[r][cc];
+                } else if (r < nch_u) {
+                    out[(size_t)r * c_len + t0 + cc] = tile[r][cc];
+                }
             }
             wave_lds_fence();
         }
     }
+}
+
+__global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
+                                                          long long num_chunks, int channels,
+                                                          const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
+                                                          double* __restrict__ yc, const int* __restrict__ tail_list,
+                                                          const If0TailGroup* __restrict__ tail_groups) {
+    __shared__ double tile[64][17];
+    __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
+    const int full = channels >> 6;
+    If0TailGroup g = {0, 0};
+    if ((long long)blockIdx.x < num_chunks * full) {
+        if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
+                                 blockIdx.x / full, (int)(blockIdx.x % full) * 64, 64, g);
+        return;
+    }
+    g = tail_groups[blockIdx.x - num_chunks * full];
+    if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
+        if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
+                                 tail_list[g.first], 64 * full, channels & 63, g);
+    else
+        if0_frontend_body<true>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
+                                0, g);
 }
 
 // ------------------------------------------------------------------ spectrum
@@ -762,7 +795,12 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     std::vector<If0TailGroup> tail_groups;
     const int full_groups = p.channels / 64, nt = p.channels % 64;
     if (nt) {
-        const int per_wave = 64 / nt;
+        // A packed wave is ~13 % slower per step (per-lane input streams), and the pass is as long as the busiest SIMD:
+        // pack exactly when that lowers the number of waves the busiest SIMD has to take (800 chunks: 2 -> 1; one
+        // clip: 1 -> 1, 1024 clips: 2 -> 2, where packing would only slow the leftovers down).
+        const long long simds = 4LL * ctx->num_cus, pw = 64 / nt;
+        const long long unpacked = nchunks * (full_groups + 1), packed = nchunks * full_groups + (nchunks + pw - 1) / pw;
+        const int per_wave = (unpacked + simds - 1) / simds > (packed + simds - 1) / simds ? (int)pw : 1;
         for (long long i = 0; i < nchunks; ++i) {
             if (tail_groups.empty() || tail_groups.back().count == per_wave ||
                 chunks[(size_t)tail_list[(size_t)tail_groups.back().first]].len != chunks[(size_t)i].len ||
