@@ -126,7 +126,7 @@ def main():
     n = x.numel()
     steps, warmup = args.steps, args.warmup
     d_frames = torch.empty((FRAMES, 12), dtype=torch.float64, device=dev)
-    d_sums = torch.zeros((max(steps, warmup, 1), 12), dtype=torch.float64, device=dev)
+    d_sums = torch.zeros((max(steps, warmup, nstreams, 1), 12), dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
 
     def step(i):
