@@ -14,6 +14,8 @@ MPX_OK, MPX_EINVAL, MPX_ENOMEM, MPX_EHIP, MPX_EUNSUPPORTED = 0, -1, -2, -3, -4
 MPX_FLAG_F32 = 0x1
 MPX_FLAG_DETERMINISTIC = 0x2
 MPX_ENHANCE_LIBROSA010, MPX_ENHANCE_NOOP = 0, 1
+MPX_NOTES_UNICODE, MPX_NOTES_ASCII = 0, 1
+NOTE_NAMES = {"unicode": MPX_NOTES_UNICODE, "ascii": MPX_NOTES_ASCII}
 STAGES = {"wfir": 0, "x_lo": 1, "x_hi": 2, "sacf": 3, "esacf": 4}
 
 
@@ -23,19 +25,19 @@ class HeParams(C.Structure):
 
 class PrimeParams(C.Structure):
     _fields_ = [("num_harmonic", C.c_int), ("num_octave", C.c_int), ("harmonic_multiples_elim", C.c_int),
-                ("harmonic_elim_runs", C.c_int)]
+                ("harmonic_elim_runs", C.c_int), ("note_names", C.c_int)]
 
 
 class If0Params(C.Structure):
     _fields_ = [("frame_size", C.c_int), ("power", C.c_double), ("channels", C.c_int), ("zeta0", C.c_double),
                 ("zeta1", C.c_double), ("max_voices", C.c_int), ("tau_min", C.c_double), ("tau_max", C.c_double),
                 ("tau_prec", C.c_double), ("Q", C.c_int), ("M", C.c_int), ("epsilon1", C.c_double),
-                ("epsilon2", C.c_double), ("gamma", C.c_double)]
+                ("epsilon2", C.c_double), ("gamma", C.c_double), ("note_names", C.c_int)]
 
 
 class EsacfParams(C.Structure):
     _fields_ = [("n_peaks_elim", C.c_int), ("peak_thresh", C.c_double),
-                ("peak_min_dist", C.c_int), ("enhance_mode", C.c_int)]
+                ("peak_min_dist", C.c_int), ("enhance_mode", C.c_int), ("note_names", C.c_int)]
 
 
 _fp = C.POINTER(C.c_float)
@@ -108,7 +110,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.mpx_abi_version() != 1:
+    if lib.mpx_abi_version() != 2:
         raise RuntimeError("libmpx_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -66,8 +66,9 @@ def synth_chunk(clip_ids, fs, seconds, device=None):
     return out.to(torch.float32)
 
 
-def _engine_compute(method, clips, fs, device):
-    return np.stack([c.as_array() for c in METHODS[method].compute_batch(clips, fs, device=device)])
+def _engine_compute(method, clips, fs, device, note_names="unicode"):
+    kw = {} if method == 2 else {"note_names": note_names}   # method 2 never spells a note (harmonic_energy.py:66-67)
+    return np.stack([c.as_array() for c in METHODS[method].compute_batch(clips, fs, device=device, **kw)])
 
 
 _SECOND_ENGINE = {}
@@ -82,11 +83,15 @@ def _second_engine(device):
 
 
 def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, device=0,
-               compute=None, synth_device=None, overlap=True):
+               compute=None, synth_device=None, overlap=True, note_names="unicode"):
     """Process this rank's block.  Returns (lo, hi, chroma[hi-lo, len(methods), 12] float64, seconds per method).
     `compute(method, clips, fs, device) -> [n,12]` defaults to the HIP engine's batch entry points; tests
     substitute a CPU function to exercise the sharding logic without a GPU."""
-    compute = compute or _engine_compute
+    if compute is None:
+        compute = _engine_compute
+        engine_path = True
+    else:
+        engine_path = False
     lo, hi = partition(n_clips, world, rank)
     out = np.zeros((hi - lo, len(methods), 12), dtype=np.float64)
     spent = [0.0] * len(methods)
@@ -95,29 +100,42 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
         clips = synth_chunk(ids, fs, seconds, synth_device)
         # synthesised on the GPU and consumed by the engine: the chunk stays in HBM (include/mpx.h, "where the samples
         # live"); a substituted compute function and a CPU synthesis get a host array
-        clips = clips if (clips.is_cuda and compute is _engine_compute) else clips.cpu().numpy()
+        clips = clips if (clips.is_cuda and engine_path) else clips.cpu().numpy()
         rows = slice(c0 - lo, c0 - lo + len(ids))
+
+        failed = []
 
         def run(mi, m, fn):
             t0 = time.perf_counter()
-            out[rows, mi] = fn()   # [n, L] array: packed as it is
+            try:
+                out[rows, mi] = fn()   # [n, L] array: packed as it is
+            except BaseException as exc:   # re-raised by the caller's thread below: a dead side thread must not
+                failed.append(exc)         # leave all-zero chroma behind a normal-looking summary
             spent[mi] += time.perf_counter() - t0
 
         side = None
-        if overlap and compute is _engine_compute and 3 in methods and len(methods) > 1:
+        if overlap and engine_path and 3 in methods and len(methods) > 1:
             # Iterative-F0's front end is one serial chain per lane and leaves most issue slots of a SIMD free: it runs on
             # a second context and stream (ctypes releases the GIL) while the other methods go through the first one
             import threading
             mi3 = list(methods).index(3)
             eng2 = _second_engine(device)
-            side = threading.Thread(target=run, args=(mi3, 3, lambda: eng2.iterative_f0_batch(clips, fs)))
+            side = threading.Thread(target=run, args=(mi3, 3, lambda: eng2.iterative_f0_batch(clips, fs,
+                                                                                             note_names=note_names)))
             side.start()
         for mi, m in enumerate(methods):
             if side is not None and m == 3:
                 continue
-            run(mi, m, lambda m=m: compute(m, clips, fs, device))
+            if engine_path:
+                run(mi, m, lambda m=m: compute(m, clips, fs, device, note_names))
+            else:
+                run(mi, m, lambda m=m: compute(m, clips, fs, device))
+            if failed:
+                break
         if side is not None:
             side.join()
+        if failed:
+            raise failed[0]
     return lo, hi, out, spent
 
 
@@ -171,6 +189,8 @@ def main(argv=None):
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--out", default=None, help="write per-clip chroma [clips, methods, 12] to this .npz")
     ap.add_argument("--no-overlap", action="store_true", help="run Iterative-F0 after the other methods instead of next to them")
+    ap.add_argument("--note-names", choices=("unicode", "ascii"), default="unicode",
+                    help="spelling of sharps by the librosa the reference runs with (include/mpx.h MPX_NOTES_*)")
     args = ap.parse_args(argv)
     methods = [int(m) for m in args.methods.split(",")]
     rank = int(os.environ.get("RANK", "0"))
@@ -184,7 +204,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=dev)
     t0 = time.perf_counter()
     lo, hi, block, spent = run_corpus(args.clips, methods, args.fs, args.seconds, args.chunk, rank, world, local,
-                                      synth_device=dev, overlap=not args.no_overlap)
+                                      synth_device=dev, overlap=not args.no_overlap, note_names=args.note_names)
     chroma = gather_blocks(block, args.clips, world, rank, dev if world > 1 else None)
     wall = time.perf_counter() - t0
     if world > 1:

@@ -1614,7 +1614,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 
 // ------------------------------------------------------------------ kernel 4
 __global__ __launch_bounds__(64) void scatter_kernel(long long frame0, long long num_frames, int fs, int Mh, int maxp,
-                                                     const double* __restrict__ y,
+                                                     int note_names, const double* __restrict__ y,
                                                      const int* __restrict__ peak_count,
                                                      const int* __restrict__ peak_idx,
                                                      const double* __restrict__ center,
@@ -1637,8 +1637,9 @@ __global__ __launch_bounds__(64) void scatter_kernel(long long frame0, long long
         if (!(midi == midi) || isinf(midi)) continue;  // NaN -> ValueError -> skipped (esacf.py:70-71)
         const long long note = (long long)nearbyint(midi);
         const int pc = (int)(((note % 12) + 12) % 12);
-        // unicode-sharp quirk (A.18): C#, D#, F#, G#, A# land in a stray dict key and are lost
-        if (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10) continue;
+        // unicode-sharp quirk (A.18, MPX_NOTES_UNICODE): C#, D#, F#, G#, A# land in a stray dict key and are lost;
+        // with ASCII note names (librosa < 0.8) every pitch class accumulates
+        if (note_names == MPX_NOTES_UNICODE && (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) continue;
 #pragma unroll
         for (int q = 0; q < 12; ++q)
             if (q == pc) chroma[q] += weight;
@@ -1816,7 +1817,7 @@ static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStr
 int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
               int fs, const mpx_esacf_params* params, int frame, int hop, double* d_chroma_frames, int stage,
               double* d_stage_out, hipStream_t st) {
-    mpx_esacf_params p = params ? *params : mpx_esacf_params{6, 0.1, 10, MPX_ENHANCE_LIBROSA010};
+    mpx_esacf_params p = params ? *params : mpx_esacf_params{6, 0.1, 10, MPX_ENHANCE_LIBROSA010, MPX_NOTES_UNICODE};
     // bit-reproducible mode (MPX_FLAG_DETERMINISTIC; MPX_DETERMINISTIC=1 overrides per call): every gaussian fit is
     // finished on the lane that started it
     const bool deterministic = (ctx->flags & MPX_FLAG_DETERMINISTIC) || (getenv("MPX_DETERMINISTIC") && atoi(getenv("MPX_DETERMINISTIC")));
@@ -1827,6 +1828,8 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         return set_error(ctx, MPX_EINVAL, "ESACF: unknown enhance_mode %d", p.enhance_mode);
     if (p.peak_min_dist < 0 || p.n_peaks_elim < 0 || p.n_peaks_elim > 64)
         return set_error(ctx, MPX_EINVAL, "ESACF: bad peak parameters");
+    if (p.note_names != MPX_NOTES_UNICODE && p.note_names != MPX_NOTES_ASCII)
+        return set_error(ctx, MPX_EINVAL, "ESACF: unknown note_names %d", p.note_names);
     if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
     // librosa.effects.time_stretch is a pure truncation only while its STFT has <= 2 frames; above that
     // (Mh >= 1024 lags) the real phase vocoder runs in its own kernel between the SACF and the peak picking
@@ -1979,7 +1982,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d\n", nf, h[0] + h[2], h[0], h[3]);
         }
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,
-                           y, peak_count, peak_idx, center, okf, d_chroma_frames);
+                           p.note_names, y, peak_count, peak_idx, center, okf, d_chroma_frames);
         MPX_HIP(ctx, hipGetLastError());
     }
     return MPX_OK;

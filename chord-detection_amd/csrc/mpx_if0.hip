@@ -296,6 +296,7 @@ struct If0PerArgs {
     double fs, K;       // K = window_size / fs
     double wsize;       // window_size (frame_size) as a double
     int max_voices, Q, M;
+    int note_names;  // MPX_NOTES_*
     double tau_min, tau_max, tau_prec, epsilon1, epsilon2, gamma;
     double* chroma;     // [F, 12]
 };
@@ -482,7 +483,9 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
                 if (midi == midi && !isinf(midi)) {  // unused voices: fs/0 = inf -> OverflowError -> skipped (A.13)
                     const long long note = (long long)nearbyint(midi);
                     const int pc = (int)(((note % 12) + 12) % 12);
-                    if (!(pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) chroma[pc] += voice_sal[i];  // A.18
+                    // A.18: unicode note names drop the sharps
+                    if (a.note_names == MPX_NOTES_ASCII || !(pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10))
+                        chroma[pc] += voice_sal[i];
                 }
             }
         }
@@ -690,12 +693,14 @@ static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* f
 int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                  const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out) {
     mpx_if0_params p = params ? *params
-                              : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66};
+                              : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
     if (p.frame_size != 1024 && p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192)
         return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: 1024, 2048, 4096, 8192)", p.frame_size);
     if (p.channels < 1 || p.channels > IF0_MAXCH || p.max_voices < 1 || p.max_voices > 8 || p.Q < 2 || p.Q > 32 || p.M < 2 ||
         p.M > 64 || !(p.tau_min > 0) || !(p.tau_max > p.tau_min) || fs <= 0)
         return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
+    if (p.note_names != MPX_NOTES_UNICODE && p.note_names != MPX_NOTES_ASCII)
+        return set_error(ctx, MPX_EINVAL, "iterative F0: unknown note_names %d", p.note_names);
     const int NF = p.frame_size, n2 = 2 * NF;
     // periodicity.py indexes Ur up to M*K/tau_min: must stay inside the 2*frame spectrum
     if ((p.M - 1) * ((double)NF / fs) / p.tau_min + 1.5 >= n2)
@@ -864,6 +869,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     a.K = (double)NF / (double)fs;
     a.wsize = (double)NF;
     a.max_voices = p.max_voices;
+    a.note_names = p.note_names;
     a.Q = p.Q;
     a.M = p.M;
     a.tau_min = p.tau_min;

@@ -36,7 +36,7 @@ constexpr int PRIME_MAX_RUNS = 4;
 template <int L, int T>
 __global__ __launch_bounds__(T) void prime_kernel(const float* __restrict__ sig, const PrimeItem* __restrict__ items,
                                                   const PrimeCand* __restrict__ cands, int runs, int elim,
-                                                  int* out_pc, double* out_val, int per_clip, long long clip_len,
+                                                  int note_names, int* out_pc, double* out_val, int per_clip, long long clip_len,
                                                   long long clip_slots) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
@@ -127,8 +127,9 @@ __global__ __launch_bounds__(T) void prime_kernel(const float* __restrict__ sig,
                         for (int j = k * idx - 1; j <= k * idx + 1; ++j)
                             if (j >= 0 && j < half && (double)j * c.val == target) mag[j] = 0.0;
                     }
-                    // unicode-sharp quirk A.18: sharps land in a stray key and are lost
-                    if (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10) pc = -1;
+                    // unicode-sharp quirk A.18 (MPX_NOTES_UNICODE): sharps land in a stray key and are lost, but the
+                    // elimination above has happened; ASCII note names (librosa < 0.8) keep every pitch class
+                    if (note_names == MPX_NOTES_UNICODE && (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) pc = -1;
                 }
             }
             out_pc[it.slot * PRIME_MAX_RUNS + run] = pc;
@@ -257,22 +258,24 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
 
 template <int L, int T>
 static void prime_launch(const float* d_sig, const PrimeItem* d_items, size_t count, const PrimeCand* d_cands, int runs,
-                         int elim, int* d_pc, double* d_val, hipStream_t st, int per_clip, long long clip_len,
+                         int elim, int note_names, int* d_pc, double* d_val, hipStream_t st, int per_clip, long long clip_len,
                          long long clip_slots) {
     if (!count) return;
     const size_t lds = sizeof(cx<double>) * lds_slots(L);  // the magnitudes alias the upper half of the buffer
     auto kern = prime_kernel<L, T>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, st, d_sig, d_items, d_cands, runs, elim, d_pc, d_val, per_clip, clip_len, clip_slots);
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, st, d_sig, d_items, d_cands, runs, elim, note_names, d_pc, d_val, per_clip, clip_len, clip_slots);
 }
 
 // signals: packed clips on the HOST; offsets[C+1]; out: [C,12] on the host
 int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                    const mpx_prime_params* params, double* chroma_sums) {
-    mpx_prime_params p = params ? *params : mpx_prime_params{1, 2, 5, 2};
+    mpx_prime_params p = params ? *params : mpx_prime_params{1, 2, 5, 2, MPX_NOTES_UNICODE};
     if (p.num_harmonic < 1 || p.num_octave < 1 || p.num_harmonic * p.num_octave > 64 || p.harmonic_multiples_elim < 1 ||
         p.harmonic_multiples_elim > 64 || p.harmonic_elim_runs < 0 || p.harmonic_elim_runs > PRIME_MAX_RUNS)
         return set_error(ctx, MPX_EINVAL, "bad prime-multiF0 params");
+    if (p.note_names != MPX_NOTES_UNICODE && p.note_names != MPX_NOTES_ASCII)
+        return set_error(ctx, MPX_EINVAL, "prime-multiF0: unknown note_names %d", p.note_names);
     if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
     PrimePlan plan_storage;
     int rc = prime_plan(ctx, fs, p, plan_storage);
@@ -334,10 +337,10 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         const PrimeItem* di = (const PrimeItem*)(d_items + off);
         const int per_clip = uniform ? (int)items[cls].size() : 0;
         const size_t count = uniform ? items[cls].size() * (size_t)num_clips : items[cls].size();
-        if (cls == 0) prime_launch<1024, 64>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 1) prime_launch<2048, 128>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 2) prime_launch<4096, 256>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 3) prime_launch<8192, 512>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 0) prime_launch<1024, 64>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 1) prime_launch<2048, 128>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 2) prime_launch<4096, 256>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 3) prime_launch<8192, 512>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
         off += bytes;
     }
     if (num_clips)

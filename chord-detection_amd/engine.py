@@ -144,11 +144,19 @@ class Engine:
 
     # ------------------------------------------------------------- method 1
     @staticmethod
-    def _esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode):
+    def _notes(note_names):
+        """'unicode' (librosa >= 0.8: the reference drops the five sharps, include/mpx.h) or 'ascii' (they count)."""
+        if note_names not in _lib.NOTE_NAMES:
+            raise ValueError("note_names must be one of %s" % sorted(_lib.NOTE_NAMES))
+        return _lib.NOTE_NAMES[note_names]
+
+    @staticmethod
+    def _esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode, note_names="unicode"):
         modes = {"librosa010": _lib.MPX_ENHANCE_LIBROSA010, "noop": _lib.MPX_ENHANCE_NOOP}
         if enhance_mode not in modes:
             raise ValueError("enhance_mode must be one of %s" % sorted(modes))
-        return _lib.EsacfParams(int(n_peaks_elim), float(peak_thresh), int(peak_min_dist), modes[enhance_mode])
+        return _lib.EsacfParams(int(n_peaks_elim), float(peak_thresh), int(peak_min_dist), modes[enhance_mode],
+                                Engine._notes(note_names))
 
     def _ensure_remez(self, fs):
         """Warped-FIR taps are a design constant (dsp/wfir.py:13-21); 22050/44100 Hz are built in, other
@@ -164,10 +172,10 @@ class Engine:
         self._remez_done = getattr(self, "_remez_done", set()) | {fs}
 
     def esacf(self, x, fs, frame, hop=None, n_peaks_elim=6, peak_thresh=0.1, peak_min_dist=10,
-              enhance_mode="librosa010", return_frames=False):
+              enhance_mode="librosa010", return_frames=False, note_names="unicode"):
         x = self._sig(x)
         hop = int(hop or frame)
-        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode, note_names)
         self._ensure_remez(fs)
         nf = max(self.num_frames(x.shape[0], frame, hop), 0)
         total = np.zeros(12, dtype=np.float64)
@@ -178,9 +186,9 @@ class Engine:
         return (total, frames) if return_frames else total
 
     def esacf_batch(self, clips, fs, frame, hop=None, n_peaks_elim=6, peak_thresh=0.1, peak_min_dist=10,
-                    enhance_mode="librosa010"):
+                    enhance_mode="librosa010", note_names="unicode"):
         flat, offsets = self._pack(clips)
-        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode, note_names)
         self._ensure_remez(fs)
         out = np.zeros((len(offsets) - 1, 12), dtype=np.float64)
         self._check(self.lib.mpx_esacf_batch(
@@ -189,8 +197,8 @@ class Engine:
         return out
 
     def esacf_dev(self, d_signal, n, fs, frame, hop, d_frames, d_sum, stream=None, n_peaks_elim=6,
-                  peak_thresh=0.1, peak_min_dist=10, enhance_mode="librosa010"):
-        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode)
+                  peak_thresh=0.1, peak_min_dist=10, enhance_mode="librosa010", note_names="unicode"):
+        p = self._esacf_params(n_peaks_elim, peak_thresh, peak_min_dist, enhance_mode, note_names)
         self._ensure_remez(fs)
         self._check(self.lib.mpx_esacf_dev(self.ctx, d_signal, int(n), int(fs), C.byref(p), int(frame), int(hop),
                                            d_frames, d_sum, stream))
@@ -214,10 +222,10 @@ class Engine:
     @staticmethod
     def _if0_params(frame_size=8192, power=1.0, channels=70, zeta0=2.3, zeta1=0.39, max_voices=4,
                     tau_min=1.0 / 2100.0, tau_max=1.0 / 40.0, tau_prec=0.0000001, Q=20, M=20, epsilon1=20,
-                    epsilon2=320, gamma=0.66):
+                    epsilon2=320, gamma=0.66, note_names="unicode"):
         return _lib.If0Params(int(frame_size), float(power), int(channels), float(zeta0), float(zeta1),
                               int(max_voices), float(tau_min), float(tau_max), float(tau_prec), int(Q), int(M),
-                              float(epsilon1), float(epsilon2), float(gamma))
+                              float(epsilon1), float(epsilon2), float(gamma), Engine._notes(note_names))
 
     def iterative_f0(self, x, fs, return_frames=False, **kw):
         x = self._sig(x)
@@ -254,18 +262,21 @@ class Engine:
         return ut
 
     # ------------------------------------------------------------- method 4
-    def prime_multif0(self, x, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5, harmonic_elim_runs=2):
+    def prime_multif0(self, x, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5, harmonic_elim_runs=2,
+                      note_names="unicode"):
         x = self._sig(x)
-        p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs)
+        p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs,
+                             self._notes(note_names))
         total = np.zeros(12, dtype=np.float64)
         self._check(self.lib.mpx_prime_multif0(self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p),
                                                total.ctypes.data_as(_lib._dp)))
         return total
 
     def prime_multif0_batch(self, clips, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5,
-                            harmonic_elim_runs=2):
+                            harmonic_elim_runs=2, note_names="unicode"):
         flat, offsets = self._pack(clips)
-        p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs)
+        p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs,
+                             self._notes(note_names))
         out = np.zeros((len(offsets) - 1, 12), dtype=np.float64)
         self._check(self.lib.mpx_prime_multif0_batch(
             self.ctx, flat.ctypes.data_as(_lib._fp), offsets.ctypes.data_as(_lib._ip), len(offsets) - 1, int(fs),

@@ -6,9 +6,12 @@ from .multipitch import Multipitch
 
 class MultipitchHarmonicEnergy(Multipitch):
     def __init__(
-        self, audio_path, frame_size=8192, num_harmonic=2, num_octave=2, num_bins=2, hop=None, fs=None, device=0
+        self, audio_path, frame_size=8192, num_harmonic=2, num_octave=2, num_bins=2, hop=None, fs=None, device=0,
+        note_names="unicode",
     ):
-        super().__init__(audio_path, fs=fs, device=device)
+        # note_names: accepted for a uniform constructor; this method indexes the chromagram by integer
+        # (harmonic_energy.py:66-67) and never spells a note
+        super().__init__(audio_path, fs=fs, device=device, note_names=note_names)
         self.frame_size = frame_size
         self.num_harmonic = num_harmonic
         self.num_octave = num_octave

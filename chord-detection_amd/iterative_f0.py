@@ -20,8 +20,9 @@ class MultipitchIterativeF0(Multipitch):
         harmonic_multiples_elim=5,
         fs=None,
         device=0,
+        note_names="unicode",
     ):
-        super().__init__(audio_path, fs=fs, device=device)
+        super().__init__(audio_path, fs=fs, device=device, note_names=note_names)
         self.frame_size = frame_size
         self.num_frames = math.ceil(self.x.shape[0] / self.frame_size)
         self.power = power
@@ -52,15 +53,17 @@ class MultipitchIterativeF0(Multipitch):
             x, n = self.x, self.x.shape[0]
             _, _, frames = stream.run_stream_rank(lambda a, b: x[a:b], n, self.fs, 0, 1, self.frame_size, self.device,
                                                   sub=2, channels=self.num_channels, power=self.power,
-                                                  zeta0=self.zeta0, zeta1=self.zeta1)
+                                                  zeta0=self.zeta0, zeta1=self.zeta1, note_names=self.note_names)
             return stream.chroma_of(frames)
         total = get_engine(self.device).iterative_f0(
             self.x, self.fs, frame_size=self.frame_size, power=self.power, channels=self.num_channels,
-            zeta0=self.zeta0, zeta1=self.zeta1)
+            zeta0=self.zeta0, zeta1=self.zeta1, note_names=self.note_names)
         return Chromagram(total)
 
     @classmethod
-    def compute_batch(cls, clips, fs, frame_size=8192, power=1.0, channels=70, zeta0=2.3, zeta1=0.39, device=0):
+    def compute_batch(cls, clips, fs, frame_size=8192, power=1.0, channels=70, zeta0=2.3, zeta1=0.39, device=0,
+                      note_names="unicode"):
         sums = get_engine(device).iterative_f0_batch(clips, fs, frame_size=frame_size, power=power,
-                                                     channels=channels, zeta0=zeta0, zeta1=zeta1)
+                                                     channels=channels, zeta0=zeta0, zeta1=zeta1,
+                                                     note_names=note_names)
         return [Chromagram(s) for s in sums]

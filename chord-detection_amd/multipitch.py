@@ -4,7 +4,10 @@ Differences from the reference, all additive:
   * besides a path, the constructor accepts in-memory audio: a 1-D array with
     the keyword `fs=`, or an (x, fs) tuple -- loading/resampling is outside the
     accelerated path;
-  * `device=` selects the GPU (default 0).
+  * `device=` selects the GPU (default 0);
+  * `note_names=` ("unicode" default | "ascii") says how the librosa the reference runs with spells sharps in
+    `hz_to_note` -- with unicode names the reference's `chromagram[note] += v` loses C#, D#, F#, G#, A#
+    (chromagram.py:19-29; include/mpx.h MPX_NOTES_*).  Methods 1, 3, 4; method 2 never calls hz_to_note.
 """
 from abc import ABCMeta, abstractmethod
 from collections import OrderedDict
@@ -30,7 +33,10 @@ class Multipitch(object):
         METHODS[cls.method_number()] = cls
 
     @abstractmethod
-    def __init__(self, audio_path, fs=None, device=0):
+    def __init__(self, audio_path, fs=None, device=0, note_names="unicode"):
+        if note_names not in ("unicode", "ascii"):
+            raise ValueError("note_names must be 'unicode' or 'ascii'")
+        self.note_names = note_names
         if isinstance(audio_path, tuple) and len(audio_path) == 2:
             x, self.fs = numpy.asarray(audio_path[0]), audio_path[1]
             self.clip_name = "<array>"

@@ -106,12 +106,17 @@ def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub
     rounds = max(1, -(-((F1 - F0) * per_frame) // (sub * PIECE_BYTES)))
     pieces = sub * rounds
     parts = [None] * pieces
+    failed = []
 
     def work(j):   # context j takes pieces j, j + sub, j + 2 sub, ...
-        for q in range(j, pieces, sub):
-            a, b = partition(F1 - F0, pieces, q)
-            parts[q] = run_stream_shard(read, n, fs, rank, world, frame_size, device, compute=_engine_frames_on(j),
-                                        frames=(F0 + a, F0 + b), channels=channels, **kw)
+        try:
+            for q in range(j, pieces, sub):
+                a, b = partition(F1 - F0, pieces, q)
+                parts[q] = run_stream_shard(read, n, fs, rank, world, frame_size, device,
+                                            compute=_engine_frames_on(j), frames=(F0 + a, F0 + b), channels=channels,
+                                            **kw)
+        except BaseException as exc:   # a side thread's exception is re-raised by the caller below
+            failed.append(exc)
 
     threads = [threading.Thread(target=work, args=(j,)) for j in range(1, sub)]
     for t in threads:
@@ -119,6 +124,8 @@ def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub
     work(0)
     for t in threads:
         t.join()
+    if failed:
+        raise failed[0]
     if any(p is None for p in parts):
         raise RuntimeError("a time shard failed")
     return parts[0][0], parts[-1][1], np.concatenate([p[2] for p in parts], axis=0)

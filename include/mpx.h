@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define MPX_ABI_VERSION 1
+#define MPX_ABI_VERSION 2
 
 typedef enum mpx_status {
     MPX_OK = 0,
@@ -106,6 +106,19 @@ int mpx_harmonic_energy_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int 
                             const mpx_he_params* params, int frame, int hop,
                             double* d_chroma_frames, double* d_chroma_sum, void* stream);
 
+/* ---- note spelling of librosa.hz_to_note (methods 1, 3, 4) ---------------------
+ * The reference adds a detected pitch with `chromagram[librosa.hz_to_note(f, octave=False)] += v`
+ * (esacf.py:68-69, periodicity.py:107-108, prime_multif0.py:70-72).  What that does to the five sharp pitch
+ * classes depends on the librosa the reference runs with (requirements.txt:3 leaves it unpinned):
+ *   MPX_NOTES_UNICODE  librosa >= 0.8 spells "C♯".  Chromagram.__getitem__ maps it to "C#" (chromagram.py:21),
+ *                      __setitem__ does not (chromagram.py:27-29), so the sum lands in a stray key that
+ *                      __add__ (chromagram.py:42-45) never reads: C#, D#, F#, G#, A# are silently dropped.
+ *                      This is what the reference computes with a librosa installed today; it is the default.
+ *   MPX_NOTES_ASCII    librosa < 0.8 spells "C#": every pitch class accumulates.  This is what the reference's
+ *                      README strings (README.md:33-73) and tests/test.py:14-20 expectations were written for. */
+#define MPX_NOTES_UNICODE 0
+#define MPX_NOTES_ASCII 1
+
 /* ---- ESACF (method 1): esacf.py:17-31 ctor kwargs ------------------------- */
 #define MPX_ENHANCE_LIBROSA010 0   /* librosa >= 0.10 time_stretch semantics (default) */
 #define MPX_ENHANCE_NOOP 1         /* time_stretch returns nothing: ESACF = clip(SACF, 0) */
@@ -115,6 +128,7 @@ typedef struct mpx_esacf_params {
     double peak_thresh;    /* default 0.1 */
     int peak_min_dist;     /* default 10 */
     int enhance_mode;      /* MPX_ENHANCE_* */
+    int note_names;        /* MPX_NOTES_* (default MPX_NOTES_UNICODE) */
 } mpx_esacf_params;
 
 /* One signal, host buffers.  replaces esacf.py:41-91.  frame = ham_samples
@@ -144,6 +158,7 @@ typedef struct mpx_prime_params {
     int num_octave;                /* default 2 */
     int harmonic_multiples_elim;   /* default 5 */
     int harmonic_elim_runs;        /* default 2 */
+    int note_names;                /* MPX_NOTES_* (default MPX_NOTES_UNICODE) */
 } mpx_prime_params;
 
 int mpx_prime_multif0(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
@@ -174,6 +189,7 @@ typedef struct mpx_if0_params {
     double epsilon1;     /* default 20 */
     double epsilon2;     /* default 320 */
     double gamma;        /* default 0.66 */
+    int note_names;      /* MPX_NOTES_* (default MPX_NOTES_UNICODE) */
 } mpx_if0_params;
 
 int mpx_iterative_f0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,

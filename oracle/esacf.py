@@ -21,7 +21,19 @@ SACF_K = 0.67  # esacf.py:95-96: self.k is never forwarded (quirk A.6)
 # Chromagram.__add__ (chromagram.py:43-44) never reads: every sharp pitch class
 # is silently dropped by the hz_to_note-based methods (1, 3, 4).  Method 2
 # indexes by int and is unaffected.
+# That is the behaviour with librosa >= 0.8 (note_names="unicode", what an install
+# of the reference gets today: requirements.txt:3 is unpinned).  librosa < 0.8
+# spelled "C#" (note_names="ascii"): nothing is lost, and that is what the
+# reference's README strings and tests/test.py:14-20 expectations were written for.
 SHARP_PITCH_CLASSES = (1, 3, 6, 8, 10)
+NOTE_NAME_MODES = ("unicode", "ascii")
+
+
+def dropped_pitch_classes(note_names="unicode"):
+    """Pitch classes `chromagram[hz_to_note(f)] += v` loses (chromagram.py:19-29)."""
+    if note_names not in NOTE_NAME_MODES:
+        raise ValueError("note_names must be one of %s" % (NOTE_NAME_MODES,))
+    return SHARP_PITCH_CLASSES if note_names == "unicode" else ()
 
 
 def ham_samples(fs, ham_ms=46.4):
@@ -70,13 +82,14 @@ def esacf_enhance(x2, n_peaks=6, mode="librosa010"):
     return x2tmp
 
 
-def frame_chroma(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, detail=False):
+def frame_chroma(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, detail=False, note_names="unicode"):
     """reference esacf.py:56-71: peak pick, gaussian interpolation, pitch-class
     scatter.  The i-th *interpolated* lag is paired with the i-th peak index
     (quirk A.8)."""
     peaks = tp.peak_indexes(x_esacf, thres=peak_thresh, min_dist=peak_min_dist)
     interp = tp.peak_interpolate(np.arange(x_esacf.shape[0]), x_esacf, peaks)
     chroma = np.zeros(12)
+    dropped = dropped_pitch_classes(note_names)
     for i, tau in enumerate(interp):
         with np.errstate(all="ignore"):
             pitch = fs / tau
@@ -84,7 +97,7 @@ def frame_chroma(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, detail=False):
             pc = tp.hz_to_pitch_class(pitch)
         except ValueError:
             continue
-        if pc in SHARP_PITCH_CLASSES:
+        if pc in dropped:
             continue
         chroma[pc] += x_esacf[peaks[i]]
     if detail:
@@ -92,18 +105,18 @@ def frame_chroma(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, detail=False):
     return chroma
 
 
-def frame_fragility(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, eps=1e-12, trials=2):
+def frame_fragility(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, eps=1e-12, trials=2, note_names="ascii"):
     """Test helper: True when the REFERENCE ALGORITHM ITSELF is ill-conditioned on this frame,
     i.e. a relative perturbation of 1e-12 of the ESACF row (far below anything float64 FFTs
     can promise) changes the frame's chroma by more than 1e-6.  That happens when a gaussian
     fit runs away from its 21-sample window (MINPACK then stops wherever its tolerances say,
     and the "centre" decides the pitch class) or a pitch rounds on a pitch-class boundary.
     Such frames are compared on identical inputs only (tests/test_gpu_esacf.py)."""
-    base = frame_chroma(x_esacf, fs, peak_thresh, peak_min_dist)
+    base = frame_chroma(x_esacf, fs, peak_thresh, peak_min_dist, note_names=note_names)
     rng = np.random.default_rng(12345)
     for _ in range(trials):
         pert = x_esacf * (1.0 + eps * rng.standard_normal(x_esacf.shape[0]))
-        other = frame_chroma(pert, fs, peak_thresh, peak_min_dist)
+        other = frame_chroma(pert, fs, peak_thresh, peak_min_dist, note_names=note_names)
         if not np.allclose(base, other, rtol=1e-6, atol=1e-12):
             return True
     return False
@@ -121,7 +134,7 @@ def frame_has_runaway_fit(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, width=
 
 
 def esacf_frames(x, fs, frame_size=None, hop=None, n_peaks_elim=6, peak_thresh=0.1,
-                 peak_min_dist=10, enhance_mode="librosa010"):
+                 peak_min_dist=10, enhance_mode="librosa010", note_names="unicode"):
     if frame_size is None:
         frame_size = ham_samples(fs)
     frames = dsp.frame_matrix(x, frame_size, hop)
@@ -130,7 +143,7 @@ def esacf_frames(x, fs, frame_size=None, hop=None, n_peaks_elim=6, peak_thresh=0
     out = np.zeros((frames.shape[0], 12))
     for f in range(frames.shape[0]):
         e = esacf_enhance(s[f], n_peaks_elim, enhance_mode)
-        out[f] = frame_chroma(e, fs, peak_thresh, peak_min_dist)
+        out[f] = frame_chroma(e, fs, peak_thresh, peak_min_dist, note_names=note_names)
     return out
 
 

@@ -12,7 +12,7 @@ import math
 import numpy as np
 
 from . import dsp
-from .esacf import SHARP_PITCH_CLASSES
+from .esacf import dropped_pitch_classes
 from .thirdparty import hz_to_pitch_class
 
 try:  # same call the reference makes; C speed matters for 70 channels x whole-signal filters
@@ -82,7 +82,8 @@ class Periodicity:
     """periodicity.py:14-163 restated (plain Python floats; numpy only for the array)."""
 
     def __init__(self, fs, window_size, max_voices=4, tau_min=1.0 / 2100.0, tau_max=1.0 / 40.0, tau_prec=0.0000001,
-                 Q=20, M=20, epsilon1=20, epsilon2=320, gamma=0.66):
+                 Q=20, M=20, epsilon1=20, epsilon2=320, gamma=0.66, note_names="unicode"):
+        self.dropped = dropped_pitch_classes(note_names)
         self.fs, self.window_size, self.K = fs, window_size, window_size / fs
         self.max_voices, self.tau_min, self.tau_max, self.tau_prec = max_voices, tau_min, tau_max, tau_prec
         self.Q, self.M, self.epsilon1, self.epsilon2, self.gamma = Q, M, epsilon1, epsilon2, gamma
@@ -159,16 +160,16 @@ class Periodicity:
                 pc = hz_to_pitch_class(pitch)
             except OverflowError:  # unused voices: fs/0 = inf (quirk A.13)
                 continue
-            if pc not in SHARP_PITCH_CLASSES:  # quirk A.18
+            if pc not in self.dropped:  # quirk A.18
                 chroma[pc] += sal[i]
         return chroma, sal, per
 
 
-def iterative_f0_frames(x, fs, frame_size=8192, power=1.0, channels=70, zeta0=2.3, zeta1=0.39):
+def iterative_f0_frames(x, fs, frame_size=8192, power=1.0, channels=70, zeta0=2.3, zeta1=0.39, note_names="unicode"):
     """Per-frame chroma [F,12].  One Periodicity object for the whole clip, like the reference
     (iterative_f0.py:45): its smax[] scratch leaks from frame to frame."""
     Ut = summary_spectra(x, fs, frame_size, power, channels, zeta0, zeta1)
-    est = Periodicity(fs, frame_size)
+    est = Periodicity(fs, frame_size, note_names=note_names)
     return np.array([est.compute(U)[0] for U in Ut]), Ut
 
 

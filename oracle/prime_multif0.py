@@ -9,7 +9,7 @@ numpy.hanning, and librosa's closed-form note helpers.
 import numpy as np
 
 from . import dsp
-from .esacf import SHARP_PITCH_CLASSES
+from .esacf import dropped_pitch_classes
 from .thirdparty import cqt_frequencies, hz_to_pitch_class, note_to_hz
 
 
@@ -32,10 +32,11 @@ def freq_axis(n, fs):
     return np.arange(0, n // 2 + 1) * val
 
 
-def frame_contributions(s, f, harmonic_multiples_elim=5, harmonic_elim_runs=2):
+def frame_contributions(s, f, harmonic_multiples_elim=5, harmonic_elim_runs=2, note_names="unicode"):
     """prime_multif0.py:66-82 on one half-spectrum: list of (pitch_class, value)."""
     s = s.copy()
     out = []
+    dropped = dropped_pitch_classes(note_names)
     for _ in range(harmonic_elim_runs):
         idx = int(s.argmax(axis=0))
         max_f = f[idx]
@@ -44,14 +45,15 @@ def frame_contributions(s, f, harmonic_multiples_elim=5, harmonic_elim_runs=2):
                 pc = hz_to_pitch_class(max_f)
         except (ValueError, OverflowError):
             continue
-        if pc not in SHARP_PITCH_CLASSES:  # quirk A.18
+        if pc not in dropped:  # quirk A.18 (the elimination below still happens)
             out.append((pc, float(s[idx])))
         for k in range(1, harmonic_multiples_elim):
             s[np.where(f == k * max_f)] = 0.0
     return out
 
 
-def prime_compute(x, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5, harmonic_elim_runs=2):
+def prime_compute(x, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5, harmonic_elim_runs=2,
+                  note_names="unicode"):
     """Summed chroma [12] == MultipitchPrimeMultiF0.compute_pitches()."""
     overall = np.zeros(12)
     for _, ws in candidates(fs, num_harmonic, num_octave):
@@ -63,7 +65,7 @@ def prime_compute(x, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5
         chroma = np.zeros(12)
         for fr in range(frames.shape[0]):
             for pc, v in frame_contributions(spec[fr, :half_s], freqs[:half_f], harmonic_multiples_elim,
-                                             harmonic_elim_runs):
+                                             harmonic_elim_runs, note_names):
                 chroma[pc] += v
         overall = overall + chroma
     return overall

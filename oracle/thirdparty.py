@@ -18,7 +18,8 @@ import math
 
 import numpy as np
 
-NOTE_NAMES_UNICODE = ["C", "C♯", "D", "D♯", "E", "F", "F♯", "G", "G♯", "A", "A♯", "B"]
+NOTE_NAMES_UNICODE = ["C", "C♯", "D", "D♯", "E", "F", "F♯", "G", "G♯", "A", "A♯", "B"]  # librosa >= 0.8
+NOTE_NAMES_ASCII = ["C", "C#", "D", "D#", "E", "F", "F#", "G", "G#", "A", "A#", "B"]    # librosa < 0.8
 
 
 # --------------------------------------------------------------------------
@@ -36,9 +37,11 @@ def hz_to_pitch_class(f):
     return int(np.round(midi)) % 12
 
 
-def hz_to_note(f, octave=False):
+def hz_to_note(f, octave=False, unicode=True):
+    """librosa.hz_to_note(f, octave=...).  The spelling of sharps changed in librosa 0.8 ("C#" -> "C♯");
+    `unicode=False` is the older one (see oracle/esacf.py on what that does to the reference's chromagram)."""
     pc = hz_to_pitch_class(f)
-    name = NOTE_NAMES_UNICODE[pc]
+    name = (NOTE_NAMES_UNICODE if unicode else NOTE_NAMES_ASCII)[pc]
     if octave:
         name += str(int(np.round(float(hz_to_midi(f)))) // 12 - 1)
     return name

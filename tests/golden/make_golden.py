@@ -19,6 +19,13 @@ Provenance labels stored with every array:
   ref-code       reference code + numpy/scipy only           (pins the oracle)
   ref-code+stub  reference code calling our librosa.effects.time_stretch /
                  peakutils stand-ins (ESACF stages a7-a9)    (parity UNPINNED)
+  ref-code+notes reference code + numpy/scipy/matplotlib, with a stand-in for
+                 librosa.hz_to_note (closed form) whose SPELLING of sharps is a
+                 choice: librosa >= 0.8 writes "C♯", librosa < 0.8 wrote "C#".
+                 The reference's Chromagram loses unicode sharps on `+=`
+                 (chromagram.py:19-29), so methods 1, 3 and 4 have TWO sets of
+                 expected values: keys `<clip>/sum` ... are the unicode
+                 spelling, `<clip>/sum_ascii` ... the ASCII one.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -49,7 +56,7 @@ def install_stubs():
 
     librosa = types.ModuleType("librosa")
     librosa.load = lambda path, *a, **k: (_CLIPS[str(path)][0].copy(), _CLIPS[str(path)][1])
-    librosa.hz_to_note = tp.hz_to_note
+    librosa.hz_to_note = tp.hz_to_note   # unicode spelling; set_spelling() swaps it
     librosa.note_to_hz = tp.note_to_hz
     librosa.cqt_frequencies = tp.cqt_frequencies
     librosa.tone = tp.tone
@@ -87,6 +94,16 @@ def install_stubs():
                       ("numba", numba), ("soundfile", soundfile)):
         sys.modules[name] = mod
     sys.path.insert(0, REFERENCE)
+
+
+def set_spelling(mode):
+    """Which librosa the stand-in imitates: 'unicode' (>= 0.8) or 'ascii' (< 0.8).  The reference looks
+    `librosa.hz_to_note` up at call time, so swapping the module attribute is enough."""
+    uni = {"unicode": True, "ascii": False}[mode]
+    sys.modules["librosa"].hz_to_note = lambda f, octave=False: tp.hz_to_note(f, octave=octave, unicode=uni)
+
+
+SPELLINGS = (("unicode", ""), ("ascii", "_ascii"))   # (mode, key suffix)
 
 
 # ---------------------------------------------------------------- inputs (G1)
@@ -190,6 +207,11 @@ def main():
             warnings.simplefilter("ignore")
             assert o_chroma.detect_key(np.asarray(v, dtype=float)) == key
     consts["pack_key_cases"] = pack_cases
+    # the expectations the reference's tests/test.py:14-20 declares (and only prints) for its five tone clips:
+    # data, kept so the GPU tests can print them next to the engine's strings in both note spellings
+    consts["test_py_expected"] = {
+        "tone_Csharp3": "010000000000", "tone_E4": "000010000000", "tones_E2_F3": "000011000000",
+        "tones_G3_Asharp4": "000000010010", "tones_G2_B2_Gsharp3": "000000011001"}
     with open(os.path.join(HERE, "constants.json"), "w") as fh:
         json.dump(consts, fh, indent=1)
 
@@ -280,20 +302,23 @@ def main():
 
     # ------------------------------------------------------ ESACF end to end (ref-code+stub)
     es = {"provenance": np.array("ref-code+stub")}
-    for name, x in clips.items():
-        obj = chord_detection.MultipitchESACF(name)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            total = obj.compute_pitches()
-        es[name + "/sum"] = np.array([total[i] for i in range(12)])
-        es[name + "/repr"] = np.array(repr(total))
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            es[name + "/key"] = np.array(total.key())
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            mine = o_esacf.esacf_compute(x, fs)
-        np.testing.assert_allclose(mine, es[name + "/sum"], rtol=1e-6, atol=1e-9)
+    for mode, sfx in SPELLINGS:
+        set_spelling(mode)
+        for name, x in clips.items():
+            obj = chord_detection.MultipitchESACF(name)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                total = obj.compute_pitches()
+            es[name + "/sum" + sfx] = np.array([total[i] for i in range(12)])
+            es[name + "/repr" + sfx] = np.array(repr(total))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                es[name + "/key" + sfx] = np.array(total.key())
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                mine = o_esacf.esacf_compute(x, fs, note_names=mode)
+            np.testing.assert_allclose(mine, es[name + "/sum" + sfx], rtol=1e-6, atol=1e-9)
+    set_spelling("unicode")
     # enhancement + peak stages on a few SACF frames
     sd = np.load(os.path.join(HERE, "esacf_stages.npz"))
     for name in ("piano_like_Cmaj", "poly_seed1"):
@@ -314,41 +339,50 @@ def main():
 
     # ------------------------------------------------------ Prime-multiF0 (ref-code: real matplotlib.mlab inside)
     from oracle import prime_multif0 as o_prime
-    pr = {"provenance": np.array("ref-code")}
-    for name, x in clips.items():
+    pr = {"provenance": np.array("ref-code+notes")}
+    _CLIPS["__kw__"] = (clips["poly_seed1"], fs)
+    for mode, sfx in SPELLINGS:
+        set_spelling(mode)
+        for name, x in clips.items():
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                total = chord_detection.MultipitchPrimeMultiF0(name).compute_pitches()
+                pr[name + "/sum" + sfx] = np.array([total[i] for i in range(12)])
+                pr[name + "/repr" + sfx] = np.array(repr(total))
+                pr[name + "/key" + sfx] = np.array(total.key())
+                np.testing.assert_allclose(o_prime.prime_compute(x, fs, note_names=mode), pr[name + "/sum" + sfx],
+                                           rtol=1e-12, atol=0)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            total = chord_detection.MultipitchPrimeMultiF0(name).compute_pitches()
-            pr[name + "/sum"] = np.array([total[i] for i in range(12)])
-            pr[name + "/repr"] = np.array(repr(total))
-            pr[name + "/key"] = np.array(total.key())
-            np.testing.assert_allclose(o_prime.prime_compute(x, fs), pr[name + "/sum"], rtol=1e-12, atol=0)
-    _CLIPS["__kw__"] = (clips["poly_seed1"], fs)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        c = chord_detection.MultipitchPrimeMultiF0("__kw__", num_harmonic=2, num_octave=3, harmonic_multiples_elim=3,
-                                                   harmonic_elim_runs=3).compute_pitches()
-    pr["kwargs_h2_o3_e3_r3/sum"] = np.array([c[i] for i in range(12)])
-    np.testing.assert_allclose(o_prime.prime_compute(clips["poly_seed1"], fs, 2, 3, 3, 3), pr["kwargs_h2_o3_e3_r3/sum"], rtol=1e-12)
+            c = chord_detection.MultipitchPrimeMultiF0("__kw__", num_harmonic=2, num_octave=3,
+                                                       harmonic_multiples_elim=3, harmonic_elim_runs=3).compute_pitches()
+        pr["kwargs_h2_o3_e3_r3/sum" + sfx] = np.array([c[i] for i in range(12)])
+        np.testing.assert_allclose(o_prime.prime_compute(clips["poly_seed1"], fs, 2, 3, 3, 3, note_names=mode),
+                                   pr["kwargs_h2_o3_e3_r3/sum" + sfx], rtol=1e-12)
+    set_spelling("unicode")
     np.savez_compressed(os.path.join(HERE, "prime_multif0.npz"), **pr)
 
     # ------------------------------------------------------ Iterative F0 (ref-code: only closed-form librosa helpers)
     from oracle import iterative_f0 as o_if0
-    it = {"provenance": np.array("ref-code")}
-    for name in ("tone_E4", "tones_G2_B2_Gsharp3", "piano_like_Cmaj", "poly_seed1", "poly_seed2", "short_ragged"):
-        x = clips[name]
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            obj = chord_detection.MultipitchIterativeF0(name)
-            total = obj.compute_pitches()
-            it[name + "/sum"] = np.array([total[i] for i in range(12)])
-            it[name + "/repr"] = np.array(repr(total))
-            it[name + "/key"] = np.array(total.key())
-            per, Ut = o_if0.iterative_f0_frames(x, fs)
-            np.testing.assert_allclose(per.sum(0), it[name + "/sum"], rtol=1e-12, atol=0)
-        # a thin slice of the summary spectrum of frame 0 (full rows are 16384 doubles each)
-        it[name + "/ut0_head"] = Ut[0][:512].copy()
-        it[name + "/frames"] = per
+    it = {"provenance": np.array("ref-code+notes")}
+    for mode, sfx in SPELLINGS:
+        set_spelling(mode)
+        for name in ("tone_Csharp3", "tone_E4", "tones_G3_Asharp4", "tones_G2_B2_Gsharp3", "piano_like_Cmaj",
+                     "poly_seed1", "poly_seed2", "short_ragged"):
+            x = clips[name]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                obj = chord_detection.MultipitchIterativeF0(name)
+                total = obj.compute_pitches()
+                it[name + "/sum" + sfx] = np.array([total[i] for i in range(12)])
+                it[name + "/repr" + sfx] = np.array(repr(total))
+                it[name + "/key" + sfx] = np.array(total.key())
+                per, Ut = o_if0.iterative_f0_frames(x, fs, note_names=mode)
+                np.testing.assert_allclose(per.sum(0), it[name + "/sum" + sfx], rtol=1e-12, atol=0)
+            # a thin slice of the summary spectrum of frame 0 (full rows are 16384 doubles each)
+            it[name + "/ut0_head"] = Ut[0][:512].copy()
+            it[name + "/frames" + sfx] = per
+    set_spelling("unicode")
     np.savez_compressed(os.path.join(HERE, "iterative_f0.npz"), **it)
     print("golden fixtures written to", HERE)
 

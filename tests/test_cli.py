@@ -36,3 +36,24 @@ def test_cli_all_methods_on_generated_clip(tmp_path, capsys):
     assert out[6] == "3 - Iterative F0 (Klapuri, Anssi)" and out[9] == "4 - Prime-multiF0 (Camacho, Kaver-Oreamuno)"
     for i in (1, 4, 7, 10):
         assert len(out[i]) == 12 and out[i].isdigit()
+    # ... and the printed strings / keys are the oracle's for the samples the loader hands over, in both note spellings
+    import warnings
+    from oracle import chromagram as o_chroma, esacf as o_esacf, harmonic_energy as o_he
+    from oracle import iterative_f0 as o_if0, prime_multif0 as o_prime
+    y, fs = audio.load(path)
+    for mode in ("unicode", "ascii"):
+        assert chord_detect.main_cli(["--method", "-1", "--key", "--note-names", mode, str(path)]) == 0
+        got = capsys.readouterr().out.strip().splitlines()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = [o_esacf.esacf_compute(y, fs, note_names=mode), o_he.he_compute(y, fs),
+                    o_if0.iterative_f0_compute(y, fs, note_names=mode), o_prime.prime_compute(y, fs, note_names=mode)]
+            for m, w in enumerate(want):
+                assert got[3 * m + 1] == o_chroma.pack(w), (mode, m + 1, got[3 * m + 1], o_chroma.pack(w))
+                assert got[3 * m + 2] == o_chroma.detect_key(w), (mode, m + 1)
+
+
+def test_cli_note_names_flag_parses(tmp_path):
+    from chord_detection_amd import chord_detect
+    with pytest.raises(SystemExit):
+        chord_detect.main_cli(["--note-names", "latin1", str(tmp_path / "nope.wav")])

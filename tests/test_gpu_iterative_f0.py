@@ -1,6 +1,7 @@
 """GPU parity: Iterative-F0 (reference method 3) through the C ABI vs fixtures made by the
 reference's own code and vs the oracle.  fp64.  The summary spectra are held to 1e-9; the chroma to the
 north_star 1e-5 (the saliences are ~1e13 because of quirk A.11, and the period search is discrete)."""
+import json
 import os
 import warnings
 
@@ -9,6 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 FS = 22050
+SPELLINGS = (("unicode", ""), ("ascii", "_ascii"))   # note_names mode, fixture key suffix (make_golden.py)
 
 
 @pytest.fixture(scope="module")
@@ -28,18 +30,31 @@ def test_golden_clips(eng, clips, golden_dir):
     d = np.load(os.path.join(golden_dir, "iterative_f0.npz"))
     assert cd.METHODS[3] is cd.MultipitchIterativeF0 and list(cd.METHODS.keys()) == [1, 2, 3, 4]
     assert cd.MultipitchIterativeF0.display_name() == "Iterative F0 (Klapuri, Anssi)"
-    for name in ("tone_E4", "tones_G2_B2_Gsharp3", "piano_like_Cmaj", "poly_seed1", "poly_seed2", "short_ragged"):
+    expected = json.load(open(os.path.join(golden_dir, "constants.json")))["test_py_expected"]
+    for name in ("tone_Csharp3", "tone_E4", "tones_G3_Asharp4", "tones_G2_B2_Gsharp3", "piano_like_Cmaj", "poly_seed1",
+                 "poly_seed2", "short_ragged"):
         x = clips[name]
         ut = eng.iterative_f0_spectra(x, FS)
         np.testing.assert_allclose(ut[0][:512], d[name + "/ut0_head"], rtol=1e-9)
-        total, per = eng.iterative_f0(x, FS, return_frames=True)
-        np.testing.assert_allclose(per, d[name + "/frames"], rtol=1e-5, atol=0)
-        np.testing.assert_allclose(total, d[name + "/sum"], rtol=1e-5, atol=0)
-        c = cd.MultipitchIterativeF0((x, FS)).compute_pitches()
-        assert repr(c) == str(d[name + "/repr"])
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            assert c.key() == str(d[name + "/key"])
+        for mode, sfx in SPELLINGS:
+            total, per = eng.iterative_f0(x, FS, return_frames=True, note_names=mode)
+            np.testing.assert_allclose(per, d[name + "/frames" + sfx], rtol=1e-5, atol=0)
+            np.testing.assert_allclose(total, d[name + "/sum" + sfx], rtol=1e-5, atol=0)
+            c = cd.MultipitchIterativeF0((x, FS), note_names=mode).compute_pitches()
+            assert repr(c) == str(d[name + "/repr" + sfx])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                assert c.key() == str(d[name + "/key" + sfx])
+            if mode == "unicode":
+                assert all(total[pc] == 0.0 for pc in (1, 3, 6, 8, 10))   # quirk A.18
+            if name in expected:
+                print("if0    %-8s %-20s engine %s  tests/test.py expects %s" % (mode, name, repr(c), expected[name]))
+    got = eng.iterative_f0_batch([clips["tone_Csharp3"], clips["tone_E4"]], FS, note_names="ascii")
+    np.testing.assert_allclose(got[0], d["tone_Csharp3/sum_ascii"], rtol=1e-5)
+    np.testing.assert_allclose(got[1], d["tone_E4/sum_ascii"], rtol=1e-5)
+    assert got[0][1] > 0      # the C# bin of the C#3 tone survives with ASCII names
+    with pytest.raises(ValueError):
+        eng.iterative_f0(clips["tone_E4"], FS, note_names="latin1")
 
 
 def test_spectra_and_batch_vs_oracle(eng, clips):

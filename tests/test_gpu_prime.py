@@ -1,6 +1,7 @@
 """GPU parity: Prime-multiF0 (reference method 4) through the C ABI vs fixtures made by
 the reference's own code (with the real matplotlib.mlab) and vs the oracle.  fp64; north_star bar 1e-5,
 held here at 1e-9."""
+import json
 import os
 import warnings
 
@@ -10,6 +11,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 FS = 22050
 RTOL = 1e-9
+SPELLINGS = (("unicode", ""), ("ascii", "_ascii"))   # note_names mode, fixture key suffix (make_golden.py)
 
 
 @pytest.fixture(scope="module")
@@ -29,16 +31,27 @@ def test_golden_clips_sum_string_key(eng, clips, golden_dir):
     d = np.load(os.path.join(golden_dir, "prime_multif0.npz"))
     assert cd.METHODS[4] is cd.MultipitchPrimeMultiF0
     assert cd.MultipitchPrimeMultiF0.display_name() == "Prime-multiF0 (Camacho, Kaver-Oreamuno)"
-    for name, x in clips.items():
-        c = cd.MultipitchPrimeMultiF0((x, FS)).compute_pitches()
-        np.testing.assert_allclose(c.as_array(), d[name + "/sum"], rtol=RTOL, atol=0)
-        assert repr(c) == str(d[name + "/repr"])
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            assert c.key() == str(d[name + "/key"])
-        assert all(c[pc] == 0.0 for pc in (1, 3, 6, 8, 10))   # quirk A.18
-    got = eng.prime_multif0(clips["poly_seed1"], FS, 2, 3, 3, 3)
-    np.testing.assert_allclose(got, d["kwargs_h2_o3_e3_r3/sum"], rtol=RTOL)
+    expected = json.load(open(os.path.join(golden_dir, "constants.json")))["test_py_expected"]
+    for mode, sfx in SPELLINGS:
+        for name, x in clips.items():
+            c = cd.MultipitchPrimeMultiF0((x, FS), note_names=mode).compute_pitches()
+            np.testing.assert_allclose(c.as_array(), d[name + "/sum" + sfx], rtol=RTOL, atol=0)
+            assert repr(c) == str(d[name + "/repr" + sfx])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                assert c.key() == str(d[name + "/key" + sfx])
+            if mode == "unicode":
+                assert all(c[pc] == 0.0 for pc in (1, 3, 6, 8, 10))   # quirk A.18
+            if name in expected:
+                print("prime  %-8s %-20s engine %s  tests/test.py expects %s" % (mode, name, repr(c), expected[name]))
+        got = eng.prime_multif0(clips["poly_seed1"], FS, 2, 3, 3, 3, note_names=mode)
+        np.testing.assert_allclose(got, d["kwargs_h2_o3_e3_r3/sum" + sfx], rtol=RTOL)
+    assert np.any(eng.prime_multif0(clips["tone_Csharp3"], FS, note_names="ascii")[[1, 3, 6, 8, 10]] > 0)
+    got = eng.prime_multif0_batch([clips["tone_Csharp3"], clips["tone_E4"]], FS, note_names="ascii")
+    np.testing.assert_allclose(got[0], d["tone_Csharp3/sum_ascii"], rtol=RTOL)
+    np.testing.assert_allclose(got[1], d["tone_E4/sum_ascii"], rtol=RTOL)
+    with pytest.raises(ValueError):
+        eng.prime_multif0(clips["tone_E4"], FS, note_names="latin1")
 
 
 def test_batch_edge_cases_vs_oracle(eng, clips):
