@@ -57,6 +57,22 @@ void* upload(mpx_ctx* ctx, const void* host, size_t bytes) {
     return d;
 }
 
+void prof_mark_slow(mpx_ctx* ctx, hipStream_t st, const char* name) {
+    if (ctx->prof_marks.size() >= (size_t)1 << 20) return;  // bounded: a forgotten mpx_profile_end must not eat the host
+    hipEvent_t ev = nullptr;
+    if (!ctx->prof_pool.empty()) {
+        ev = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+    } else if (hipEventCreate(&ev) != hipSuccess) {
+        return;
+    }
+    if (hipEventRecord(ev, st) != hipSuccess) {
+        ctx->prof_pool.push_back(ev);
+        return;
+    }
+    ctx->prof_marks.push_back({name, ev});
+}
+
 static int64_t num_frames_of(int64_t n, int frame, int hop) {
     if (n <= 0) return 0;
     if (hop == frame) return (n + frame - 1) / frame;
@@ -140,6 +156,8 @@ void mpx_destroy(mpx_ctx* ctx) {
     for (DevBuf* b : {&ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
                       &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3, &ctx->d_counter})
         if (b->p) hipFree(b->p);
+    for (auto& m : ctx->prof_marks) hipEventDestroy(m.ev);
+    for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -172,6 +190,47 @@ int mpx_timer_end(mpx_ctx* ctx, void* stream, float* ms) {
     MPX_HIP(ctx, hipEventRecord(ctx->ev1, stream ? (hipStream_t)stream : ctx->stream));
     MPX_HIP(ctx, hipEventSynchronize(ctx->ev1));
     MPX_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return MPX_OK;
+}
+
+int mpx_profile_begin(mpx_ctx* ctx) {
+    if (!ctx) return MPX_EINVAL;
+    for (auto& m : ctx->prof_marks) ctx->prof_pool.push_back(m.ev);
+    ctx->prof_marks.clear();
+    ctx->prof_on = true;
+    return MPX_OK;
+}
+
+int mpx_profile_end(mpx_ctx* ctx, char* report, int cap) {
+    if (!ctx || !report || cap < 1) return MPX_EINVAL;
+    ctx->prof_on = false;
+    report[0] = 0;
+    std::map<std::string, std::pair<long long, double>> acc;
+    std::vector<std::string> order;
+    for (size_t i = 0; i + 1 < ctx->prof_marks.size(); ++i) {
+        const auto& a = ctx->prof_marks[i];
+        if (!a.name) continue;
+        MPX_HIP(ctx, hipEventSynchronize(ctx->prof_marks[i + 1].ev));
+        float ms = 0.f;
+        MPX_HIP(ctx, hipEventElapsedTime(&ms, a.ev, ctx->prof_marks[i + 1].ev));
+        auto it = acc.find(a.name);
+        if (it == acc.end()) {
+            order.push_back(a.name);
+            it = acc.emplace(a.name, std::make_pair(0LL, 0.0)).first;
+        }
+        it->second.first += 1;
+        it->second.second += ms;
+    }
+    std::string out;
+    for (const auto& name : order) {
+        char line[256];
+        snprintf(line, sizeof line, "%s %lld %.6f\n", name.c_str(), acc[name].first, acc[name].second);
+        out += line;
+    }
+    for (auto& m : ctx->prof_marks) ctx->prof_pool.push_back(m.ev);
+    ctx->prof_marks.clear();
+    if ((int)out.size() + 1 > cap) return set_error(ctx, MPX_EINVAL, "mpx_profile_end: report needs %zu bytes", out.size() + 1);
+    memcpy(report, out.c_str(), out.size() + 1);
     return MPX_OK;
 }
 

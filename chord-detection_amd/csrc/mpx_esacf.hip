@@ -1871,6 +1871,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     for (long long f0 = 0; f0 < num_frames; f0 += batch) {
         const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
         double* xw = (stage == MPX_STAGE_WFIR) ? d_stage_out + (size_t)f0 * N : nullptr;
+        prof_mark(ctx, st, "bandsplit_kernel");
         if (xw)
             hipLaunchKernelGGL(bandsplit_kernel<true>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
                                (long long)n, d_desc, f0, nf, N, hop, coef, xb, xw);
@@ -1882,6 +1883,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             hipLaunchKernelGGL(band_unpack_kernel, dim3((unsigned)nf), dim3(256), 0, st, xb, nf, N, stage == MPX_STAGE_XHI ? 1 : 0,
                                d_stage_out + (size_t)f0 * N);
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
+        prof_mark(ctx, st, nullptr);
         MPX_HIP(ctx, hipMemsetAsync(total, 0, 6 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts
         SacfArgs a;
         a.xb = xb;
@@ -1908,6 +1910,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         // two frames makes results depend on the batch neighbour and flips 0.075 % of the frames (ill-conditioned fits)
         a.pair = !deterministic && getenv("MPX_SACF_PAIR") && atoi(getenv("MPX_SACF_PAIR")) ? 1 : 0;
         a.ablate = getenv("MPX_SACF_ABLATE") ? atoi(getenv("MPX_SACF_ABLATE")) : 0;
+        prof_mark(ctx, st, plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel");
         if (plan.L == 8192) {
             const size_t lds = sizeof(cx<double>) * lds_slots(8192) + sizeof(double) * (size_t)(Mh + 2);
             auto kern = sacf_big_kernel<8192, 512>;
@@ -1945,8 +1948,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             pa.tw = (const cx<double>*)pit->second[0];
             const size_t pv_lds = sizeof(cx<double>) * lds_slots(PV_NFFT) + sizeof(double) * (size_t)(Mh + 2);
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)pv_enhance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_lds));
+            prof_mark(ctx, st, "pv_enhance_kernel");
             hipLaunchKernelGGL(pv_enhance_kernel, dim3((unsigned)nf), dim3(PV_T), pv_lds, st, pa);
             const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
+            prof_mark(ctx, st, "peakpick_kernel");
             hipLaunchKernelGGL(peakpick_kernel<256>, dim3((unsigned)nf), dim3(256), pk_lds, st, a);
             MPX_HIP(ctx, hipGetLastError());
         }
@@ -1954,6 +1959,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
             hipLaunchKernelGGL(peakpick_kernel<64>, dim3((unsigned)nf), dim3(64), pk_lds, st, a);
         }
+        prof_mark(ctx, st, nullptr);
         if (stage == MPX_STAGE_ESACF)
             MPX_HIP(ctx, hipMemcpyAsync(d_stage_out + (size_t)f0 * Mh, y, (size_t)nf * Mh * 8,
                                         hipMemcpyDeviceToDevice, st));
@@ -1966,23 +1972,28 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             // MINPACK: maxfev = 200 (n + 1); the env knobs are for profiling
             const int maxfev = getenv("MPX_FIT_MAXFEV") ? atoi(getenv("MPX_FIT_MAXFEV")) : 200 * (lm::NP + 1);
             const bool park = !deterministic && !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
+            prof_mark(ctx, st, "peakfit_kernel");
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : (nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
                                getenv("MPX_FIT_PARK_LIVE") ? atoi(getenv("MPX_FIT_PARK_LIVE")) : PARK_LIVE,
                                getenv("MPX_FIT_PARK_CAP") ? atoi(getenv("MPX_FIT_PARK_CAP")) : PARK_CAP);
+            if (park) prof_mark(ctx, st, "coopfit_kernel");
             if (park)  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
                 hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 12)), dim3(64), 0, st, parked, total + 3,
                                    total + 4, y, center, okf, maxfev);
         }
+        prof_mark(ctx, st, nullptr);
         if (getenv("MPX_DEBUG_FITS")) {  // profiling aid: work-list counters of this batch
             int h[5];
             MPX_HIP(ctx, hipMemcpyAsync(h, total, sizeof(h), hipMemcpyDeviceToHost, st));
             MPX_HIP(ctx, hipStreamSynchronize(st));
             fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d\n", nf, h[0] + h[2], h[0], h[3]);
         }
+        prof_mark(ctx, st, "scatter_kernel");
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,
                            p.note_names, y, peak_count, peak_idx, center, okf, d_chroma_frames);
+        prof_mark(ctx, st, nullptr);
         MPX_HIP(ctx, hipGetLastError());
     }
     return MPX_OK;

@@ -670,7 +670,9 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
         a.sum = d_sum;
         a.counter = (unsigned*)ctx->d_counter.p;
     }
+    prof_mark(ctx, stream, "he_kernel");
     hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(T), lds, stream, a);
+    prof_mark(ctx, stream, nullptr);
     MPX_HIP(ctx, hipGetLastError());
     return MPX_OK;
 }
@@ -900,7 +902,9 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
     auto launch = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 160 * 1024) return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame %d needs %zu B of LDS", N, lds);
         if (lds > 48 * 1024) MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_mark(ctx, stream, "he_blue_kernel");
         hipLaunchKernelGGL(kern, dim3((unsigned)num_frames), dim3(T), lds, stream, a);
+        prof_mark(ctx, stream, nullptr);
         MPX_HIP(ctx, hipGetLastError());
         return MPX_OK;
     };

@@ -850,15 +850,18 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     double* ut = (double*)ctx->d_ws1.p;
     double* ur = ut + (size_t)nframes * n2;
     double* ud = ur + (size_t)nframes * n2;
+    prof_mark(ctx, st, "if0_frontend_kernel");
     hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
                        (const float*)ctx->d_signal.p, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
                        d_tail_groups);
     MPX_HIP(ctx, hipGetLastError());
+    prof_mark(ctx, st, "if0_spectrum_kernel");
     if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     else rc = if0_spectrum_launch<8192, 512>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
     if (rc) return rc;
+    prof_mark(ctx, st, nullptr);
     if (ut_out) MPX_HIP(ctx, hipMemcpyAsync(ut_out, ut, (size_t)nframes * n2 * sizeof(double), hipMemcpyDeviceToHost, st));
     If0PerArgs a;
     a.ut = ut;
@@ -879,7 +882,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     a.epsilon2 = p.epsilon2;
     a.gamma = p.gamma;
     a.chroma = (double*)ctx->d_frames_out.p;
+    prof_mark(ctx, st, "if0_periodicity_kernel");
     hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
     if (chroma_frames)
         MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nframes * 12 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -61,6 +61,14 @@ struct mpx_ctx {
     std::map<std::string, int> occupancy;      // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answers
     std::map<int, std::vector<double>> remez;  // user-registered warped-FIR taps per sample rate
     std::vector<void*> owned;  // plan tables, freed in mpx_destroy
+    // per-kernel timing (mpx_profile_begin / mpx_profile_end): an event in front of every launch while enabled
+    struct ProfMark {
+        const char* name;  // kernel launched right after the event; nullptr closes the previous region
+        hipEvent_t ev;
+    };
+    bool prof_on = false;
+    std::vector<ProfMark> prof_marks;
+    std::vector<hipEvent_t> prof_pool;
 };
 
 namespace mpx {
@@ -68,6 +76,11 @@ namespace mpx {
 int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
 void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failure (error set)
+// While profiling is on: record an event on `st`; the time to the next mark is booked on `name` (nullptr: on nothing).
+void prof_mark_slow(mpx_ctx* ctx, hipStream_t st, const char* name);
+inline void prof_mark(mpx_ctx* ctx, hipStream_t st, const char* name) {
+    if (ctx->prof_on) prof_mark_slow(ctx, st, name);
+}
 
 #define MPX_HIP(ctx, call)                                                                   \
     do {                                                                                     \

@@ -331,6 +331,7 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     int* d_pc = (int*)(d_val + (nitems + 1) * PRIME_MAX_RUNS);
     char* d_items = (char*)ctx->d_desc.p;
     size_t off = 0;
+    prof_mark(ctx, st, "prime_kernel");
     for (int cls = 0; cls < 4; ++cls) {
         const size_t bytes = items[cls].size() * sizeof(PrimeItem);
         if (bytes) MPX_HIP(ctx, hipMemcpyAsync(d_items + off, items[cls].data(), bytes, hipMemcpyHostToDevice, st));
@@ -343,9 +344,11 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         if (cls == 3) prime_launch<8192, 512>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
         off += bytes;
     }
+    prof_mark(ctx, st, "prime_sum_kernel");
     if (num_clips)
         hipLaunchKernelGGL(prime_sum_kernel, dim3(num_clips), dim3(64), 0, st, (const long long*)ctx->d_offsets.p,
                            p.harmonic_elim_runs, d_pc, d_val, (double*)ctx->d_sum.p);
+    prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
     if (num_clips)
         MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -293,6 +293,21 @@ class Engine:
         return float(ms.value)
 
 
+    def profile_begin(self):
+        """Per-kernel HIP-event timing of everything this context launches until profile_end (include/mpx.h)."""
+        self._check(self.lib.mpx_profile_begin(self.ctx))
+
+    def profile_end(self):
+        """{kernel name: (launches, total milliseconds)} in order of first launch."""
+        buf = C.create_string_buffer(1 << 16)
+        self._check(self.lib.mpx_profile_end(self.ctx, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, launches, ms = line.rsplit(" ", 2)
+            out[name] = (int(launches), float(ms))
+        return out
+
+
 def get_engine(device=0, f32=False):
     """Process-wide engine per (device, dtype)."""
     key = (int(device), bool(f32))

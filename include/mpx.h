@@ -235,6 +235,17 @@ int mpx_test_gaussian_fit(const double* xs, const double* ys, int m, double* cen
 int mpx_timer_begin(mpx_ctx* ctx, void* stream);
 int mpx_timer_end(mpx_ctx* ctx, void* stream, float* ms);
 
+/* ---- per-kernel timing ------------------------------------------------------
+ * Between mpx_profile_begin and mpx_profile_end the library records a HIP event on the launching stream in front of
+ * every kernel it launches (and one behind the last kernel of a call); the time from one event to the next is booked
+ * on the kernel launched in between.  mpx_profile_end waits for the events and writes one line per kernel name,
+ * "name launches total_ms\n", in order of first launch, into report[cap] (NUL terminated).  The events sit between
+ * back-to-back launches on one stream, so a figure includes the launch gap (a few microseconds): meant for kernels
+ * of a tenth of a millisecond and up -- bench.py times the 50-microsecond Harmonic-Energy kernel over many launches
+ * with mpx_timer_begin/_end instead.  Off by default: costs nothing unless enabled. */
+int mpx_profile_begin(mpx_ctx* ctx);
+int mpx_profile_end(mpx_ctx* ctx, char* report, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,13 +11,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(*extra):
+def _run_bench(*extra, cpu_budget="1"):
+    env = dict(os.environ, MPX_BENCH_CPU_BUDGET=cpu_budget)   # seconds per CPU leg: the contract, not the figures
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "6", *extra],
-                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout          # ONE JSON line
     return json.loads(lines[0])
+
+
+def _check_roofline(r):
+    assert r["bound"] in ("hbm", "valu_f64") and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
+    assert 0.0 < r["frac"] < 1.0 and 0.0 < r["hbm_frac"] < 1.0 and r["kernel_ms"] > 0
+    if r["bound"] == "hbm":
+        assert r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert r["achieved"] == pytest.approx(r["bytes_per_unit"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)
+    else:
+        assert r["unit"] == "TFLOP/s" and r["peak"] == 78.65
+        assert r["achieved"] == pytest.approx(r["flops_per_unit"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12, rel=1e-6)
 
 
 def test_bench_line_has_the_contract_fields():
@@ -28,26 +40,46 @@ def test_bench_line_has_the_contract_fields():
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "model" not in d["config"]
     assert "configs[1]" in d["config"]["workload"] and d["config"]["frames_per_gpu"] == 8192
     assert d["value"] == pytest.approx(8192 / (d["ms_per_step"] * 1e-3), rel=1e-6)
-    assert 1e7 < d["value"] < 2e9                  # between a broken launch and the HBM roofline (1.93e9 frames/s)
+    assert d["value_one_in_flight"] == pytest.approx(8192 / (d["ms_per_step_one_in_flight"] * 1e-3), rel=1e-6)
+    assert 1e7 < d["value_one_in_flight"] <= d["value"] * 1.05 < 2e9   # between a broken launch and the HBM roofline (1.93e9 frames/s)
+    # the steps rotate over more input than the Infinity Cache holds
+    assert d["config"]["distinct_input_signals"] == 9 and d["config"]["input_bytes_rotated_over"] > 256 * 2 ** 20
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
     assert r["achieved"] == pytest.approx(4144 * 8192 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)   # algorithmic bytes / kernel time
     assert 0.0 < r["kernel_ms"] <= r["step_ms_hip_events"] * 1.05     # the kernel is inside the (one-at-a-time) step
     assert d["config"]["batches_in_flight"] == 2 and r["in_flight"]["batches"] == 2
-    assert d["ms_per_step"] <= r["step_ms_hip_events"] * 1.05         # two batches in flight are not slower than one
     assert r["in_flight"]["frac"] == pytest.approx(4144 * 8192 / (d["ms_per_step"] * 1e-3) / 8.0e12, rel=1e-6)
     assert r["traffic"] is None or r["traffic"] >= 0.9 * 4144 * 8192
     assert r["secondary"]["bound"] == "valu_f64" and 0.0 < r["secondary"]["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "frames/s" and c["value"] > 0 and "sample" in c
-    assert d["value"] > 100 * c["value"]
+    assert c["host"]["model"] and c["host"]["physical"] >= 1
+    if c["host"]["workers"] > 1:
+        assert c["all_cores"]["cores"] == c["host"]["workers"] and c["all_cores"]["value"] > 0
+    # every BASELINE workload and the north star's Target are in the same line, each with its own roofline and CPU leg
+    w = d["workloads"]
+    assert set(w) == {"esacf_clips_4096", "esacf_stft_8192", "corpus_4096_all_methods", "if0_stream_1h"}
+    assert w["esacf_clips_4096"]["unit"] == "frames/s" and w["esacf_clips_4096"]["config"]["frames_per_gpu"] == 4096 * 44
+    assert w["esacf_clips_4096"]["oracle_spot_check"] is True and w["esacf_stft_8192"]["oracle_spot_check"] is True
+    assert w["esacf_stft_8192"]["config"]["frames_per_gpu"] == 8192
+    assert w["esacf_stft_8192"]["value_three_in_flight"] >= 0.9 * w["esacf_stft_8192"]["value"]
+    assert w["corpus_4096_all_methods"]["unit"] == "clips/s" and w["corpus_4096_all_methods"]["nonzero_rows"] > 4 * 4000
+    assert w["if0_stream_1h"]["unit"] == "x real time" and w["if0_stream_1h"]["frames"] == 19380
+    for name, rec in w.items():
+        assert rec["value"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["unit"] == rec["unit"], name
+        assert "kernel" in rec["roofline"] and rec["roofline"]["kernel_ms"] > 0, name
+        for r in rec.get("rooflines", {}).values():
+            _check_roofline(r)
+    _check_roofline(w["esacf_clips_4096"]["roofline"])
+    _check_roofline(w["if0_stream_1h"]["roofline"])
 
 
 def test_bench_without_cpu_leg_and_smoke():
-    d = _run_bench("--no-cpu-baseline", "--streams", "1")
-    assert d["config"]["batches_in_flight"] == 1
-    assert "roofline" in d and d.get("cpu_baseline") in (None, {}) or "cpu_baseline" not in d
+    d = _run_bench("--no-cpu-baseline", "--streams", "1", "--headline-only")
+    assert d["config"]["batches_in_flight"] == 1 and "workloads" not in d
+    assert "roofline" in d and "cpu_baseline" not in d
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]
