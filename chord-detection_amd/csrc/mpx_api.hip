@@ -134,6 +134,7 @@ mpx_ctx* mpx_create(int device, int flags) {
     }
     ctx->device = device;
     ctx->flags = flags;
+    if (getenv("MPX_DETERMINISTIC") && atoi(getenv("MPX_DETERMINISTIC"))) ctx->flags |= MPX_FLAG_DETERMINISTIC;  // read once
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)

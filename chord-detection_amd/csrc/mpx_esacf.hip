@@ -912,16 +912,50 @@ __device__ __forceinline__ double keep_if(bool c, double v) {
     return c ? v : 0.0;
 }
 
+#pragma clang fp contract(off)  // until the end of peakfit_kernel: see below
+// ---- ONE arithmetic for both fit kernels ---------------------------------------------------------------
+// peakfit_kernel (a fit per lane, its 21 rows in registers) and coopfit_kernel (a fit per 16-lane row, rows l and
+// l + 16 per lane) must produce the SAME BITS for the same fit: which of them finishes a runaway fit depends on the
+// timing of a launch, so any difference in rounding would make results vary from run to run on fits whose outcome
+// hangs on the last bit.  Hence (a) every sum over the rows of a fit is taken in the order the cooperative kernel's
+// DPP all-reduce imposes -- leaf l = term(row l) [+ term(row l + 16) for l < 5, fused], then the balanced tree
+// ((l0 + l1) + (l2 + l3)) + ... over the 16 leaves -- and (b) every multiply-add whose contraction the compiler could
+// decide differently in the two kernels is spelled out: this part of the file is compiled with contraction off, so
+// only the fma()s written here (and in mpx_lm.hpp) fuse.
+__device__ __forceinline__ double prod(double a, double b) { return a * b; }
+__device__ __forceinline__ double fma_as_written(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// leaf l of a row sum: p = x_l y_l (0 for rows above `from`), plus x_{l+16} y_{l+16} where that row can exist
+__device__ __forceinline__ double row_leaf(bool live, double xl, double yl) { return live ? prod(xl, yl) : 0.0; }
+__device__ __forceinline__ double tree16(const double* t) {
+    const double q0 = (t[0] + t[1]) + (t[2] + t[3]), q1 = (t[4] + t[5]) + (t[6] + t[7]);
+    const double q2 = (t[8] + t[9]) + (t[10] + t[11]), q3 = (t[12] + t[13]) + (t[14] + t[15]);
+    return (q0 + q1) + (q2 + q3);
+}
+// sum_{i >= from} x(i) y(i) over the lm::MAXM rows a lane of peakfit_kernel holds (rows >= m are exact zeros)
+template <typename FX, typename FY>
+__device__ __forceinline__ double dot_rows(int from, FX x, FY y) {
+    static_assert(lm::MAXM > 16 && lm::MAXM <= 21, "rows 16.. pair with leaves 0..4");
+    auto leaf = [&](int l) {
+        const double p = row_leaf(l >= from, x(l), y(l));
+        return l + 16 < lm::MAXM ? fma_as_written(x(l + 16), y(l + 16), p) : p;
+    };
+    // the balanced tree of tree16, quad by quad (four leaves live at a time, not sixteen)
+    double q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) q[k] = (leaf(4 * k) + leaf(4 * k + 1)) + (leaf(4 * k + 2) + leaf(4 * k + 3));
+    return (q[0] + q[1]) + (q[2] + q[3]);
+}
+
 struct GaussEval {
     double ampl, mu, ninv;  // ninv = -1 / (2 dev^2 + eps)   (peakutils.gaussian)
     const double* tab;      // 2^(j/64), LDS
 };
 __device__ __forceinline__ GaussEval gauss_prep(const double* p, const double* tab) {
-    return {p[0], p[1], -1.0 / (2.0 * p[2] * p[2] + lm::EPSMCH), tab};
+    return {p[0], p[1], -1.0 / fma_as_written(2.0, prod(p[2], p[2]), lm::EPSMCH), tab};
 }
 __device__ __forceinline__ double gauss_resid(const GaussEval& g, double xi, double yi) {
     const double d = xi - g.mu;
-    return g.ampl * exp_nonpos((d * d) * g.ninv, g.tab) - yi;
+    return fma_as_written(g.ampl, exp_nonpos(prod(d, d) * g.ninv, g.tab), -yi);
 }
 __device__ __forceinline__ void load_samples(const double* __restrict__ row, int m, double* ys) {
 #pragma unroll
@@ -974,6 +1008,12 @@ __device__ __forceinline__ double row_bcast(double v, int j) {  // j in 0..2, a 
 struct D2 {  // this lane's two samples: rows l and l + 16 of the m <= 21 rows
     double a, b;
 };
+// this lane's leaf of sum_{i >= from} x(i) y(i) (see dot_rows): row l counts from `from` on, row l + 16 exists for l < 5
+__device__ __forceinline__ double coop_leaf(int l, int from, D2 x, D2 y) {
+    const double p = row_leaf(l >= from, x.a, y.a);
+    const double f = fma_as_written(x.b, y.b, p);
+    return l + 16 < lm::MAXM ? f : p;
+}
 
 // Cooperative continuation of parked fits: one fit per 16-lane row (4 per wave), lane l holding samples l and
 // l + 16 (lm::gaussian_fit restated from a resume point, m-vectors across lanes, with the same reciprocal / column-0 / exponential
@@ -1041,9 +1081,9 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
             nfev += NP;
             int ipvt[NP] = {0, 1, 2};
             double acnorm[NP], rdiag[NP], wa[NP];
-            acnorm[0] = sqrt(row_sum(J0.a * J0.a + J0.b * J0.b));
-            acnorm[1] = sqrt(row_sum(J1.a * J1.a + J1.b * J1.b));
-            acnorm[2] = sqrt(row_sum(J2.a * J2.a + J2.b * J2.b));
+            acnorm[0] = sqrt(row_sum(coop_leaf(l, 0, J0, J0)));
+            acnorm[1] = sqrt(row_sum(coop_leaf(l, 0, J1, J1)));
+            acnorm[2] = sqrt(row_sum(coop_leaf(l, 0, J2, J2)));
 #pragma unroll
             for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
             double qtf[NP];
@@ -1072,7 +1112,7 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                 }
                 D2& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
                 const bool below = l >= j;  // rows j..15 of the first slot; the second slot (rows 16..) is always below
-                double ajnorm = sqrt(row_sum((below ? cj.a * cj.a : 0.0) + cj.b * cj.b));
+                double ajnorm = sqrt(row_sum(coop_leaf(l, j, cj, cj)));
                 if (ajnorm != 0.0) {
                     if (row_bcast(cj.a, j) < 0.0) ajnorm = -ajnorm;
                     const double inv_aj = 1.0 / ajnorm;
@@ -1083,23 +1123,23 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
                         D2& ck = k == 1 ? J1 : J2;
-                        const double temp = row_sum((below ? cj.a * ck.a : 0.0) + cj.b * ck.b) * inv_ajj;
-                        if (below) ck.a -= temp * cj.a;
-                        ck.b -= temp * cj.b;
+                        const double temp = row_sum(coop_leaf(l, j, cj, ck)) * inv_ajj;
+                        if (below) ck.a = fma_as_written(-temp, cj.a, ck.a);
+                        ck.b = fma_as_written(-temp, cj.b, ck.b);
                         if (rdiag[k] != 0.0) {
                             const double t = row_bcast(ck.a, j) / rdiag[k];
-                            const double u = 1.0 - t * t;
+                            const double u = fma(-t, t, 1.0);
                             rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
                             const double q = rdiag[k] / wa[k];
                             if (0.05 * q * q <= EPSMCH) {
-                                rdiag[k] = sqrt(row_sum((l > j ? ck.a * ck.a : 0.0) + ck.b * ck.b));
+                                rdiag[k] = sqrt(row_sum(coop_leaf(l, j + 1, ck, ck)));
                                 wa[k] = rdiag[k];
                             }
                         }
                     }
-                    const double temp = -row_sum((below ? cj.a * w4.a : 0.0) + cj.b * w4.b) * inv_ajj;
-                    if (below) w4.a += cj.a * temp;
-                    w4.b += cj.b * temp;
+                    const double temp = -row_sum(coop_leaf(l, j, cj, w4)) * inv_ajj;
+                    if (below) w4.a = fma_as_written(cj.a, temp, w4.a);
+                    w4.b = fma_as_written(cj.b, temp, w4.b);
                 }
                 rdiag[j] = -ajnorm;
                 qtf[j] = row_bcast(w4.a, j);
@@ -1131,7 +1171,7 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                     if (an != 0.0) {
                         double s2 = 0.0;
 #pragma unroll
-                        for (int i = 0; i <= j; ++i) s2 += r[i * NP + j] * (qtf[i] / fnorm);
+                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], qtf[i] / fnorm, s2);
                         const double g = fabs(s2 / an);
                         gnorm = g > gnorm ? g : gnorm;
                     }
@@ -1158,11 +1198,11 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                 if (it == 1) delta = delta < pnorm ? delta : pnorm;
                 const D2 fn = resid(xnew);
                 ++nfev;
-                const double fnorm1 = sqrt(row_sum(fn.a * fn.a + fn.b * fn.b));
+                const double fnorm1 = sqrt(row_sum(coop_leaf(l, 0, fn, fn)));
                 double actred = -1.0;
                 if (0.1 * fnorm1 < fnorm) {
                     const double q = fnorm1 / fnorm;
-                    actred = 1.0 - q * q;
+                    actred = fma(-q, q, 1.0);
                 }
 #pragma unroll
                 for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
@@ -1170,12 +1210,12 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
                 for (int j = 0; j < NP; ++j) {
                     const double temp = sel3(p, ipvt[j]);
 #pragma unroll
-                    for (int i = 0; i <= j; ++i) wa3[i] += r[i * NP + j] * temp;
+                    for (int i = 0; i <= j; ++i) wa3[i] = fma(r[i * NP + j], temp, wa3[i]);
                 }
                 const double temp1 = enorm3(wa3) / fnorm;
                 const double temp2 = (sqrt(par) * pnorm) / fnorm;
-                const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-                const double dirder = -(temp1 * temp1 + temp2 * temp2);
+                const double prered = fma(temp1, temp1, temp2 * temp2 / 0.5);
+                const double dirder = -fma(temp1, temp1, temp2 * temp2);
                 const double ratio = prered != 0.0 ? actred / prered : 0.0;
                 if (ratio <= 0.25) {
                     double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
@@ -1369,9 +1409,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             double acnorm[NP], rdiag[NP], wa[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                double q = 0.0;
-#pragma unroll
-                for (int i = 0; i < MAXM; ++i) q += a[i][j] * a[i][j];
+                const double q = dot_rows(0, [&](int i) { return a[i][j]; }, [&](int i) { return a[i][j]; });
                 acnorm[j] = sqrt(q);
                 rdiag[j] = wa[j] = acnorm[j];
             }
@@ -1400,9 +1438,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     ipvt[j] = sel3(ipvt, kmax);
                     put3(ipvt, kmax, t);
                 }
-                double q = 0.0;
-#pragma unroll
-                for (int i = j; i < MAXM; ++i) q += a[i][j] * a[i][j];
+                const double q = dot_rows(j, [&](int i) { return a[i][j]; }, [&](int i) { return a[i][j]; });
                 double ajnorm = sqrt(q);
                 if (ajnorm != 0.0) {
                     if (a[j][j] < 0.0) ajnorm = -ajnorm;
@@ -1413,21 +1449,17 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     const double inv_ajj = 1.0 / a[j][j];
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
-                        double sum = 0.0;
-#pragma unroll
-                        for (int i = j; i < MAXM; ++i) sum += a[i][j] * a[i][k];
+                        const double sum = dot_rows(j, [&](int i) { return a[i][j]; }, [&](int i) { return a[i][k]; });
                         const double temp = sum * inv_ajj;
 #pragma unroll
-                        for (int i = j; i < MAXM; ++i) a[i][k] -= temp * a[i][j];
+                        for (int i = j; i < MAXM; ++i) a[i][k] = fma_as_written(-temp, a[i][j], a[i][k]);
                         if (rdiag[k] != 0.0) {
                             const double t = a[j][k] / rdiag[k];
-                            const double u = 1.0 - t * t;
+                            const double u = fma(-t, t, 1.0);
                             rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
                             const double qq = rdiag[k] / wa[k];
                             if (0.05 * qq * qq <= EPSMCH) {
-                                double s2 = 0.0;
-#pragma unroll
-                                for (int i = j + 1; i < MAXM; ++i) s2 += a[i][k] * a[i][k];
+                                const double s2 = dot_rows(j + 1, [&](int i) { return a[i][k]; }, [&](int i) { return a[i][k]; });
                                 rdiag[k] = sqrt(s2);
                                 wa[k] = rdiag[k];
                             }
@@ -1436,12 +1468,10 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     // the same reflection applied to the copy of fvec (MINPACK does this after qrfac; rows >= m
                     // of both the vector and the column are zero)
                     {
-                        double sum = 0.0;
-#pragma unroll
-                        for (int i = j; i < MAXM; ++i) sum += a[i][j] * w[i];
+                        const double sum = dot_rows(j, [&](int i) { return a[i][j]; }, [&](int i) { return w[i]; });
                         const double temp = -sum * inv_ajj;
 #pragma unroll
-                        for (int i = j; i < MAXM; ++i) w[i] += a[i][j] * temp;
+                        for (int i = j; i < MAXM; ++i) w[i] = fma_as_written(a[i][j], temp, w[i]);
                     }
                 }
                 rdiag[j] = -ajnorm;
@@ -1470,7 +1500,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     if (an != 0.0) {
                         double s2 = 0.0;
 #pragma unroll
-                        for (int i = 0; i <= j; ++i) s2 += r[i * NP + j] * (qtf[i] / fnorm);
+                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], qtf[i] / fnorm, s2);
                         const double g = fabs(s2 / an);
                         gnorm = g > gnorm ? g : gnorm;
                     }
@@ -1525,17 +1555,14 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 #pragma unroll
             for (int j = 0; j < NP; ++j) xnew[j] = x[j] + p[j];
             double rn[MAXM];  // residuals at the trial point (MINPACK's wa4)
-            double s1 = 0.0;
             {
                 double ys[MAXM];
                 load_samples(row, m, ys);
                 const GaussEval g = gauss_prep(xnew, exp_tab);
 #pragma unroll
-                for (int i = 0; i < MAXM; ++i) {
-                    rn[i] = keep_if(i < m, gauss_resid(g, x0 + (double)i, ys[i]));
-                    s1 += rn[i] * rn[i];
-                }
+                for (int i = 0; i < MAXM; ++i) rn[i] = keep_if(i < m, gauss_resid(g, x0 + (double)i, ys[i]));
             }
+            const double s1 = dot_rows(0, [&](int i) { return rn[i]; }, [&](int i) { return rn[i]; });
             if (fresh) {  // lmdif's prologue: fvec at the initial point
 #pragma unroll
                 for (int i = 0; i < MAXM; ++i)
@@ -1553,7 +1580,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             double actred = -1.0;
             if (0.1 * fnorm1 < fnorm) {
                 const double q = fnorm1 / fnorm;
-                actred = 1.0 - q * q;
+                actred = fma(-q, q, 1.0);
             }
 #pragma unroll
             for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
@@ -1561,12 +1588,12 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             for (int j = 0; j < NP; ++j) {
                 const double temp = sel3(p, ipvt[j]);
 #pragma unroll
-                for (int i = 0; i <= j; ++i) wa3[i] += r[i * NP + j] * temp;
+                for (int i = 0; i <= j; ++i) wa3[i] = fma(r[i * NP + j], temp, wa3[i]);
             }
             const double temp1 = enorm3(wa3) / fnorm;
             const double temp2 = (sqrt(par) * pnorm) / fnorm;
-            const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-            const double dirder = -(temp1 * temp1 + temp2 * temp2);
+            const double prered = fma(temp1, temp1, temp2 * temp2 / 0.5);
+            const double dirder = -fma(temp1, temp1, temp2 * temp2);
             const double ratio = prered != 0.0 ? actred / prered : 0.0;
             if (ratio <= 0.25) {
                 double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
@@ -1611,6 +1638,8 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         }
     }
 }
+
+#pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------ kernel 4
 __global__ __launch_bounds__(64) void scatter_kernel(long long frame0, long long num_frames, int fs, int Mh, int maxp,
@@ -1818,9 +1847,11 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
               int fs, const mpx_esacf_params* params, int frame, int hop, double* d_chroma_frames, int stage,
               double* d_stage_out, hipStream_t st) {
     mpx_esacf_params p = params ? *params : mpx_esacf_params{6, 0.1, 10, MPX_ENHANCE_LIBROSA010, MPX_NOTES_UNICODE};
-    // bit-reproducible mode (MPX_FLAG_DETERMINISTIC; MPX_DETERMINISTIC=1 overrides per call): every gaussian fit is
-    // finished on the lane that started it
-    const bool deterministic = (ctx->flags & MPX_FLAG_DETERMINISTIC) || (getenv("MPX_DETERMINISTIC") && atoi(getenv("MPX_DETERMINISTIC")));
+    // MPX_FLAG_DETERMINISTIC (mpx_create folds MPX_DETERMINISTIC=1 of its environment into it): every gaussian fit is
+    // finished on the lane that started it.  Results do not depend on it any more -- the cooperative kernel and the
+    // lane kernel round identically (see "ONE arithmetic for both fit kernels") -- it remains as the slower way of
+    // computing the same bits, for cross-checks.
+    const bool deterministic = (ctx->flags & MPX_FLAG_DETERMINISTIC) != 0;
     const int N = frame, Mh = (N - 1) / 2;
     if (N < 64 || N > 4096)
         return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: frame length %d outside [64, 4096]", N);

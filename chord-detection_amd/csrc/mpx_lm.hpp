@@ -11,6 +11,11 @@
 
 #define MPX_HD __host__ __device__
 
+// Everything in this header is compiled with floating-point contraction OFF and its multiply-adds spelled as fma():
+// the two GPU kernels that inline these functions (peakfit_kernel and coopfit_kernel, csrc/mpx_esacf.hip) must round
+// identically, and which a*b+c the compiler fuses must not depend on the code around the inlined copy.
+#pragma clang fp contract(off)
+
 namespace mpx {
 namespace lm {
 
@@ -38,7 +43,7 @@ MPX_HD inline double enorm(const double* v, int n) {
     for (int i = 0; i < n; ++i) s += v[i] * v[i];
     return sqrt(s);
 }
-MPX_HD inline double enorm3(const double* v) { return sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]); }
+MPX_HD inline double enorm3(const double* v) { return sqrt(fma(v[2], v[2], fma(v[1], v[1], v[0] * v[0]))); }
 
 // a: [m][NP] row-major, modified in place.
 MPX_HD inline void qrfac(double* a, int m, int* ipvt, double* rdiag, double* acnorm) {
@@ -151,14 +156,14 @@ MPX_HD inline void qrsolv(double* r, const int* ipvt, const double* diag, const 
 #endif
                     const double c1 = c0 * t;
                     const double sn = small ? c0 : c1, cs = small ? c1 : c0;
-                    r[k * NP + k] = cs * r[k * NP + k] + sn * sdiag[k];
-                    const double temp = cs * wa[k] + sn * qtbpj;
-                    qtbpj = -sn * wa[k] + cs * qtbpj;
+                    r[k * NP + k] = fma(cs, r[k * NP + k], sn * sdiag[k]);
+                    const double temp = fma(cs, wa[k], sn * qtbpj);
+                    qtbpj = fma(-sn, wa[k], cs * qtbpj);
                     wa[k] = temp;
 #pragma unroll
                     for (int i = k + 1; i < NP; ++i) {
-                        const double t = cs * r[i * NP + k] + sn * sdiag[i];
-                        sdiag[i] = -sn * r[i * NP + k] + cs * sdiag[i];
+                        const double t = fma(cs, r[i * NP + k], sn * sdiag[i]);
+                        sdiag[i] = fma(-sn, r[i * NP + k], cs * sdiag[i]);
                         r[i * NP + k] = t;
                     }
                 }
@@ -179,7 +184,7 @@ MPX_HD inline void qrsolv(double* r, const int* ipvt, const double* diag, const 
             double s = 0.0;
 #pragma unroll
             for (int i = j + 1; i < NP; ++i)
-                if (i < nsing) s += r[i * NP + j] * wa[i];
+                if (i < nsing) s = fma(r[i * NP + j], wa[i], s);
             wa[j] = (wa[j] - s) / sdiag[j];
         }
     }
@@ -203,7 +208,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
             wa1[j] /= r[j * NP + j];
             const double temp = wa1[j];
 #pragma unroll
-            for (int i = 0; i < j; ++i) wa1[i] -= r[i * NP + j] * temp;
+            for (int i = 0; i < j; ++i) wa1[i] = fma(-r[i * NP + j], temp, wa1[i]);
         }
     }
 #pragma unroll
@@ -236,7 +241,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
         for (int j = 0; j < NP; ++j) {
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < j; ++i) s += r[i * NP + j] * wa1[i];
+            for (int i = 0; i < j; ++i) s = fma(r[i * NP + j], wa1[i], s);
             wa1[j] = (wa1[j] - s) / r[j * NP + j];
         }
         const double temp = enorm3(wa1);
@@ -250,7 +255,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
     for (int j = 0; j < NP; ++j) {
         double s = 0.0;
 #pragma unroll
-        for (int i = 0; i <= j; ++i) s += r[i * NP + j] * qtb[i];
+        for (int i = 0; i <= j; ++i) s = fma(r[i * NP + j], qtb[i], s);
         wa1[j] = s / sel3(diag, ipvt[j]);
     }
     const double gnorm = enorm3(wa1);
@@ -291,7 +296,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
             wa1[j] /= sdiag[j];
             const double t = wa1[j];
 #pragma unroll
-            for (int i = j + 1; i < NP; ++i) wa1[i] -= r[i * NP + j] * t;
+            for (int i = j + 1; i < NP; ++i) wa1[i] = fma(-r[i * NP + j], t, wa1[i]);
         }
         temp = enorm3(wa1);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -448,3 +453,5 @@ MPX_HD inline int gaussian_fit(const Problem& pr, double* center) {
 
 }  // namespace lm
 }  // namespace mpx
+
+#pragma clang fp contract(fast)  // the compiler's default for HIP, for whatever follows the include

@@ -308,13 +308,14 @@ class Engine:
         return out
 
 
-def get_engine(device=0, f32=False):
-    """Process-wide engine per (device, dtype)."""
-    key = (int(device), bool(f32))
+def get_engine(device=0, f32=False, deterministic=False):
+    """Process-wide engine per (device, dtype, lane-mode fits).  `deterministic` = MPX_FLAG_DETERMINISTIC: the slower way
+    of computing the SAME bits (include/mpx.h); results are reproducible either way."""
+    key = (int(device), bool(f32), bool(deterministic))
     with _lock:
         eng = _engines.get(key)
         if eng is None:
-            eng = _engines[key] = Engine(device, f32)
+            eng = _engines[key] = Engine(device, f32, deterministic)
         return eng
 
 

@@ -44,17 +44,24 @@ typedef enum mpx_status {
 
 /* mpx_create flags */
 #define MPX_FLAG_F32 0x1    /* opt-in fp32 arithmetic (default: fp64, the reference's dtype) */
-#define MPX_FLAG_DETERMINISTIC 0x2 /* ESACF: bit-reproducible runs (every gaussian fit finished on the lane that started
-                                      it; ~3 ms per 176 k frames slower).  By default the runaway fits still open when
-                                      the work list runs dry are finished cooperatively (other summation order): 3-5
-                                      frames in 176 573 -- ones on which the reference's own fit is ill-conditioned
-                                       -- can differ from run to run. */
+#define MPX_FLAG_DETERMINISTIC 0x2 /* ESACF: every gaussian fit is finished on the lane that started it (~3 ms per
+                                      176 k frames slower).  NOT needed for reproducible results: by default the runaway
+                                      fits still open when the work list runs dry are finished by a cooperative kernel
+                                      whose arithmetic is bit-identical to the lane kernel's (same summation tree, same
+                                      fused multiply-adds), so every run of every entry point returns the same bits
+                                      whichever kernel finished which fit.  The flag (or MPX_DETERMINISTIC=1 in the
+                                      environment of mpx_create) remains as a cross-check of exactly that. */
 
 typedef struct mpx_ctx mpx_ctx;
 
 int mpx_abi_version(void);
 int mpx_device_count(void);
-/* NULL on failure; mpx_last_error(NULL) then holds the reason. */
+/* NULL on failure; mpx_last_error(NULL) then holds the reason.
+ * A context owns ONE set of grow-only device workspaces and reduction counters: it is neither thread-safe nor
+ * multi-stream.  Everything enqueued on a context -- through its own stream or through the `stream` argument of the
+ * *_dev entry points -- must be ordered on one stream at a time: finish (or order behind) the work of the previous
+ * stream before handing the same context another one.  For several batches in flight create one context per batch
+ * (bench.py: two contexts, two streams). */
 mpx_ctx* mpx_create(int device, int flags);
 void mpx_destroy(mpx_ctx* ctx);
 const char* mpx_last_error(const mpx_ctx* ctx);

@@ -133,6 +133,26 @@ def frame_has_runaway_fit(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, width=
     return bool(np.any(np.abs(np.asarray(interp) - np.asarray(peaks, dtype=np.float64)) > width + 0.5))
 
 
+def runaway_fit_bins(x_esacf, fs, peak_thresh=0.1, peak_min_dist=10, width=10):
+    """Test helper.  (pairing_shifted, bins): `pairing_shifted` is True when a gaussian fit of this frame FAILED, which
+    shifts the index/lag pairing of every later peak (quirk A.8: then any bin may move with the last bits of the
+    arithmetic); `bins` are the pitch classes that an ACCEPTED fit whose centre left its 21-sample window feeds -- such a
+    centre sits somewhere along a flat valley of MINPACK's objective, and another rounding of the same algorithm moves
+    that peak's height from this bin to another one (so at most 2 bins of the frame change per such fit)."""
+    _, peaks, interp = frame_chroma(x_esacf, fs, peak_thresh, peak_min_dist, detail=True, note_names="ascii")
+    if len(interp) != len(peaks):
+        return True, []
+    bins = []
+    for pk, tau in zip(peaks, interp):
+        if abs(float(tau) - float(pk)) > width + 0.5:
+            try:
+                with np.errstate(all="ignore"):
+                    bins.append(tp.hz_to_pitch_class(fs / tau))
+            except (ValueError, OverflowError):
+                bins.append(-1)
+    return False, bins
+
+
 def esacf_frames(x, fs, frame_size=None, hop=None, n_peaks_elim=6, peak_thresh=0.1,
                  peak_min_dist=10, enhance_mode="librosa010", note_names="unicode"):
     if frame_size is None:

@@ -12,7 +12,6 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "coop_endgame: run the ESACF fit kernel with its default cooperative end game")
 
 
 @pytest.fixture(scope="session")
@@ -21,12 +20,8 @@ def golden_dir():
 
 
 @pytest.fixture(autouse=True)
-def lane_mode_fits(monkeypatch, request):
-    """Parity tests run ESACF in its bit-reproducible mode (what MPX_FLAG_DETERMINISTIC selects; MPX_DETERMINISTIC=1
-    is the per-call override of the same switch).  The default hands the last runaway gaussian fits to a
-    cooperative kernel with another summation order, which flips ~3 frames in 100 000 on which the reference's own
-    fit is ill-conditioned; tests marked `coop_endgame` run with the default and bound exactly that."""
-    if request.node.get_closest_marker("coop_endgame"):
-        monkeypatch.delenv("MPX_DETERMINISTIC", raising=False)
-    else:
-        monkeypatch.setenv("MPX_DETERMINISTIC", "1")
+def product_defaults(monkeypatch):
+    """Every test runs the library as a user gets it: no environment switches (MPX_DETERMINISTIC would make mpx_create
+    select the lane-mode fit kernel; the parity tests must exercise the default, cooperative end game included)."""
+    for k in ("MPX_DETERMINISTIC", "MPX_FIT_NOPARK", "MPX_FIT_PARK_NFEV", "MPX_FIT_MAXFEV", "MPX_SACF_PAIR", "MPX_SACF_ABLATE"):
+        monkeypatch.delenv(k, raising=False)

@@ -38,11 +38,27 @@ def _oracle_sum(x, fs, **kw):
         return o_esacf.esacf_compute(x, fs, **kw)
 
 
-def _check_frames(eng, x, fs, frame, per, hop=None, max_fragile=0.1, **kw):
-    """Per-frame chroma vs the oracle.  The reference's own peak fit is ill-conditioned on some
-    frames (a runaway gaussian fit lands wherever MINPACK stops and moves with 1e-12 input noise):
-    oracle.frame_fragility detects those by perturbation; they are compared with the oracle fed
-    the GPU's own ESACF row (identical input), all others end to end."""
+# Ill-conditioned frames SEEN by each check (fixed seeds and a deterministic engine => fixed numbers; measured on MI355X,
+# asserted as "<= measured + 1" so that a change in the last bits of an upstream kernel does not fail the suite):
+#   key -> (frames, fragile, loose): `fragile` = frames on which the reference algorithm itself is ill-conditioned
+#   (oracle.frame_fragility: a 1e-12 relative perturbation of the ESACF row changes its chroma), compared with the oracle
+#   fed the GPU's own ESACF row; `loose` = the ones among them that differ EVEN THEN, which is only accepted in bins an
+#   escaped gaussian fit feeds (oracle.runaway_fit_bins).
+MEASURED = {   # MI355X, round 2 (deterministic engine, default mode): 13 checks, 193 frames, 2 fragile, 1 loose
+    "full_frames/piano_like_Cmaj": (44, 0, 0), "full_frames/poly_seed2": (44, 2, 1),
+    "44100/2046": (7, 0, 0), "44100/2046/params": (7, 0, 0), "44100/2046/noop": (7, 0, 0),
+    "44100/2048/hop1024": (12, 0, 0), "16000/742": (11, 0, 0), "48000/2227": (4, 0, 0), "48000/3000/noop": (3, 0, 0),
+    "48000/4095/noop": (2, 0, 0), "44100/4096/hop1024": (6, 0, 0), "44100/4096/hop1024/elim3": (6, 0, 0),
+}
+SEEN = {}
+E2E_FRAGILE_CLIPS = {"poly_seed2"}   # the one golden clip with an ill-conditioned frame (2 of its 44): 8 of 9 clips are strict
+
+
+def _check_frames(eng, x, fs, frame, per, hop=None, key=None, **kw):
+    """Per-frame chroma vs the oracle, in the product's default mode and with ASCII note names (every bin visible).
+    The reference's own peak fit is ill-conditioned on some frames (a runaway gaussian fit lands wherever MINPACK
+    stops and moves with 1e-12 input noise): oracle.frame_fragility detects those by perturbation; they are compared
+    with the oracle fed the GPU's own ESACF row (identical input), all others end to end."""
     from oracle import esacf as o_esacf
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -50,24 +66,35 @@ def _check_frames(eng, x, fs, frame, per, hop=None, max_fragile=0.1, **kw):
         mode = kw.get("enhance_mode", "librosa010")
         okw = {k: v for k, v in kw.items() if k in ("peak_thresh", "peak_min_dist")}
         want = o_esacf.esacf_frames(x, fs, frame_size=frame, hop=hop, enhance_mode=mode,
-                                    n_peaks_elim=kw.get("n_peaks_elim", 6), **okw)
-        fragile = 0
+                                    n_peaks_elim=kw.get("n_peaks_elim", 6), note_names="ascii", **okw)
+        fragile = loose = 0
         for f in range(per.shape[0]):
-            if o_esacf.frame_fragility(e_gpu[f], fs, **okw):
-                fragile += 1
-                same_input = o_esacf.frame_chroma(e_gpu[f], fs, **okw)
-                if not np.allclose(per[f], same_input, rtol=RTOL_CHROMA, atol=1e-12):
-                    # runaway fits may stop elsewhere under FMA contraction; every well-fitted bin must agree
-                    assert np.sum(~np.isclose(per[f], same_input, rtol=RTOL_CHROMA, atol=1e-12)) <= 2
-            else:
+            if not o_esacf.frame_fragility(e_gpu[f], fs, **okw):
                 np.testing.assert_allclose(per[f], want[f], rtol=RTOL_CHROMA, atol=1e-12)
-    assert fragile <= max(1, int(max_fragile * per.shape[0])), "too many ill-conditioned frames: %d" % fragile
+                continue
+            fragile += 1
+            same_input = o_esacf.frame_chroma(e_gpu[f], fs, note_names="ascii", **okw)
+            differ = np.flatnonzero(~np.isclose(per[f], same_input, rtol=RTOL_CHROMA, atol=1e-12))
+            if differ.size == 0:
+                continue
+            loose += 1
+            shifted, bins = o_esacf.runaway_fit_bins(e_gpu[f], fs, **okw)
+            # a failed fit shifts the pairing of all later peaks (quirk A.8); otherwise every escaped fit moves ONE peak
+            # height out of the bin the oracle's rounding put it in, into one other bin
+            assert shifted or (bins and differ.size <= 2 * len(bins) and set(bins) & set(differ.tolist())), \
+                (key, f, differ.tolist(), bins, per[f], same_input)
+    if key is not None:
+        SEEN[key] = (int(per.shape[0]), fragile, loose)
+        print("esacf ill-conditioned frames  %-28s frames %4d  fragile %3d  loose %3d  (measured %s)"
+              % (key, per.shape[0], fragile, loose, MEASURED.get(key)))
+        assert key in MEASURED, key
+        assert fragile <= MEASURED[key][1] + 1 and loose <= MEASURED[key][2] + 1, (key, fragile, loose, MEASURED[key])
     return fragile
 
 
-def _check_clip(eng, x, fs, frame, hop=None, **kw):
-    total, per = eng.esacf(x, fs, frame, hop, return_frames=True, **kw)
-    fragile = _check_frames(eng, x, fs, frame, per, hop, max_fragile=0.25, **kw)
+def _check_clip(eng, x, fs, frame, hop=None, key=None, **kw):
+    total, per = eng.esacf(x, fs, frame, hop, return_frames=True, note_names="ascii", **kw)
+    fragile = _check_frames(eng, x, fs, frame, per, hop, key=key, **kw)
     np.testing.assert_allclose(total, per.sum(0), rtol=1e-12, atol=0)
     return total, fragile
 
@@ -109,8 +136,8 @@ def test_enhancement_and_full_frames_vs_oracle(eng, clips):
             got = eng.esacf_stage("esacf", x, FS, 1023, enhance_mode=mode)
             want = np.array([o_esacf.esacf_enhance(r, 6, mode) for r in s])
             np.testing.assert_allclose(got, want, rtol=0, atol=1e-11 * np.abs(want).max())
-        total, per = eng.esacf(x, FS, 1023, return_frames=True)
-        _check_frames(eng, x, FS, 1023, per)
+        total, per = eng.esacf(x, FS, 1023, return_frames=True, note_names="ascii")
+        _check_frames(eng, x, FS, 1023, per, key="full_frames/" + name)
         np.testing.assert_allclose(total, per.sum(0), rtol=1e-12)
 
 
@@ -123,12 +150,14 @@ def test_end_to_end_golden_strings_and_keys(eng, clips, golden_dir):
     from oracle import esacf as o_esacf
     d = np.load(os.path.join(golden_dir, "esacf_e2e.npz"))
     expected = json.load(open(os.path.join(golden_dir, "constants.json")))["test_py_expected"]
-    strict = 0
+    strict, fragile_clips = 0, []
     for name, x in clips.items():
         e_gpu = eng.esacf_stage("esacf", x, FS, 1023)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             fragile = any(o_esacf.frame_fragility(r, FS) for r in e_gpu)
+        if fragile:
+            fragile_clips.append(name)
         for mode, sfx in SPELLINGS:
             c = cd.MultipitchESACF((x, FS), note_names=mode).compute_pitches()
             if mode == "unicode":
@@ -143,7 +172,10 @@ def test_end_to_end_golden_strings_and_keys(eng, clips, golden_dir):
                 warnings.simplefilter("ignore")
                 assert c.key() == str(d[name + "/key" + sfx])
         strict += not fragile
-    assert strict >= 6, "only %d of %d clips could be compared strictly" % (strict, len(clips))
+    # clips in which some frame is ill-conditioned in the reference itself cannot be pinned by a sum (they are covered
+    # frame by frame in test_enhancement_and_full_frames_vs_oracle); measured on MI355X: see E2E_FRAGILE_CLIPS
+    print("esacf end-to-end: strict %d of %d, clips with an ill-conditioned frame: %s" % (strict, len(clips), fragile_clips))
+    assert set(fragile_clips) <= E2E_FRAGILE_CLIPS, fragile_clips
 
 
 def test_note_names_ascii_keeps_the_sharps(eng, clips, golden_dir):
@@ -180,13 +212,13 @@ def test_parameters_and_44100_default_frame(eng):
         for h in range(1, 6):
             x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
     x = (0.3 * x + 0.005 * rng.standard_normal(n)).astype(np.float32)
-    _check_clip(eng, x, 44100, 2046)
-    _check_clip(eng, x, 44100, 2046, n_peaks_elim=3, peak_thresh=0.3, peak_min_dist=25)
-    _check_clip(eng, x, 44100, 2046, enhance_mode="noop", peak_min_dist=1)
+    _check_clip(eng, x, 44100, 2046, key="44100/2046")
+    _check_clip(eng, x, 44100, 2046, key="44100/2046/params", n_peaks_elim=3, peak_thresh=0.3, peak_min_dist=25)
+    _check_clip(eng, x, 44100, 2046, key="44100/2046/noop", enhance_mode="noop", peak_min_dist=1)
     # power-of-two frame (direct FFT instead of Bluestein) and hop < frame
-    _check_clip(eng, x, 44100, 2048, hop=1024)
+    _check_clip(eng, x, 44100, 2048, hop=1024, key="44100/2048/hop1024")
     # a sample rate without a built-in remez table
-    _check_clip(eng, x[:8000], 16000, 742)
+    _check_clip(eng, x[:8000], 16000, 742, key="16000/742")
 
 
 def test_48k_default_frame_8192_point_bluestein(eng):
@@ -208,9 +240,9 @@ def test_48k_default_frame_8192_point_bluestein(eng):
     frames.reshape(-1)[:n] = x
     _, lo, hi = o_esacf.band_split(frames, 48000)
     np.testing.assert_allclose(got, o_esacf.sacf(lo, hi), rtol=0, atol=1e-10 * np.abs(got).max())
-    _check_clip(eng, x, 48000, 2227)
-    _check_clip(eng, x, 48000, 3000, enhance_mode="noop")
-    _check_clip(eng, x[:2 * 4095], 48000, 4095, enhance_mode="noop")
+    _check_clip(eng, x, 48000, 2227, key="48000/2227")
+    _check_clip(eng, x, 48000, 3000, key="48000/3000/noop", enhance_mode="noop")
+    _check_clip(eng, x[:2 * 4095], 48000, 4095, key="48000/4095/noop", enhance_mode="noop")
 
 
 def test_phase_vocoder_enhancement_4096_frames(eng):
@@ -233,8 +265,8 @@ def test_phase_vocoder_enhancement_4096_frames(eng):
     want = np.array([o_esacf.esacf_enhance(r, 6, "librosa010") for r in s])
     assert not np.allclose(want, np.clip(s, 0, None))            # the vocoder really did something
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.abs(s).max())
-    _check_clip(eng, x, 44100, 4096, hop=1024)
-    _check_clip(eng, x, 44100, 4096, hop=1024, n_peaks_elim=3)
+    _check_clip(eng, x, 44100, 4096, hop=1024, key="44100/4096/hop1024")
+    _check_clip(eng, x, 44100, 4096, hop=1024, key="44100/4096/hop1024/elim3", n_peaks_elim=3)
 
 
 def test_edge_cases_and_batch(eng, clips):
@@ -266,11 +298,10 @@ def det_eng():
     e.close()
 
 
-@pytest.mark.coop_endgame
 def test_many_clips_properties(eng, det_eng):
-    """BASELINE config[2]-style batch (scaled to what the oracle can spot-check): clip results
-    are independent of batching and -- with MPX_FLAG_DETERMINISTIC -- bit-reproducible."""
-    fast_eng, eng = eng, det_eng
+    """BASELINE config[2]-style batch (scaled to what the oracle can spot-check): clip results are bit-reproducible,
+    independent of batching, and the same bits whether the runaway fits are finished by the cooperative kernel (the
+    default) or on their own lanes (MPX_FLAG_DETERMINISTIC)."""
     rng = np.random.default_rng(20260102)
     clips = []
     for c in range(96):
@@ -284,23 +315,18 @@ def test_many_clips_properties(eng, det_eng):
         clips.append((0.2 * x).astype(np.float32))
     a = eng.esacf_batch(clips, 44100, 2046)
     b = eng.esacf_batch(clips, 44100, 2046)
-    assert np.array_equal(a, b)                                    # deterministic
+    assert np.array_equal(a, b)                                    # run-to-run reproducible, default engine
     c = eng.esacf_batch(clips[::-1], 44100, 2046)[::-1]
     assert np.array_equal(a, c)                                    # independent of position in the batch
+    assert np.array_equal(a, det_eng.esacf_batch(clips, 44100, 2046))   # same bits from the lane-mode kernel
     for i in (0, 17, 95):
         np.testing.assert_array_equal(eng.esacf(clips[i], 44100, 2046), a[i])
         np.testing.assert_allclose(a[i], _oracle_sum(clips[i], 44100), rtol=RTOL_CHROMA, atol=1e-12)
-    # default engine: the runaway fits left over when the work list runs dry are finished cooperatively (other
-    # summation order).  Only fits on which the reference itself is ill-conditioned can come out differently:
-    # measured 5 frames in 176 573.
-    d = fast_eng.esacf_batch(clips, 44100, 2046)
-    assert int((~np.isclose(d, a, rtol=1e-9, atol=1e-12)).any(axis=1).sum()) <= 1
 
 
-@pytest.mark.coop_endgame
-def test_cooperative_finish_agrees_with_lane_mode(eng, det_eng):
+def test_cooperative_finish_is_bit_identical_to_lane_mode(eng, det_eng):
     """A few thousand frames, so that the end game of the fit kernel (parking + coopfit_kernel) certainly runs:
-    per-frame chroma of the default engine vs MPX_FLAG_DETERMINISTIC."""
+    per-frame chroma of the default engine == MPX_FLAG_DETERMINISTIC, bit for bit, and == itself on a second run."""
     rng = np.random.default_rng(7)
     n = 64 * 44 * 2046
     t = np.arange(44 * 2046) / 44100.0
@@ -315,30 +341,31 @@ def test_cooperative_finish_agrees_with_lane_mode(eng, det_eng):
         sig[c] *= 0.9 / np.abs(sig[c]).max()
     x = sig.reshape(-1).astype(np.float32)
     assert x.shape[0] == n
-    a, fa = det_eng.esacf(x, 44100, 2046, return_frames=True)
-    b, fb = eng.esacf(x, 44100, 2046, return_frames=True)
-    a2, fa2 = det_eng.esacf(x, 44100, 2046, return_frames=True)
-    assert fa.shape == (64 * 44, 12)
-    np.testing.assert_array_equal(fa, fa2)
-    assert int((~np.isclose(fa, fb, rtol=1e-9, atol=1e-12)).any(axis=1).sum()) <= 2   # expectation ~0.1 frame
-    np.testing.assert_allclose(b, a, rtol=1e-2)                # a differing frame moves one peak height between bins
+    for fs, frame in ((44100, 2046), (22050, 1023)):     # 1023-sample frames: 11 % of the fits run away
+        a, fa = det_eng.esacf(x, fs, frame, return_frames=True, note_names="ascii")
+        b, fb = eng.esacf(x, fs, frame, return_frames=True, note_names="ascii")
+        b2, fb2 = eng.esacf(x, fs, frame, return_frames=True, note_names="ascii")
+        assert fa.shape == (-(-n // frame), 12)
+        np.testing.assert_array_equal(fb, fb2)
+        np.testing.assert_array_equal(fa, fb)
+        np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.coop_endgame
 def test_full_size_batch_is_periodic_in_the_clips(eng, det_eng):
     """BASELINE configs[2] at full size: 4096 clips x 2 s @44.1 kHz (176 573 frames, ~2 M gaussian fits) made of
     64 distinct clips repeated 64 times.  Size-independent property: a clip's chroma does not depend on where it
-    sits in the batch -- bit-exactly with MPX_FLAG_DETERMINISTIC, and for all but a handful of clips (the
-    cooperative end game of the fit kernel) by default."""
+    sits in the batch, nor on which kernel finished its runaway fits -- bit-exactly, in the default mode."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import bench_esacf as B
     uniq = B.synth_clips()
     clips = [uniq[c % 64] for c in range(4096)]
-    a = det_eng.esacf_batch(clips, B.FS, B.N)
+    a = eng.esacf_batch(clips, B.FS, B.N)
     assert a.shape == (4096, 12) and np.isfinite(a).all() and (a.sum(axis=1) > 0).all()
     np.testing.assert_array_equal(a, np.tile(a[:64], (64, 1)))
-    b = eng.esacf_batch(clips, B.FS, B.N)
-    bad = (~np.isclose(b, a, rtol=1e-9, atol=1e-12)).any(axis=1)
-    assert int(bad.sum()) <= 40, int(bad.sum())     # measured: 3-5 frames of 176 573, i.e. <= 5 clips
-    np.testing.assert_allclose(b.sum(axis=0), a.sum(axis=0), rtol=1e-4)
+    np.testing.assert_array_equal(a, eng.esacf_batch(clips, B.FS, B.N))
+    np.testing.assert_array_equal(a, det_eng.esacf_batch(clips, B.FS, B.N))
+    asc = eng.esacf_batch(clips, B.FS, B.N, note_names="ascii")
+    keep = [0, 2, 4, 5, 7, 9, 11]
+    np.testing.assert_array_equal(asc[:, keep], a[:, keep])       # unicode names = ASCII names minus the sharps
+    assert np.all(a[:, [1, 3, 6, 8, 10]] == 0) and np.any(asc[:, [1, 3, 6, 8, 10]] > 0)
