@@ -771,7 +771,8 @@ def wl_if0_stream(c):
     world, rank, local = c["world"], c["rank"], c["local_rank"]
     n = int(round(secs * fs))
     total_frames = stream.num_frames(n, nf_size)
-    f0, f1, s0, s1, _ = stream.shard_window(n, nf_size, world, rank)
+    warm = stream.WARMUP if c["stub"] is not None else stream.engine_warmup(fs, local, frame_size=nf_size)
+    f0, f1, s0, s1, _ = stream.shard_window(n, nf_size, world, rank, warm)
     sdev = c["dev"] if c["dev"].type == "cuda" else None
     x = stream.synth_stream(s0, s1, fs, sdev)
     c["dev_sync"]()

@@ -425,6 +425,15 @@ int mpx_iterative_f0_spectra(mpx_ctx* ctx, const float* signal, int64_t n, int f
     return if0_run_host(ctx, signal, offsets, 1, fs, params, nullptr, nullptr, ut);
 }
 
+int mpx_iterative_f0_warmup(mpx_ctx* ctx, int fs, const mpx_if0_params* params, int64_t* samples, double* pole_radius) {
+    if (!ctx || !samples) return MPX_EINVAL;
+    long long w = 0;
+    int rc = if0_warmup_samples(ctx, fs, params, &w, pole_radius);
+    if (rc) return rc;
+    *samples = (int64_t)w;
+    return MPX_OK;
+}
+
 // ------------------------------------------------------------------ method 4
 int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                             const mpx_prime_params* params, double* chroma_sums) {

@@ -6,9 +6,10 @@
 //                           coefficients), 12-stage warped all-pass + 13-tap FIR residual (dsp/wfir.py),
 //                           |.|, (y + butter2-LP(y, fc))/2.  Output [t][channel] so that the 70 lanes of a
 //                           chunk store contiguously.  The reference filters the WHOLE signal
-//                           sequentially; every stage is stable with pole radius <= 0.999, so a chunk that
-//                           starts from zero state 65536 samples early reproduces the sequential result to
-//                           fp64 rounding (0.999^65536 ~ 1e-29) and chunks run in parallel.
+//                           sequentially; every stage is stable, so a chunk that starts from zero state W
+//                           samples early reproduces the sequential result to fp64 rounding and chunks run in
+//                           parallel.  W comes from the slowest pole of the chain the parameters produce
+//                           (if0_warmup: rho^W W^3 <= 1e-15; the defaults give rho = 0.99893 and W = 65536).
 //  2. if0_spectrum_kernel   one workgroup per frame: for every channel, Hamming x frame, zero-pad to
 //                           2*frame (iterative_f0.py:72-77), real FFT as a frame-point complex LDS FFT,
 //                           |X|^power accumulated over channels in registers (iterative_f0.py:80-85).
@@ -28,7 +29,8 @@ namespace mpx {
 constexpr int IF0_MAXCH = 128;
 constexpr long long IF0_CHUNK = 262144;   // largest front-end chunk (samples; multiple of every frame size)
 constexpr long long IF0_CHUNK_MIN = 16384;
-constexpr long long IF0_WARMUP = 65536;   // zero-state run-in before a chunk that does not start a clip
+constexpr long long IF0_WARMUP = 65536;   // SHORTEST zero-state run-in before a chunk that does not start a clip (if0_warmup)
+constexpr long long IF0_WARMUP_MAX = 1 << 22;
 
 struct If0ChanCoef {   // per channel, built on the host in double
     double r1b0, r1b2, r1a1, r1a2;   // resonator 1: b = [rho1, 0, -rho1], a = [1, -A cos1, A^2]
@@ -502,6 +504,27 @@ struct If0Plan {
     If0Wfir wf;
 };
 
+// Slowest pole radius of the per-channel chain (2 x resonator 1, 2 x resonator 2: radius A each; the 12 all-pass
+// stages of the warped FIR: |a|; the Butterworth low-pass at the channel frequency: sqrt(a2)), computed from the SAME
+// closed forms if0_plan uses, and the run-in it needs: the zero-input response of four cascaded sections of radius
+// rho decays like n^3 rho^n, so W is the smallest multiple of 8192 (a multiple of every frame size), at least
+// IF0_WARMUP, with rho^W W^3 <= 1e-15.  0 when the chain is too slow for IF0_WARMUP_MAX (or unstable).
+static long long if0_warmup(int fs, const mpx_if0_params& p, double* rho_out) {
+    double rho = std::fabs(1.0674 * std::sqrt((2.0 / M_PI) * std::atan(0.06583 * fs / 1000.0)) - 0.1916);
+    for (int c = 0; c < p.channels; ++c) {
+        const double fc = 229 * (std::pow(10.0, (p.zeta1 * c + p.zeta0) / 21.4) - 1);
+        const double A = std::exp(-(3.0 / 4) * M_PI / (fc * std::sqrt(std::pow(2.0, 1.0 / 4) - 1)));   // quirk A.1: "fs" is fc
+        const double kk = std::tan(M_PI * fc / fs);
+        const double a2 = (1.0 - std::sqrt(2.0) * kk + kk * kk) / (1.0 + std::sqrt(2.0) * kk + kk * kk);
+        rho = std::max(rho, std::max(A, std::sqrt(std::fabs(a2))));
+    }
+    if (rho_out) *rho_out = rho;
+    if (!(rho < 1.0)) return 0;
+    for (long long w = IF0_WARMUP; w <= IF0_WARMUP_MAX; w += 8192)
+        if (w * std::log(rho) + 3.0 * std::log((double)w) <= std::log(1e-15)) return w;
+    return 0;
+}
+
 int remez_taps_for(mpx_ctx* ctx, int fs, double* c13);  // mpx_esacf.hip
 
 static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan) {
@@ -736,6 +759,11 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     If0Plan plan;
     int rc = if0_plan(ctx, fs, p, plan);
     if (rc) return rc;
+    double rho = 0.0;
+    const long long warmup = if0_warmup(fs, p, &rho);
+    if (!warmup)
+        return set_error(ctx, MPX_EINVAL, "iterative F0: the slowest pole of the filter chain has radius %.9f; chunks and time "
+                         "shards start from zero state and would need more than %lld samples of run-in", rho, IF0_WARMUP_MAX);
 
     // chunks and frames
     std::vector<If0Chunk> chunks;
@@ -751,7 +779,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     auto lane_steps = [&](long long chunk) {  // samples the busiest lane of the longest clip walks through
         long long worst = 0;
         for (int64_t t0 = 0; t0 < longest; t0 += chunk)
-            worst = std::max<long long>(worst, std::min<long long>(t0, IF0_WARMUP) + std::min<long long>(chunk, longest - t0));
+            worst = std::max<long long>(worst, std::min<long long>(t0, warmup) + std::min<long long>(chunk, longest - t0));
         return worst;
     };
     long long chunk = IF0_CHUNK;
@@ -775,8 +803,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             const int64_t want = nfr * NF - t0;            // produce whole frames (zero input beyond the clip)
             ck.len = (int)(want < chunk ? want : chunk);
             const int64_t left = len - t0;
-            ck.clip_left = (int)(left > chunk + IF0_WARMUP ? chunk + IF0_WARMUP : (left > 0 ? left : 0));
-            ck.warm = (int)(t0 < IF0_WARMUP ? t0 : IF0_WARMUP);
+            ck.clip_left = (int)(left > chunk + warmup ? chunk + warmup : (left > 0 ? left : 0));
+            ck.warm = (int)(t0 < warmup ? t0 : warmup);
             ck.pad = 0;
             ck.yc_row0 = yc_rows;
             yc_rows += ck.len;
@@ -826,7 +854,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if (yc_bytes > ((size_t)96 << 30))
         return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: %lld chunks need %zu GiB of workspace; split the call", nchunks,
                          yc_bytes >> 30);
-    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + IF0_WARMUP * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + warmup * 4))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)nframes * n2 * sizeof(double) * 3))) return rc;   // ut | ur | ud
     if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
@@ -895,6 +923,19 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     MPX_HIP(ctx, hipStreamSynchronize(st));
+    return MPX_OK;
+}
+
+int if0_warmup_samples(mpx_ctx* ctx, int fs, const mpx_if0_params* params, long long* samples, double* rho) {
+    mpx_if0_params p = params ? *params
+                              : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
+    if (p.channels < 1 || p.channels > IF0_MAXCH || fs <= 0) return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
+    double r = 0.0;
+    const long long w = if0_warmup(fs, p, &r);
+    if (rho) *rho = r;
+    if (!w)
+        return set_error(ctx, MPX_EINVAL, "iterative F0: slowest pole radius %.9f needs more than %lld samples of run-in", r, IF0_WARMUP_MAX);
+    *samples = w;
     return MPX_OK;
 }
 

@@ -249,6 +249,14 @@ class Engine:
             C.byref(p), out.ctypes.data_as(_lib._dp)))
         return out
 
+    def iterative_f0_warmup(self, fs, **kw):
+        """(run-in samples, slowest pole radius) of this parameter set's filter chain (include/mpx.h); ValueError when the
+        chain decays too slowly to be cut into chunks or time shards."""
+        p = self._if0_params(**kw)
+        w, rho = C.c_int64(0), C.c_double(0.0)
+        self._check(self.lib.mpx_iterative_f0_warmup(self.ctx, int(fs), C.byref(p), C.byref(w), C.byref(rho)))
+        return int(w.value), float(rho.value)
+
     def iterative_f0_spectra(self, x, fs, **kw):
         """Summary spectra Ut [F, 2*frame_size] (iterative_f0.py:80-85), for parity tests."""
         x = self._sig(x)

@@ -19,7 +19,7 @@ import numpy as np
 from .chromagram import Chromagram
 from .corpus import gather_blocks, partition
 
-WARMUP = 65536  # samples; a multiple of every Iterative-F0 frame size (1024 ... 8192)
+WARMUP = 65536  # samples; the run-in of the DEFAULT filter chain, a multiple of every Iterative-F0 frame size (1024 ... 8192)
 SEED = 20260103  # + segment id
 SEGMENT_SECONDS = 0.5
 
@@ -29,20 +29,29 @@ def num_frames(n, frame_size):
     return -(-int(n) // int(frame_size)) if n > 0 else 0
 
 
-def shard_window(n, frame_size, world, rank):
+def engine_warmup(fs, device=0, **kw):
+    """Run-in samples the LIBRARY asks for with these filter-bank parameters (mpx_iterative_f0_warmup: from the slowest
+    pole of the chain; 65536 for the defaults, more for channel sets that reach higher or lower).  ValueError when the
+    chain cannot be cut into shards at all."""
+    from .engine import get_engine
+    keys = ("frame_size", "power", "channels", "zeta0", "zeta1")
+    return get_engine(device).iterative_f0_warmup(fs, **{k: v for k, v in kw.items() if k in keys})[0]
+
+
+def shard_window(n, frame_size, world, rank, warmup=WARMUP):
     """(f0, f1, s0, s1, skip): this rank owns frames [f0, f1) of the stream, computes on samples [s0, s1)
     and drops the first `skip` frames of what it computed (the warm-up)."""
-    if WARMUP % int(frame_size):
-        raise ValueError("frame size must divide the %d-sample warm-up" % WARMUP)
+    if int(warmup) % int(frame_size):
+        raise ValueError("frame size must divide the %d-sample warm-up" % warmup)
     f0, f1 = partition(num_frames(n, frame_size), world, rank)
-    return (f0, f1) + window_of(n, frame_size, f0, f1)
+    return (f0, f1) + window_of(n, frame_size, f0, f1, warmup)
 
 
-def window_of(n, frame_size, f0, f1):
+def window_of(n, frame_size, f0, f1, warmup=WARMUP):
     """(s0, s1, skip) for frames [f0, f1): the samples to compute on and the warm-up frames to drop."""
     if f1 <= f0:
         return 0, 0, 0
-    s0 = max(0, f0 * frame_size - WARMUP)
+    s0 = max(0, f0 * frame_size - int(warmup))
     s1 = min(int(n), f1 * frame_size)
     return s0, s1, (f0 * frame_size - s0) // frame_size
 
@@ -52,19 +61,22 @@ def _engine_frames(x, fs, frame_size, device, **kw):
     return get_engine(device).iterative_f0(x, fs, return_frames=True, frame_size=frame_size, **kw)[1]
 
 
-def run_stream_shard(read, n, fs, rank=0, world=1, frame_size=8192, device=0, compute=None, frames=None, **kw):
+def run_stream_shard(read, n, fs, rank=0, world=1, frame_size=8192, device=0, compute=None, frames=None, warmup=None,
+                     **kw):
     """`read(s0, s1) -> float32[s1-s0]` hands out samples of the stream (a slice of an array, a memmap, a
     generator seeded by position).  Returns (f0, f1, frames[f1-f0, 12] float64) for this rank's frames.
     `compute(x, fs, frame_size, device, **kw) -> [F,12]` defaults to the HIP engine; tests substitute the CPU
     checker to exercise the halo logic without a GPU."""
+    if warmup is None:   # the engine knows what its filter chain needs; a substituted checker gets the default chain's
+        warmup = engine_warmup(fs, device, frame_size=frame_size, **kw) if compute is None else WARMUP
     compute = compute or _engine_frames
     if frames is None:
-        f0, f1, s0, s1, skip = shard_window(n, frame_size, world, rank)
+        f0, f1, s0, s1, skip = shard_window(n, frame_size, world, rank, warmup)
     else:   # an explicit frame range (a time shard inside a rank's block)
-        if WARMUP % int(frame_size):
-            raise ValueError("frame size must divide the %d-sample warm-up" % WARMUP)
+        if int(warmup) % int(frame_size):
+            raise ValueError("frame size must divide the %d-sample warm-up" % warmup)
         f0, f1 = frames
-        s0, s1, skip = window_of(n, frame_size, f0, f1)
+        s0, s1, skip = window_of(n, frame_size, f0, f1, warmup)
     if f1 == f0:
         return f0, f1, np.zeros((0, 12), dtype=np.float64)
     x = read(s0, s1)
@@ -99,6 +111,7 @@ def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub
     other.  Same halo logic as between ranks: the rank's block of frames is partitioned once more.
     Returns (f0, f1, frames[f1-f0, 12])."""
     import threading
+    warmup = engine_warmup(fs, device, frame_size=frame_size, channels=channels, **kw)
     F0, F1 = partition(num_frames(n, frame_size), world, rank)
     # pieces: a multiple of `sub`, each small enough for PIECE_BYTES of front-end output (a two-hour stream would
     # otherwise ask one context for 180 GB, and the library refuses beyond 96 GiB per call)
@@ -113,8 +126,8 @@ def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub
             for q in range(j, pieces, sub):
                 a, b = partition(F1 - F0, pieces, q)
                 parts[q] = run_stream_shard(read, n, fs, rank, world, frame_size, device,
-                                            compute=_engine_frames_on(j), frames=(F0 + a, F0 + b), channels=channels,
-                                            **kw)
+                                            compute=_engine_frames_on(j), frames=(F0 + a, F0 + b), warmup=warmup,
+                                            channels=channels, **kw)
         except BaseException as exc:   # a side thread's exception is re-raised by the caller below
             failed.append(exc)
 
@@ -204,7 +217,8 @@ def main(argv=None):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    f0, f1, s0, s1, _ = shard_window(n, args.frame_size, world, rank)
+    f0, f1, s0, s1, _ = shard_window(n, args.frame_size, world, rank,
+                                     engine_warmup(args.fs, local, frame_size=args.frame_size))
     x = read(s0, s1)
     torch.cuda.synchronize()   # the synthesis is asynchronous; it is not part of the measured path
     torch.cuda.empty_cache()  # the synthesis' cached blocks: with them in place the engine's first hipMalloc of its workspace takes ~1 s

@@ -179,8 +179,9 @@ int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* o
  * WHOLE signal (quirk A.1 kept), warped-FIR compression, full-wave rectifier, (y + LP(y, fc))/2,
  * frames of `frame_size` (1024/2048/4096/8192) x Hamming zero-padded to 2*frame_size, sum over channels of
  * |FFT|^power, then the iterative period search / harmonic cancellation per frame.
- * Long signals are filtered in 262144-sample chunks with a 65536-sample zero-state warm-up (every pole
- * of the chain has decayed below 1e-30 by then), so chunks run in parallel and shard across GPUs. */
+ * Long signals are filtered in chunks of up to 262144 samples, each with a zero-state run-in of
+ * mpx_iterative_f0_warmup samples (65536 for the defaults: the chain has decayed to fp64 rounding by then), so
+ * chunks run in parallel and shard across GPUs. */
 typedef struct mpx_if0_params {
     int frame_size;      /* default 8192 */
     double power;        /* default 1.0 */
@@ -204,6 +205,13 @@ int mpx_iterative_f0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const
 
 int mpx_iterative_f0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                            const mpx_if0_params* params, double* chroma_sums /* [C,12] */);
+
+/* Zero-state run-in (samples, a multiple of 8192, >= 65536) after which this parameter set's filter chain has
+ * forgotten its start to fp64 rounding: rho^W W^3 <= 1e-15 for the slowest pole radius rho of the chain (also returned
+ * when pole_radius != NULL; 0.99893 and 65536 for the defaults at any sample rate).  The library uses it for its own
+ * chunks; a caller that shards one stream over GPUs starts each shard this many samples early (stream.py).
+ * MPX_EINVAL when the chain is unstable or would need more than 4 M samples: mpx_iterative_f0* then refuse too. */
+int mpx_iterative_f0_warmup(mpx_ctx* ctx, int fs, const mpx_if0_params* params, int64_t* samples, double* pole_radius);
 
 /* Debug tap: summary spectra Ut [F, 2*frame_size] (iterative_f0.py:80-85), host buffers. */
 int mpx_iterative_f0_spectra(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,

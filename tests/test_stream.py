@@ -143,3 +143,87 @@ def test_drop_in_class_takes_the_sharded_route_for_long_audio(monkeypatch):
     got = cd.MultipitchIterativeF0((x, FS)).compute_pitches()
     np.testing.assert_allclose(got.as_array(), want.as_array(), rtol=1e-9)
     assert repr(got) == repr(want)
+
+
+@pytest.mark.gpu
+def test_iterative_f0_at_44100_across_chunk_and_piece_boundaries(monkeypatch):
+    """BASELINE configs[4] runs at 44.1 kHz.  The oracle filters the whole signal sequentially; the engine cuts it into
+    chunks with a zero-state run-in, and the stream driver cuts a rank's frames into pieces once more.  40 frames
+    (7.4 s): every frame against the oracle, in particular the ones on both sides of a chunk boundary and of a piece
+    boundary; the summary spectra too."""
+    import chord_detection_amd as cd
+    from oracle import iterative_f0 as o_if0
+    fs = 44100
+    n = 40 * FRAME + 1234
+    x = stream.synth_stream(0, n, fs, "cuda:0").cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want, Ut = o_if0.iterative_f0_frames(x, fs)
+    assert want.shape == (41, 12) and np.abs(want).sum() > 0
+    eng = cd.get_engine(0)
+    w, rho = eng.iterative_f0_warmup(fs)
+    assert w == 65536 and 0.99892 < rho < 0.99894          # the default chain: what DESIGN.md and stream.WARMUP assume
+    total, got = eng.iterative_f0(x, fs, return_frames=True)
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
+    ut = eng.iterative_f0_spectra(x, fs)
+    np.testing.assert_allclose(ut, Ut, rtol=1e-9, atol=1e-9 * np.abs(Ut).max())
+    # time shards (2, 3 ranks) and pieces of 4 frames inside a rank: piece boundaries at frames 4, 8, ...
+    monkeypatch.setattr(stream, "PIECE_BYTES", 4 * FRAME * 70 * 8)
+    for world in (1, 2, 3):
+        rows = [stream.run_stream_rank(lambda a, b: x[a:b], n, fs, r, world, FRAME, 0, sub=2)[2] for r in range(world)]
+        sharded = np.concatenate(rows)
+        np.testing.assert_allclose(sharded, want, rtol=1e-5, atol=0)
+        np.testing.assert_allclose(sharded, got, rtol=1e-9, atol=1e-12)
+    assert repr(stream.chroma_of(got)) == repr(stream.chroma_of(want))
+
+
+@pytest.mark.gpu
+def test_run_in_follows_the_slowest_pole():
+    """The library derives the run-in from the parameters instead of assuming 0.999: a channel set that reaches higher
+    has slower resonators and gets a longer run-in; one that cannot be sharded at all is refused."""
+    import chord_detection_amd as cd
+    eng = cd.get_engine(0)
+    w0, r0 = eng.iterative_f0_warmup(22050)
+    w1, r1 = eng.iterative_f0_warmup(44100, channels=80, zeta1=0.45)        # top channel near 20 kHz
+    assert w0 == 65536 and r1 > r0 and w1 > w0 and w1 % 8192 == 0
+    assert r1 ** w1 * float(w1) ** 3 <= 1e-15 < r1 ** (w1 - 8192) * float(w1 - 8192) ** 3
+    n = w1 + 5 * FRAME
+    x = stream.synth_stream(0, n, 44100, "cuda:0").cpu().numpy()
+    kw = dict(channels=80, zeta1=0.45)
+    _, whole = eng.iterative_f0(x, 44100, return_frames=True, **kw)
+    for world in (2, 3):
+        rows = [stream.run_stream_shard(lambda a, b: x[a:b], n, 44100, r, world, FRAME, **kw)[2] for r in range(world)]
+        np.testing.assert_allclose(np.concatenate(rows), whole, rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        eng.iterative_f0_warmup(768000, channels=100, zeta1=0.65)           # top channel at 298 kHz: pole radius 0.99998,
+                                                                            # 4.4 M samples of run-in: refused
+    with pytest.raises(ValueError):
+        eng.iterative_f0(np.zeros(9000, dtype=np.float32), 768000, channels=100, zeta1=0.65)
+
+
+@pytest.mark.gpu
+def test_one_hour_stream_shard_count_invariance():
+    """BASELINE configs[4] at full size: Iterative-F0 over ONE 1 h stream @44.1 kHz (19 380 frames).  Size-independent
+    property: the frames do not depend on how many time shards (GPUs) the stream was cut into -- 1, 2, 3 and 8 shards,
+    each started 65536 samples early from zero state, agree to 1e-9, and the run is reproducible."""
+    import time
+    fs, secs = 44100, 3600.0
+    n = int(round(secs * fs))
+    x = stream.synth_stream(0, n, fs, "cuda:0")
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    ref = None
+    for world in (1, 2, 3, 8):
+        t0 = time.perf_counter()
+        rows = [stream.run_stream_rank(lambda a, b: x[a:b], n, fs, r, world, FRAME, 0, sub=2, note_names="ascii")[2]
+                for r in range(world)]
+        got = np.concatenate(rows)
+        print("1 h stream, %d shard(s): %.2f s" % (world, time.perf_counter() - t0))
+        assert got.shape == (19380, 12) and np.isfinite(got).all() and (got.sum(axis=1) > 0).all()   # ASCII names: every voice counts
+        if ref is None:
+            ref = got
+            again = stream.run_stream_rank(lambda a, b: x[a:b], n, fs, 0, 1, FRAME, 0, sub=2, note_names="ascii")[2]
+            np.testing.assert_array_equal(again, ref)
+        else:
+            np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12)
+    assert repr(stream.chroma_of(got)) == repr(stream.chroma_of(ref))
