@@ -346,6 +346,10 @@ def dominant(prof):
 
 # ---------------------------------------------------------------------------------------------------------------
 def main():
+    # tests only: a stand-in for torch.cuda + the HIP engine, so that the world > 1 code below runs over gloo on CPU
+    stub = importlib.import_module(os.environ["MPX_BENCH_STUB"]) if os.environ.get("MPX_BENCH_STUB") else None
+    if stub is not None:
+        stub.configure(sys.modules[__name__])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # defaults: 0.1 s of GPU work.  The device needs on the order of 0.05 s under load to reach its sustained clock; the
@@ -367,10 +371,6 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    # tests only: a stand-in for torch.cuda + the HIP engine, so that the world > 1 code below runs over gloo on CPU
-    stub = importlib.import_module(os.environ["MPX_BENCH_STUB"]) if os.environ.get("MPX_BENCH_STUB") else None
-    if stub is not None:
-        stub.configure(sys.modules[__name__])
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # rank 0 at N=1 only, and before the GPU is touched
@@ -413,7 +413,7 @@ def main():
     nsig = max(1, args.signals)
     engs = [make_engine() for _ in range(nstreams)]
     eng = engs[0]
-    sigs = [synth_signal_device(20260101 + 1000 * rank + k, dev) for k in range(nsig)]
+    sigs = [synth_signal_device(20260101 + 1000 * rank + k, dev, FRAMES) for k in range(nsig)]
     x_host = sigs[0].cpu().numpy()
     n = sigs[0].numel()
     steps, warmup = args.steps, args.warmup

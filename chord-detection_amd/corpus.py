@@ -178,7 +178,9 @@ def summarise(chroma, methods, seconds_per_method, n_clips, wall):
     return res
 
 
-def main(argv=None):
+def main(argv=None, compute=None, device="cuda", backend="nccl"):
+    """`compute`, `device`, `backend`: injection points for the CPU tests (a checker instead of the engine, CPU tensors,
+    gloo): the command line never sets them -- without a GPU and the HIP library this driver fails, it has no fallback."""
     import argparse
     import os
     ap = argparse.ArgumentParser(description="all four methods over a synthetic corpus, clip-sharded over the visible GPUs")
@@ -197,15 +199,20 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    dev = torch.device("cuda", local)
+    on_gpu = device == "cuda"
+    dev = torch.device("cuda", local) if on_gpu else torch.device(device)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gpu:
+            torch.cuda.set_device(dev)
+            dist.init_process_group(backend, device_id=dev)
+        else:
+            dist.init_process_group(backend)
     t0 = time.perf_counter()
     lo, hi, block, spent = run_corpus(args.clips, methods, args.fs, args.seconds, args.chunk, rank, world, local,
-                                      synth_device=dev, overlap=not args.no_overlap, note_names=args.note_names)
-    chroma = gather_blocks(block, args.clips, world, rank, dev if world > 1 else None)
+                                      compute=compute, synth_device=dev if on_gpu else None, overlap=not args.no_overlap,
+                                      note_names=args.note_names)
+    chroma = gather_blocks(block, args.clips, world, rank, dev if (world > 1 and on_gpu) else None)
     wall = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist

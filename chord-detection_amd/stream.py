@@ -188,7 +188,9 @@ def synth_stream(s0, s1, fs, device=None):
     return out
 
 
-def main(argv=None):
+def main(argv=None, compute=None, device="cuda", backend="nccl"):
+    """`compute`, `device`, `backend`: injection points for the CPU tests (a checker instead of the engine, CPU tensors,
+    gloo): the command line never sets them -- without a GPU and the HIP library this driver fails, it has no fallback."""
     import argparse
     import os
     ap = argparse.ArgumentParser(description="Iterative-F0 over one long synthetic stream, time-sharded over the GPUs of a node")
@@ -200,32 +202,46 @@ def main(argv=None):
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     import torch
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    on_gpu = device == "cuda"
+    dev = torch.device("cuda", local) if on_gpu else torch.device(device)
+    if on_gpu:
+        torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if on_gpu:
+            dist.init_process_group(backend, device_id=dev)
+        else:
+            dist.init_process_group(backend)
     n = int(round(args.seconds * args.fs))
     total_frames = num_frames(n, args.frame_size)
+
+    def dev_sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def read(s0, s1):   # stays in HBM: the engine takes device memory (include/mpx.h, "where the samples live")
         return synth_stream(s0, s1, args.fs, dev)
 
-    for j in range(max(1, args.shards_per_gpu)):   # plans, tables, clocks -- of every context
-        _engine_frames_on(j)(read(0, min(n, 4 * args.frame_size)), args.fs, args.frame_size, local)
+    if compute is None:
+        for j in range(max(1, args.shards_per_gpu)):   # plans, tables, clocks -- of every context
+            _engine_frames_on(j)(read(0, min(n, 4 * args.frame_size)), args.fs, args.frame_size, local)
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     t0 = time.perf_counter()
-    f0, f1, s0, s1, _ = shard_window(n, args.frame_size, world, rank,
-                                     engine_warmup(args.fs, local, frame_size=args.frame_size))
+    warm = engine_warmup(args.fs, local, frame_size=args.frame_size) if compute is None else WARMUP
+    f0, f1, s0, s1, _ = shard_window(n, args.frame_size, world, rank, warm)
     x = read(s0, s1)
-    torch.cuda.synchronize()   # the synthesis is asynchronous; it is not part of the measured path
-    torch.cuda.empty_cache()  # the synthesis' cached blocks: with them in place the engine's first hipMalloc of its workspace takes ~1 s
+    dev_sync()   # the synthesis is asynchronous; it is not part of the measured path
+    if on_gpu:
+        torch.cuda.empty_cache()  # the synthesis' cached blocks: with them in place the engine's first hipMalloc of its workspace takes ~1 s
     t1 = time.perf_counter()
     t_synth = t1 - t0
 
     def compute_block():
+        if compute is not None:    # the CPU tests' checker: one shard per rank, same halo logic
+            return run_stream_shard(lambda a, b: x.numpy(), n, args.fs, rank, world, args.frame_size, local,
+                                    compute=compute)[2]
         if args.shards_per_gpu > 1:
             return run_stream_rank(lambda a, b: x[a - s0:b - s0], n, args.fs, rank, world, args.frame_size, local,
                                    sub=args.shards_per_gpu)[2]
@@ -240,7 +256,7 @@ def main(argv=None):
     t1 = time.perf_counter()
     block = compute_block()
     t2 = time.perf_counter()
-    frames = gather_frames(block, total_frames, world, rank, dev if world > 1 else None)
+    frames = gather_frames(block, total_frames, world, rank, dev if (world > 1 and on_gpu) else None)
     spent = torch.tensor([t_synth, t2 - t1, t_cold], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(spent, op=dist.ReduceOp.MAX)

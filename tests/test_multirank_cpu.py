@@ -1,0 +1,94 @@
+"""CPU, two ranks over gloo, launched the way the driver launches them (python -m torch.distributed.run): bench.py
+itself, scripts/run_corpus.py and scripts/run_stream.py execute their world > 1 branches -- process-group set-up,
+barriers, the job's single all_gather, max-over-ranks timing, rank 0's one JSON line -- with a stand-in engine
+(tests/bench_stub.py, selected HERE through the environment / the test launcher; the product has no such switch)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(nproc, script_and_args, extra_env=None, timeout=600):
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_and_args
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout           # rank 0 alone prints, exactly one line
+    return json.loads(lines[0])
+
+
+def test_bench_py_two_ranks():
+    d = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2"], {"MPX_BENCH_STUB": "tests.bench_stub"})
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["frames_per_gpu"] == 8                     # the stand-in's toy size
+    # whole-job aggregate over both ranks, max-over-ranks time
+    assert np.isclose(d["value"], 2 * 8 * 5 / (d["ms_per_step"] * 5e-3), rtol=1e-9)
+    assert np.isclose(d["value_one_in_flight"], 2 * 8 * 5 / (d["ms_per_step_one_in_flight"] * 5e-3), rtol=1e-9)
+    assert "cpu_baseline" not in d                                # rank 0 at N = 1 only
+    w = d["workloads"]
+    assert set(w) == {"esacf_clips_4096", "esacf_stft_8192", "corpus_4096_all_methods", "if0_stream_1h"}
+    assert w["esacf_clips_4096"]["scaling"] == "weak" and w["corpus_4096_all_methods"]["scaling"] == "weak"
+    assert w["if0_stream_1h"]["scaling"] == "strong" and w["if0_stream_1h"]["frames"] == -(-int(9.0 * 22050) // 8192)
+    assert w["corpus_4096_all_methods"]["nonzero_rows"] == 2 * 3 * 4      # both ranks' clips arrived through the gather
+    for rec in w.values():
+        assert rec["value"] > 0 and "cpu_baseline" not in rec
+
+
+def test_bench_py_one_rank_stub_matches_contract():
+    env = dict(os.environ, PYTHONPATH=ROOT, MPX_BENCH_STUB="tests.bench_stub", MPX_BENCH_CPU_BUDGET="0.2")
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--headline-only"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and "workloads" not in d
+    c = d["cpu_baseline"]                                          # the CPU legs ran first, before anything else
+    assert c["cores"] == 1 and c["value"] > 0 and c["host"]["workers"] >= 1 and c["host"]["model"]
+    if c["host"]["workers"] > 1:
+        assert c["all_cores"]["cores"] == c["host"]["workers"]
+
+
+def test_run_corpus_script_two_ranks():
+    d = _torchrun(2, ["tests/tools/launch_cpu_rank.py", "corpus", "--clips", "5", "--seconds", "0.25", "--chunk", "2",
+                      "--methods", "2,4"])
+    assert d["n_gpus"] == 2 and d["clips"] == 5 and set(d["methods"]) == {"2", "4"}
+    assert len(d["methods"]["2"]["first_clip"]) == 12 and d["clips_per_s"] > 0
+    # the same job on one rank gives the same summary numbers (the gather put every rank's block in place)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    one = subprocess.run([sys.executable, "tests/tools/launch_cpu_rank.py", "corpus", "--clips", "5", "--seconds", "0.25",
+                          "--chunk", "2", "--methods", "2,4"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    s = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    # rank 1's block starts at clip 3 = a chunk boundary of neither job, so only the tonal part agrees exactly per
+    # clip; the means agree to the noise level
+    assert s["methods"]["2"]["first_clip"] == d["methods"]["2"]["first_clip"]
+    np.testing.assert_allclose(s["methods"]["2"]["mean_chroma"], d["methods"]["2"]["mean_chroma"], rtol=0.2)
+
+
+def test_run_stream_script_two_ranks():
+    args = ["tests/tools/launch_cpu_rank.py", "stream", "--seconds", "9", "--fs", "22050", "--frame-size", "8192"]
+    d = _torchrun(2, args)
+    frames = -(-int(9 * 22050) // 8192)
+    assert d["n_gpus"] == 2 and d["frames"] == frames and d["frames_per_rank"] == frames - frames // 2
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    one = subprocess.run([sys.executable] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-3000:]
+    s = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert s["n_gpus"] == 1 and s["chroma"] == d["chroma"] and s["key"] == d["key"]   # sharded == unsharded
