@@ -72,6 +72,8 @@ SIGNATURES = {
     "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),
     "mpx_timer_begin": (C.c_int, [_vp, _vp]),
     "mpx_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "mpx_host_alloc": (_vp, [C.c_size_t]),
+    "mpx_host_free": (None, [_vp]),
     "mpx_profile_begin": (C.c_int, [_vp]),
     "mpx_profile_end": (C.c_int, [_vp, C.c_char_p, C.c_int]),
 }

@@ -57,6 +57,17 @@ void* upload(mpx_ctx* ctx, const void* host, size_t bytes) {
     return d;
 }
 
+// Samples into device memory, enqueued on `st`.  One hipMemcpyAsync whatever the source: measured on the MI355X box
+// (scripts/h2d_probe.py, profiles/r2/h2d_probe.json) the runtime moves PAGEABLE host memory at 45 GB/s for the 33.5 MB
+// headline signal and 55 GB/s for a 1.4 GB clip batch (it pins the caller's pages and DMAs from them), pinned memory
+// at 49 GB/s -- a staging ring of our own (four host threads copying 2 MiB pieces into pinned buffers, two each) reached
+// 33 and 39 GB/s and was removed again: a memcpy per byte costs more than the page pinning it avoids.
+int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return MPX_OK;
+    MPX_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
+    return MPX_OK;
+}
+
 void prof_mark_slow(mpx_ctx* ctx, hipStream_t st, const char* name) {
     if (ctx->prof_marks.size() >= (size_t)1 << 20) return;  // bounded: a forgotten mpx_profile_end must not eat the host
     hipEvent_t ev = nullptr;
@@ -159,10 +170,26 @@ void mpx_destroy(mpx_ctx* ctx) {
         if (b->p) hipFree(b->p);
     for (auto& m : ctx->prof_marks) hipEventDestroy(m.ev);
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
+    for (hipEvent_t e : ctx->copy_ev)
+        if (e) hipEventDestroy(e);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+void* mpx_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void mpx_host_free(void* p) {
+    if (p) hipHostFree(p);
 }
 
 const char* mpx_last_error(const mpx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -304,7 +331,7 @@ static int method_host(mpx_ctx* ctx, run_fn run, const float* signal, int64_t n,
     if ((rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
-    if (n) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyDefault, ctx->stream));
+    if (n && (rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) return rc;
     rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
                     chroma_frames ? (double*)ctx->d_frames_out.p : nullptr, (double*)ctx->d_sum.p, ctx->stream);
     if (rc) return rc;
@@ -338,13 +365,67 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
     hipStream_t st = ctx->stream;
-    if (total) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyDefault, st));
     if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     bool did_sum = false;
-    if (nf && (rc = run(ctx, (const float*)ctx->d_signal.p, total, (const FrameDesc*)ctx->d_desc.p, nf, fs, params,
-                        frame, hop, (double*)ctx->d_frames_out.p, nullptr, &did_sum, st)))
-        return rc;
+    // A large batch in HOST memory goes over PCIe in pieces on a second stream, the kernels of piece k running next to
+    // the copy of piece k+1 (ESACF, 4096 clips: the 1.4 GB copy and the 27 ms of kernels take about as long as each
+    // other).  Device-resident batches and small ones: one copy, one pass.
+    int pieces = 1;
+    {
+        hipPointerAttribute_t attr;
+        bool on_device = false;
+        if (hipPointerGetAttributes(&attr, signals) == hipSuccess)
+            on_device = attr.type == hipMemoryTypeDevice;
+        else
+            (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
+        const bool off = getenv("MPX_NO_COPY_OVERLAP") && atoi(getenv("MPX_NO_COPY_OVERLAP"));
+        if (!on_device && !off && (size_t)total * sizeof(float) >= (size_t(64) << 20) && num_clips >= 8) {
+            pieces = getenv("MPX_COPY_PIECES") ? atoi(getenv("MPX_COPY_PIECES")) : 4;
+            pieces = pieces < 1 ? 1 : (pieces > 7 ? 7 : pieces);
+        }
+    }
+    if (pieces > 1 && !ctx->copy_stream) {
+        if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->copy_stream = nullptr;
+            pieces = 1;
+        }
+        for (int k = 0; k < 8 && pieces > 1; ++k)
+            if (hipEventCreateWithFlags(&ctx->copy_ev[k], hipEventDisableTiming) != hipSuccess) pieces = 1;
+    }
+    if (pieces == 1) {
+        if (total && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
+        if (nf && (rc = run(ctx, (const float*)ctx->d_signal.p, total, (const FrameDesc*)ctx->d_desc.p, nf, fs, params,
+                            frame, hop, (double*)ctx->d_frames_out.p, nullptr, &did_sum, st)))
+            return rc;
+    } else {
+        // the staging buffer may still be read by work queued earlier on the compute stream
+        MPX_HIP(ctx, hipEventRecord(ctx->copy_ev[7], st));
+        MPX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->copy_ev[7], 0));
+        int c0 = 0;
+        int bounds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bounds[pieces] = num_clips;
+        for (int k = 1; k < pieces; ++k) {   // clip boundaries nearest to k/pieces of the samples
+            const int64_t want = total / pieces * k;
+            while (c0 < num_clips && offsets[c0] < want) ++c0;
+            bounds[k] = c0;
+        }
+        for (int k = 0; k < pieces; ++k) {
+            // copy of piece k, then the (asynchronous) kernels of piece k: a copy from pageable memory keeps the CALLING
+            // THREAD busy until it is done, so it is the next piece's copy that runs next to these kernels
+            const int64_t s0 = offsets[bounds[k]], s1 = offsets[bounds[k + 1]];
+            if (s1 > s0)
+                MPX_HIP(ctx, hipMemcpyAsync((float*)ctx->d_signal.p + s0, signals + s0, (size_t)(s1 - s0) * sizeof(float),
+                                            hipMemcpyDefault, ctx->copy_stream));
+            MPX_HIP(ctx, hipEventRecord(ctx->copy_ev[k], ctx->copy_stream));
+            const long long f0 = seg[bounds[k]], f1 = seg[bounds[k + 1]];
+            MPX_HIP(ctx, hipStreamWaitEvent(st, ctx->copy_ev[k], 0));
+            if (f1 > f0 && (rc = run(ctx, (const float*)ctx->d_signal.p, total, (const FrameDesc*)ctx->d_desc.p + f0, f1 - f0,
+                                     fs, params, frame, hop, (double*)ctx->d_frames_out.p + f0 * 12, nullptr, &did_sum, st)))
+                return rc;
+        }
+    }
     if ((rc = segment_sum(ctx, (const double*)ctx->d_frames_out.p, (const long long*)ctx->d_offsets.p, num_clips, nf,
                           (double*)ctx->d_sum.p, st)))
         return rc;
@@ -485,7 +566,7 @@ int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int
     if ((rc = ensure(ctx, ctx->d_signal, (size_t)n * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nf * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws2, (size_t)nf * len * sizeof(double) + 16))) return rc;
-    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signal, (size_t)n * sizeof(float), hipMemcpyDefault, ctx->stream));
+    if ((rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) return rc;
     if ((rc = esacf_run(ctx, (const float*)ctx->d_signal.p, n, nullptr, nf, fs, params, frame, hop,
                         (double*)ctx->d_frames_out.p, stage, (double*)ctx->d_ws2.p, ctx->stream)))
         return rc;

@@ -866,7 +866,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     If0Frame* d_frames = (If0Frame*)((char*)ctx->d_desc.p + ((chunks.size() * sizeof(If0Chunk) + 15) & ~(size_t)15));
     If0TailGroup* d_tail_groups = (If0TailGroup*)((char*)d_frames + ((frames.size() * sizeof(If0Frame) + 15) & ~(size_t)15));
     int* d_tail_list = (int*)((char*)d_tail_groups + ((tail_groups.size() * sizeof(If0TailGroup) + 15) & ~(size_t)15));
-    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyDefault, st));
+    if ((rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
     MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(d_frames, frames.data(), frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
     if (nt) {

@@ -51,6 +51,8 @@ struct mpx_ctx {
     int flags = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;        // host batches: the copy of piece k+1 runs next to the kernels of piece k
+    hipEvent_t copy_ev[8] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<std::tuple<int, int, int, int, int>, mpx::HePlan> he_plans;
@@ -76,6 +78,8 @@ namespace mpx {
 int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
 void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failure (error set)
+// Samples (host or device memory) into device memory, enqueued on `st` (see mpx_api.hip for the measured rates).
+int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
 // While profiling is on: record an event on `st`; the time to the next mark is booked on `name` (nullptr: on nothing).
 void prof_mark_slow(mpx_ctx* ctx, hipStream_t st, const char* name);
 inline void prof_mark(mpx_ctx* ctx, hipStream_t st, const char* name) {

@@ -325,7 +325,7 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, (nitems + 1) * PRIME_MAX_RUNS * (sizeof(int) + sizeof(double)) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)(num_clips ? num_clips : 1) * 12 * sizeof(double)))) return rc;
-    if (total) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_signal.p, signals, (size_t)total * sizeof(float), hipMemcpyDefault, st));
+    if (total && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     double* d_val = (double*)ctx->d_ws0.p;
     int* d_pc = (int*)(d_val + (nitems + 1) * PRIME_MAX_RUNS);

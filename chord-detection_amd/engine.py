@@ -316,6 +316,40 @@ class Engine:
         return out
 
 
+class _Pinned:
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self.lib.mpx_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+def pinned_empty(n, dtype=np.float32):
+    """A 1-D NumPy array in pinned host memory (mpx_host_alloc): as an input of the host entry points it crosses PCIe
+    in one DMA instead of going through the staging ring (include/mpx.h, "where the samples live")."""
+    lib = _lib.load()
+    dtype = np.dtype(dtype)
+    nbytes = int(n) * dtype.itemsize
+    ptr = lib.mpx_host_alloc(nbytes)
+    if not ptr:
+        raise MemoryError("mpx_host_alloc(%d) failed" % nbytes)
+    owner = _Pinned(lib, ptr)
+    buf = (C.c_char * nbytes).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(n))
+    arr = arr.view(_PinnedArray)
+    arr._mpx_owner = (owner, buf)
+    return arr
+
+
+class _PinnedArray(np.ndarray):
+    def __array_finalize__(self, obj):
+        self._mpx_owner = getattr(obj, "_mpx_owner", None)
+
+
+
 def get_engine(device=0, f32=False, deterministic=False):
     """Process-wide engine per (device, dtype, lane-mode fits).  `deterministic` = MPX_FLAG_DETERMINISTIC: the slower way
     of computing the SAME bits (include/mpx.h); results are reproducible either way."""
