@@ -14,19 +14,20 @@ import numpy as np
 
 
 def _resample(x, sr_in, sr_out):
+    """Windowed-sinc polyphase resampler: scipy.signal.resample_poly evaluates only the outputs that are kept (one
+    sub-filter per output phase), so 48 kHz -> 22.05 kHz (up 147, down 320, 10 241 taps) costs 32 multiply-adds per
+    output sample instead of a 10 241-tap convolution over the zero-stuffed signal."""
     if sr_in == sr_out:
         return x
+    import scipy.signal
     g = math.gcd(int(sr_in), int(sr_out))
     up, down = int(sr_out) // g, int(sr_in) // g
     cutoff = 1.0 / max(up, down)
     half = 16 * max(up, down)
     n = np.arange(-half, half + 1)
     h = cutoff * np.sinc(cutoff * n) * np.hanning(2 * half + 1)
-    h = h * up / h.sum() * (1.0 if up == 1 else 1.0)
-    y = np.zeros(x.shape[0] * up, dtype=np.float64)
-    y[::up] = x
-    y = np.convolve(y, h, mode="same")
-    return y[::down].astype(np.float32)
+    h = h / h.sum()          # unit DC gain; resample_poly applies the factor `up` itself
+    return scipy.signal.resample_poly(np.asarray(x, dtype=np.float64), up, down, window=h).astype(np.float32)
 
 
 def load(path, sr=22050):

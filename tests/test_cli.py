@@ -20,6 +20,15 @@ def test_wav_loader_roundtrip(tmp_path):
     audio.write_wav(tmp_path / "b.wav", np.sin(2 * np.pi * 440 * np.arange(44100) / 44100.0), 44100)
     z, fs2 = audio.load(tmp_path / "b.wav")        # resampled to 22050 like librosa.load's default
     assert fs2 == 22050 and abs(z.shape[0] - 22050) <= 1
+    # 48 kHz -> 22.05 kHz (up 147 / down 320): polyphase, milliseconds, and the tone survives
+    import time
+    t48 = np.arange(2 * 48000) / 48000.0
+    audio.write_wav(tmp_path / "c.wav", 0.5 * np.sin(2 * np.pi * 440 * t48), 48000)
+    t0 = time.perf_counter()
+    u, fs3 = audio.load(tmp_path / "c.wav")
+    assert time.perf_counter() - t0 < 5.0 and fs3 == 22050 and u.shape == (44100,)
+    tt = np.arange(44100) / 22050.0
+    assert np.max(np.abs(u[2000:-2000] - 0.5 * np.sin(2 * np.pi * 440 * tt[2000:-2000]))) < 1e-3
 
 
 @pytest.mark.gpu
