@@ -187,6 +187,12 @@ struct SacfArgs {
     long long num_frames;  // frames in this launch
     int pair;              // 1: a workgroup takes two frames and shares the second DFT between them
     int ablate;         // profiling knob (env MPX_SACF_ABLATE): 1 no pow, 2 no peak picking, 4 no 2nd DFT, 8 no 1st DFT
+    // prime-factor engine (sacf_pfa_kernel): N = A0 * 3 * 11 * 31
+    const unsigned short* pfa_pos;    // [N]   array position of index n (input sample n; output lag n)
+    const unsigned short* pfa_pairs;  // [npairs][2] positions (p, mirror p), p <= mirror p
+    const cx<double>* pfa_cs31;       // [16][16] (cos, sin)(2 pi n k / 31), k = 0..15, n = 0..15
+    const cx<double>* pfa_cs11;       // [6][5]   (cos, sin)(2 pi n k / 11)
+    int pfa_npairs;
 };
 
 __device__ __forceinline__ cx<double> cconj(cx<double> a) { return {a.x, -a.y}; }
@@ -608,6 +614,342 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
         if (a.ablate & (2 | 16)) continue;  // 16: peak picking runs as its own one-wave-per-frame kernel
         peak_pick<T>(a, f, yh, smem, tid);
         __syncthreads();  // frame a's scratch is dead before frame b's
+    }
+}
+
+// ------------------------------------------------------------------ kernel 2, prime-factor engine
+// The reference's own frame lengths are products of small coprimes: 1023 = 3 * 11 * 31 (46.4 ms at 22.05 kHz) and
+// 2046 = 2 * 3 * 11 * 31 (44.1 kHz).  Good-Thomas: with the input index written as n = sum_i n_i N/N_i (mod N) and the
+// output index by its residues k_i = k mod N_i, W_N^(nk) = prod_i W_(N_i)^(n_i k_i): the N-point DFT IS a multi-dimensional
+// DFT over the array [A0][3][11][31] -- no twiddle factors, no zero padding (the chirp-z path runs four 4096-point
+// transforms per 2046-sample frame).  And the same array DFT maps residue-indexed input to sum-indexed output, so the
+// second transform of the SACF (DFT of S, which sits at residue positions after the first) runs in place on the same
+// layout and leaves lag n at the position sample n was loaded to: one position table serves both ends.
+//   axis 31, axis 11: one line per 16 / 6 lanes; lane k holds cos/sin(2 pi n k / P) for its k in registers and computes the
+//     output pair X[k], X[P-k] from the line's sums s[n] = a[n] + a[P-n] and differences d[n] = a[n] - a[P-n]:
+//     X[k], X[P-k] = a0 + sum_n s[n] cos(nk) -+ i sum_n d[n] sin(nk): (P-1)/2 * 4 fused multiply-adds per pair instead
+//     of 4 (P-1) for a plain matrix row.  The lanes of a line sit in one wave: the passes are ordered by the wave's own
+//     LDS queue, workgroup barriers only between axes.
+//   axes A0 x 3: one thread per line, a 6- (or 3-) point DFT in registers.
+constexpr int PFA_T = 256;
+// LDS map of sacf_pfa_kernel: [buf: N complex][cs31: 256 complex][cs11: 30 complex]; once the second transform has been
+// read out, buf is dead and holds [peak-picking scratch][yv: Mh + 2 doubles].  37.3 KB at N = 2046: four workgroups per CU
+// (with the lags and the position table in LDS as well it was 49.6 KB and three).
+#define PFA_TAB_OFF(N, Mh) (16 * (size_t)(N))
+#define PFA_LDS_BYTES(N, Mh) (PFA_TAB_OFF(N, Mh) + 16 * (256 + 30))
+#define PFA_YV_OFF(Mh) ((peak_scratch_bytes(Mh) + 15) & ~(size_t)15)
+
+// value of lane (lane -/+ J) mod 16 of the caller's 16-lane DPP row (row_ror:J); the direction is never assumed: the
+// kernel rotates the lane's own k the same way and picks its coefficients by what arrives
+template <int J>
+__device__ __forceinline__ int ror16_i32(int v) {
+    return __builtin_amdgcn_mov_dpp(v, 0x120 + J, 0xf, 0xf, true);   // every lane of a row is a valid source
+}
+template <int J>
+__device__ __forceinline__ double ror16_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = ror16_i32<J>(lo);
+    hi = ror16_i32<J>(hi);
+    return __hiloint2double(hi, lo);
+}
+
+// Axis 31: a line per 16-lane DPP row, lane k holds s[k] = a[k] + a[31-k] and d[k] = a[k] - a[31-k] (lane 0: a[0], 0)
+// and needs all sixteen of each: fifteen row rotations bring them past (register to register: the first version read
+// them back from LDS, 31 broadcast reads per lane, and the pass was bound by the LDS pipe at 5.8 k cycles per transform).
+// Every lane reads and writes only its own two elements: no fences inside the pass.
+struct Pfa31Coef {
+    double c[16], s[16];   // [0]: own term (n = k); [J]: the term that rotation J delivers
+};
+
+template <int J>
+__device__ __forceinline__ void pfa31_term(cx<double>& sv, cx<double>& dv, const Pfa31Coef& w, cx<double>& pp, cx<double>& qq) {
+    const double sx = ror16_f64<J>(sv.x), sy = ror16_f64<J>(sv.y), dx = ror16_f64<J>(dv.x), dy = ror16_f64<J>(dv.y);
+    pp.x = fma(sx, w.c[J], pp.x);
+    pp.y = fma(sy, w.c[J], pp.y);
+    qq.x = fma(dx, w.s[J], qq.x);
+    qq.y = fma(dy, w.s[J], qq.y);
+    // One term after the other: the rotations depend on nothing but sv and dv, and a scheduler that is free to do so
+    // issues all 120 of a round first and sinks the multiply-adds behind them -- 120 live temporaries, the coefficients
+    // in scratch.  The empty statement makes the next term's rotations wait for this term's sums.
+    asm volatile("" : "+v"(pp.x), "+v"(pp.y), "+v"(qq.x), "+v"(qq.y), "+v"(sv.x), "+v"(sv.y), "+v"(dv.x), "+v"(dv.y));
+}
+
+// Real input (the second transform of the SACF acts on S): the sums and differences are real, so are P and Q, and
+// X[31-k] = conj X[k] -- half the rotations, half the multiply-adds, and only X[k], k <= 15, is stored: the later axes
+// then run on the 16 of 31 residues that are kept (the caller reads lag n from its mirror position when it must).
+template <int J>
+__device__ __forceinline__ void pfa31_term_real(double& sv, double& dv, const Pfa31Coef& w, double& pp, double& qq) {
+    const double sx = ror16_f64<J>(sv), dx = ror16_f64<J>(dv);
+    pp = fma(sx, w.c[J], pp);
+    qq = fma(dx, w.s[J], qq);
+    asm volatile("" : "+v"(pp), "+v"(qq), "+v"(sv), "+v"(dv));
+}
+
+// cs31: LDS copy of the [16][16] table (cos, sin)(2 pi n k / 31); a lane's sixteen entries are fetched at the start of a
+// pass (bank = 4 ((k -+ J) mod 16): conflict free) and live in registers only while the pass runs
+template <bool REAL>
+__device__ __forceinline__ void pfa_pass31(cx<double>* buf, int nlines, const cx<double>* cs31, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int sub = lane >> 4, k = lane & 15;
+    Pfa31Coef w;
+    {
+        int src[16];
+        src[0] = k;
+        src[1] = ror16_i32<1>(k);
+        src[2] = ror16_i32<2>(k);
+        src[3] = ror16_i32<3>(k);
+        src[4] = ror16_i32<4>(k);
+        src[5] = ror16_i32<5>(k);
+        src[6] = ror16_i32<6>(k);
+        src[7] = ror16_i32<7>(k);
+        src[8] = ror16_i32<8>(k);
+        src[9] = ror16_i32<9>(k);
+        src[10] = ror16_i32<10>(k);
+        src[11] = ror16_i32<11>(k);
+        src[12] = ror16_i32<12>(k);
+        src[13] = ror16_i32<13>(k);
+        src[14] = ror16_i32<14>(k);
+        src[15] = ror16_i32<15>(k);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const cx<double> v = cs31[k * 16 + (src[j] & 15)];
+            w.c[j] = v.x;
+            w.s[j] = v.y;
+        }
+    }
+    for (int l0 = 0; l0 < nlines; l0 += 16) {
+        if (l0 + wave * 4 >= nlines) break;      // the last round of 66 lines has work for one wave only (wave-uniform)
+        const int l = l0 + wave * 4 + sub;
+        const bool active = l < nlines;           // uniform per 16-lane row
+        cx<double>* e = buf + (active ? l : 0) * 31;
+        const int ia = k, ib = k ? 31 - k : 0;
+        if (REAL) {
+            const double ur = e[ia].x, vr = e[ib].x;
+            double sv = k ? ur + vr : ur, dv = k ? ur - vr : 0.0;
+            double pp = sv * w.c[0], qq = dv * w.s[0];
+            pfa31_term_real<1>(sv, dv, w, pp, qq);
+            pfa31_term_real<2>(sv, dv, w, pp, qq);
+            pfa31_term_real<3>(sv, dv, w, pp, qq);
+            pfa31_term_real<4>(sv, dv, w, pp, qq);
+            pfa31_term_real<5>(sv, dv, w, pp, qq);
+            pfa31_term_real<6>(sv, dv, w, pp, qq);
+            pfa31_term_real<7>(sv, dv, w, pp, qq);
+            pfa31_term_real<8>(sv, dv, w, pp, qq);
+            pfa31_term_real<9>(sv, dv, w, pp, qq);
+            pfa31_term_real<10>(sv, dv, w, pp, qq);
+            pfa31_term_real<11>(sv, dv, w, pp, qq);
+            pfa31_term_real<12>(sv, dv, w, pp, qq);
+            pfa31_term_real<13>(sv, dv, w, pp, qq);
+            pfa31_term_real<14>(sv, dv, w, pp, qq);
+            pfa31_term_real<15>(sv, dv, w, pp, qq);
+            if (active) e[ia] = {pp, -qq};   // X[k] = P - iQ
+            continue;
+        }
+        const cx<double> u = e[ia], v = e[ib];
+        cx<double> sv = k ? cx<double>{u.x + v.x, u.y + v.y} : u;
+        cx<double> dv = k ? cx<double>{u.x - v.x, u.y - v.y} : cx<double>{0.0, 0.0};
+        cx<double> pp = {sv.x * w.c[0], sv.y * w.c[0]}, qq = {dv.x * w.s[0], dv.y * w.s[0]};
+        pfa31_term<1>(sv, dv, w, pp, qq);
+        pfa31_term<2>(sv, dv, w, pp, qq);
+        pfa31_term<3>(sv, dv, w, pp, qq);
+        pfa31_term<4>(sv, dv, w, pp, qq);
+        pfa31_term<5>(sv, dv, w, pp, qq);
+        pfa31_term<6>(sv, dv, w, pp, qq);
+        pfa31_term<7>(sv, dv, w, pp, qq);
+        pfa31_term<8>(sv, dv, w, pp, qq);
+        pfa31_term<9>(sv, dv, w, pp, qq);
+        pfa31_term<10>(sv, dv, w, pp, qq);
+        pfa31_term<11>(sv, dv, w, pp, qq);
+        pfa31_term<12>(sv, dv, w, pp, qq);
+        pfa31_term<13>(sv, dv, w, pp, qq);
+        pfa31_term<14>(sv, dv, w, pp, qq);
+        pfa31_term<15>(sv, dv, w, pp, qq);
+        if (active) {
+            // X[k] = P - iQ, X[31-k] = P + iQ   (a[0] is the n = 0 term of P)
+            e[ia] = {pp.x + qq.y, pp.y - qq.x};
+            if (k) e[ib] = {pp.x - qq.y, pp.y + qq.x};
+        }
+    }
+}
+
+template <int P, int KL>   // P = 11, KL = (P + 1) / 2 lanes per line; csP: LDS table [KL][H] (cos, sin)(2 pi n k / P), n = 1..H
+__device__ __forceinline__ void pfa_prime_pass(cx<double>* buf, int nlines, int inner, int outer_stride, int stride,
+                                               const cx<double>* csP, int tid) {
+    constexpr int H = (P - 1) / 2, LW = 64 / KL, LPR = LW * (PFA_T / 64);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int sub = lane / KL, k = lane - sub * KL;
+    double cosv[H], sinv[H];
+#pragma unroll
+    for (int n = 0; n < H; ++n) {
+        const cx<double> v = csP[k * H + n];
+        cosv[n] = v.x;
+        sinv[n] = v.y;
+    }
+    for (int l0 = 0; l0 < nlines; l0 += LPR) {
+        if (l0 + wave * LW >= nlines) break;     // wave-uniform
+        const int l = l0 + wave * LW + sub;
+        const bool active = sub < LW && l < nlines;
+        // line l -> first element: lines are numbered (outer, inner) with `inner` consecutive positions
+        const int base = active ? (l / inner) * outer_stride + (l % inner) : 0;
+        cx<double>* e = buf + base;
+        if (active && k >= 1) {
+            const cx<double> u = e[k * stride], v = e[(P - k) * stride];
+            e[k * stride] = {u.x + v.x, u.y + v.y};
+            e[(P - k) * stride] = {u.x - v.x, u.y - v.y};
+        }
+        wave_lds_fence();
+        cx<double> a0 = {0.0, 0.0}, pp = {0.0, 0.0}, qq = {0.0, 0.0};
+        if (active) {
+            a0 = e[0];
+#pragma unroll
+            for (int n = 1; n <= H; ++n) {
+                const cx<double> sv = e[n * stride], dv = e[(P - n) * stride];
+                pp.x = fma(sv.x, cosv[n - 1], pp.x);
+                pp.y = fma(sv.y, cosv[n - 1], pp.y);
+                qq.x = fma(dv.x, sinv[n - 1], qq.x);
+                qq.y = fma(dv.y, sinv[n - 1], qq.y);
+            }
+        }
+        wave_lds_fence();
+        if (active) {
+            // X[k] = a0 + P - iQ, X[P-k] = a0 + P + iQ
+            const double br = a0.x + pp.x, bi = a0.y + pp.y;
+            e[k * stride] = {br + qq.y, bi - qq.x};
+            if (k >= 1) e[(P - k) * stride] = {br - qq.y, bi + qq.x};
+        }
+        wave_lds_fence();
+    }
+}
+
+// y = DFT_3(x), forward
+__device__ __forceinline__ void dft3(cx<double>& x0, cx<double>& x1, cx<double>& x2) {
+    const double H3 = 0.8660254037844386467637;  // sqrt(3)/2
+    const cx<double> t = {x1.x + x2.x, x1.y + x2.y}, u = {x1.x - x2.x, x1.y - x2.y};
+    const cx<double> m = {fma(-0.5, t.x, x0.x), fma(-0.5, t.y, x0.y)};
+    x0 = {x0.x + t.x, x0.y + t.y};
+    // -i (sqrt3/2) u = ((sqrt3/2) u.y, -(sqrt3/2) u.x)
+    x1 = {fma(H3, u.y, m.x), fma(-H3, u.x, m.y)};
+    x2 = {fma(-H3, u.y, m.x), fma(H3, u.x, m.y)};
+}
+
+template <int A0, int K3>   // K3: residues of axis 31 that are live (31, or 16 behind a real-input pass)
+__device__ __forceinline__ void pfa_small_pass(cx<double>* buf, int tid) {
+    constexpr int Q = 11 * 31;   // lines; element j = n0 * 3 + n1 of line q at j * Q + q
+    for (int idx = tid; idx < 11 * K3; idx += PFA_T) {
+        const int q = K3 == 31 ? idx : (idx / K3) * 31 + idx % K3;
+        cx<double> v[3 * A0];
+#pragma unroll
+        for (int j = 0; j < 3 * A0; ++j) v[j] = buf[j * Q + q];
+#pragma unroll
+        for (int n0 = 0; n0 < A0; ++n0) dft3(v[3 * n0], v[3 * n0 + 1], v[3 * n0 + 2]);
+        if (A0 == 2) {
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1) {
+                const cx<double> a = v[k1], b = v[3 + k1];
+                v[k1] = {a.x + b.x, a.y + b.y};
+                v[3 + k1] = {a.x - b.x, a.y - b.y};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3 * A0; ++j) buf[j * Q + q] = v[j];
+    }
+}
+
+template <int A0, bool REAL>
+__device__ __forceinline__ void pfa_dft(cx<double>* buf, const cx<double>* cs31, const cx<double>* cs11, int tid) {
+    constexpr int K3 = REAL ? 16 : 31;
+    pfa_pass31<REAL>(buf, A0 * 3 * 11, cs31, tid);                               // line l: elements l*31 + n3
+    __syncthreads();
+    pfa_prime_pass<11, 6>(buf, A0 * 3 * K3, K3, 11 * 31, 31, cs11, tid);           // line (m, n3): m*341 + n3 + 31 n2
+    __syncthreads();
+    pfa_small_pass<A0, K3>(buf, tid);
+    __syncthreads();
+}
+
+// One workgroup per frame; the cosine/sine tables and the position table go to LDS first.
+template <int A0>
+__global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
+    constexpr int T = PFA_T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, Mh = a.Mh;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                      // [A0][3][11][31]
+    double* yv = reinterpret_cast<double*>(smem + PFA_YV_OFF(Mh));              // Mh + 2 doubles, inside the dead buf
+    const unsigned short* __restrict__ pos = a.pfa_pos;                         // [N] position of index n (L2-resident)
+    cx<double>* cs31 = reinterpret_cast<cx<double>*>(smem + PFA_TAB_OFF(N, Mh));   // [16][16]
+    cx<double>* cs11 = cs31 + 256;                                                    // [6][5]
+    {
+        const int tid = threadIdx.x;
+        cs31[tid] = a.pfa_cs31[tid];
+        if (tid < 30) cs11[tid] = a.pfa_cs11[tid];
+    }
+    __syncthreads();
+    const double inv_n = 1.0 / (double)N;
+    {
+        // (one workgroup per frame: as persistent workgroups looping over frames the compiler hoisted the loop-invariant
+        //  addresses of everything below -- peak picking alone has dozens -- and spilled 350 B per lane; the tables a
+        //  workgroup loads above are 8.6 KB from L2 against 32 KB of frame data)
+        const long long f = blockIdx.x;
+        const int tid = threadIdx.x;
+        const cx<double>* xin = a.xb + band_index(f, 0, N);
+        for (int n = tid; n < N; n += T) buf[pos[n]] = xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)];
+        __syncthreads();
+        if (!(a.ablate & 8)) pfa_dft<A0, false>(buf, cs31, cs11, tid);
+        // S[k] = |X_lo[k]|^0.67 + |X_hi[k]|^0.67 from Z[k] and its mirror bin Z[N-k]: one thread per pair, both positions
+        // get the (real, even) value; nobody else touches the pair
+        for (int i = tid; i < a.pfa_npairs; i += T) {
+            const int p = a.pfa_pairs[2 * i], q = a.pfa_pairs[2 * i + 1];
+            const cx<double> A = buf[p];
+            const cx<double> B = cconj(buf[q]);
+            const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+            const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+            const double sv = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);
+            buf[p] = {sv, 0.0};
+            buf[q] = {sv, 0.0};
+        }
+        __syncthreads();
+        if (!(a.ablate & 4)) pfa_dft<A0, true>(buf, cs31, cs11, tid);
+        double lag[4];   // Mh <= 1022 lags, four per thread: through registers, because yv lies inside buf
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = tid + r * T;
+            lag[r] = 0.0;
+            if (n < Mh) {
+                // the real-input transform keeps residues 0..15 of axis 31; lag n at one of the others is read from lag
+                // N - n (S is real and even, so is its transform)
+                const int p0 = pos[n], p1 = pos[N - n > N - 1 ? 0 : N - n];
+                lag[r] = buf[p0 % 31 > 15 ? p1 : p0].x * inv_n;
+            }
+        }
+        __syncthreads();   // buf is dead from here on: the peak-picking scratch and yv alias it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = tid + r * T;
+            if (n < Mh) {
+                yv[n] = lag[r];
+                if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = lag[r];
+            }
+        }
+        __syncthreads();
+        double* yrow = a.y_out + f * (long long)Mh;
+        if (a.defer_enhance) {
+            for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+        } else {
+            for (int n = tid; n < Mh; n += T) {   // enhancement (esacf.py:108-129), truncation regime: see sacf_kernel
+                double v = yv[n];
+                for (int r = 2; r <= a.n_peaks_elim; ++r) {
+                    int cut = 0;
+                    if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+                    v = v < 0.0 ? 0.0 : v;
+                    if (n < cut) v = v - v;
+                    v = v < 0.0 ? 0.0 : v;
+                }
+                yv[n] = v;
+                yrow[n] = v;
+            }
+            __syncthreads();
+            if (!(a.ablate & (2 | 16))) peak_pick<T>(a, f, yv, smem, tid);
+        }
+        __syncthreads();   // the next frame overwrites buf (peak-picking scratch) and yv
     }
 }
 
@@ -1778,6 +2120,85 @@ static int esacf_plan(mpx_ctx* ctx, int N, EsacfPlan& plan) {
     return MPX_OK;
 }
 
+// Tables of the prime-factor SACF engine for N = A0 * 3 * 11 * 31 (A0 = 1, 2), cached per N.
+struct PfaPlan {
+    const unsigned short* pos = nullptr;
+    const unsigned short* pairs = nullptr;
+    const cx<double>* cs31 = nullptr;
+    const cx<double>* cs11 = nullptr;
+    int npairs = 0, a0 = 0;
+};
+
+static bool pfa_supported(int N) { return N == 3 * 11 * 31 || N == 2 * 3 * 11 * 31; }
+
+static int pfa_plan(mpx_ctx* ctx, int N, PfaPlan& plan) {
+    const std::string key = "pfa_N" + std::to_string(N);
+    const int A0 = N / (3 * 11 * 31);
+    plan.a0 = A0;
+    plan.npairs = N / 2 + 1;
+    auto it = ctx->misc_plans.find(key);
+    if (it != ctx->misc_plans.end()) {
+        plan.pos = (const unsigned short*)it->second[0];
+        plan.pairs = (const unsigned short*)it->second[1];
+        plan.cs31 = (const cx<double>*)it->second[2];
+        plan.cs11 = (const cx<double>*)it->second[3];
+        return MPX_OK;
+    }
+    const int dims[4] = {A0, 3, 11, 31};
+    auto position = [&](const int* r) { return ((r[0] * 3 + r[1]) * 11 + r[2]) * 31 + r[3]; };
+    // index n = sum_i n_i (N / N_i) mod N  <=>  n_i = n * (N / N_i)^-1 mod N_i
+    int inv[4];
+    for (int i = 0; i < 4; ++i) {
+        inv[i] = 0;
+        for (int c = 0; c < dims[i]; ++c)
+            if (((long long)(N / dims[i]) * c) % dims[i] == 1 % dims[i]) inv[i] = c;
+    }
+    std::vector<unsigned short> pos(N), pairs;
+    for (int n = 0; n < N; ++n) {
+        int r[4];
+        for (int i = 0; i < 4; ++i) r[i] = (int)(((long long)(n % dims[i]) * inv[i]) % dims[i]);
+        pos[n] = (unsigned short)position(r);
+    }
+    // mirror bin of the residue-indexed spectrum: position (k_i) <-> position (-k_i mod N_i)
+    for (int p = 0; p < N; ++p) {
+        int r[4], m[4], q = p;
+        r[3] = q % 31; q /= 31;
+        r[2] = q % 11; q /= 11;
+        r[1] = q % 3;  q /= 3;
+        r[0] = q;
+        for (int i = 0; i < 4; ++i) m[i] = (dims[i] - r[i]) % dims[i];
+        const int mp = position(m);
+        if (p <= mp) {
+            pairs.push_back((unsigned short)p);
+            pairs.push_back((unsigned short)mp);
+        }
+    }
+    if ((int)pairs.size() != 2 * plan.npairs) return set_error(ctx, MPX_EHIP, "internal: PFA pair table (%zu)", pairs.size());
+    auto table = [](int P, int K, int H) {
+        std::vector<cx<double>> t((size_t)K * H);
+        for (int k = 0; k < K; ++k)
+            for (int n = 1; n <= H; ++n) {
+                const long double ang = 2.0L * M_PIl * (long double)((n * k) % P) / (long double)P;
+                t[(size_t)k * H + n - 1] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+        return t;
+    };
+    std::vector<cx<double>> t31(16 * 16);   // [k][n], n = 0..15: (cos, sin)(2 pi n k / 31)
+    for (int k = 0; k < 16; ++k)
+        for (int n = 0; n < 16; ++n) {
+            const long double ang = 2.0L * M_PIl * (long double)((n * k) % 31) / 31.0L;
+            t31[(size_t)k * 16 + n] = {(double)cosl(ang), (double)sinl(ang)};
+        }
+    const auto t11 = table(11, 6, 5);
+    plan.pos = (const unsigned short*)upload(ctx, pos.data(), pos.size() * sizeof(unsigned short));
+    plan.pairs = (const unsigned short*)upload(ctx, pairs.data(), pairs.size() * sizeof(unsigned short));
+    plan.cs31 = (const cx<double>*)upload(ctx, t31.data(), t31.size() * sizeof(cx<double>));
+    plan.cs11 = (const cx<double>*)upload(ctx, t11.data(), t11.size() * sizeof(cx<double>));
+    if (!plan.pos || !plan.pairs || !plan.cs31 || !plan.cs11) return MPX_ENOMEM;
+    ctx->misc_plans[key] = {(void*)plan.pos, (void*)plan.pairs, (void*)plan.cs31, (void*)plan.cs11};
+    return MPX_OK;
+}
+
 struct BandCoef;
 int remez_taps_for(mpx_ctx* ctx, int fs, double* c13);
 static int band_coefs_rest(int fs, BandCoef& k);
@@ -1871,6 +2292,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if (rc) return rc;
     EsacfPlan plan;
     if ((rc = esacf_plan(ctx, N, plan))) return rc;
+    // the reference's own frame lengths (1023, 2046) run on the prime-factor engine; MPX_SACF_BLUESTEIN=1 forces the chirp-z
+    const bool use_pfa = pfa_supported(N) && !(getenv("MPX_SACF_BLUESTEIN") && atoi(getenv("MPX_SACF_BLUESTEIN")));
+    PfaPlan pfa;
+    if (use_pfa && (rc = pfa_plan(ctx, N, pfa))) return rc;
     if (plan.L > 8192)
         return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: non power-of-two frame %d needs a %d-point FFT (> 8192)", N, plan.L);
     const int maxp = p.peak_min_dist > 1 ? Mh / (p.peak_min_dist + 1) + 2 : Mh / 2 + 2;
@@ -1941,8 +2366,24 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         // two frames makes results depend on the batch neighbour and flips 0.075 % of the frames (ill-conditioned fits)
         a.pair = !deterministic && getenv("MPX_SACF_PAIR") && atoi(getenv("MPX_SACF_PAIR")) ? 1 : 0;
         a.ablate = getenv("MPX_SACF_ABLATE") ? atoi(getenv("MPX_SACF_ABLATE")) : 0;
-        prof_mark(ctx, st, plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel");
-        if (plan.L == 8192) {
+        prof_mark(ctx, st, use_pfa ? "sacf_pfa_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel"));
+        if (use_pfa) {
+            a.pfa_pos = pfa.pos;
+            a.pfa_pairs = pfa.pairs;
+            a.pfa_cs31 = pfa.cs31;
+            a.pfa_cs11 = pfa.cs11;
+            a.pfa_npairs = pfa.npairs;
+            a.pair = 0;
+            const size_t lds = PFA_LDS_BYTES(N, Mh);
+            if (PFA_YV_OFF(Mh) + 8 * (size_t)(Mh + 2) > sizeof(cx<double>) * (size_t)N || Mh > 4 * PFA_T)
+                return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", N);
+            const long long g = nf;
+            if (pfa.a0 == 2)
+                hipLaunchKernelGGL(sacf_pfa_kernel<2>, dim3((unsigned)g), dim3(PFA_T), lds, st, a);
+            else
+                hipLaunchKernelGGL(sacf_pfa_kernel<1>, dim3((unsigned)g), dim3(PFA_T), lds, st, a);
+            MPX_HIP(ctx, hipGetLastError());
+        } else if (plan.L == 8192) {
             const size_t lds = sizeof(cx<double>) * lds_slots(8192) + sizeof(double) * (size_t)(Mh + 2);
             auto kern = sacf_big_kernel<8192, 512>;
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
