@@ -65,7 +65,7 @@ def test_bench_line_has_the_contract_fields():
     assert w["esacf_clips_4096"]["oracle_spot_check"] is True and w["esacf_stft_8192"]["oracle_spot_check"] is True
     assert w["esacf_stft_8192"]["config"]["frames_per_gpu"] == 8192
     assert w["esacf_stft_8192"]["value_three_in_flight"] >= 0.9 * w["esacf_stft_8192"]["value"]
-    assert w["corpus_4096_all_methods"]["unit"] == "clips/s" and w["corpus_4096_all_methods"]["nonzero_rows"] > 4 * 4000
+    assert w["corpus_4096_all_methods"]["unit"] == "clips/s" and w["corpus_4096_all_methods"]["nonzero_rows"] > 0.9 * 4 * 4096
     assert w["if0_stream_1h"]["unit"] == "x real time" and w["if0_stream_1h"]["frames"] == 19380
     for name, rec in w.items():
         assert rec["value"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["unit"] == rec["unit"], name
