@@ -313,6 +313,7 @@ def kernel_models(n, mh, channels=70, nf=8192):
         "bandsplit_kernel": (4 * n + 16 * n, 90 * n, "frame"),            # fp32 in, (x_lo, x_hi) fp64 out; 12 all-pass + 13-tap FIR + 3 biquads
         "sacf_kernel": (16 * n + 8 * mh, 2 * 5 * n * lg + 40 * n, "frame"),   # two n-point complex DFTs + |.|^0.67 (log+exp) per bin
         "sacf_big_kernel": (16 * n + 8 * mh, 2 * 5 * n * lg + 40 * n, "frame"),
+        "sacf_pfa_kernel": (16 * n + 8 * mh, 2 * 5 * n * lg + 40 * n, "frame"),   # the same algorithmic count whatever the engine
         "pv_enhance_kernel": (16 * mh, 2 * 6 * 2.5 * 2048 * 11, "frame"),  # two real vocoder rates x (4 STFT + 2 ISTFT) 2048-point real FFTs
         "peakpick_kernel": (8 * mh, 4 * mh, "frame"),
         "scatter_kernel": (96, 0, "frame"),
@@ -337,6 +338,24 @@ def roofline_of(name, ms, units, model):
               "bytes_per_unit": b, "flops_per_unit": f, "hbm_frac": hbm_frac, "valu_f64_frac": valu_frac,
               "traffic": None})
     return r
+
+
+FLOPS_PER_FIT_EVAL = 21 * 35   # one MINPACK function evaluation of a gaussian peak fit: 21 residuals x (exp ~30 flops + 5)
+
+
+def fit_roofline(kms, stats):
+    """The two gaussian-fit kernels together (peakfit_kernel runs the fits, coopfit_kernel finishes the runaway ones): work
+    counted in MINPACK function evaluations (mpx_esacf_fit_stats) x 735 flops for the model evaluation alone -- the QR of
+    the 21 x 3 jacobian and the 3 x 3 trust-region algebra of an iteration come on top and are not counted -- against the
+    fp64 vector peak.  Bytes: the 21-sample window (168 B) in, 12 B out per fit: nothing."""
+    ms = kms.get("peakfit_kernel", 0.0) + kms.get("coopfit_kernel", 0.0)
+    fl = stats["evaluations"] * FLOPS_PER_FIT_EVAL / (ms * 1e-3) if ms > 0 else 0.0
+    hbm = stats["fits"] * 180 / (ms * 1e-3) if ms > 0 else 0.0
+    return {"bound": "valu_f64", "achieved": fl / 1e12, "peak": F64_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / F64_PEAK,
+            "kernel": "peakfit_kernel+coopfit_kernel", "kernel_ms": ms, "units_per_launch": stats["evaluations"],
+            "unit_of_work": "function evaluation", "bytes_per_unit": 0, "flops_per_unit": FLOPS_PER_FIT_EVAL,
+            "hbm_frac": hbm / HBM_PEAK, "valu_f64_frac": fl / F64_PEAK, "traffic": None, "fits": stats["fits"],
+            "evaluations_per_fit": stats["evaluations"] / max(stats["fits"], 1), "fits_finished_cooperatively": stats["parked"]}
 
 
 def dominant(prof):
@@ -616,6 +635,7 @@ def wl_esacf_clips(c):
     eng.profile_begin()
     eng.esacf_batch(x, fs, frame)
     prof = eng.profile_end()
+    stats = eng.esacf_fit_stats() if hasattr(eng, "esacf_fit_stats") else None
     if not np.array_equal(got, first):
         sys.exit("bench: ESACF batch results differ between runs (non-deterministic)")
     ok = None
@@ -636,8 +656,11 @@ def wl_esacf_clips(c):
            "config": {"workload": "ESACF, %d clips x %.0f s @%d Hz per GPU, %d-sample frames (BASELINE.json configs[2])"
                                   % (clips, secs, fs, frame), "frames_per_gpu": frames, "entry": "mpx_esacf_batch, clips in HBM"},
            "kernels_ms": kms, "kernel_ms_total": sum(kms.values()), "oracle_spot_check": ok,
-           "roofline": roofline_of(dom, dms, frames, models[dom]) if dom in models else {"kernel": dom, "kernel_ms": dms},
+           "roofline": roofline_of(dom, dms, frames, models[dom]) if dom in models else
+           (fit_roofline(kms, stats) if stats else {"kernel": dom, "kernel_ms": dms}),
            "rooflines": {k: roofline_of(k, ms, frames, models[k]) for k, ms in kms.items() if k in models}}
+    if stats:
+        rec["rooflines"]["peakfit_kernel+coopfit_kernel"] = fit_roofline(kms, stats)
     rec["hbm_frac_whole_path"] = (4 * frame + 48) * rec["value"] / c["world"] / HBM_PEAK
     if _cpu_rec(c, "esacf_clips"):
         rec["cpu_baseline"] = _cpu_rec(c, "esacf_clips")
@@ -677,6 +700,7 @@ def wl_esacf_stft(c):
     eng.esacf_dev(sigs[0].data_ptr(), n, FS, N_FFT, HOP, outs[0][0].data_ptr(), outs[0][1].data_ptr())
     eng.synchronize()
     prof = eng.profile_end()
+    stats = eng.esacf_fit_stats() if hasattr(eng, "esacf_fit_stats") else None
     ok = None
     if c["stub"] is None:
         import warnings
@@ -697,8 +721,7 @@ def wl_esacf_stft(c):
                                   "(BASELINE.json north_star Target)", "frames_per_gpu": nf, "entry": "mpx_esacf_dev"},
            "kernels_ms": kms, "kernel_ms_total": sum(kms.values()), "oracle_spot_check": ok,
            "roofline": roofline_of(dom, dms, nf, models[dom]) if dom in models else
-           {"kernel": dom, "kernel_ms": dms, "bound": "latency", "frac": None, "traffic": None,
-            "note": "data-dependent Levenberg-Marquardt iterations (gaussian peak fits); no algorithmic byte or flop count"},
+           (fit_roofline(kms, stats) if stats else {"kernel": dom, "kernel_ms": dms, "bound": "latency", "frac": None, "traffic": None}),
            "rooflines": {k: roofline_of(k, ms, nf, models[k]) for k, ms in kms.items() if k in models},
            "hbm_frac_whole_path": B_ALG * nf / wall1 / HBM_PEAK,
            "hbm_frac_whole_path_three_in_flight": B_ALG * nf / wall3 / HBM_PEAK}
@@ -745,6 +768,8 @@ def wl_corpus(c):
                                   "[clips, 4, 12] (BASELINE.json configs[3]); wall clock includes the on-device synthesis"
                                   % (per, fs), "clips_per_gpu": per},
            "seconds_per_method_rank0": {str(m): s for m, s in zip((1, 2, 3, 4), spent)},
+           "synthesis_seconds_rank0": corpus.LAST_SYNTH_SECONDS,
+           "value_without_synthesis": per * world / max(wall - corpus.LAST_SYNTH_SECONDS, 1e-9),
            "kernels_ms_total": ktot, "nonzero_rows": int((np.abs(chroma).sum(axis=2) > 0).sum())}
     if ktot:
         dom = max(ktot, key=ktot.get)
@@ -753,6 +778,18 @@ def wl_corpus(c):
         models = kernel_models(int(fs * 46.4 / 1000), (int(fs * 46.4 / 1000) - 1) // 2)
         units = {"if0_frontend_kernel": samples, "if0_spectrum_kernel": per * -(-int(round(2.0 * fs)) // 8192),
                  "if0_periodicity_kernel": per * -(-int(round(2.0 * fs)) // 8192)}
+        # Prime-multiF0, unit = clip: 12 * num_octave candidate frequencies, each cuts the clip into frames of int(8/f*fs)
+        # samples and takes a real FFT of every frame: 2.5 N log2 N flops and 4 N bytes per frame
+        ncl = int(round(2.0 * fs))
+        pf = pb = 0.0
+        for note in range(12):
+            for octave in (1, 2):
+                nc = int(8.0 / (130.8127826502993 * 2.0 ** (note / 12.0) * octave) * fs)
+                nfr = -(-ncl // nc)
+                pf += nfr * 2.5 * nc * math.log2(nc)
+                pb += nfr * 4 * nc
+        models["prime_kernel"] = (pb, pf, "clip")
+        units["prime_kernel"] = per
         if dom in models:
             rec["roofline"] = roofline_of(dom, ktot[dom], units.get(dom, frames1), models[dom])
         else:

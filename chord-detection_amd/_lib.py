@@ -76,6 +76,7 @@ SIGNATURES = {
     "mpx_host_free": (None, [_vp]),
     "mpx_profile_begin": (C.c_int, [_vp]),
     "mpx_profile_end": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "mpx_esacf_fit_stats": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -72,6 +72,7 @@ def _engine_compute(method, clips, fs, device, note_names="unicode"):
 
 
 _SECOND_ENGINE = {}
+LAST_SYNTH_SECONDS = 0.0   # input synthesis inside the last run_corpus call of this process (reported next to the wall clock)
 
 
 def _second_engine(device):
@@ -95,9 +96,16 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
     lo, hi = partition(n_clips, world, rank)
     out = np.zeros((hi - lo, len(methods), 12), dtype=np.float64)
     spent = [0.0] * len(methods)
+    global LAST_SYNTH_SECONDS
+    LAST_SYNTH_SECONDS = 0.0
     for c0 in range(lo, hi, chunk):
         ids = list(range(c0, min(c0 + chunk, hi)))
+        t_s = time.perf_counter()
         clips = synth_chunk(ids, fs, seconds, synth_device)
+        if clips.is_cuda:
+            import torch
+            torch.cuda.synchronize(clips.device)   # the engine's stream waits for the chunk anyway (engine._pack)
+        LAST_SYNTH_SECONDS += time.perf_counter() - t_s
         # synthesised on the GPU and consumed by the engine: the chunk stays in HBM (include/mpx.h, "where the samples
         # live"); a substituted compute function and a CPU synthesis get a host array
         clips = clips if (clips.is_cuda and engine_path) else clips.cpu().numpy()
@@ -222,6 +230,7 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     if rank == 0:
         res = summarise(chroma, methods, spent, args.clips, wall)
         res["n_gpus"] = world
+        res["synthesis_seconds_rank0"] = LAST_SYNTH_SECONDS
         if args.out:
             np.savez_compressed(args.out, chroma=chroma, methods=np.array(methods))
         print(json.dumps(res))

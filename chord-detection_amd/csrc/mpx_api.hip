@@ -225,7 +225,14 @@ int mpx_profile_begin(mpx_ctx* ctx) {
     if (!ctx) return MPX_EINVAL;
     for (auto& m : ctx->prof_marks) ctx->prof_pool.push_back(m.ev);
     ctx->prof_marks.clear();
+    ctx->fit_stats[0] = ctx->fit_stats[1] = ctx->fit_stats[2] = 0;
     ctx->prof_on = true;
+    return MPX_OK;
+}
+
+int mpx_esacf_fit_stats(mpx_ctx* ctx, int64_t* stats3) {
+    if (!ctx || !stats3) return MPX_EINVAL;
+    for (int i = 0; i < 3; ++i) stats3[i] = ctx->fit_stats[i];
     return MPX_OK;
 }
 

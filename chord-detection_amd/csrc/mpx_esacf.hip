@@ -1363,6 +1363,19 @@ __device__ __forceinline__ double coop_leaf(int l, int from, D2 x, D2 y) {
 // all-reduces that leave identical bits in every lane of the row, so the row runs the 3x3 part redundantly and
 // uniformly.  A trip costs ~3.3 k instructions per FOUR fits instead of ~8.5 k and, more to the point, every
 // parked fit gets its own lanes instead of waiting behind 63 finished ones.
+// wave sum of a per-lane count into a 64-bit counter kept as two 32-bit words (one atomic per wave)
+__device__ __forceinline__ void count_evals(int* counter, unsigned mine) {
+    unsigned long long v = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) {
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        const unsigned old = atomicAdd(reinterpret_cast<unsigned*>(counter), lo);
+        const unsigned carry = (old + lo < old) ? 1u : 0u;
+        if (hi + carry) atomicAdd(reinterpret_cast<unsigned*>(counter) + 1, hi + carry);
+    }
+}
+
 __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
                                                      int* next_parked, const double* __restrict__ y, double* center,
                                                      int* ok, int maxfev) {
@@ -1372,6 +1385,7 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
     __syncthreads();
     const int l = threadIdx.x & 15;
     const int total = *parked_count;
+    unsigned my_evals = 0;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const double eps = sqrt(EPSMCH);
     for (;;) {
@@ -1597,8 +1611,10 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
         if (l == 0) {
             ok[pf.out] = (info >= 1 && info <= 4) ? 1 : 0;
             center[pf.out] = x[1];
+            my_evals += (unsigned)(nfev - pf.nfev);
         }
     }
+    count_evals(next_parked + 2, my_evals);   // total[6..7]: function evaluations of the batch (statistics only)
 }
 
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
@@ -1619,6 +1635,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     const double eps = sqrt(EPSMCH);
 
     int phase = FIT_NEED_WORK;
+    unsigned my_evals = 0;   // statistics: MINPACK function evaluations this lane has run
     bool drained = false;  // wave-uniform: some lane has found the work list empty
     bool cap_hit = false;  // wave-uniform: the cooperative kernel is full, park only from a thinned-out wave
     // per-fit state
@@ -1700,6 +1717,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             pf.nfev = nfev;
             pf.pad = 0;
             parked[atomicAdd(parked_count, 1)] = pf;
+            my_evals += (unsigned)nfev;
             phase = FIT_DONE;
         }
         if (__all(phase == FIT_DONE)) break;
@@ -1976,9 +1994,11 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         if (info != 0) {
             ok[out] = (info >= 1 && info <= 4) ? 1 : 0;
             center[out] = x[1];
+            my_evals += (unsigned)nfev;
             phase = FIT_NEED_WORK;
         }
     }
+    count_evals(parked_count + 3, my_evals);   // total[6..7]
 }
 
 #pragma clang fp contract(fast)
@@ -2340,7 +2360,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                d_stage_out + (size_t)f0 * N);
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
         prof_mark(ctx, st, nullptr);
-        MPX_HIP(ctx, hipMemsetAsync(total, 0, 6 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, 8 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts; [6..7] evaluations
         SacfArgs a;
         a.xb = xb;
         a.N = N;
@@ -2461,6 +2481,14 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             MPX_HIP(ctx, hipMemcpyAsync(h, total, sizeof(h), hipMemcpyDeviceToHost, st));
             MPX_HIP(ctx, hipStreamSynchronize(st));
             fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d\n", nf, h[0] + h[2], h[0], h[3]);
+        }
+        if (ctx->prof_on) {  // fit statistics of the profiled call (mpx_esacf_fit_stats): one small synchronous copy per batch
+            unsigned h[8];
+            MPX_HIP(ctx, hipMemcpyAsync(h, total, sizeof(h), hipMemcpyDeviceToHost, st));
+            MPX_HIP(ctx, hipStreamSynchronize(st));
+            ctx->fit_stats[0] += (long long)h[0] + (long long)h[2];
+            ctx->fit_stats[1] += (long long)h[6] + ((long long)h[7] << 32);
+            ctx->fit_stats[2] += (long long)h[3];
         }
         prof_mark(ctx, st, "scatter_kernel");
         hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, f0, nf, fs, Mh, maxp,

@@ -68,6 +68,7 @@ struct mpx_ctx {
         const char* name;  // kernel launched right after the event; nullptr closes the previous region
         hipEvent_t ev;
     };
+    long long fit_stats[3] = {0, 0, 0};   // gaussian fits, MINPACK function evaluations, parked fits since mpx_profile_begin
     bool prof_on = false;
     std::vector<ProfMark> prof_marks;
     std::vector<hipEvent_t> prof_pool;

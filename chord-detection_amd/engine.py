@@ -316,6 +316,16 @@ class Engine:
         return out
 
 
+def _fit_stats(self):
+    """{fits, evaluations, parked} of the ESACF calls made between profile_begin and profile_end (include/mpx.h)."""
+    out = (C.c_int64 * 3)()
+    self._check(self.lib.mpx_esacf_fit_stats(self.ctx, out))
+    return {"fits": int(out[0]), "evaluations": int(out[1]), "parked": int(out[2])}
+
+
+Engine.esacf_fit_stats = _fit_stats
+
+
 class _Pinned:
     def __init__(self, lib, ptr):
         self.lib, self.ptr = lib, ptr

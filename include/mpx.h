@@ -266,6 +266,9 @@ int mpx_timer_end(mpx_ctx* ctx, void* stream, float* ms);
  * with mpx_timer_begin/_end instead.  Off by default: costs nothing unless enabled. */
 int mpx_profile_begin(mpx_ctx* ctx);
 int mpx_profile_end(mpx_ctx* ctx, char* report, int cap);
+/* ESACF calls made while profiling was on: stats3 = {gaussian peak fits, MINPACK function evaluations they took, fits that
+ * were handed to the cooperative kernel}.  (What the fit kernels' roofline is counted in: bench.py.) */
+int mpx_esacf_fit_stats(mpx_ctx* ctx, int64_t* stats3);
 
 #ifdef __cplusplus
 }
