@@ -18,16 +18,18 @@ def bind(path):
 
 libs = [(p, bind(p)) for p in sys.argv[1:]]
 dev = torch.device("cuda", 0)
-x = torch.from_numpy(bench.synth_signal(20260101)).to(dev); n = x.numel()
+sigs = [bench.synth_signal_device(20260101 + k, dev) for k in range(9)]; n = sigs[0].numel()   # 302 MB > the Infinity Cache
 rows = torch.empty((8192, 12), dtype=torch.float64, device=dev)
 sums = torch.zeros(12, dtype=torch.float64, device=dev)
 ctxs = [lib.mpx_create(0, 0) for _, lib in libs]
 p = L.HeParams(2, 2, 2)
+for _, lib in libs:
+    assert lib.mpx_abi_version() == 2
 def run(lib, ctx, reps, full):
     ms = C.c_float(0)
     lib.mpx_timer_begin(ctx, None)
-    for _ in range(reps):
-        rc = lib.mpx_harmonic_energy_dev(ctx, x.data_ptr(), n, 44100, C.byref(p), 4096, 1024,
+    for r in range(reps):
+        rc = lib.mpx_harmonic_energy_dev(ctx, sigs[r % 9].data_ptr(), n, 44100, C.byref(p), 4096, 1024,
                                          None if full else rows.data_ptr(), sums.data_ptr() if full else None, None)
         assert rc == 0, lib.mpx_last_error(ctx)
     lib.mpx_timer_end(ctx, None, C.byref(ms))
