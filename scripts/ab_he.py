@@ -34,8 +34,14 @@ def run(lib, ctx, reps, full):
         assert rc == 0, lib.mpx_last_error(ctx)
     lib.mpx_timer_end(ctx, None, C.byref(ms))
     return ms.value / reps * 1e3
+outs = []
 for (path, lib), ctx in zip(libs, ctxs):
     run(lib, ctx, 20, False); run(lib, ctx, 20, True)
+    lib.mpx_harmonic_energy_dev(ctx, sigs[0].data_ptr(), n, 44100, C.byref(p), 4096, 1024, rows.data_ptr(), None, None)
+    lib.mpx_synchronize(ctx)
+    outs.append(rows.clone())
+for (path, _), o in zip(libs, outs):
+    print("%-28s rows vs first library: max relative difference %.2e" % (os.path.basename(path), float(((o - outs[0]).abs() / outs[0].abs().clamp_min(1e-300)).max())))
 res = {path: ([], []) for path, _ in libs}
 for r in range(15):
     for (path, lib), ctx in zip(libs, ctxs):
