@@ -65,6 +65,8 @@ SIGNATURES = {
     "mpx_prime_multif0_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(PrimeParams), _dp]),
     "mpx_iterative_f0": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(If0Params), _dp, _dp]),
     "mpx_iterative_f0_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(If0Params), _dp]),
+    "mpx_iterative_f0_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(If0Params), _vp, _vp, _vp]),
+    "mpx_prime_multif0_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(PrimeParams), _vp, _vp]),
     "mpx_iterative_f0_warmup": (C.c_int, [_vp, C.c_int, C.POINTER(If0Params), C.POINTER(C.c_int64), _dp]),
     "mpx_iterative_f0_spectra": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(If0Params), _dp]),
     "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),

@@ -503,6 +503,21 @@ int mpx_iterative_f0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const
     return if0_run_host(ctx, signal, offsets, 1, fs, params, chroma_frames, chroma_sum, nullptr);
 }
 
+int mpx_iterative_f0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_if0_params* params,
+                         double* d_chroma_frames, double* d_chroma_sum, void* stream) {
+    if (!ctx) return MPX_EINVAL;
+    if (n < 0 || (!d_chroma_frames && !d_chroma_sum)) return set_error(ctx, MPX_EINVAL, "bad arguments");
+    const int64_t offsets[2] = {0, n};
+    int rc = if0_common(ctx, d_signal, offsets, 1);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    if (n == 0) {
+        if (d_chroma_sum) MPX_HIP(ctx, hipMemsetAsync(d_chroma_sum, 0, 12 * sizeof(double), st));
+        return MPX_OK;
+    }
+    return if0_run_host(ctx, d_signal, offsets, 1, fs, params, d_chroma_frames, d_chroma_sum, nullptr, true, st);
+}
+
 int mpx_iterative_f0_spectra(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,
                              double* ut) {
     if (!ctx) return MPX_EINVAL;
@@ -533,6 +548,16 @@ int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* o
     if (offsets[num_clips] > 0 && !signals) return set_error(ctx, MPX_EINVAL, "signal pointer/length invalid");
     MPX_HIP(ctx, hipSetDevice(ctx->device));
     return prime_run_host(ctx, signals, offsets, num_clips, fs, params, chroma_sums);
+}
+
+int mpx_prime_multif0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_prime_params* params,
+                          double* d_chroma_sum, void* stream) {
+    if (!ctx) return MPX_EINVAL;
+    ctx->err.clear();
+    if (n < 0 || !d_chroma_sum || (n > 0 && !d_signal)) return set_error(ctx, MPX_EINVAL, "bad arguments");
+    MPX_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t offsets[2] = {0, n};
+    return prime_run_host(ctx, d_signal, offsets, 1, fs, params, d_chroma_sum, true, stream ? (hipStream_t)stream : ctx->stream);
 }
 
 int mpx_prime_multif0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_prime_params* params,

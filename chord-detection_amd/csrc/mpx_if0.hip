@@ -713,8 +713,12 @@ static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* f
 
 // Packed clips on the HOST.  chroma_frames ([F,12], may be NULL), chroma_sums ([C,12], may be NULL),
 // ut ([F, 2*frame], may be NULL) are host buffers.
+// dev_io: `signals` is DEVICE memory used in place, chroma_frames / chroma_sums are device buffers, the kernels are only
+// enqueued on `stream` (the small host-built tables are uploaded and waited for first); otherwise host-style I/O on the
+// context's stream, synchronous at return.
 int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
-                 const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out) {
+                 const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out, bool dev_io,
+                 hipStream_t stream) {
     mpx_if0_params p = params ? *params
                               : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
     if (p.frame_size != 1024 && p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192)
@@ -748,12 +752,12 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
             for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
             const size_t frames_first = rows_first / NF;
-            int rc1 = if0_run_host(ctx, signals, offsets, mid, fs, &p, chroma_frames, chroma_sums, ut_out);
+            int rc1 = if0_run_host(ctx, signals, offsets, mid, fs, &p, chroma_frames, chroma_sums, ut_out, dev_io, stream);
             if (rc1) return rc1;
             return if0_run_host(ctx, signals + (offsets[mid] - offsets[0]), off2.data(), num_clips - mid, fs, &p,
                                 chroma_frames ? chroma_frames + frames_first * 12 : nullptr,
                                 chroma_sums ? chroma_sums + (size_t)mid * 12 : nullptr,
-                                ut_out ? ut_out + frames_first * n2 : nullptr);
+                                ut_out ? ut_out + frames_first * n2 : nullptr, dev_io, stream);
         }
     }
     If0Plan plan;
@@ -844,9 +848,10 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         }
     }
     const int64_t total = offsets[num_clips];
-    hipStream_t st = ctx->stream;
+    hipStream_t st = stream ? stream : ctx->stream;
     if (nframes == 0) {
-        if (chroma_sums) std::memset(chroma_sums, 0, (size_t)num_clips * 12 * sizeof(double));
+        if (chroma_sums && dev_io) MPX_HIP(ctx, hipMemsetAsync(chroma_sums, 0, (size_t)num_clips * 12 * sizeof(double), st));
+        else if (chroma_sums) std::memset(chroma_sums, 0, (size_t)num_clips * 12 * sizeof(double));
         return MPX_OK;
     }
     // the [t][channel] buffer of the front end is the big one: 560 B per sample at 70 channels
@@ -854,7 +859,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if (yc_bytes > ((size_t)96 << 30))
         return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: %lld chunks need %zu GiB of workspace; split the call", nchunks,
                          yc_bytes >> 30);
-    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + warmup * 4))) return rc;
+    if (!dev_io && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)nframes * n2 * sizeof(double) * 3))) return rc;   // ut | ur | ud
     if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
@@ -866,7 +871,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     If0Frame* d_frames = (If0Frame*)((char*)ctx->d_desc.p + ((chunks.size() * sizeof(If0Chunk) + 15) & ~(size_t)15));
     If0TailGroup* d_tail_groups = (If0TailGroup*)((char*)d_frames + ((frames.size() * sizeof(If0Frame) + 15) & ~(size_t)15));
     int* d_tail_list = (int*)((char*)d_tail_groups + ((tail_groups.size() * sizeof(If0TailGroup) + 15) & ~(size_t)15));
-    if ((rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
+    if (!dev_io && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
+    const float* d_in = dev_io ? signals : (const float*)ctx->d_signal.p;   // the front end reads inside the clips only
     MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(d_frames, frames.data(), frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
     if (nt) {
@@ -874,13 +880,14 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         MPX_HIP(ctx, hipMemcpyAsync(d_tail_list, tail_list.data(), tail_list.size() * sizeof(int), hipMemcpyHostToDevice, st));
     }
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    if (dev_io) MPX_HIP(ctx, hipStreamSynchronize(st));   // the tables above are host vectors of this call
     double* yc = (double*)ctx->d_ws0.p;
     double* ut = (double*)ctx->d_ws1.p;
     double* ur = ut + (size_t)nframes * n2;
     double* ud = ur + (size_t)nframes * n2;
     prof_mark(ctx, st, "if0_frontend_kernel");
     hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
-                       (const float*)ctx->d_signal.p, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
+                       d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
                        d_tail_groups);
     MPX_HIP(ctx, hipGetLastError());
     prof_mark(ctx, st, "if0_spectrum_kernel");
@@ -909,11 +916,15 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     a.epsilon1 = p.epsilon1;
     a.epsilon2 = p.epsilon2;
     a.gamma = p.gamma;
-    a.chroma = (double*)ctx->d_frames_out.p;
+    a.chroma = (dev_io && chroma_frames) ? chroma_frames : (double*)ctx->d_frames_out.p;
     prof_mark(ctx, st, "if0_periodicity_kernel");
     hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
     prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
+    if (dev_io) {
+        if (chroma_sums) return segment_sum(ctx, a.chroma, (const long long*)ctx->d_offsets.p, num_clips, nframes, chroma_sums, st);
+        return MPX_OK;
+    }
     if (chroma_frames)
         MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nframes * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     if (chroma_sums) {

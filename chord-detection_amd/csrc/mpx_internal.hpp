@@ -107,9 +107,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
               double* d_chroma_frames, int stage, double* d_stage_out, hipStream_t stream);
 
 int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
-                 const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out);
+                 const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out,
+                 bool dev_io = false, hipStream_t stream = nullptr);
 int if0_warmup_samples(mpx_ctx* ctx, int fs, const mpx_if0_params* params, long long* samples, double* rho);
 int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
-                   const mpx_prime_params* params, double* chroma_sums);
+                   const mpx_prime_params* params, double* chroma_sums, bool dev_io = false, hipStream_t stream = nullptr);
 
 }  // namespace mpx

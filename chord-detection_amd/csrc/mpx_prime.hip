@@ -268,8 +268,10 @@ static void prime_launch(const float* d_sig, const PrimeItem* d_items, size_t co
 }
 
 // signals: packed clips on the HOST; offsets[C+1]; out: [C,12] on the host
+// dev_io: `signals` is DEVICE memory used in place and chroma_sums a device buffer; the kernels are only enqueued on
+// `stream` (the host-built item lists are uploaded and waited for first).
 int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
-                   const mpx_prime_params* params, double* chroma_sums) {
+                   const mpx_prime_params* params, double* chroma_sums, bool dev_io, hipStream_t stream) {
     mpx_prime_params p = params ? *params : mpx_prime_params{1, 2, 5, 2, MPX_NOTES_UNICODE};
     if (p.num_harmonic < 1 || p.num_octave < 1 || p.num_harmonic * p.num_octave > 64 || p.harmonic_multiples_elim < 1 ||
         p.harmonic_multiples_elim > 64 || p.harmonic_elim_runs < 0 || p.harmonic_elim_runs > PRIME_MAX_RUNS)
@@ -316,8 +318,8 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         for (int cidx = 1; cidx < num_clips; ++cidx) seg.push_back(clip_slots * (cidx + 1));
         slot = clip_slots * num_clips;
     }
-    hipStream_t st = ctx->stream;
-    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
+    hipStream_t st = stream ? stream : ctx->stream;
+    if (!dev_io && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
     const size_t nitems = (size_t)slot;
     size_t item_bytes = 0;
     for (auto& v : items) item_bytes += v.size() * sizeof(PrimeItem);
@@ -325,31 +327,39 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, (nitems + 1) * PRIME_MAX_RUNS * (sizeof(int) + sizeof(double)) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)(num_clips ? num_clips : 1) * 12 * sizeof(double)))) return rc;
-    if (total && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
+    if (!dev_io && total && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
+    const float* d_in = dev_io ? signals : (const float*)ctx->d_signal.p;   // the kernel reads valid samples only
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     double* d_val = (double*)ctx->d_ws0.p;
     int* d_pc = (int*)(d_val + (nitems + 1) * PRIME_MAX_RUNS);
     char* d_items = (char*)ctx->d_desc.p;
     size_t off = 0;
-    prof_mark(ctx, st, "prime_kernel");
     for (int cls = 0; cls < 4; ++cls) {
         const size_t bytes = items[cls].size() * sizeof(PrimeItem);
         if (bytes) MPX_HIP(ctx, hipMemcpyAsync(d_items + off, items[cls].data(), bytes, hipMemcpyHostToDevice, st));
+        off += bytes;
+    }
+    if (dev_io) MPX_HIP(ctx, hipStreamSynchronize(st));   // seg and items are host vectors of this call
+    off = 0;
+    prof_mark(ctx, st, "prime_kernel");
+    for (int cls = 0; cls < 4; ++cls) {
+        const size_t bytes = items[cls].size() * sizeof(PrimeItem);
         const PrimeItem* di = (const PrimeItem*)(d_items + off);
         const int per_clip = uniform ? (int)items[cls].size() : 0;
         const size_t count = uniform ? items[cls].size() * (size_t)num_clips : items[cls].size();
-        if (cls == 0) prime_launch<1024, 64>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 1) prime_launch<2048, 128>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 2) prime_launch<4096, 256>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 3) prime_launch<8192, 512>((const float*)ctx->d_signal.p, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 0) prime_launch<1024, 64>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 1) prime_launch<2048, 128>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 2) prime_launch<4096, 256>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 3) prime_launch<8192, 512>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
         off += bytes;
     }
     prof_mark(ctx, st, "prime_sum_kernel");
     if (num_clips)
         hipLaunchKernelGGL(prime_sum_kernel, dim3(num_clips), dim3(64), 0, st, (const long long*)ctx->d_offsets.p,
-                           p.harmonic_elim_runs, d_pc, d_val, (double*)ctx->d_sum.p);
+                           p.harmonic_elim_runs, d_pc, d_val, dev_io ? chroma_sums : (double*)ctx->d_sum.p);
     prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
+    if (dev_io) return MPX_OK;
     if (num_clips)
         MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     // the item vectors are read by the async copies above: wait before they go out of scope

@@ -249,6 +249,17 @@ class Engine:
             C.byref(p), out.ctypes.data_as(_lib._dp)))
         return out
 
+    def iterative_f0_dev(self, d_signal, n, fs, d_frames, d_sum, stream=None, **kw):
+        """Device pointers (ints); the signal is read in place.  Only enqueues; the caller synchronises."""
+        p = self._if0_params(**kw)
+        self._ensure_remez(fs)
+        self._check(self.lib.mpx_iterative_f0_dev(self.ctx, d_signal, int(n), int(fs), C.byref(p), d_frames, d_sum, stream))
+
+    def prime_multif0_dev(self, d_signal, n, fs, d_sum, stream=None, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5,
+                          harmonic_elim_runs=2, note_names="unicode"):
+        p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs, self._notes(note_names))
+        self._check(self.lib.mpx_prime_multif0_dev(self.ctx, d_signal, int(n), int(fs), C.byref(p), d_sum, stream))
+
     def iterative_f0_warmup(self, fs, **kw):
         """(run-in samples, slowest pole radius) of this parameter set's filter chain (include/mpx.h); ValueError when the
         chain decays too slowly to be cut into chunks or time shards."""

@@ -180,6 +180,11 @@ int mpx_prime_multif0(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
 int mpx_prime_multif0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips,
                             int fs, const mpx_prime_params* params, double* chroma_sums);
 
+/* Device-resident variant: d_signal is read in place, d_chroma_sum ([12]) is a device buffer, the kernels are enqueued on
+ * `stream` (NULL = the context's) -- after the few KB of host-built frame lists have been uploaded and waited for. */
+int mpx_prime_multif0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_prime_params* params,
+                          double* d_chroma_sum, void* stream);
+
 /* ---- Iterative F0 (method 3): iterative_f0.py:21-33, periodicity.py:15-28 kwargs ----
  * replaces iterative_f0.py:54-96 + periodicity.py:48-163: 70-channel resonator filterbank over the
  * WHOLE signal (quirk A.1 kept), warped-FIR compression, full-wave rectifier, (y + LP(y, fc))/2,
@@ -211,6 +216,12 @@ int mpx_iterative_f0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const
 
 int mpx_iterative_f0_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                            const mpx_if0_params* params, double* chroma_sums /* [C,12] */);
+
+/* Device-resident variant: d_signal is read in place (a stream that lives in HBM is not copied), d_chroma_frames ([F,12],
+ * may be NULL) and d_chroma_sum ([12], may be NULL; not both) are device buffers, the kernels are enqueued on `stream`
+ * (NULL = the context's) -- after the chunk / frame tables built on the host have been uploaded and waited for. */
+int mpx_iterative_f0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_if0_params* params,
+                         double* d_chroma_frames, double* d_chroma_sum, void* stream);
 
 /* Zero-state run-in (samples, a multiple of 8192, >= 65536) after which this parameter set's filter chain has
  * forgotten its start to fp64 rounding: rho^W W^3 <= 1e-15 for the slowest pole radius rho of the chain (also returned

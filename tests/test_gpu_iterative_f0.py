@@ -141,3 +141,35 @@ def test_channel_counts_and_packed_leftover_waves(eng, clips, channels):
     np.testing.assert_array_equal(got[0], got[2])
     np.testing.assert_array_equal(got[1], got[4])
     np.testing.assert_array_equal(got[0], eng.iterative_f0(batch[0], FS, channels=channels))
+
+
+def test_device_resident_entry_equals_host_entry(eng, clips):
+    """mpx_iterative_f0_dev: the stream is read where it lies in HBM, results stay there, the caller's stream carries
+    the kernels.  Bit-equal to the host entry (same kernels, same order), per frame and summed, both spellings; a
+    sub-frame tail, a clip shorter than one frame and the empty stream included."""
+    import torch
+    side = torch.cuda.Stream(device="cuda:0")
+    for name, mode in (("poly_seed1", "unicode"), ("piano_like_Cmaj", "ascii"), ("short_ragged", "unicode")):
+        x = clips[name]
+        want_sum, want_frames = eng.iterative_f0(x, FS, return_frames=True, note_names=mode)
+        xd = torch.from_numpy(x).to("cuda:0")
+        d_frames = torch.full((want_frames.shape[0], 12), -1.0, dtype=torch.float64, device="cuda:0")
+        d_sum = torch.full((12,), -1.0, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        eng.iterative_f0_dev(xd.data_ptr(), x.shape[0], FS, d_frames.data_ptr(), d_sum.data_ptr(), stream=side.cuda_stream,
+                             note_names=mode)
+        side.synchronize()
+        np.testing.assert_array_equal(d_frames.cpu().numpy(), want_frames)
+        np.testing.assert_array_equal(d_sum.cpu().numpy(), want_sum)
+        d_sum.fill_(-1.0)
+        torch.cuda.synchronize()
+        eng.iterative_f0_dev(xd.data_ptr(), x.shape[0], FS, None, d_sum.data_ptr(), note_names=mode)   # context's stream
+        eng.synchronize()
+        np.testing.assert_array_equal(d_sum.cpu().numpy(), want_sum)
+    d_sum = torch.full((12,), -1.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.iterative_f0_dev(None, 0, FS, None, d_sum.data_ptr())
+    eng.synchronize()
+    assert not d_sum.cpu().numpy().any()
+    with pytest.raises(Exception):
+        eng.iterative_f0_dev(xd.data_ptr(), 100, FS, None, None)

@@ -101,3 +101,30 @@ def test_equal_length_clips_share_one_item_list(eng, clips):
     np.testing.assert_array_equal(got[0], got[4])
     two = eng.prime_multif0_batch(np.zeros((3, 0), dtype=np.float32), FS)      # equal length zero
     assert two.shape == (3, 12) and np.all(two == 0)
+
+
+def test_device_resident_entry_equals_host_entry(eng, clips):
+    """mpx_prime_multif0_dev: signal and result in HBM, kernels on the caller's stream; bit-equal to the host entry."""
+    import torch
+    side = torch.cuda.Stream(device="cuda:0")
+    for name, mode in (("poly_seed1", "unicode"), ("piano_like_Cmaj", "ascii"), ("short_ragged", "unicode")):
+        x = clips[name]
+        want = eng.prime_multif0(x, FS, note_names=mode)
+        xd = torch.from_numpy(x).to("cuda:0")
+        d_sum = torch.full((12,), -1.0, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        eng.prime_multif0_dev(xd.data_ptr(), x.shape[0], FS, d_sum.data_ptr(), stream=side.cuda_stream, note_names=mode)
+        side.synchronize()
+        np.testing.assert_array_equal(d_sum.cpu().numpy(), want)
+        d_sum.fill_(-1.0)
+        torch.cuda.synchronize()
+        eng.prime_multif0_dev(xd.data_ptr(), x.shape[0], FS, d_sum.data_ptr(), note_names=mode)
+        eng.synchronize()
+        np.testing.assert_array_equal(d_sum.cpu().numpy(), want)
+    d_sum = torch.full((12,), -1.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    eng.prime_multif0_dev(None, 0, FS, d_sum.data_ptr())
+    eng.synchronize()
+    assert not d_sum.cpu().numpy().any()
+    with pytest.raises(Exception):
+        eng.prime_multif0_dev(xd.data_ptr(), 100, FS, None)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the ESACF path (deterministic mode) against the oracle: random frame sizes, sample rates,
+"""Differential fuzz of the ESACF path (lane-mode fits; FUZZ_DEFAULT_MODE=1: the default mode) against the oracle: random frame sizes, sample rates,
 peak parameters and signals with silences / hard clipping (plateaus in the SACF).  Frames that differ end to end are accepted only if they agree on identical
 inputs (the oracle fed the GPU's ESACF row) or the oracle flags them as ill-conditioned (perturbation test, or an
 accepted gaussian fit whose centre left its 21-sample window).  Not part of the test suite
@@ -20,7 +20,9 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for case in range(cases):
         fs = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
-        N = int(rng.choice([64, 100, 255, 256, 511, 512, 742, 1000, 1023, 1024, 1500, 2046, 2047, 2048, 2049, 2227, 3000, 4095, 4096]))
+        sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
+            [64, 100, 255, 256, 511, 512, 742, 1000, 1023, 1024, 1500, 2046, 2047, 2048, 2049, 2227, 3000, 4095, 4096]
+        N = int(rng.choice(sizes))   # FUZZ_SIZES=1023,2046: the prime-factor SACF engine only
         nfr = int(rng.integers(1, 5))
         n = nfr * N - int(rng.integers(0, N // 2))
         t = np.arange(n) / fs
@@ -39,15 +41,17 @@ with warnings.catch_warnings():
         x = x.astype(np.float32)
         kw = dict(n_peaks_elim=int(rng.integers(2, 8)), peak_thresh=float(rng.choice([0.05, 0.1, 0.3, 0.6])),
                   peak_min_dist=int(rng.choice([1, 2, 5, 10, 25])), enhance_mode=str(rng.choice(["librosa010", "noop"])))
-        tot, per = eng.esacf(x, fs, N, return_frames=True, **kw)
+        nn = str(rng.choice(["unicode", "ascii"]))
+        tot, per = eng.esacf(x, fs, N, return_frames=True, note_names=nn, **kw)
         e_gpu = eng.esacf_stage("esacf", x, fs, N, **kw)
         okw = dict(peak_thresh=kw["peak_thresh"], peak_min_dist=kw["peak_min_dist"])
-        want = o_esacf.esacf_frames(x, fs, frame_size=N, n_peaks_elim=kw["n_peaks_elim"], enhance_mode=kw["enhance_mode"], **okw)
+        want = o_esacf.esacf_frames(x, fs, frame_size=N, n_peaks_elim=kw["n_peaks_elim"], enhance_mode=kw["enhance_mode"],
+                                    note_names=nn, **okw)
         for f in range(per.shape[0]):
             frames += 1
             if np.allclose(per[f], want[f], rtol=1e-5, atol=1e-12):
                 continue
-            same = o_esacf.frame_chroma(e_gpu[f], fs, **okw)
+            same = o_esacf.frame_chroma(e_gpu[f], fs, note_names=nn, **okw)
             if (np.allclose(per[f], same, rtol=1e-5, atol=1e-12) or o_esacf.frame_fragility(e_gpu[f], fs, **okw)
                     or o_esacf.frame_has_runaway_fit(e_gpu[f], fs, **okw)):
                 frag += 1
