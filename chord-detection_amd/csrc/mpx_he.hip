@@ -23,6 +23,7 @@
 #include "mpx_fft.hpp"
 #include "mpx_fft_dif.hpp"
 #include "mpx_internal.hpp"
+#include "mpx_he_wave.hpp"
 
 namespace mpx {
 
@@ -51,15 +52,6 @@ struct HeArgs {
     unsigned* counter;      // arrival ticket for that hand-off; zero before and after every launch
 };
 
-// XCD-aware bijective remap: workgroup b runs on XCD b%8 (observed dispatch
-// order; a wrong guess only costs speed).  Give each XCD a contiguous block of
-// frames so the (N-hop)-sample overlap between neighbours hits its own L2.
-__device__ __forceinline__ long long xcd_contiguous(long long b, long long g) {
-    const long long q = g >> 3, r = g & 7;
-    const long long xcd = b & 7, slot = b >> 3;
-    const long long base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + slot;
-}
 
 // This thread's EPT sample pairs of one frame (pair e starts at sample 2*(tid + e*STRIDE)); zero
 // beyond `valid` (the frame_cutter padding).  Full, 8-byte aligned frames -- all but the tail of
@@ -522,6 +514,8 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
                          "harmonic-energy window [%d,%d) outside the %d-bin spectrum (the reference "
                          "raises IndexError / wraps here)", kmin, kmax, M + 1);
     plan.nwin = (int)k0.size();
+    plan.h_k0 = k0;   // (bin numbers; the device arrays below index the compact bin list)
+    plan.h_k1 = k1;
     plan.wins_per_note = p.num_octave * p.num_harmonic;
     plan.num_harmonic = p.num_harmonic;
     plan.kmin = kmin;
@@ -571,10 +565,92 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
     return MPX_OK;
 }
 
+// The wave-per-frame kernel (mpx_he_wave.hpp) for the headline shape: 4096-sample frames, fp64, at most 256 window bins.
+constexpr int HEW_WAVES = 8, HEW_ROUNDS = 4;
+static bool he_wave_applies(const HePlan& plan) {
+    if (getenv("MPX_HE_WG")) return false;   // A/B switch: the workgroup-per-frame kernel below
+    return plan.nb <= 64 * HEW_ROUNDS && plan.nwin <= 192;
+}
+static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n, const FrameDesc* d_desc,
+                          int64_t num_frames, int hop, double* d_out, double* d_sum, hipStream_t stream) {
+    constexpr int N = 4096, M = N / 2;
+    if (!plan.whalf) {
+        std::vector<double> wh(M);
+        for (int i = 0; i < M; ++i) wh[i] = (double)(0.54L - 0.46L * cosl(2.0L * M_PIl * i / (long double)(N - 1)));   // scipy.signal.hamming(N), harmonic_energy.py:42
+        std::vector<unsigned> sl(2 * plan.h_bins.size());
+        for (size_t i = 0; i < plan.h_bins.size(); ++i) {
+            const int kp = plan.h_bins[i] & 1023, km = (1024 - kp) & 1023;
+            sl[2 * i] = (unsigned)hw_slot(0, kp) | ((unsigned)hw_slot(0, km) << 16);
+            sl[2 * i + 1] = (unsigned)hw_slot(1, kp) | ((unsigned)hw_slot(1, km) << 16);
+        }
+        plan.wslots = (unsigned*)upload(ctx, sl.data(), sl.size() * sizeof(unsigned));
+        plan.whalf = upload(ctx, wh.data(), wh.size() * sizeof(double));
+        if (!plan.whalf || !plan.wslots) return MPX_ENOMEM;
+        // one window per lane and one note per quad needs the reference's 12 x 2 x 2 windows, none empty, none wider than 8
+        bool quad = plan.nwin == 48 && plan.wins_per_note == 4 && plan.num_harmonic == 2;
+        for (size_t w = 0; quad && w < plan.h_k0.size(); ++w) quad = plan.h_k1[w] > plan.h_k0[w] && plan.h_k1[w] - plan.h_k0[w] <= 8;
+        plan.quad_tail = quad ? 1 : 0;
+    }
+    HeWaveArgs a;
+    a.sig = d_signal;
+    a.n = n;
+    a.desc = d_desc;
+    a.num_frames = num_frames;
+    a.hop = hop;
+    a.whalf = (const double*)plan.whalf;
+    a.tw = (const cx<double>*)plan.tw;
+    a.wk0 = plan.wk0;
+    a.wk1 = plan.wk1;
+    a.ww = (const double*)plan.ww;
+    a.slots = plan.wslots;
+    a.twnb = (const cx<double>*)plan.twnb;
+    a.nb = plan.nb;
+    a.nwin = plan.nwin;
+    a.wins_per_note = plan.wins_per_note;
+    a.num_harmonic = plan.num_harmonic;
+    a.quad_tail = plan.quad_tail;
+    if (!d_out) {   // the sum over frames goes through the rows: which wave computes a frame is decided at run time
+        int rc = ensure(ctx, ctx->d_frames_out, (size_t)num_frames * 12 * sizeof(double));
+        if (rc) return rc;
+        d_out = (double*)ctx->d_frames_out.p;
+    }
+    a.out = d_out;
+    a.partial = nullptr;
+    // one workgroup of eight waves per CU, each owning a contiguous run of frames
+    long long g = ctx->num_cus < num_frames ? ctx->num_cus : num_frames;
+    const long long per = (num_frames + g - 1) / g;
+    g = (num_frames + per - 1) / per;
+    if (d_sum) {
+        int rc = ensure(ctx, ctx->d_partials, (size_t)g * 12 * sizeof(double));
+        if (rc) return rc;
+        a.partial = (double*)ctx->d_partials.p;
+    }
+    const size_t lds = (size_t)hw_shared_bytes(HEW_ROUNDS, plan.nwin) + (size_t)HEW_WAVES * HW_XBUF;
+    auto kern = he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false>;
+    if (!ctx->occupancy.count("he_wave_lds")) {
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->occupancy["he_wave_lds"] = 1;
+    }
+    prof_mark(ctx, stream, "he_wave_kernel");
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(HEW_WAVES * 64), lds, stream, a, (cx<double>*)nullptr);
+    prof_mark(ctx, stream, nullptr);
+    MPX_HIP(ctx, hipGetLastError());
+    if (d_sum) {
+        prof_mark(ctx, stream, "sum_all_kernel");
+        hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, stream, (const double*)a.partial, g, d_sum);
+        prof_mark(ctx, stream, nullptr);
+        MPX_HIP(ctx, hipGetLastError());
+    }
+    return MPX_OK;
+}
+
 template <int N, int T, typename Real>
 static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n,
                      const FrameDesc* d_desc, int64_t num_frames, int hop, double* d_out, double* d_sum,
                      hipStream_t stream) {
+    if constexpr (N == 4096 && std::is_same<Real, double>::value) {
+        if (he_wave_applies(plan)) return he_wave_launch(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+    }
     HeArgs<Real> a;
     a.sig = d_signal;
     a.n = n;

@@ -1,0 +1,511 @@
+// Harmonic-Energy chroma for 4096-sample frames, fp64: ONE WAVE PER FRAME, the frame held in registers.
+//
+// The workgroup-per-frame kernel (mpx_he.hip) keeps the 2048-point complex FFT of a frame in 32 KB of LDS and walks
+// it four times (radix 8.8.8.4, 8 points per thread): its time is LDS round trips + fp64 issue + three workgroup
+// barriers per frame, at 4 waves per SIMD.  Here a wave64 owns a frame: 32 complex points per lane live in 128 VGPRs
+// and the 4096-point real transform is two 1024-point complex ones, 1024 = 32 x 32, one per lane parity:
+//   x[4m + j], j < 4, are four real sequences; even lanes transform zA[m] = x[4m] + i x[4m+1], odd lanes
+//   zB[m] = x[4m+2] + i x[4m+3] (lane L holds the sample pairs 2(L + 64 n1), n1 < 32: coalesced loads);
+//   A. a 32-point DFT over n1 IN REGISTERS (no exchange at all);
+//   B. times W_1024^(l k1), l = L >> 1 (per-lane power chain);
+//   C. one transpose through LDS inside each parity class (real parts, then imaginary parts, through the same 16.6 KB
+//      per wave) hands lane (k1, parity) its whole row, and a second 32-point DFT in registers finishes ZA, ZB;
+//   D. only for the bins the 48 windows look at: Y_j from the conjugate-symmetric split of ZA, ZB, and
+//      X[k] = (Y0 + W^k Y1) + W^2k (Y2 + W^k Y3), W = W_4096 -- the last two radix-2 levels of the real transform are
+//      never computed for the other 1800 bins.
+// One LDS round trip instead of four, no workgroup barrier in the frame loop, a wave never waits for another wave.
+// The price is 2 waves per SIMD (<= 256 VGPRs); the long register-resident runs have the instruction-level
+// parallelism to cover fp64 latency without more waves.
+//
+// Same arithmetic contract as he_kernel (harmonic_energy.py:42-67): x * hamming_sym(N) in fp64, real-split on the
+// window bins only, |X|^2 maxima, fourth root of the 48 maxima, the reference's summation order inside a frame.
+#pragma once
+#include "mpx_fft.hpp"
+#include "mpx_fft_dif.hpp"
+#include "mpx_internal.hpp"
+
+namespace mpx {
+
+// XCD-aware bijective remap: workgroup b runs on XCD b%8 (observed dispatch
+// order; a wrong guess only costs speed).  Give each XCD a contiguous block of
+// frames so the (N-hop)-sample overlap between neighbours hits its own L2.
+__device__ __forceinline__ long long xcd_contiguous(long long b, long long g) {
+    const long long q = g >> 3, r = g & 7;
+    const long long xcd = b & 7, slot = b >> 3;
+    const long long base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+struct HeWaveArgs {
+    const float* sig;
+    long long n;
+    const FrameDesc* desc;  // nullptr => frame f starts at f*hop
+    long long num_frames;
+    int hop;
+    const double* whalf;      // [2048] hamming_sym(4096)[0..2047] (the other half is its mirror image)
+    const cx<double>* tw;     // [2048] W_2048^j
+    const int* wk0;           // windows as index ranges into the bin list
+    const int* wk1;
+    const double* ww;         // 1/harmonic per window
+    const unsigned* slots;    // [nb][2] per window bin k, k' = k mod 1024: (ZA[k'] | ZA[-k'] << 16), (ZB[k'] | ZB[-k'] << 16): double
+                              // indices into the bin-ordered LDS copy (hw_slot)
+    const cx<double>* twnb;   // W_4096^k per window bin
+    int nb, nwin, wins_per_note, num_harmonic;
+    int quad_tail;            // host: nwin == 48, 4 windows per note, 2 harmonics, every window 1..8 bins wide
+    double* out;              // [F,12] per-frame chroma, never null: the sums over frames are taken over these rows
+    double* partial;          // [gridDim.x,12] or null: sum of each workgroup's rows, in row order (a second, tiny launch adds them)
+};
+
+// Transpose buffer of a wave: the rows (k1, 0) and (k1, 1) interleaved element by element, 528 B per pair (512 + 16 of
+// padding).  The writers of one register (lane L holds column L >> 1 of row (k1, L & 1)) then store 64 consecutive
+// doubles, and the readers (lane 2 k1 + parity owns row (k1, parity), elements 16 B apart) start in 64 different 8-byte
+// slots, 16 k1 + 8 parity modulo the bank sweep: no bank conflict however the hardware groups the lanes.  (The first
+// layout, 264-byte rows per parity, collided two-way on the paired reads and on the stores: SQ_LDS_BANK_CONFLICT was
+// 46 % of SQ_LDS_IDX_ACTIVE.)  The bin-ordered copy interleaves ZA and ZB the same way.
+constexpr int HW_PAIR = 528;
+constexpr int HW_XBUF = 32 * HW_PAIR;  // per wave: 16 896 B
+__host__ __device__ constexpr int hw_slot(int parity, int k) { return 2 * (k & 1023) + parity; }
+
+__host__ __device__ constexpr int hw_br5(int p) {
+    return ((p & 1) << 4) | ((p & 2) << 2) | (p & 4) | ((p & 8) >> 2) | ((p & 16) >> 4);
+}
+
+// cos / sin of 2 pi e / 32, e < 16
+__device__ constexpr double HW_C[16] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                         0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785,
+                                         0.0, -0.19509032201612826785, -0.38268343236508977173, -0.55557023301960222474,
+                                         -0.70710678118654752440, -0.83146961230254523708, -0.92387953251128675613, -0.98078528040323044913};
+__device__ constexpr double HW_S[16] = {0.0, 0.19509032201612826785, 0.38268343236508977173, 0.55557023301960222474,
+                                         0.70710678118654752440, 0.83146961230254523708, 0.92387953251128675613, 0.98078528040323044913,
+                                         1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                         0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785};
+
+// d * W_32^E, E a compile-time exponent < 16
+template <int E>
+__device__ __forceinline__ cx<double> hw_mul_w32(cx<double> d) {
+    if constexpr (E == 0) {
+        return d;
+    } else if constexpr (E == 8) {
+        return {d.y, -d.x};
+    } else if constexpr (E == 4) {
+        return {HW_C[4] * (d.x + d.y), HW_C[4] * (d.y - d.x)};
+    } else if constexpr (E == 12) {
+        return {HW_C[4] * (d.y - d.x), -HW_C[4] * (d.x + d.y)};
+    } else {
+        constexpr double c = HW_C[E], s = HW_S[E];   // W = c - i s
+        return {d.x * c + d.y * s, d.y * c - d.x * s};
+    }
+}
+
+template <int S, int G, int J>
+__device__ __forceinline__ void hw_bfly(cx<double>* r) {
+    const cx<double> a = r[G + J], b = r[G + J + S];
+    r[G + J] = cadd(a, b);
+    r[G + J + S] = hw_mul_w32<J * (16 / S)>(csub(a, b));
+}
+template <int S, int G, int J>
+__device__ __forceinline__ void hw_stage_j(cx<double>* r) {
+    if constexpr (J < S) {
+        hw_bfly<S, G, J>(r);
+        hw_stage_j<S, G, J + 1>(r);
+    }
+}
+template <int S, int G>
+__device__ __forceinline__ void hw_stage_g(cx<double>* r) {
+    if constexpr (G < 32) {
+        hw_stage_j<S, G, 0>(r);
+        hw_stage_g<S, G + 2 * S>(r);
+    }
+}
+// 32-point DFT in registers, decimation in frequency: natural order in, r[p] = X[br5(p)] out
+__device__ __forceinline__ void hw_fft32(cx<double>* r) {
+    hw_stage_g<16, 0>(r);
+    hw_stage_g<8, 0>(r);
+    hw_stage_g<4, 0>(r);
+    hw_stage_g<2, 0>(r);
+    hw_stage_g<1, 0>(r);
+}
+
+// Phase boundary for the instruction scheduler: with 32 complex points per lane the frame loop is one enormous basic
+// block, and instructions hoisted across phases (all 32 window reads before the first conversion ...) end in scratch --
+// whose reloads wait on vmcnt, i.e. on the prefetch of the next frame.
+__device__ __forceinline__ void hw_phase() { __builtin_amdgcn_sched_barrier(0); }
+// Two waves share a SIMD.  The one in an exchange phase (a few LDS instructions, then waiting) goes first so that its
+// requests are on their way at once; the one in a long register-only stretch fills whatever issue slots are left.
+#ifndef HW_PRIO
+#define HW_PRIO 1
+#endif
+__device__ __forceinline__ void hw_prio_exchange() {
+    if (HW_PRIO) __builtin_amdgcn_s_setprio(3);
+}
+__device__ __forceinline__ void hw_prio_compute() {
+    if (HW_PRIO) __builtin_amdgcn_s_setprio(0);
+}
+// opaque copy of the lane id: what is derived from it is rebuilt on the spot instead of living across the transforms
+__device__ __forceinline__ int hw_opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// value of lane (l ^ X) of the same quad, X = 1 or 2
+template <int X>
+__device__ __forceinline__ double hw_quad_xor(double v) {
+    constexpr int ctrl = X == 1 ? 0xB1 : 0x4E;   // quad_perm [1,0,3,2] / [2,3,0,1]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// This lane's 32 sample pairs of one frame: pair n1 starts at sample 2*(lane + 64*n1)
+template <bool FAST>
+__device__ __forceinline__ void hw_load_frame(float2* raw, const float* __restrict__ x, int lane, int valid) {
+    const float* p = x + 2 * lane;
+    if (FAST) {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) raw[e] = *reinterpret_cast<const float2*>(p + 128 * e);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 32; ++e) {
+            const int s = 2 * lane + 128 * e;
+            raw[e].x = s < valid ? p[128 * e] : 0.f;
+            raw[e].y = s + 1 < valid ? p[128 * e + 1] : 0.f;
+        }
+    }
+}
+
+#ifdef HW_FAST_ONLY   // tests/tools/he_wave_check.hip: only the branch-free loader, to read the register allocation
+#define HW_SLOW_PATH 0
+#else
+#define HW_SLOW_PATH 1
+#endif
+// shared LDS tables in front of the waves' buffers (bytes): whalf | slots | twnb | ww | wk | frame counter
+__host__ __device__ constexpr int hw_shared_bytes(int rounds, int nwin) {
+    return 16384 + 8 * 64 * rounds + 16 * 64 * rounds + ((16 * nwin + 15) & ~15) + 16;
+}
+
+template <int WAVES, int ROUNDS, bool DEBUG>
+__global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx<double>* dbg) {
+    constexpr int N = 4096, T = WAVES * 64, NBP = 64 * ROUNDS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* whalf = reinterpret_cast<double*>(smem);                            // 16 KB, shared by the waves
+    uint2* slots_lds = reinterpret_cast<uint2*>(smem + 16384);                  // [NBP]
+    cx<double>* twnb_lds = reinterpret_cast<cx<double>*>(slots_lds + NBP);       // [NBP]
+    double* ww_lds = reinterpret_cast<double*>(twnb_lds + NBP);                 // [nwin]
+    int* wk_lds = reinterpret_cast<int*>(ww_lds + a.nwin);                      // [2 nwin]
+    unsigned* next_frame = reinterpret_cast<unsigned*>(smem + hw_shared_bytes(ROUNDS, a.nwin) - 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* xbuf = smem + hw_shared_bytes(ROUNDS, a.nwin) + wave * HW_XBUF;
+
+    // Frames of this workgroup: a contiguous run (neighbouring frames share 3/4 of their samples), handed out to its
+    // waves one at a time by an LDS counter.  The two waves of a SIMD do not run at the same speed (the hardware favours the
+    // older one: 15 000 against 31 000 clocks per frame), equal shares leave the younger ones working alone at the end.
+    // Which wave computed a frame changes nothing: every frame is a row of `out`, summed afterwards in a fixed order.
+    const long long w = xcd_contiguous(blockIdx.x, gridDim.x);
+    const long long per = (a.num_frames + gridDim.x - 1) / gridDim.x;
+    const long long g0 = w * per;
+    long long g1 = g0 + per;
+    if (g1 > a.num_frames) g1 = a.num_frames;
+    auto grab = [&]() -> long long {   // wave-uniform
+        unsigned t = 0;
+        if (lane == 0) t = atomicAdd(next_frame, 1u);
+        return g0 + (long long)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    auto frame_span = [&](long long f, long long& start, int& valid) {
+        if (a.desc) {
+            start = a.desc[f].start;
+            valid = a.desc[f].valid;
+        } else {
+            start = f * (long long)a.hop;
+            const long long left = a.n - start;
+            valid = left >= N ? N : (left > 0 ? (int)left : 0);
+        }
+    };
+    bool fast = g0 < g1 && (reinterpret_cast<uintptr_t>(a.sig) & 7) == 0;
+    if (fast) {
+        if (a.desc) {
+            for (long long f = g0 + lane; f < g1; f += 64) fast = fast && a.desc[f].valid >= N && (a.desc[f].start & 1) == 0;
+            fast = __all(fast);
+        } else {
+            fast = (a.hop & 1) == 0 && (g1 - 1) * (long long)a.hop + N <= a.n;
+        }
+    }
+    if (tid == 0) *next_frame = 0;
+    auto fill_tables = [&]() {
+        for (int i = tid; i < 1024; i += T) reinterpret_cast<double2*>(whalf)[i] = reinterpret_cast<const double2*>(a.whalf)[i];
+        for (int i = tid; i < NBP; i += T) {   // (entries past the last bin: bin 0, results dropped)
+            slots_lds[i] = reinterpret_cast<const uint2*>(a.slots)[i < a.nb ? i : 0];
+            twnb_lds[i] = a.twnb[i < a.nb ? i : 0];
+        }
+        for (int i = tid; i < a.nwin; i += T) {
+            ww_lds[i] = a.ww[i];
+            wk_lds[2 * i] = a.wk0[i];
+            wk_lds[2 * i + 1] = a.wk1[i];
+        }
+    };
+    __syncthreads();   // the counter
+
+#ifdef HW_TRACE   // timing experiments only: shader-clock stamps of workgroup 0 at the phase boundaries, [wave][frame][16]
+#define HW_STAMP(pt)                                                                                                \
+    do {                                                                                                            \
+        if (dbg && blockIdx.x == 0 && lane == 0 && nframe < 32)                                                     \
+            reinterpret_cast<long long*>(dbg)[(wave * 32 + nframe) * 16 + (pt)] = (long long)__builtin_amdgcn_s_memtime(); \
+        hw_phase();                                                                                                 \
+    } while (0)
+#else
+#define HW_STAMP(pt) do {} while (0)
+#endif
+    const bool quad_tail = a.quad_tail != 0;
+    auto run = [&](auto fast_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        float2 raw[32];
+        long long f = grab();
+        const long long f0 = f;
+        (void)f0;
+        if (f < g1) {   // the first frame is on its way while the tables are filled
+            long long start;
+            int valid;
+            frame_span(f, start, valid);
+            hw_load_frame<FAST>(raw, a.sig + start, lane, valid);
+        }
+        fill_tables();
+        __syncthreads();
+        [[maybe_unused]] int nframe = 0;
+        while (f < g1) {
+            cx<double> z[32];
+            HW_STAMP(0);
+            // this wave's next frame: asked for now, read once the window reads below have drained the LDS queue anyway
+            unsigned grabbed = 0;
+            if (hw_opaque(lane) == 0) grabbed = atomicAdd(next_frame, 1u);
+            // W_1024^(lane >> 1), the base of the twiddle powers of phase B: 16 bytes from L1/L2 per frame instead of four
+            // registers across the loop (the load is behind this frame's samples in vmcnt order and has all of A to arrive)
+            const cx<double> w1 = a.tw[2 * (hw_opaque(lane) >> 1)];
+            {
+                // window pairs through LDS, eight at a time and one group ahead of their use (the scheduler, left alone,
+                // requests each pair right before the multiplication and eats the LDS latency 32 times).  Pair index
+                // m = lane + 64 n1 for n1 < 16, the mirrored pair 2047 - m (values swapped) above.
+                const int ol = hw_opaque(lane);
+                const char* wlo = reinterpret_cast<const char*>(whalf) + 16 * ol;
+                const char* whi = reinterpret_cast<const char*>(whalf) + 16 * (63 - ol);
+                auto wload = [&](int e) -> double2 {
+                    return e < 16 ? *reinterpret_cast<const double2*>(wlo + 1024 * e)
+                                  : *reinterpret_cast<const double2*>(whi + 1024 * (31 - e));
+                };
+                double2 wv[8], nx[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wv[j] = wload(j);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g < 3) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) nx[j] = wload(8 * (g + 1) + j);
+                    }
+                    hw_phase();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int e = 8 * g + j;
+                        const double w0 = e < 16 ? wv[j].x : wv[j].y, w1 = e < 16 ? wv[j].y : wv[j].x;
+                        z[e] = {(double)raw[e].x * w0, (double)raw[e].y * w1};
+                    }
+                    hw_phase();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wv[j] = nx[j];
+                }
+            }
+            const long long fn = g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed);
+            hw_prio_compute();
+            HW_STAMP(1);
+            // A: DFT over n1 in registers; z[p] = A[k1 = br5(p)]
+            hw_fft32(z);
+            hw_phase();
+            HW_STAMP(2);
+            // B: times W_1024^((lane >> 1) * k1).  The powers are rebuilt every frame from a base fetched here: hoisted
+            // out of the loop they are 124 registers, i.e. scratch.
+            {
+                cx<double> pw_ = w1;
+#pragma unroll
+                for (int k = 1; k < 32; ++k) {
+                    z[hw_br5(k)] = cmul(z[hw_br5(k)], pw_);
+                    if (k < 31) pw_ = cmul(pw_, w1);
+                }
+            }
+            hw_phase();
+            hw_prio_exchange();
+            HW_STAMP(3);
+            // C: transpose inside the parity class (real parts, then imaginary parts)
+            cx<double> b[32];
+            {
+                const int ol = hw_opaque(lane);
+                char* wr = xbuf + 8 * ol;
+                const char* rd = xbuf + HW_PAIR * (ol >> 1) + 8 * (ol & 1);
+#pragma unroll
+                for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].x;
+                wave_lds_fence();
+#pragma unroll
+                for (int c = 0; c < 32; ++c) b[c].x = *reinterpret_cast<const double*>(rd + 16 * c);
+                wave_lds_fence();
+#pragma unroll
+                for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].y;
+                wave_lds_fence();
+#pragma unroll
+                for (int c = 0; c < 32; ++c) b[c].y = *reinterpret_cast<const double*>(rd + 16 * c);
+                wave_lds_fence();
+            }
+            hw_phase();
+            hw_prio_compute();
+            HW_STAMP(4);
+            // second DFT over the 32 columns: b[p] = Z_parity[(lane >> 1) + 32 br5(p)], parity = lane & 1
+            hw_fft32(b);
+            hw_phase();
+            hw_prio_exchange();
+            HW_STAMP(5);
+            const int ol = hw_opaque(lane);
+            if constexpr (DEBUG) {
+#pragma unroll
+                for (int p = 0; p < 32; ++p) dbg[(f * 2 + (ol & 1)) * 1024 + (ol >> 1) + 32 * hw_br5(p)] = b[p];
+            }
+            // D: bin-ordered copy in LDS (real parts, then imaginary parts), from which the lanes of the window bins gather.
+            // Their per-lane constants are fetched now (the 32 stores cover the latency) rather than held across the transforms.
+            double* xb = reinterpret_cast<double*>(xbuf);
+            double* mine = xb + ol;   // hw_slot(parity, (lane >> 1) + 32 q) = lane + 64 q
+            cx<double> twk[ROUNDS];
+            uint2 sl[ROUNDS];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                sl[r] = slots_lds[ol + 64 * r];
+                twk[r] = twnb_lds[ol + 64 * r];
+            }
+            int wstart = 0, wlast = 0;
+            double wweight = 0.0;
+            if (quad_tail) {
+                const int wi = ol < 48 ? ol : 47;
+                wstart = wk_lds[2 * wi];
+                wlast = wk_lds[2 * wi + 1] - 1;
+                wweight = ww_lds[wi];
+            }
+#pragma unroll
+            for (int p = 0; p < 32; ++p) mine[64 * hw_br5(p)] = b[p].x;
+            wave_lds_fence();
+            {
+                // the registers of the real parts are free: request the next frame (a wave without one re-reads its own)
+                long long start;
+                int valid;
+                frame_span(fn < g1 ? fn : f, start, valid);
+                hw_load_frame<FAST>(raw, a.sig + start, ol, valid);
+            }
+            double re[ROUNDS][4], mg[ROUNDS];
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                re[r][0] = xb[sl[r].x & 0xffffu];
+                re[r][1] = xb[sl[r].x >> 16];
+                re[r][2] = xb[sl[r].y & 0xffffu];
+                re[r][3] = xb[sl[r].y >> 16];
+            }
+            wave_lds_fence();
+#pragma unroll
+            for (int p = 0; p < 32; ++p) mine[64 * hw_br5(p)] = b[p].y;
+            wave_lds_fence();
+            hw_phase();
+            HW_STAMP(6);
+            // Y0 + W^k Y1 = E - i W^k D with E = (Z[k'] + conj Z[-k']) / 2, D = (Z[k'] - conj Z[-k']) / 2 (ZA), likewise
+            // Y2 + W^k Y3 (ZB); X[k] = (Y0 + W^k Y1) + W^2k (Y2 + W^k Y3).  Lanes past the last bin redo bin 0.
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const cx<double> A = {re[r][0], xb[sl[r].x & 0xffffu]}, Am = {re[r][1], -xb[sl[r].x >> 16]};
+                const cx<double> B = {re[r][2], xb[sl[r].y & 0xffffu]}, Bm = {re[r][3], -xb[sl[r].y >> 16]};
+                const cx<double> EA = {0.5 * (A.x + Am.x), 0.5 * (A.y + Am.y)}, DA = {0.5 * (A.x - Am.x), 0.5 * (A.y - Am.y)};
+                const cx<double> EB = {0.5 * (B.x + Bm.x), 0.5 * (B.y + Bm.y)}, DB = {0.5 * (B.x - Bm.x), 0.5 * (B.y - Bm.y)};
+                const cx<double> PA = cadd(EA, mul_mi(cmul(twk[r], DA)));
+                const cx<double> PB = cadd(EB, mul_mi(cmul(twk[r], DB)));
+                const cx<double> X = cadd(PA, cmul(cmul(twk[r], twk[r]), PB));
+                mg[r] = X.x * X.x + X.y * X.y;
+            }
+            wave_lds_fence();
+            hw_phase();
+            HW_STAMP(7);
+            double* mag = xb;              // |X|^2 per window bin, over the dead spectrum
+            double* winmax = xb + NBP;
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const int i = ol + 64 * r;
+                if (i < a.nb) mag[i] = mg[r];
+            }
+            wave_lds_fence();
+            if (quad_tail) {
+                // The reference's own window shape: lane wi < 48 owns window wi and the four windows of a note sit in one
+                // quad.  Eight reads at once (indices clamped to the window's last bin: seeing a bin twice does not change
+                // a maximum), compared in bin order like the reference's loop (harmonic_energy.py:58-62).
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = mag[wstart + j < wlast ? wstart + j : wlast];
+                double m = v[0];
+#pragma unroll
+                for (int j = 1; j < 8; ++j) m = v[j] > m ? v[j] : m;
+                const double t = sqrt(sqrt(m)) * wweight;   // sqrt(|X|) of the maximum, times 1/harmonic
+                // chroma = (max_0 + max_1/2) + (max_2 + max_3/2) over the quad: the reference's association (its sums start at 0.0)
+                const double u = t + hw_quad_xor<1>(t);
+                const double chroma = u + hw_quad_xor<2>(u);
+                if (ol < 48 && (ol & 3) == 0) a.out[f * 12 + (ol >> 2)] = chroma;
+                wave_lds_fence();
+                HW_STAMP(9);
+                f = fn;
+                ++nframe;
+                continue;
+            }
+            for (int wi = ol; wi < a.nwin; wi += 64) {  // half-open window maxima (harmonic_energy.py:58-62)
+                double m = -INFINITY;
+                const int k1 = wk_lds[2 * wi + 1], kl = k1 - 1;
+                for (int k = wk_lds[2 * wi]; k < k1; k += 4) {
+                    const double v0 = mag[k], v1 = mag[k + 1 < kl ? k + 1 : kl], v2 = mag[k + 2 < kl ? k + 2 : kl],
+                                 v3 = mag[k + 3 < kl ? k + 3 : kl];
+                    m = v0 > m ? v0 : m;
+                    m = v1 > m ? v1 : m;
+                    m = v2 > m ? v2 : m;
+                    m = v3 > m ? v3 : m;
+                }
+                winmax[wi] = m < 0.0 ? m : sqrt(sqrt(m));   // sqrt(|X|) of the maximum; an empty window keeps -inf
+            }
+            wave_lds_fence();
+            if (ol < 12) {   // chroma[n] = sum_octave ( sum_harmonic max/h ), same association as the reference
+                double chroma = 0.0;
+                const int base = ol * a.wins_per_note;
+                for (int oc = 0; oc < a.wins_per_note; oc += a.num_harmonic) {
+                    double note_sum = 0.0;
+                    for (int h = 0; h < a.num_harmonic; ++h) note_sum += winmax[base + oc + h] * ww_lds[base + oc + h];
+                    chroma += note_sum;
+                }
+                a.out[f * 12 + ol] = chroma;
+            }
+            wave_lds_fence();
+            HW_STAMP(9);
+            f = fn;
+            ++nframe;
+        }
+    };
+    if (fast || !HW_SLOW_PATH)
+        run(std::true_type{});
+    else
+        run(std::false_type{});
+
+    // Which wave computed a frame is decided at run time, so the sum over frames is taken over the rows, in row order:
+    // 16 strided sub-sums per bin, combined in a fixed order.  (The rows were stored by this workgroup: the barrier's
+    // workgroup-scope release/acquire makes them visible.)  One row per workgroup; the library's sum_all_kernel adds those.
+    if (a.partial) {
+        __syncthreads();
+        double* sh = reinterpret_cast<double*>(smem);
+        const int bin = tid % 12, sub = tid / 12;
+        if (sub < 16) {
+            double t = 0.0;
+            for (long long f = g0 + sub; f < g1; f += 16) t += a.out[f * 12 + bin];
+            sh[sub * 12 + bin] = t;
+        }
+        __syncthreads();
+        if (tid < 12) {
+            double t = 0.0;
+            for (int j = 0; j < 16; ++j) t += sh[j * 12 + tid];
+            a.partial[w * 12 + tid] = t;
+        }
+    }
+
+}
+
+}  // namespace mpx

@@ -34,7 +34,11 @@ struct HePlan {
     int* wk0 = nullptr;      // [nwin] window start (index into `bins`)
     int* wk1 = nullptr;      // [nwin] window end (exclusive, harmonic_energy.py:58)
     std::vector<int> h_bins;  // [nb] the bins some window looks at, ascending (host)
+    std::vector<int> h_k0, h_k1;  // [nwin] window bin ranges [k0, k1) (host)
     mutable unsigned* slots = nullptr;  // [nb] LDS slots of Z[k], Z[M-k] for the engine of this frame size (he_launch)
+    mutable void* whalf = nullptr;      // he_wave_kernel (N = 4096, fp64): hamming_sym(N)[0 .. N/2), double
+    mutable unsigned* wslots = nullptr; //   [nb][2] positions of ZA[k'], ZA[-k'] | ZB[k'], ZB[-k'] in its bin-ordered LDS copy
+    mutable int quad_tail = -1;         //   the reference's window shape (one window per lane, a note per quad)?  -1: not decided
     void* twnb = nullptr;    // cx[nb] W_N^k at those bins (so that the load does not wait for bins[i])
     int nb = 0;
     void* ww = nullptr;      // Real[nwin] 1/harmonic
