@@ -324,6 +324,12 @@ def kernel_models(n, mh, channels=70, nf=8192):
     }
 
 
+def he_kernel_name(f32):
+    """The dominant kernel of the headline step: fp64 4096-sample frames run the wave-per-frame kernel (csrc/mpx_he_wave.hpp),
+    fp32 the workgroup-per-frame one."""
+    return "he_kernel<4096,256,float>" if f32 else "he_wave_kernel<8,4>"
+
+
 def roofline_of(name, ms, units, model):
     """Both roofs for one kernel; `bound` is the one it sits closer to."""
     b, f, unit = model
@@ -528,7 +534,7 @@ def main():
     try:  # HBM bytes per launch from the last PMC probe of this kernel (bench.py cannot run rocprofv3 on itself)
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
             tr = json.load(fh)
-        if tr.get("kernel") == "he_kernel<4096,256,%s>" % ("float" if args.f32 else "double"):
+        if tr.get("kernel") == he_kernel_name(args.f32):
             traffic, traffic_note = tr["bytes_per_launch"], tr.get("method")
     except Exception:
         traffic = None
@@ -547,7 +553,7 @@ def main():
 
     if rank == 0:
         total_frames = FRAMES * world * steps
-        kname = "he_kernel<4096,256,%s>" % ("float" if args.f32 else "double")
+        kname = he_kernel_name(args.f32)
         out = {
             "metric": "frames/sec STFT->chromagram (4096-pt FFT, hop 1024)",
             "value": total_frames / elapsed,

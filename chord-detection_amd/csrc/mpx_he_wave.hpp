@@ -7,7 +7,7 @@
 //   x[4m + j], j < 4, are four real sequences; even lanes transform zA[m] = x[4m] + i x[4m+1], odd lanes
 //   zB[m] = x[4m+2] + i x[4m+3] (lane L holds the sample pairs 2(L + 64 n1), n1 < 32: coalesced loads);
 //   A. a 32-point DFT over n1 IN REGISTERS (no exchange at all);
-//   B. times W_1024^(l k1), l = L >> 1 (per-lane power chain);
+//   B. the twiddles W_1024^(l k1), l = L >> 1, are folded into the second transform (a modulated DFT, see hw_fft32_modulated);
 //   C. one transpose through LDS inside each parity class (real parts, then imaginary parts, through the same 16.6 KB
 //      per wave) hands lane (k1, parity) its whole row, and a second 32-point DFT in registers finishes ZA, ZB;
 //   D. only for the bins the 48 windows look at: Y_j from the conjugate-symmetric split of ZA, ZB, and
@@ -126,6 +126,44 @@ __device__ __forceinline__ void hw_fft32(cx<double>* r) {
     hw_stage_g<1, 0>(r);
 }
 
+// The same transform of the MODULATED sequence x[c] * theta^c (theta per lane): in decimation in frequency the factor
+// theta^c of a pair (c, c + S) splits into theta^c -- which stays with the half-length subsequence -- and theta^S on the
+// second element, so every stage multiplies its second inputs by ONE per-lane constant th[s] = theta^S, fused into the
+// butterfly: u = a + th b (four FMAs), a - th b = 2a - u (two).  Two instructions more per butterfly than the plain one,
+// against four for a separate twiddle multiplication plus four for producing each twiddle.
+template <int S, int G, int J>
+__device__ __forceinline__ void hw_bfly_mod(cx<double>* r, cx<double> th) {
+    const cx<double> a = r[G + J], b = r[G + J + S];
+    cx<double> u;
+    u.x = fma(th.x, b.x, fma(-th.y, b.y, a.x));
+    u.y = fma(th.x, b.y, fma(th.y, b.x, a.y));
+    const cx<double> d = {fma(2.0, a.x, -u.x), fma(2.0, a.y, -u.y)};
+    r[G + J] = u;
+    r[G + J + S] = hw_mul_w32<J * (16 / S)>(d);
+}
+template <int S, int G, int J>
+__device__ __forceinline__ void hw_stage_mod_j(cx<double>* r, cx<double> th) {
+    if constexpr (J < S) {
+        hw_bfly_mod<S, G, J>(r, th);
+        hw_stage_mod_j<S, G, J + 1>(r, th);
+    }
+}
+template <int S, int G>
+__device__ __forceinline__ void hw_stage_mod_g(cx<double>* r, cx<double> th) {
+    if constexpr (G < 32) {
+        hw_stage_mod_j<S, G, 0>(r, th);
+        hw_stage_mod_g<S, G + 2 * S>(r, th);
+    }
+}
+// th[0..4] = theta^16, theta^8, theta^4, theta^2, theta
+__device__ __forceinline__ void hw_fft32_modulated(cx<double>* r, const cx<double>* th) {
+    hw_stage_mod_g<16, 0>(r, th[0]);
+    hw_stage_mod_g<8, 0>(r, th[1]);
+    hw_stage_mod_g<4, 0>(r, th[2]);
+    hw_stage_mod_g<2, 0>(r, th[3]);
+    hw_stage_mod_g<1, 0>(r, th[4]);
+}
+
 // Phase boundary for the instruction scheduler: with 32 complex points per lane the frame loop is one enormous basic
 // block, and instructions hoisted across phases (all 32 window reads before the first conversion ...) end in scratch --
 // whose reloads wait on vmcnt, i.e. on the prefetch of the next frame.
@@ -178,9 +216,9 @@ __device__ __forceinline__ void hw_load_frame(float2* raw, const float* __restri
 #else
 #define HW_SLOW_PATH 1
 #endif
-// shared LDS tables in front of the waves' buffers (bytes): whalf | slots | twnb | ww | wk | frame counter
+// shared LDS tables in front of the waves' buffers (bytes): whalf | slots | twnb | ww | wk | theta powers | frame counter
 __host__ __device__ constexpr int hw_shared_bytes(int rounds, int nwin) {
-    return 16384 + 8 * 64 * rounds + 16 * 64 * rounds + ((16 * nwin + 15) & ~15) + 16;
+    return 16384 + 8 * 64 * rounds + 16 * 64 * rounds + ((16 * nwin + 15) & ~15) + 5 * 32 * 16 + 16;
 }
 
 template <int WAVES, int ROUNDS, bool DEBUG>
@@ -193,6 +231,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
     double* ww_lds = reinterpret_cast<double*>(twnb_lds + NBP);                 // [nwin]
     int* wk_lds = reinterpret_cast<int*>(ww_lds + a.nwin);                      // [2 nwin]
     unsigned* next_frame = reinterpret_cast<unsigned*>(smem + hw_shared_bytes(ROUNDS, a.nwin) - 16);
+    cx<double>* theta_lds = reinterpret_cast<cx<double>*>(smem + hw_shared_bytes(ROUNDS, a.nwin) - 16 - 5 * 32 * 16);   // [5][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char* xbuf = smem + hw_shared_bytes(ROUNDS, a.nwin) + wave * HW_XBUF;
 
@@ -205,9 +244,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
     const long long g0 = w * per;
     long long g1 = g0 + per;
     if (g1 > a.num_frames) g1 = a.num_frames;
+    auto take = [&]() -> unsigned { return atomicAdd(next_frame, 1u); };   // one lane: the workgroup's next frame index
     auto grab = [&]() -> long long {   // wave-uniform
         unsigned t = 0;
-        if (lane == 0) t = atomicAdd(next_frame, 1u);
+        if (lane == 0) t = take();
         return g0 + (long long)__builtin_amdgcn_readfirstlane((int)t);
     };
     auto frame_span = [&](long long f, long long& start, int& valid) {
@@ -236,6 +276,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             slots_lds[i] = reinterpret_cast<const uint2*>(a.slots)[i < a.nb ? i : 0];
             twnb_lds[i] = a.twnb[i < a.nb ? i : 0];
         }
+        // W_1024^(k1 * 16 >> s): the per-stage constants of the modulated second transform of row k1 (a.tw is W_2048^j)
+        if (tid < 160) theta_lds[tid] = a.tw[(2 * (tid & 31) * (16 >> (tid >> 5))) & 2047];
         for (int i = tid; i < a.nwin; i += T) {
             ww_lds[i] = a.ww[i];
             wk_lds[2 * i] = a.wk0[i];
@@ -275,10 +317,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             HW_STAMP(0);
             // this wave's next frame: asked for now, read once the window reads below have drained the LDS queue anyway
             unsigned grabbed = 0;
-            if (hw_opaque(lane) == 0) grabbed = atomicAdd(next_frame, 1u);
-            // W_1024^(lane >> 1), the base of the twiddle powers of phase B: 16 bytes from L1/L2 per frame instead of four
-            // registers across the loop (the load is behind this frame's samples in vmcnt order and has all of A to arrive)
-            const cx<double> w1 = a.tw[2 * (hw_opaque(lane) >> 1)];
+            if (hw_opaque(lane) == 0) grabbed = take();
             {
                 // window pairs through LDS, eight at a time and one group ahead of their use (the scheduler, left alone,
                 // requests each pair right before the multiplication and eats the LDS latency 32 times).  Pair index
@@ -311,32 +350,26 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                     for (int j = 0; j < 8; ++j) wv[j] = nx[j];
                 }
             }
-            const long long fn = g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed);
+            long long fn = g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed);
             hw_prio_compute();
             HW_STAMP(1);
             // A: DFT over n1 in registers; z[p] = A[k1 = br5(p)]
             hw_fft32(z);
             hw_phase();
             HW_STAMP(2);
-            // B: times W_1024^((lane >> 1) * k1).  The powers are rebuilt every frame from a base fetched here: hoisted
-            // out of the loop they are 124 registers, i.e. scratch.
-            {
-                cx<double> pw_ = w1;
-#pragma unroll
-                for (int k = 1; k < 32; ++k) {
-                    z[hw_br5(k)] = cmul(z[hw_br5(k)], pw_);
-                    if (k < 31) pw_ = cmul(pw_, w1);
-                }
-            }
+            // B: the twiddles W_1024^(column * k1) between the two transforms are not applied here: the reader of row k1 sees
+            // them as a modulation theta^column, theta = W_1024^k1, of its input, and folds it into the second transform
             hw_phase();
             hw_prio_exchange();
             HW_STAMP(3);
             // C: transpose inside the parity class (real parts, then imaginary parts)
-            cx<double> b[32];
+            cx<double> b[32], th[5];
             {
                 const int ol = hw_opaque(lane);
                 char* wr = xbuf + 8 * ol;
                 const char* rd = xbuf + HW_PAIR * (ol >> 1) + 8 * (ol & 1);
+#pragma unroll
+                for (int st = 0; st < 5; ++st) th[st] = theta_lds[32 * st + (ol >> 1)];
 #pragma unroll
                 for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].x;
                 wave_lds_fence();
@@ -353,8 +386,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             hw_phase();
             hw_prio_compute();
             HW_STAMP(4);
-            // second DFT over the 32 columns: b[p] = Z_parity[(lane >> 1) + 32 br5(p)], parity = lane & 1
-            hw_fft32(b);
+            // second DFT over the 32 columns, modulated: b[p] = Z_parity[(lane >> 1) + 32 br5(p)], parity = lane & 1
+            hw_fft32_modulated(b, th);
             hw_phase();
             hw_prio_exchange();
             HW_STAMP(5);
@@ -386,7 +419,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             for (int p = 0; p < 32; ++p) mine[64 * hw_br5(p)] = b[p].x;
             wave_lds_fence();
             {
-                // the registers of the real parts are free: request the next frame (a wave without one re-reads its own)
+                // the registers of the real parts are free: request the next frame.  Unconditionally -- a wave without a
+                // next frame re-reads its own, mostly from L2: under `if (fn < g1)` the compiler keeps both versions of
+                // the 64 sample registers alive across the join (240 B of scratch, 93 instead of 44 us per launch)
                 long long start;
                 int valid;
                 frame_span(fn < g1 ? fn : f, start, valid);
@@ -444,7 +479,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 // chroma = (max_0 + max_1/2) + (max_2 + max_3/2) over the quad: the reference's association (its sums start at 0.0)
                 const double u = t + hw_quad_xor<1>(t);
                 const double chroma = u + hw_quad_xor<2>(u);
-                if (ol < 48 && (ol & 3) == 0) a.out[f * 12 + (ol >> 2)] = chroma;
+                // bin n sits in lane 4n: pulled into lane n, so that the row is one 96-byte store of 12 neighbouring lanes
+                const int src = (ol < 12 ? 4 * ol : ol) * 4;
+                const double row = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(chroma)),
+                                                    __builtin_amdgcn_ds_bpermute(src, __double2loint(chroma)));
+                if (ol < 12) a.out[f * 12 + ol] = row;
                 wave_lds_fence();
                 HW_STAMP(9);
                 f = fn;
