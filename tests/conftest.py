@@ -23,5 +23,5 @@ def golden_dir():
 def product_defaults(monkeypatch):
     """Every test runs the library as a user gets it: no environment switches (MPX_DETERMINISTIC would make mpx_create
     select the lane-mode fit kernel; the parity tests must exercise the default, cooperative end game included)."""
-    for k in ("MPX_DETERMINISTIC", "MPX_FIT_NOPARK", "MPX_FIT_PARK_NFEV", "MPX_FIT_MAXFEV", "MPX_SACF_PAIR", "MPX_SACF_ABLATE"):
+    for k in ("MPX_DETERMINISTIC", "MPX_FIT_NOPARK", "MPX_FIT_PARK_NFEV", "MPX_FIT_MAXFEV", "MPX_SACF_PAIR", "MPX_SACF_ABLATE", "MPX_HE_WG"):
         monkeypatch.delenv(k, raising=False)
