@@ -168,17 +168,6 @@ __device__ __forceinline__ void hw_fft32_modulated(cx<double>* r, const cx<doubl
 // block, and instructions hoisted across phases (all 32 window reads before the first conversion ...) end in scratch --
 // whose reloads wait on vmcnt, i.e. on the prefetch of the next frame.
 __device__ __forceinline__ void hw_phase() { __builtin_amdgcn_sched_barrier(0); }
-// Two waves share a SIMD.  The one in an exchange phase (a few LDS instructions, then waiting) goes first so that its
-// requests are on their way at once; the one in a long register-only stretch fills whatever issue slots are left.
-#ifndef HW_PRIO
-#define HW_PRIO 1
-#endif
-__device__ __forceinline__ void hw_prio_exchange() {
-    if (HW_PRIO) __builtin_amdgcn_s_setprio(3);
-}
-__device__ __forceinline__ void hw_prio_compute() {
-    if (HW_PRIO) __builtin_amdgcn_s_setprio(0);
-}
 // opaque copy of the lane id: what is derived from it is rebuilt on the spot instead of living across the transforms
 __device__ __forceinline__ int hw_opaque(int v) {
     asm volatile("" : "+v"(v));
@@ -351,7 +340,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 }
             }
             long long fn = g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed);
-            hw_prio_compute();
             HW_STAMP(1);
             // A: DFT over n1 in registers; z[p] = A[k1 = br5(p)]
             hw_fft32(z);
@@ -360,7 +348,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             // B: the twiddles W_1024^(column * k1) between the two transforms are not applied here: the reader of row k1 sees
             // them as a modulation theta^column, theta = W_1024^k1, of its input, and folds it into the second transform
             hw_phase();
-            hw_prio_exchange();
             HW_STAMP(3);
             // C: transpose inside the parity class (real parts, then imaginary parts)
             cx<double> b[32], th[5];
@@ -384,12 +371,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 wave_lds_fence();
             }
             hw_phase();
-            hw_prio_compute();
             HW_STAMP(4);
             // second DFT over the 32 columns, modulated: b[p] = Z_parity[(lane >> 1) + 32 br5(p)], parity = lane & 1
             hw_fft32_modulated(b, th);
             hw_phase();
-            hw_prio_exchange();
             HW_STAMP(5);
             const int ol = hw_opaque(lane);
             if constexpr (DEBUG) {
