@@ -301,6 +301,23 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
         fill_tables();
         __syncthreads();
         [[maybe_unused]] int nframe = 0;
+        // The tail of a frame with the reference's window shape -- the maximum of eight |X|^2 already on their way from
+        // LDS, two square roots, the quad sums, the store: a chain of dependent latencies with a dozen instructions in it --
+        // is finished one iteration later, behind the first transform of the NEXT frame, which covers it.
+        double pend_m = 0.0, pend_w = 0.0;
+        long long pend_f = -1;
+        auto finish_tail = [&]() {
+            const int ol = hw_opaque(lane);
+            const double t = sqrt(sqrt(pend_m)) * pend_w;   // sqrt(|X|) of the maximum, times 1/harmonic
+            // chroma = (max_0 + max_1/2) + (max_2 + max_3/2) over the quad: the reference's association (its sums start at 0.0)
+            const double u = t + hw_quad_xor<1>(t);
+            const double chroma = u + hw_quad_xor<2>(u);
+            // bin n sits in lane 4n: pulled into lane n, so that the row is one 96-byte store of 12 neighbouring lanes
+            const int src = (ol < 12 ? 4 * ol : ol) * 4;
+            const double row = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(chroma)),
+                                                __builtin_amdgcn_ds_bpermute(src, __double2loint(chroma)));
+            if (ol < 12) a.out[pend_f * 12 + ol] = row;
+        };
         while (f < g1) {
             cx<double> z[32];
             HW_STAMP(0);
@@ -343,6 +360,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             HW_STAMP(1);
             // A: DFT over n1 in registers; z[p] = A[k1 = br5(p)]
             hw_fft32(z);
+            hw_phase();
+            if (pend_f >= 0) finish_tail();
             hw_phase();
             HW_STAMP(2);
             // B: the twiddles W_1024^(column * k1) between the two transforms are not applied here: the reader of row k1 sees
@@ -453,22 +472,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             if (quad_tail) {
                 // The reference's own window shape: lane wi < 48 owns window wi and the four windows of a note sit in one
                 // quad.  Eight reads at once (indices clamped to the window's last bin: seeing a bin twice does not change
-                // a maximum), compared in bin order like the reference's loop (harmonic_energy.py:58-62).
+                // a maximum, harmonic_energy.py:58-62); the rest is finish_tail, one iteration later.
                 double v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = mag[wstart + j < wlast ? wstart + j : wlast];
                 double m = v[0];
 #pragma unroll
-                for (int j = 1; j < 8; ++j) m = v[j] > m ? v[j] : m;
-                const double t = sqrt(sqrt(m)) * wweight;   // sqrt(|X|) of the maximum, times 1/harmonic
-                // chroma = (max_0 + max_1/2) + (max_2 + max_3/2) over the quad: the reference's association (its sums start at 0.0)
-                const double u = t + hw_quad_xor<1>(t);
-                const double chroma = u + hw_quad_xor<2>(u);
-                // bin n sits in lane 4n: pulled into lane n, so that the row is one 96-byte store of 12 neighbouring lanes
-                const int src = (ol < 12 ? 4 * ol : ol) * 4;
-                const double row = __hiloint2double(__builtin_amdgcn_ds_bpermute(src, __double2hiint(chroma)),
-                                                    __builtin_amdgcn_ds_bpermute(src, __double2loint(chroma)));
-                if (ol < 12) a.out[f * 12 + ol] = row;
+                for (int j = 1; j < 8; ++j) m = v[j] > m ? v[j] : m;   // in bin order, like the reference's loop
+                pend_m = m;
+                pend_w = wweight;
+                pend_f = f;
                 wave_lds_fence();
                 HW_STAMP(9);
                 f = fn;
@@ -504,6 +517,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             f = fn;
             ++nframe;
         }
+        if (pend_f >= 0) finish_tail();
     };
     if (fast || !HW_SLOW_PATH)
         run(std::true_type{});
