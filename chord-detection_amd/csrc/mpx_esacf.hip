@@ -639,83 +639,53 @@ constexpr int PFA_T = 256;
 #define PFA_LDS_BYTES(N, Mh) (PFA_TAB_OFF(N, Mh) + 16 * (256 + 30))
 #define PFA_YV_OFF(Mh) ((peak_scratch_bytes(Mh) + 15) & ~(size_t)15)
 
-// value of lane (lane -/+ J) mod 16 of the caller's 16-lane DPP row (row_ror:J); the direction is never assumed: the
-// kernel rotates the lane's own k the same way and picks its coefficients by what arrives
-template <int J>
-__device__ __forceinline__ int ror16_i32(int v) {
-    return __builtin_amdgcn_mov_dpp(v, 0x120 + J, 0xf, 0xf, true);   // every lane of a row is a valid source
-}
-template <int J>
-__device__ __forceinline__ double ror16_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = ror16_i32<J>(lo);
-    hi = ror16_i32<J>(hi);
-    return __hiloint2double(hi, lo);
-}
-
 // Axis 31: a line per 16-lane DPP row, lane k holds s[k] = a[k] + a[31-k] and d[k] = a[k] - a[31-k] (lane 0: a[0], 0)
-// and needs all sixteen of each: fifteen row rotations bring them past (register to register: the first version read
-// them back from LDS, 31 broadcast reads per lane, and the pass was bound by the LDS pipe at 5.8 k cycles per transform).
+// and needs all sixteen of each.  gfx950 lets a double-precision VOP2 take its first operand through DPP with
+// row_newbcast:n -- lane n of the row, broadcast to the row -- so term n of every lane's sums is ONE instruction,
+// v_fmac_f64_dpp acc, s (lane n), coefficient[n], and the coefficients are simply indexed by n.  (The first version read
+// s and d back from LDS, 31 broadcast reads per lane: bound by the LDS pipe.  The second rotated them past with
+// row_ror: two 32-bit v_mov_dpp per double and term, 8 moves + 4 multiply-adds where this has 4 multiply-adds.)
 // Every lane reads and writes only its own two elements: no fences inside the pass.
 struct Pfa31Coef {
-    double c[16], s[16];   // [0]: own term (n = k); [J]: the term that rotation J delivers
+    double c[16], s[16];   // (cos, sin)(2 pi n k / 31), n = 0..15, for this lane's k
 };
 
-template <int J>
-__device__ __forceinline__ void pfa31_term(cx<double>& sv, cx<double>& dv, const Pfa31Coef& w, cx<double>& pp, cx<double>& qq) {
-    const double sx = ror16_f64<J>(sv.x), sy = ror16_f64<J>(sv.y), dx = ror16_f64<J>(dv.x), dy = ror16_f64<J>(dv.y);
-    pp.x = fma(sx, w.c[J], pp.x);
-    pp.y = fma(sy, w.c[J], pp.y);
-    qq.x = fma(dx, w.s[J], qq.x);
-    qq.y = fma(dy, w.s[J], qq.y);
-    // One term after the other: the rotations depend on nothing but sv and dv, and a scheduler that is free to do so
-    // issues all 120 of a round first and sinks the multiply-adds behind them -- 120 live temporaries, the coefficients
-    // in scratch.  The empty statement makes the next term's rotations wait for this term's sums.
-    asm volatile("" : "+v"(pp.x), "+v"(pp.y), "+v"(qq.x), "+v"(qq.y), "+v"(sv.x), "+v"(sv.y), "+v"(dv.x), "+v"(dv.y));
+// acc += (value of `v` in lane N of the caller's 16-lane row) * coef
+template <int N>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double v, double coef) {
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(coef), "n"(N));
+}
+
+template <int N>
+__device__ __forceinline__ void pfa31_term(const cx<double>& sv, const cx<double>& dv, const Pfa31Coef& w, cx<double>& pp, cx<double>& qq) {
+    fmac_row_bcast<N>(pp.x, sv.x, w.c[N]);
+    fmac_row_bcast<N>(pp.y, sv.y, w.c[N]);
+    fmac_row_bcast<N>(qq.x, dv.x, w.s[N]);
+    fmac_row_bcast<N>(qq.y, dv.y, w.s[N]);
 }
 
 // Real input (the second transform of the SACF acts on S): the sums and differences are real, so are P and Q, and
-// X[31-k] = conj X[k] -- half the rotations, half the multiply-adds, and only X[k], k <= 15, is stored: the later axes
-// then run on the 16 of 31 residues that are kept (the caller reads lag n from its mirror position when it must).
-template <int J>
-__device__ __forceinline__ void pfa31_term_real(double& sv, double& dv, const Pfa31Coef& w, double& pp, double& qq) {
-    const double sx = ror16_f64<J>(sv), dx = ror16_f64<J>(dv);
-    pp = fma(sx, w.c[J], pp);
-    qq = fma(dx, w.s[J], qq);
-    asm volatile("" : "+v"(pp), "+v"(qq), "+v"(sv), "+v"(dv));
+// X[31-k] = conj X[k] -- half the multiply-adds, and only X[k], k <= 15, is stored: the later axes then run on the 16 of
+// 31 residues that are kept (the caller reads lag n from its mirror position when it must).
+template <int N>
+__device__ __forceinline__ void pfa31_term_real(double sv, double dv, const Pfa31Coef& w, double& pp, double& qq) {
+    fmac_row_bcast<N>(pp, sv, w.c[N]);
+    fmac_row_bcast<N>(qq, dv, w.s[N]);
 }
 
-// cs31: LDS copy of the [16][16] table (cos, sin)(2 pi n k / 31); a lane's sixteen entries are fetched at the start of a
-// pass (bank = 4 ((k -+ J) mod 16): conflict free) and live in registers only while the pass runs
+// cs31: LDS copy of the [16][16] table (cos, sin)(2 pi n k / 31) -- symmetric in n and k, read as row n, column k: the
+// sixteen lanes of a row read sixteen neighbouring entries (as row k the reads are 256 B apart: a sixteen-way bank
+// conflict on each).  A lane's sixteen entries are fetched at the start of a pass and live in registers only while it runs.
 template <bool REAL>
 __device__ __forceinline__ void pfa_pass31(cx<double>* buf, int nlines, const cx<double>* cs31, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int sub = lane >> 4, k = lane & 15;
     Pfa31Coef w;
-    {
-        int src[16];
-        src[0] = k;
-        src[1] = ror16_i32<1>(k);
-        src[2] = ror16_i32<2>(k);
-        src[3] = ror16_i32<3>(k);
-        src[4] = ror16_i32<4>(k);
-        src[5] = ror16_i32<5>(k);
-        src[6] = ror16_i32<6>(k);
-        src[7] = ror16_i32<7>(k);
-        src[8] = ror16_i32<8>(k);
-        src[9] = ror16_i32<9>(k);
-        src[10] = ror16_i32<10>(k);
-        src[11] = ror16_i32<11>(k);
-        src[12] = ror16_i32<12>(k);
-        src[13] = ror16_i32<13>(k);
-        src[14] = ror16_i32<14>(k);
-        src[15] = ror16_i32<15>(k);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const cx<double> v = cs31[k * 16 + (src[j] & 15)];
-            w.c[j] = v.x;
-            w.s[j] = v.y;
-        }
+    for (int n = 0; n < 16; ++n) {
+        const cx<double> v = cs31[n * 16 + k];
+        w.c[n] = v.x;
+        w.s[n] = v.y;
     }
     for (int l0 = 0; l0 < nlines; l0 += 16) {
         if (l0 + wave * 4 >= nlines) break;      // the last round of 66 lines has work for one wave only (wave-uniform)
@@ -726,7 +696,11 @@ __device__ __forceinline__ void pfa_pass31(cx<double>* buf, int nlines, const cx
         if (REAL) {
             const double ur = e[ia].x, vr = e[ib].x;
             double sv = k ? ur + vr : ur, dv = k ? ur - vr : 0.0;
-            double pp = sv * w.c[0], qq = dv * w.s[0];
+            double pp = 0.0, qq = 0.0;
+            // (a DPP operand must have been written two instructions earlier: the hazard is invisible to the compiler
+            //  inside inline assembly)
+            asm volatile("s_nop 1" : "+v"(sv), "+v"(dv));
+            pfa31_term_real<0>(sv, dv, w, pp, qq);
             pfa31_term_real<1>(sv, dv, w, pp, qq);
             pfa31_term_real<2>(sv, dv, w, pp, qq);
             pfa31_term_real<3>(sv, dv, w, pp, qq);
@@ -748,7 +722,9 @@ __device__ __forceinline__ void pfa_pass31(cx<double>* buf, int nlines, const cx
         const cx<double> u = e[ia], v = e[ib];
         cx<double> sv = k ? cx<double>{u.x + v.x, u.y + v.y} : u;
         cx<double> dv = k ? cx<double>{u.x - v.x, u.y - v.y} : cx<double>{0.0, 0.0};
-        cx<double> pp = {sv.x * w.c[0], sv.y * w.c[0]}, qq = {dv.x * w.s[0], dv.y * w.s[0]};
+        cx<double> pp = {0.0, 0.0}, qq = {0.0, 0.0};
+        asm volatile("s_nop 1" : "+v"(sv.x), "+v"(sv.y), "+v"(dv.x), "+v"(dv.y));
+        pfa31_term<0>(sv, dv, w, pp, qq);
         pfa31_term<1>(sv, dv, w, pp, qq);
         pfa31_term<2>(sv, dv, w, pp, qq);
         pfa31_term<3>(sv, dv, w, pp, qq);
