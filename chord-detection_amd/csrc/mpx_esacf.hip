@@ -696,50 +696,56 @@ __device__ __forceinline__ void pfa_pass31(cx<double>* buf, int nlines, const cx
         if (REAL) {
             const double ur = e[ia].x, vr = e[ib].x;
             double sv = k ? ur + vr : ur, dv = k ? ur - vr : 0.0;
-            double pp = 0.0, qq = 0.0;
+            // even and odd terms in separate sums: four dependent chains instead of two (the multiply-adds of one chain
+            // are a result latency apart, and in the last round of a pass a single wave is at work)
+            double pp = 0.0, qq = 0.0, pp1 = 0.0, qq1 = 0.0;
             // (a DPP operand must have been written two instructions earlier: the hazard is invisible to the compiler
             //  inside inline assembly)
             asm volatile("s_nop 1" : "+v"(sv), "+v"(dv));
             pfa31_term_real<0>(sv, dv, w, pp, qq);
-            pfa31_term_real<1>(sv, dv, w, pp, qq);
+            pfa31_term_real<1>(sv, dv, w, pp1, qq1);
             pfa31_term_real<2>(sv, dv, w, pp, qq);
-            pfa31_term_real<3>(sv, dv, w, pp, qq);
+            pfa31_term_real<3>(sv, dv, w, pp1, qq1);
             pfa31_term_real<4>(sv, dv, w, pp, qq);
-            pfa31_term_real<5>(sv, dv, w, pp, qq);
+            pfa31_term_real<5>(sv, dv, w, pp1, qq1);
             pfa31_term_real<6>(sv, dv, w, pp, qq);
-            pfa31_term_real<7>(sv, dv, w, pp, qq);
+            pfa31_term_real<7>(sv, dv, w, pp1, qq1);
             pfa31_term_real<8>(sv, dv, w, pp, qq);
-            pfa31_term_real<9>(sv, dv, w, pp, qq);
+            pfa31_term_real<9>(sv, dv, w, pp1, qq1);
             pfa31_term_real<10>(sv, dv, w, pp, qq);
-            pfa31_term_real<11>(sv, dv, w, pp, qq);
+            pfa31_term_real<11>(sv, dv, w, pp1, qq1);
             pfa31_term_real<12>(sv, dv, w, pp, qq);
-            pfa31_term_real<13>(sv, dv, w, pp, qq);
+            pfa31_term_real<13>(sv, dv, w, pp1, qq1);
             pfa31_term_real<14>(sv, dv, w, pp, qq);
-            pfa31_term_real<15>(sv, dv, w, pp, qq);
+            pfa31_term_real<15>(sv, dv, w, pp1, qq1);
+            pp += pp1;
+            qq += qq1;
             if (active) e[ia] = {pp, -qq};   // X[k] = P - iQ
             continue;
         }
         const cx<double> u = e[ia], v = e[ib];
         cx<double> sv = k ? cx<double>{u.x + v.x, u.y + v.y} : u;
         cx<double> dv = k ? cx<double>{u.x - v.x, u.y - v.y} : cx<double>{0.0, 0.0};
-        cx<double> pp = {0.0, 0.0}, qq = {0.0, 0.0};
+        cx<double> pp = {0.0, 0.0}, qq = {0.0, 0.0}, pp1 = {0.0, 0.0}, qq1 = {0.0, 0.0};
         asm volatile("s_nop 1" : "+v"(sv.x), "+v"(sv.y), "+v"(dv.x), "+v"(dv.y));
         pfa31_term<0>(sv, dv, w, pp, qq);
-        pfa31_term<1>(sv, dv, w, pp, qq);
+        pfa31_term<1>(sv, dv, w, pp1, qq1);
         pfa31_term<2>(sv, dv, w, pp, qq);
-        pfa31_term<3>(sv, dv, w, pp, qq);
+        pfa31_term<3>(sv, dv, w, pp1, qq1);
         pfa31_term<4>(sv, dv, w, pp, qq);
-        pfa31_term<5>(sv, dv, w, pp, qq);
+        pfa31_term<5>(sv, dv, w, pp1, qq1);
         pfa31_term<6>(sv, dv, w, pp, qq);
-        pfa31_term<7>(sv, dv, w, pp, qq);
+        pfa31_term<7>(sv, dv, w, pp1, qq1);
         pfa31_term<8>(sv, dv, w, pp, qq);
-        pfa31_term<9>(sv, dv, w, pp, qq);
+        pfa31_term<9>(sv, dv, w, pp1, qq1);
         pfa31_term<10>(sv, dv, w, pp, qq);
-        pfa31_term<11>(sv, dv, w, pp, qq);
+        pfa31_term<11>(sv, dv, w, pp1, qq1);
         pfa31_term<12>(sv, dv, w, pp, qq);
-        pfa31_term<13>(sv, dv, w, pp, qq);
+        pfa31_term<13>(sv, dv, w, pp1, qq1);
         pfa31_term<14>(sv, dv, w, pp, qq);
-        pfa31_term<15>(sv, dv, w, pp, qq);
+        pfa31_term<15>(sv, dv, w, pp1, qq1);
+        pp = {pp.x + pp1.x, pp.y + pp1.y};
+        qq = {qq.x + qq1.x, qq.y + qq1.y};
         if (active) {
             // X[k] = P - iQ, X[31-k] = P + iQ   (a[0] is the n = 0 term of P)
             e[ia] = {pp.x + qq.y, pp.y - qq.x};
