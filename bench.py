@@ -381,7 +381,7 @@ def main():
     # untimed pre-heat below makes the figure independent of K and W.
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight: step i goes to context/stream i %% S (1 = strictly one launch after the other)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the secondary workloads")
@@ -429,9 +429,11 @@ def main():
             dist.barrier()
         dev_sync()
 
-    # Two batches in flight: consecutive steps alternate between two contexts (own stream, own reduction scratch), so the
+    # Batches in flight: consecutive steps go round-robin to `--streams` contexts (own stream, own reduction scratch), so the
     # ramp of one launch -- dispatch, table loads, the first un-prefetched frame -- and its tail -- the last workgroups,
-    # the in-kernel reduction -- run while the other launch has the machine.  A step is still one launch over one
+    # the small reduction launch -- run while other launches have the machine.  he_wave_kernel takes a CU's whole LDS, so
+    # launches do not share CUs, they fill each other's edges: 43.4 us per step one at a time, 39.4 with two in flight,
+    # 38.4 with three, 37.0 with four, 38.1 / 37.1 with six / eight (MI355X).  A step is still one launch over one
     # 8192-frame batch.  Step i reads signal i % NSIG: together the signals exceed the 256 MiB Infinity Cache, so a
     # step's input comes from HBM, not from a cache warmed by the step before.
     nstreams = max(1, args.streams)
