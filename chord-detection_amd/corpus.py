@@ -98,13 +98,45 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
     spent = [0.0] * len(methods)
     global LAST_SYNTH_SECONDS
     LAST_SYNTH_SECONDS = 0.0
-    for c0 in range(lo, hi, chunk):
+    # The next chunk is synthesised while the engines work on the current one: on the GPU the synthesis is a few hundred
+    # memory-bound torch kernels on a stream of its own, enqueued before the (blocking) engine calls -- like a decoder
+    # thread ahead of the compute in a corpus of files.  Only the wait that is left is booked as synthesis time.
+    starts = list(range(lo, hi, chunk))
+    on_gpu = synth_device is not None and str(synth_device).startswith("cuda")
+    side_stream = None
+    if on_gpu:
+        import torch
+        side_stream = torch.cuda.Stream(device=synth_device)
+
+    def synth_ahead(c0):
         ids = list(range(c0, min(c0 + chunk, hi)))
+        if side_stream is None:
+            return ids, synth_chunk(ids, fs, seconds, synth_device), None
+        import torch
+        with torch.cuda.stream(side_stream):
+            x = synth_chunk(ids, fs, seconds, synth_device)
+            ev = torch.cuda.Event()
+            ev.record(side_stream)
+        return ids, x, ev
+
+    import threading
+
+    def start_ahead(c0):   # host part (the partial tables: Python loops) and enqueueing in a thread of their own:
+        box = []           # ctypes releases the GIL while the main thread is inside the engine
+        th = threading.Thread(target=lambda: box.append(synth_ahead(c0)))
+        th.start()
+        return th, box
+
+    ahead = start_ahead(starts[0]) if starts else None
+    for ci, c0 in enumerate(starts):
         t_s = time.perf_counter()
-        clips = synth_chunk(ids, fs, seconds, synth_device)
-        if clips.is_cuda:
-            import torch
-            torch.cuda.synchronize(clips.device)   # the engine's stream waits for the chunk anyway (engine._pack)
+        ahead[0].join()
+        if not ahead[1]:
+            raise RuntimeError("corpus synthesis thread failed")
+        ids, clips, ev = ahead[1][0]
+        if ev is not None:
+            ev.synchronize()   # the engines read the chunk through its raw pointer on their own streams
+        ahead = start_ahead(starts[ci + 1]) if ci + 1 < len(starts) else None
         LAST_SYNTH_SECONDS += time.perf_counter() - t_s
         # synthesised on the GPU and consumed by the engine: the chunk stays in HBM (include/mpx.h, "where the samples
         # live"); a substituted compute function and a CPU synthesis get a host array
