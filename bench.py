@@ -748,7 +748,9 @@ def wl_corpus(c):
     if c["stub"] is not None:
         kw = {"compute": c["stub"].corpus_compute}
     dev = c["dev"] if c["dev"].type == "cuda" else None
-    corpus.run_corpus(min(per, 256) * world, (1, 2, 3, 4), fs, 2.0, 256, rank, world, c["local_rank"], synth_device=dev, **kw)
+    # untimed pass over one full-size chunk: the contexts' grow-only workspaces reach their final size here (Iterative-F0's
+    # front end alone is 25 GB for 1024 clips; the first allocation of that size on a fresh box takes over a second)
+    corpus.run_corpus(min(per, 1024) * world, (1, 2, 3, 4), fs, 2.0, 1024, rank, world, c["local_rank"], synth_device=dev, **kw)
     profs = []
     if c["stub"] is None:
         e1, e2 = c["cd"].get_engine(c["local_rank"]), corpus._second_engine(c["local_rank"])

@@ -200,13 +200,19 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
             for (int h = 1; h <= p.num_harmonic; ++h) {
                 const double f = note * oct * h;
                 const int N = (int)((8 / f) * fs);  // prime_multif0.py:53
-                if (N < 2 || N > 4096)
+                // Only the lower half of the one-sided spectrum is looked at (prime_multif0.py:59-61): K = half outputs.  The
+                // chirp-z convolution then spans chirp[-(N-1) .. K-1], a circular length of N + K - 1 ~ 1.25 N does, not the
+                // 2 N - 1 of a full transform: most candidates run on an FFT of half the size (and frames up to 6553
+                // samples fit the 8192-point class: 96 kHz input).
+                const int half = N >= 2 ? (N / 2 + 1) / 2 : 0;
+                if (N < 2 || N + half - 1 > 8192)
                     return set_error(ctx, MPX_EUNSUPPORTED,
-                                     "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..4096)", N, f);
+                                     "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..6553)", N, f);
                 PrimeCand c;
                 c.N = N;
-                c.L = N <= 512 ? 1024 : (N <= 1024 ? 2048 : (N <= 2048 ? 4096 : 8192));
-                c.half = (N / 2 + 1) / 2;
+                const int need = N + half - 1;
+                c.L = need <= 1024 ? 1024 : (need <= 2048 ? 2048 : (need <= 4096 ? 4096 : 8192));
+                c.half = half;
                 c.val = 1.0 / (N * (1.0 / fs));
                 std::vector<double> win(N);
                 double wsum = 0.0;
@@ -223,8 +229,8 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                     const long double ang = M_PIl * (long double)q / (long double)N;
                     chirp[i] = {(double)cosl(ang), (double)sinl(ang)};
                 }
-                filt[0] = chirp[0];
-                for (int m = 1; m < N; ++m) filt[m] = filt[c.L - m] = chirp[m];
+                for (int m = 0; m < (half > 1 ? half : 1); ++m) filt[m] = chirp[m];   // chirp[k - n], k - n = 0 .. K-1
+                for (int m = 1; m < N; ++m) filt[c.L - m] = chirp[m];                 // k - n = -1 .. -(N-1) (the chirp is even)
                 prime_host_fft(filt);
                 for (auto& v : filt) {
                     v.x /= c.L;

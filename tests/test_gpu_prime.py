@@ -80,8 +80,15 @@ def test_batch_edge_cases_vs_oracle(eng, clips):
         warnings.simplefilter("ignore")
         np.testing.assert_allclose(eng.prime_multif0(x44, 44100), o_prime.prime_compute(x44.astype(np.float64), 44100),
                                    rtol=RTOL, atol=1e-7)
+    # 96 kHz: frames of 1555..5871 samples; the chirp-z spans N + N/4 points, so they fit the 8192-point class
+    t = np.arange(40000) / 96000.0
+    x96 = (0.3 * np.sin(2 * np.pi * 261.63 * t) + 0.2 * np.sin(2 * np.pi * 392.0 * t) + 1e-3 * rng.standard_normal(t.shape[0])).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(eng.prime_multif0(x96, 96000), o_prime.prime_compute(x96.astype(np.float64), 96000),
+                                   rtol=RTOL, atol=1e-7)
     with pytest.raises(NotImplementedError):
-        eng.prime_multif0(np.zeros(100, dtype=np.float32), 96000)   # 8/f*fs > 4096 samples for the low candidates
+        eng.prime_multif0(np.zeros(100, dtype=np.float32), 192000)   # 8/f*fs > 6553 samples for the low candidates
     with pytest.raises(ValueError):
         eng.prime_multif0(np.zeros((2, 2), dtype=np.float32), FS)
 
