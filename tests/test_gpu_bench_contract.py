@@ -49,7 +49,7 @@ def test_bench_line_has_the_contract_fields():
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
     assert r["achieved"] == pytest.approx(4144 * 8192 / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)   # algorithmic bytes / kernel time
     assert 0.0 < r["kernel_ms"] <= r["step_ms_hip_events"] * 1.05     # the kernel is inside the (one-at-a-time) step
-    assert d["config"]["batches_in_flight"] == 2 and r["in_flight"]["batches"] == 2
+    assert d["config"]["batches_in_flight"] == 4 and r["in_flight"]["batches"] == 4   # bench.py --streams default
     assert r["in_flight"]["frac"] == pytest.approx(4144 * 8192 / (d["ms_per_step"] * 1e-3) / 8.0e12, rel=1e-6)
     assert r["traffic"] is None or r["traffic"] >= 0.9 * 4144 * 8192
     assert r["secondary"]["bound"] == "valu_f64" and 0.0 < r["secondary"]["frac"] < 1.0
