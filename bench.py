@@ -831,7 +831,7 @@ def wl_if0_stream(c):
 
     def compute_block():
         if c["stub"] is None:
-            return stream.run_stream_rank(lambda a, b: x[a - s0:b - s0], n, fs, rank, world, nf_size, local, sub=2)[2]
+            return stream.run_stream_rank(lambda a, b: x[a - s0:b - s0], n, fs, rank, world, nf_size, local, sub=3)[2]
         return stream.run_stream_shard(lambda a, b: x.numpy(), n, fs, rank, world, nf_size, local, **kw)[2]
 
     t0 = time.perf_counter()
@@ -859,7 +859,7 @@ def wl_if0_stream(c):
            "dtype": "f64", "frames": total_frames,
            "config": {"workload": "Iterative-F0, one %.0f s stream @%d Hz, frames of %d, time-sharded over the GPUs with a "
                                   "65536-sample halo, one all_gather of [frames, 12] (BASELINE.json configs[4]); the stream "
-                                  "is resident in HBM" % (secs, fs, nf_size), "shards_in_flight_per_gpu": 2}}
+                                  "is resident in HBM" % (secs, fs, nf_size), "shards_in_flight_per_gpu": 3}}
     if prof:
         kms = {k: v[1] for k, v in prof.items()}
         dom = max(kms, key=kms.get)

@@ -105,7 +105,7 @@ def _engine_frames_on(j):
 PIECE_BYTES = 32 << 30   # front-end output of one piece (560 B per sample at 70 channels): bounds the contexts' workspaces
 
 
-def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=2, channels=70, **kw):
+def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=3, channels=70, **kw):
     """This rank's frames, computed as `sub` time shards IN FLIGHT on the same GPU (one context and one host thread
     each; ctypes releases the GIL): the front end of one shard runs next to the spectra and the period search of the
     other.  Same halo logic as between ranks: the rank's block of frames is partitioned once more.
@@ -197,7 +197,9 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     ap.add_argument("--seconds", type=float, default=3600.0)
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--frame-size", type=int, default=8192)
-    ap.add_argument("--shards-per-gpu", type=int, default=2, help="time shards in flight on each GPU (own context each)")
+    ap.add_argument("--shards-per-gpu", type=int, default=3,
+                    help="time shards in flight on each GPU, own context each (1 h @44.1 kHz on one MI355X: 18 900x real time "
+                         "with 1, 19 300x with 2, 20 800x with 3, 20 000x with 4)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
