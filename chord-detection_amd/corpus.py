@@ -11,6 +11,7 @@ Launch with ``python -m torch.distributed.run --nproc-per-node G scripts/run_cor
 """
 import json
 import math
+import os
 import time
 
 import numpy as np
@@ -78,8 +79,8 @@ LAST_SYNTH_SECONDS = 0.0   # input synthesis inside the last run_corpus call of 
 def _second_engine(device):
     """A second context (own stream, own workspaces) on the same GPU: Iterative-F0 runs there next to the other methods."""
     from .engine import Engine
-    if device not in _SECOND_ENGINE:
-        _SECOND_ENGINE[device] = Engine(device)
+    if device not in _SECOND_ENGINE:   # key: the device, or (device, n) for the n-th context on it
+        _SECOND_ENGINE[device] = Engine(device[0] if isinstance(device, tuple) else device)
     return _SECOND_ENGINE[device]
 
 
@@ -163,8 +164,16 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
             side = threading.Thread(target=run, args=(mi3, 3, lambda: eng2.iterative_f0_batch(clips, fs,
                                                                                              note_names=note_names)))
             side.start()
+        side4 = None
+        if side is not None and 4 in methods and len(methods) > 2 and os.environ.get("MPX_CORPUS_CONTEXTS", "3") == "3":
+            # ... and Prime-multiF0 (seven million small workgroups, latency-bound) on a third one
+            mi4 = list(methods).index(4)
+            eng3 = _second_engine((device, 3))
+            side4 = threading.Thread(target=run, args=(mi4, 4, lambda: eng3.prime_multif0_batch(clips, fs,
+                                                                                               note_names=note_names)))
+            side4.start()
         for mi, m in enumerate(methods):
-            if side is not None and m == 3:
+            if (side is not None and m == 3) or (side4 is not None and m == 4):
                 continue
             if engine_path:
                 run(mi, m, lambda m=m: compute(m, clips, fs, device, note_names))
@@ -174,6 +183,8 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
                 break
         if side is not None:
             side.join()
+        if side4 is not None:
+            side4.join()
         if failed:
             raise failed[0]
     return lo, hi, out, spent
