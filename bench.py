@@ -753,10 +753,10 @@ def wl_corpus(c):
     corpus.run_corpus(min(per, 1024) * world, (1, 2, 3, 4), fs, 2.0, 1024, rank, world, c["local_rank"], synth_device=dev, **kw)
     profs = []
     if c["stub"] is None:
-        e1, e2 = c["cd"].get_engine(c["local_rank"]), corpus._second_engine(c["local_rank"])
-        e1.profile_begin()
-        e2.profile_begin()
-        profs = [e1, e2]
+        profs = [c["cd"].get_engine(c["local_rank"]), corpus._second_engine(c["local_rank"]),
+                 corpus._second_engine((c["local_rank"], 3))]   # the driver's three contexts: methods 1 + 2 | 3 | 4
+        for e in profs:
+            e.profile_begin()
     c["barrier"]()
     t0 = time.perf_counter()
     lo, hi, block, spent = corpus.run_corpus(per * world, (1, 2, 3, 4), fs, 2.0, 1024, rank, world, c["local_rank"],

@@ -353,9 +353,9 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         const PrimeItem* di = (const PrimeItem*)(d_items + off);
         const int per_clip = uniform ? (int)items[cls].size() : 0;
         const size_t count = uniform ? items[cls].size() * (size_t)num_clips : items[cls].size();
-        if (cls == 0) prime_launch<1024, 64>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 1) prime_launch<2048, 128>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 2) prime_launch<4096, 256>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 0) prime_launch<1024, 128>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 1) prime_launch<2048, 256>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        if (cls == 2) prime_launch<4096, 512>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
         if (cls == 3) prime_launch<8192, 512>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
         off += bytes;
     }
