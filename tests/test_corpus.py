@@ -100,7 +100,10 @@ def test_corpus_driver_matches_oracle_on_gpu():
         for j, cid in enumerate(ids):
             x = clips[j].astype(np.float64)
             np.testing.assert_allclose(block[cid, 0], o_he.he_compute(x, 22050), rtol=1e-9, atol=1e-12)
-            np.testing.assert_allclose(block[cid, 1], o_pr.prime_compute(x, 22050), rtol=1e-7, atol=1e-7)
+            # atol: a clip's last frame of a candidate can hold one or two samples; its spectrum is FLAT (|X[k]| equal up to
+            # rounding), so which bin wins the reference's argmax -- and which pitch class receives that
+            # ~|x| * hann[1] / sum(hann) <= 4e-7 -- is decided by rounding noise (tests/test_gpu_prime.py)
+            np.testing.assert_allclose(block[cid, 1], o_pr.prime_compute(x, 22050), rtol=1e-7, atol=5e-7)
 
 
 @pytest.mark.gpu
