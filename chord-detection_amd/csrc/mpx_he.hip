@@ -886,8 +886,6 @@ static void he_host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, forw
 
 static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames, int fs,
                        const mpx_he_params& p, int N, int hop, double* d_rows, double* d_sum, hipStream_t stream) {
-    int L = 1024;
-    while (L < 2 * N - 1) L <<= 1;
     char keyb[128];
     snprintf(keyb, sizeof keyb, "he_blue_%d_%d_%d_%d_%d", fs, N, p.num_harmonic, p.num_octave, p.num_bins);
     const std::string key = keyb;
@@ -921,6 +919,15 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
             k1[w] = c0 + len;
         }
         if (bins.empty()) bins.push_back(0);
+        // Only the bins below the highest window are looked at: the chirp-z convolution spans chirp[-(N-1) .. K-1],
+        // K = that bin + 1, so a circular length of N + K - 1 does (not 2N - 1): sizes up to ~6900 samples fit the
+        // 8192-point engine with the default windows, and 2049..3500 take the 4096-point one.
+        const int K = bins.back() + 1;
+        int L = 1024;
+        while (L < N + K - 1) L <<= 1;
+        if (L > 8192)
+            return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d with windows up to bin %d needs a %d-point "
+                             "chirp-z (supported: N + highest bin <= 8192, or a power of two in [1024, 16384])", N, K - 1, L);
         std::vector<double> win(N);
         for (int i = 0; i < N; ++i) win[i] = N == 1 ? 1.0 : 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (double)(N - 1));
         std::vector<cx<double>> chirp(N), filt(L, cx<double>{0.0, 0.0}), tw(L);
@@ -929,8 +936,8 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
             const long double ang = M_PIl * (long double)q / (long double)N;
             chirp[i] = {(double)cosl(ang), (double)sinl(ang)};
         }
-        filt[0] = chirp[0];
-        for (int m = 1; m < N; ++m) filt[m] = filt[L - m] = chirp[m];
+        for (int m = 0; m < K && m < N; ++m) filt[m] = chirp[m];     // chirp[k - n], k - n = 0 .. K-1
+        for (int m = 1; m < N; ++m) filt[L - m] = chirp[m];          // k - n = -1 .. -(N-1) (the chirp is even)
         he_host_fft(filt);
         for (auto& v : filt) {
             v.x /= L;
@@ -940,7 +947,7 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
             const long double ang = -2.0L * M_PIl * j / (long double)L;
             tw[j] = {(double)cosl(ang), (double)sinl(ang)};
         }
-        std::vector<int> meta = {(int)bins.size(), (int)k0.size(), p.num_octave * p.num_harmonic, p.num_harmonic};
+        std::vector<int> meta = {(int)bins.size(), (int)k0.size(), p.num_octave * p.num_harmonic, p.num_harmonic, L};
         std::vector<void*> d = {upload(ctx, win.data(), win.size() * sizeof(double)),
                                 upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>)),
                                 upload(ctx, filt.data(), filt.size() * sizeof(cx<double>)),
@@ -982,6 +989,7 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
     a.nwin = meta[1];
     a.wins_per_note = meta[2];
     a.num_harmonic = meta[3];
+    const int L = meta[4];
     a.out = rows;
     const size_t extra = sizeof(double) * (size_t)(a.nb + a.nwin + 2);
     auto launch = [&](auto kern, int T, size_t lds) -> int {
@@ -1013,9 +1021,9 @@ int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_de
     if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
     if (num_frames == 0) return MPX_OK;
     if (frame < 1024 || frame > 16384 || (frame & (frame - 1))) {
-        if (frame < 2 || frame > 4096)
+        if (frame < 2 || frame > 8191)
             return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d (supported: powers of two in "
-                             "[1024, 16384] and any size in [2, 4096])", frame);
+                             "[1024, 16384] and any size whose chirp-z fits 8192 points: frame + highest window bin <= 8192)", frame);
         return he_blue_run(ctx, d_signal, n, d_desc, num_frames, fs, p, frame, hop, d_chroma_frames, d_chroma_sum, stream);
     }
     const bool f32 = ctx->flags & MPX_FLAG_F32;
