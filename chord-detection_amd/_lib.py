@@ -48,6 +48,7 @@ _vp = C.c_void_p
 # name -> (restype, argtypes); every symbol include/mpx.h declares
 SIGNATURES = {
     "mpx_abi_version": (C.c_int, []),
+    "mpx_dev_knobs": (C.c_int, []),
     "mpx_device_count": (C.c_int, []),
     "mpx_create": (_vp, [C.c_int, C.c_int]),
     "mpx_destroy": (None, [_vp]),

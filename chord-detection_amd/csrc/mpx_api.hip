@@ -116,6 +116,7 @@ using namespace mpx;
 extern "C" {
 
 int mpx_abi_version(void) { return MPX_ABI_VERSION; }
+int mpx_dev_knobs(void) { return mpx::DEV_KNOBS; }
 
 int mpx_device_count(void) {
     int n = 0;
@@ -146,6 +147,9 @@ mpx_ctx* mpx_create(int device, int flags) {
     ctx->device = device;
     ctx->flags = flags;
     if (getenv("MPX_DETERMINISTIC") && atoi(getenv("MPX_DETERMINISTIC"))) ctx->flags |= MPX_FLAG_DETERMINISTIC;  // read once
+    // host batches >= 64 MiB go over PCIe in this many pieces (1 = one copy, no overlap); dev builds can change it, once
+    ctx->copy_pieces = mpx::dev_env_on("MPX_NO_COPY_OVERLAP") ? 1 : mpx::dev_env_int("MPX_COPY_PIECES", 4);
+    ctx->copy_pieces = ctx->copy_pieces < 1 ? 1 : (ctx->copy_pieces > 7 ? 7 : ctx->copy_pieces);
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -386,20 +390,26 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
             on_device = attr.type == hipMemoryTypeDevice;
         else
             (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
-        const bool off = getenv("MPX_NO_COPY_OVERLAP") && atoi(getenv("MPX_NO_COPY_OVERLAP"));
-        if (!on_device && !off && (size_t)total * sizeof(float) >= (size_t(64) << 20) && num_clips >= 8) {
-            pieces = getenv("MPX_COPY_PIECES") ? atoi(getenv("MPX_COPY_PIECES")) : 4;
-            pieces = pieces < 1 ? 1 : (pieces > 7 ? 7 : pieces);
-        }
+        if (!on_device && (size_t)total * sizeof(float) >= (size_t(64) << 20) && num_clips >= 8) pieces = ctx->copy_pieces;
     }
-    if (pieces > 1 && !ctx->copy_stream) {
-        if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (pieces > 1 && !ctx->copy_ready) {
+        // the copy stream and its eight events exist together or not at all: a partial failure is undone, and the batch
+        // (and the next one: it tries again) goes in one piece
+        bool ok = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        int made = 0;
+        for (; ok && made < 8; ++made) ok = hipEventCreateWithFlags(&ctx->copy_ev[made], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
             (void)hipGetLastError();
+            for (int k = 0; k < 8; ++k) {
+                if (ctx->copy_ev[k]) (void)hipEventDestroy(ctx->copy_ev[k]);
+                ctx->copy_ev[k] = nullptr;
+            }
+            if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
             ctx->copy_stream = nullptr;
             pieces = 1;
+        } else {
+            ctx->copy_ready = true;
         }
-        for (int k = 0; k < 8 && pieces > 1; ++k)
-            if (hipEventCreateWithFlags(&ctx->copy_ev[k], hipEventDisableTiming) != hipSuccess) pieces = 1;
     }
     if (pieces == 1) {
         if (total && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;

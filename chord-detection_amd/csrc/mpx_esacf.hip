@@ -2295,7 +2295,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     EsacfPlan plan;
     if ((rc = esacf_plan(ctx, N, plan))) return rc;
     // the reference's own frame lengths (1023, 2046) run on the prime-factor engine; MPX_SACF_BLUESTEIN=1 forces the chirp-z
-    const bool use_pfa = pfa_supported(N) && !(getenv("MPX_SACF_BLUESTEIN") && atoi(getenv("MPX_SACF_BLUESTEIN")));
+    const bool use_pfa = pfa_supported(N) && !dev_env_on("MPX_SACF_BLUESTEIN");
     PfaPlan pfa;
     if (use_pfa && (rc = pfa_plan(ctx, N, pfa))) return rc;
     if (plan.L > 8192)
@@ -2366,8 +2366,8 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.num_frames = nf;
         // measured, not adopted: pairing saves 0.85 ms per 176 k frames, but the rounding-level cross-talk between the
         // two frames makes results depend on the batch neighbour and flips 0.075 % of the frames (ill-conditioned fits)
-        a.pair = !deterministic && getenv("MPX_SACF_PAIR") && atoi(getenv("MPX_SACF_PAIR")) ? 1 : 0;
-        a.ablate = getenv("MPX_SACF_ABLATE") ? atoi(getenv("MPX_SACF_ABLATE")) : 0;
+        a.pair = !deterministic && dev_env_on("MPX_SACF_PAIR") ? 1 : 0;
+        a.ablate = dev_env_int("MPX_SACF_ABLATE", 0);
         prof_mark(ctx, st, use_pfa ? "sacf_pfa_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel"));
         if (use_pfa) {
             a.pfa_pos = pfa.pos;
@@ -2444,21 +2444,21 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             long long blocks = (slots + FIT_THREADS - 1) / FIT_THREADS;
             if (blocks > fit_resident) blocks = fit_resident;
             // MINPACK: maxfev = 200 (n + 1); the env knobs are for profiling
-            const int maxfev = getenv("MPX_FIT_MAXFEV") ? atoi(getenv("MPX_FIT_MAXFEV")) : 200 * (lm::NP + 1);
-            const bool park = !deterministic && !(getenv("MPX_FIT_NOPARK") && atoi(getenv("MPX_FIT_NOPARK")));
+            const int maxfev = dev_env_int("MPX_FIT_MAXFEV", 200 * (lm::NP + 1));
+            const bool park = !deterministic && !dev_env_on("MPX_FIT_NOPARK");
             prof_mark(ctx, st, "peakfit_kernel");
             hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
-                               total + 3, getenv("MPX_FIT_PARK_NFEV") ? atoi(getenv("MPX_FIT_PARK_NFEV")) : (nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
-                               getenv("MPX_FIT_PARK_LIVE") ? atoi(getenv("MPX_FIT_PARK_LIVE")) : PARK_LIVE,
-                               getenv("MPX_FIT_PARK_CAP") ? atoi(getenv("MPX_FIT_PARK_CAP")) : PARK_CAP);
+                               total + 3, dev_env_int("MPX_FIT_PARK_NFEV", nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
+                               dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),
+                               dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP));
             if (park) prof_mark(ctx, st, "coopfit_kernel");
             if (park)  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
                 hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 12)), dim3(64), 0, st, parked, total + 3,
                                    total + 4, y, center, okf, maxfev);
         }
         prof_mark(ctx, st, nullptr);
-        if (getenv("MPX_DEBUG_FITS")) {  // profiling aid: work-list counters of this batch
+        if (dev_env("MPX_DEBUG_FITS")) {  // profiling aid: work-list counters of this batch
             int h[5];
             MPX_HIP(ctx, hipMemcpyAsync(h, total, sizeof(h), hipMemcpyDeviceToHost, st));
             MPX_HIP(ctx, hipStreamSynchronize(st));

@@ -577,7 +577,7 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
 // The wave-per-frame kernel (mpx_he_wave.hpp) for the headline shape: 4096-sample frames, fp64, at most 256 window bins.
 constexpr int HEW_WAVES = 8, HEW_ROUNDS = 4;
 static bool he_wave_applies(const HePlan& plan) {
-    if (getenv("MPX_HE_WG")) return false;   // A/B switch: the workgroup-per-frame kernel below
+    if (dev_env("MPX_HE_WG")) return false;   // A/B switch: the workgroup-per-frame kernel below
     return plan.nb <= 64 * HEW_ROUNDS && plan.nwin <= 192;
 }
 static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n, const FrameDesc* d_desc,
@@ -739,7 +739,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
         oit = ctx->occupancy.emplace(okey, o < 1 ? 1 : o).first;
     }
     const int occ = oit->second;
-    long long g = (long long)occ * ctx->num_cus * (getenv("MPX_HE_OVERSUB") ? atoi(getenv("MPX_HE_OVERSUB")) : 1);
+    long long g = (long long)occ * ctx->num_cus * dev_env_int("MPX_HE_OVERSUB", 1);
     if (g > num_frames) g = num_frames;
     const long long per = (num_frames + g - 1) / g;
     g = (num_frames + per - 1) / per;

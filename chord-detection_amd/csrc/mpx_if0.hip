@@ -692,7 +692,7 @@ __global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_dif_kernel(const doub
 template <int NF, int T>
 static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int channels,
                                double power, const If0Plan& plan, double* ut, hipStream_t st) {
-    if (getenv("MPX_IF0_STOCKHAM")) {  // profiling knob: the padded NF-point Stockham transform
+    if (dev_env("MPX_IF0_STOCKHAM")) {  // profiling knob: the padded NF-point Stockham transform
         const size_t lds = sizeof(cx<double>) * lds_slots(NF);
         auto kern = if0_spectrum_kernel<NF, T>;
         if (lds > 48 * 1024)
@@ -747,7 +747,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             rows += r;
             if (c < mid) rows_first += r;
         }
-        const size_t ws_cap = (size_t)(getenv("MPX_IF0_WS_GIB") ? atoi(getenv("MPX_IF0_WS_GIB")) : 32) << 30;
+        const size_t ws_cap = (size_t)dev_env_int("MPX_IF0_WS_GIB", 32) << 30;
         if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap) {
             std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
             for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];

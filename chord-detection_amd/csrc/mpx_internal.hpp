@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <tuple>
@@ -57,6 +58,8 @@ struct mpx_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;        // host batches: the copy of piece k+1 runs next to the kernels of piece k
     hipEvent_t copy_ev[8] = {};
+    bool copy_ready = false;                  // copy_stream and all of copy_ev exist
+    int copy_pieces = 4;                      // pieces of a large host batch (1: no overlap); fixed at mpx_create
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<std::tuple<int, int, int, int, int>, mpx::HePlan> he_plans;
@@ -79,6 +82,23 @@ struct mpx_ctx {
 };
 
 namespace mpx {
+
+// Development switches -- A/B, ablation and end-game tuning aids of csrc/, some of which change results -- exist only in
+// builds made with -DMPX_DEV_KNOBS (`make dev` -> libmpx_hip_dev.so, loaded by the tools under tests/tools and scripts/
+// through MPX_LIB_PATH).  The release library never looks at the environment for them: dev_env() is a constant there.
+// (MPX_DETERMINISTIC is not one of them: it selects MPX_FLAG_DETERMINISTIC, the same bits computed the slower way.)
+#ifdef MPX_DEV_KNOBS
+inline const char* dev_env(const char* name) { return getenv(name); }
+constexpr int DEV_KNOBS = 1;
+#else
+inline const char* dev_env(const char*) { return nullptr; }
+constexpr int DEV_KNOBS = 0;
+#endif
+inline int dev_env_int(const char* name, int dflt) {
+    const char* v = dev_env(name);
+    return v ? atoi(v) : dflt;
+}
+inline bool dev_env_on(const char* name) { return dev_env_int(name, 0) != 0; }
 
 int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);

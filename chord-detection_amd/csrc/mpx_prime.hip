@@ -1,15 +1,25 @@
 // Prime-multiF0 chroma (reference method 4, prime_multif0.py:41-91) in fp64.
 //
-// One workgroup per (candidate frequency, frame): Hann window (numpy.hanning, symmetric), N-point
+// An item is one (candidate frequency, frame): Hann window (numpy.hanning, symmetric), N-point
 // DFT of the real frame by Bluestein's chirp-z on the LDS FFT (N = int(8/f*fs) is never a power of
 // two), |X|/sum(window) for the lower half of the one-sided spectrum (prime_multif0.py:59-61), then
 // harmonic_elim_runs rounds of block argmax -> pitch class -> exact-frequency harmonic elimination
 // (prime_multif0.py:66-82).  Every item writes its <= runs (pitch class, value) pairs to a fixed slot;
 // one workgroup per clip adds them up in item order (deterministic).
+//
+// prime_pers_kernel (chirp-z lengths up to 4096): PERSISTENT workgroups, each bound to one candidate frequency.  What
+// depends on the candidate only -- window x chirp, the filter spectrum in the register order of the DIF engine, the
+// twiddle bases, the output chirp -- is loaded into registers once; the workgroup then walks that candidate's frames
+// across all clips with a stride, the next frame's samples in flight under the current frame's transforms.  The two
+// transforms run on the wave-local in-place DIF / inverse-DIT engine (mpx_fft_dif.hpp: one workgroup barrier each, the
+// pointwise product in registers with no reordering), the magnitudes never leave registers, and the argmax is a DPP
+// maximum + ballot per wave and ONE barrier per round.  (Round 2's kernel, kept for the 8192-point class only, was a
+// workgroup per item: seven million workgroups per 4096 clips that each fetched their tables from L2 and ran ~35 barriers.)
 #include <cmath>
 #include <cstring>
 
 #include "mpx_fft.hpp"
+#include "mpx_fft_dif.hpp"
 #include "mpx_internal.hpp"
 
 namespace mpx {
@@ -20,7 +30,8 @@ struct PrimeCand {          // per candidate frequency, device resident
     double wsum;            // sum(numpy.hanning(N))
     const double* win;      // [N]
     const cx<double>* chirp;  // [N]
-    const cx<double>* bhat;   // [L] FFT_L(chirp filter)/L
+    const cx<double>* bhat;   // [L] FFT_L(chirp filter)/L, natural order (8192-point class)
+    const cx<double>* bhat_r; // [8][L/8] the same in the register order dif_fft_keep_last<L> leaves (L <= 4096)
     const cx<double>* tw;     // [L] W_L
 };
 
@@ -139,6 +150,188 @@ __global__ __launch_bounds__(T) void prime_kernel(const float* __restrict__ sig,
     }
 }
 
+
+// ---- persistent kernel -------------------------------------------------------------------------------------------
+struct PrimeWork {          // per workgroup
+    int cand;               // candidate frequency this workgroup is bound to
+    int worker, workers;    // it takes items worker, worker + workers, ... of that candidate
+    int item0, count;       // the candidate's items in `items`: [item0, item0 + count) (of ONE clip when the clips are uniform)
+};
+
+template <int CTRL>
+__device__ __forceinline__ double prime_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double prime_readlane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// maximum over the wave of values that are never NaN (every lane gets it)
+__device__ __forceinline__ double prime_wave_max(double v) {
+    v = fmax(v, prime_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmax(v, prime_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmax(v, prime_dpp<0x141>(v));   // row_half_mirror
+    v = fmax(v, prime_dpp<0x140>(v));   // row_mirror: all 16 lanes of a row agree
+    return fmax(fmax(prime_readlane(v, 0), prime_readlane(v, 16)), fmax(prime_readlane(v, 32), prime_readlane(v, 48)));
+}
+
+template <int L>
+__global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restrict__ sig, const PrimeItem* __restrict__ items,
+                                                           const PrimeWork* __restrict__ work, const PrimeCand* __restrict__ cands,
+                                                           int runs, int elim, int note_names, int* out_pc, double* out_val,
+                                                           int uniform_clips, long long clip_len, long long clip_slots) {
+    constexpr int T = L / 8, NW = T / 64;
+    static_assert(T % 64 == 0, "whole waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    __shared__ double red_v[2][NW];
+    __shared__ int red_i[2][NW];
+    const int tid = threadIdx.x;
+    const PrimeWork wk = work[blockIdx.x];
+    const PrimeCand c = cands[wk.cand];
+    const int N = c.N, half = c.half;
+    // what depends on the candidate only, once per workgroup
+    cx<double> wc[8], bh[8], oc[2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = tid + r * T;
+        wc[r] = {0.0, 0.0};
+        if (n < N) {
+            const double w = c.win[n];
+            const cx<double> ch = c.chirp[n];
+            wc[r] = {w * ch.x, -(w * ch.y)};   // window x conj(chirp)
+        }
+        bh[r] = c.bhat_r[r * T + tid];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int k = tid + r * T;
+        oc[r] = {0.0, 0.0};
+        if (k < half) {
+            const cx<double> ch = c.chirp[k];
+            oc[r] = {ch.x, -ch.y};
+        }
+    }
+    const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(c.tw, tid);
+    const long long total = uniform_clips ? (long long)wk.count * uniform_clips : wk.count;
+
+    auto item_at = [&](long long i) -> PrimeItem {
+        PrimeItem it;
+        if (uniform_clips) {
+            const long long clip = i / wk.count;
+            it = items[wk.item0 + (int)(i - clip * wk.count)];
+            it.start += clip * clip_len;
+            it.slot += clip * clip_slots;
+        } else {
+            it = items[wk.item0 + i];
+        }
+        return it;
+    };
+    auto fetch = [&](const PrimeItem& it, float* xs) {
+        const float* __restrict__ x = sig + it.start;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n = tid + r * T;
+            xs[r] = n < it.valid ? x[n] : 0.0f;
+        }
+    };
+
+    long long i = wk.worker;
+    if (i >= total) return;
+    PrimeItem it = item_at(i);
+    float xs[8];
+    fetch(it, xs);
+    int par = 0;
+    for (; i < total; i += wk.workers) {
+        int t = tid;
+        asm volatile("" : "+v"(t));   // addresses are rebuilt per frame: hoisted, they cost more registers than they save
+        cx<double> regs[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const double s = (double)xs[r];
+            regs[r] = {s * wc[r].x, s * wc[r].y};
+        }
+        // the next frame's samples travel under this frame's transforms
+        const long long inext = i + wk.workers;
+        const PrimeItem itn = item_at(inext < total ? inext : i);
+        fetch(itn, xs);
+        dif_fft_keep_last<L, double>(buf, twd, regs, t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) regs[e] = cmul(regs[e], bh[e]);
+        idit_fft_from_last<L, double>(buf, twd, regs, t);
+        // X[k] = conj(chirp[k]) * y[k], k = tid and tid + T (half <= L / 5 < 2 T); mlab: np.abs(result) / window.sum()
+        double m[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const cx<double> z = cmul(regs[r], oc[r]);
+            m[r] = hypot(z.x, z.y) / c.wsum;
+        }
+        const bool has1 = tid + T < half, has0 = tid < half;
+        if (runs == 0) __syncthreads();   // the next frame's first pass overwrites what other waves may still be reading
+        for (int run = 0; run < runs; ++run) {
+            // numpy argmax: first index of the maximum (NaN never wins, as before)
+            double bv = -INFINITY;
+            if (has0 && m[0] > bv) bv = m[0];
+            if (has1 && m[1] > bv) bv = m[1];
+            const double wmax = prime_wave_max(bv);
+            const unsigned long long b0 = __ballot(has0 && m[0] == wmax), b1 = __ballot(has1 && m[1] == wmax);
+            const int wbase = tid & ~63;
+            int widx = 0x7fffffff;
+            if (wmax > -INFINITY) widx = b0 ? wbase + __builtin_ctzll(b0) : wbase + T + __builtin_ctzll(b1);
+            if ((tid & 63) == 0) {
+                red_v[par][tid >> 6] = wmax;
+                red_i[par][tid >> 6] = widx;
+            }
+            __syncthreads();
+            double best = red_v[par][0];
+            int idx = red_i[par][0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const double ov = red_v[par][w];
+                const int oi = red_i[par][w];
+                if (ov > best || (ov == best && oi < idx)) {
+                    best = ov;
+                    idx = oi;
+                }
+            }
+            par ^= 1;
+            int pc = -1;
+            double val = 0.0;
+            if (half > 0) {
+                const bool none = idx == 0x7fffffff;   // nothing compared greater than -inf: every magnitude is NaN
+                if (none) idx = 0;
+                const double max_f = (double)idx * c.val;
+                const double midi = 12.0 * (log2(max_f) - log2(440.0)) + 69.0;
+                // hz_to_note raises on NaN (ValueError) and on +-inf (OverflowError, e.g. the DC bin): the
+                // reference `continue`s: nothing is added and nothing is eliminated (prime_multif0.py:73-74)
+                if (midi == midi && !isinf(midi)) {
+                    const long long note = (long long)nearbyint(midi);
+                    pc = (int)(((note % 12) + 12) % 12);
+                    val = none ? __builtin_nan("") : best;
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        const int j = tid + r * T;
+                        for (int k = 1; k < elim; ++k) {   // f == k * max_f, exact comparison (:80), among bins k idx - 1 .. k idx + 1
+                            const int d = j - k * idx;
+                            if (j < half && d >= -1 && d <= 1 && (double)j * c.val == (double)k * max_f) m[r] = 0.0;
+                        }
+                    }
+                    // unicode-sharp quirk A.18 (MPX_NOTES_UNICODE): sharps land in a stray key and are lost, but the
+                    // elimination above has happened; ASCII note names (librosa < 0.8) keep every pitch class
+                    if (note_names == MPX_NOTES_UNICODE && (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) pc = -1;
+                }
+            }
+            if (tid == 0) {
+                out_pc[it.slot * PRIME_MAX_RUNS + run] = pc;
+                out_val[it.slot * PRIME_MAX_RUNS + run] = val;
+            }
+        }
+        it = itn;
+    }
+}
+
 // one workgroup per clip: chroma[clip] = sum over its item slots, in slot order per pitch class
 __global__ __launch_bounds__(64) void prime_sum_kernel(const long long* __restrict__ seg, int runs,
                                                        const int* __restrict__ pc, const double* __restrict__ val,
@@ -172,6 +365,16 @@ static void prime_host_fft(std::vector<cx<double>>& a) {
                 a[i + k] = {u.x + v.x, u.y + v.y};
                 a[i + k + len / 2] = {u.x - v.x, u.y - v.y};
             }
+}
+
+// frequency held by register e of thread t after dif_fft_keep_last<L>
+template <int L>
+static int prime_reg_freq_t(int t, int e) {
+    constexpr int RL = DifPlan<L>::radix(DifPlan<L>::n - 1);
+    return dif_freq<L>(dif_last_pos<L>(t, e / RL, e % RL));
+}
+static int prime_reg_freq(int L, int t, int e) {
+    return L == 1024 ? prime_reg_freq_t<1024>(t, e) : (L == 2048 ? prime_reg_freq_t<2048>(t, e) : prime_reg_freq_t<4096>(t, e));
 }
 
 struct PrimePlan {
@@ -249,6 +452,14 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                 c.win = (const double*)upload(ctx, win.data(), win.size() * sizeof(double));
                 c.chirp = (const cx<double>*)upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
                 c.bhat = (const cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
+                c.bhat_r = nullptr;
+                if (c.L <= 4096) {   // prime_pers_kernel multiplies the filter onto the registers the forward DIF leaves: [e][tid]
+                    std::vector<cx<double>> fr(c.L);
+                    for (int t = 0; t < c.L / 8; ++t)
+                        for (int e = 0; e < 8; ++e) fr[(size_t)e * (c.L / 8) + t] = filt[prime_reg_freq(c.L, t, e)];
+                    c.bhat_r = (const cx<double>*)upload(ctx, fr.data(), fr.size() * sizeof(cx<double>));
+                    if (!c.bhat_r) return MPX_ENOMEM;
+                }
                 if (!c.win || !c.chirp || !c.bhat) return MPX_ENOMEM;
                 plan.cands.push_back(c);
             }
@@ -273,6 +484,32 @@ static void prime_launch(const float* d_sig, const PrimeItem* d_items, size_t co
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(T), lds, st, d_sig, d_items, d_cands, runs, elim, note_names, d_pc, d_val, per_clip, clip_len, clip_slots);
 }
 
+template <int L>
+static int prime_pers_launch(mpx_ctx* ctx, const float* d_sig, const PrimeItem* d_items, const PrimeWork* d_work, size_t groups,
+                             const PrimeCand* d_cands, int runs, int elim, int note_names, int* d_pc, double* d_val, hipStream_t st,
+                             int uniform_clips, long long clip_len, long long clip_slots) {
+    if (!groups) return MPX_OK;
+    const size_t lds = sizeof(cx<double>) * L;
+    auto kern = prime_pers_kernel<L>;
+    if (lds > 48 * 1024) MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(L / 8), lds, st, d_sig, d_items, d_work, d_cands, runs, elim, note_names,
+                       d_pc, d_val, uniform_clips, clip_len, clip_slots);
+    return MPX_OK;
+}
+// resident workgroups of prime_pers_kernel<L> on the whole device (cached per context)
+template <int L>
+static int prime_pers_slots(mpx_ctx* ctx) {
+    const std::string key = "prime_pers_" + std::to_string(L);
+    auto it = ctx->occupancy.find(key);
+    if (it != ctx->occupancy.end()) return it->second;
+    const size_t lds = sizeof(cx<double>) * L;
+    auto kern = prime_pers_kernel<L>;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, L / 8, lds) != hipSuccess || occ < 1) occ = 1;
+    return ctx->occupancy[key] = occ * ctx->num_cus;
+}
+
 // signals: packed clips on the HOST; offsets[C+1]; out: [C,12] on the host
 // dev_io: `signals` is DEVICE memory used in place and chroma_sums a device buffer; the kernels are only enqueued on
 // `stream` (the host-built item lists are uploaded and waited for first).
@@ -290,8 +527,9 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     if (rc) return rc;
     PrimePlan* plan = &plan_storage;
     const int64_t total = offsets[num_clips];
-    // items in the reference's loop order per clip: candidate-major, then frame
-    std::vector<PrimeItem> items[4];
+    // slots in the reference's loop order (clip, candidate, frame); items grouped by CANDIDATE (all clips of a candidate
+    // together: a persistent workgroup is bound to one candidate), candidates grouped by chirp-z class
+    std::vector<std::vector<PrimeItem>> by_cand(plan->cands.size());
     std::vector<long long> seg(1, 0);
     long long slot = 0;
     // A batch of equal-length clips (a corpus) needs the item list of ONE clip: the kernel derives the others.  Building
@@ -313,10 +551,18 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
                 it.valid = (int)(left >= c.N ? c.N : left);
                 it.cand = (int)k;
                 it.slot = slot++;
-                items[c.L == 1024 ? 0 : (c.L == 2048 ? 1 : (c.L == 4096 ? 2 : 3))].push_back(it);
+                by_cand[k].push_back(it);
             }
         }
         seg.push_back(slot);
+    }
+    auto class_of = [](int L) { return L == 1024 ? 0 : (L == 2048 ? 1 : (L == 4096 ? 2 : 3)); };
+    std::vector<PrimeItem> items[4];
+    std::vector<int> cand_item0(plan->cands.size(), 0);
+    for (size_t k = 0; k < plan->cands.size(); ++k) {
+        auto& v = items[class_of(plan->cands[k].L)];
+        cand_item0[k] = (int)v.size();
+        v.insert(v.end(), by_cand[k].begin(), by_cand[k].end());
     }
     const long long clip_slots = uniform ? slot : 0, clip_len = uniform ? offsets[1] - offsets[0] : 0;
     if (uniform) {
@@ -345,18 +591,54 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         if (bytes) MPX_HIP(ctx, hipMemcpyAsync(d_items + off, items[cls].data(), bytes, hipMemcpyHostToDevice, st));
         off += bytes;
     }
-    if (dev_io) MPX_HIP(ctx, hipStreamSynchronize(st));   // seg and items are host vectors of this call
+    // work table of the persistent kernel: the resident workgroups of a class are shared out among its candidates in
+    // proportion to their items (equal cost inside a class), so that every workgroup walks about the same number of frames
+    std::vector<PrimeWork> work[3];
+    const int slots_of[3] = {prime_pers_slots<1024>(ctx), prime_pers_slots<2048>(ctx), prime_pers_slots<4096>(ctx)};
+    for (int cls = 0; cls < 3; ++cls) {
+        const long long mult = uniform ? num_clips : 1;
+        const long long class_items = (long long)items[cls].size() * mult;
+        if (!class_items) continue;
+        for (size_t k = 0; k < plan->cands.size(); ++k) {
+            if (class_of(plan->cands[k].L) != cls || by_cand[k].empty()) continue;
+            const long long mine = (long long)by_cand[k].size() * mult;
+            long long w = (long long)((double)slots_of[cls] * (double)mine / (double)class_items + 0.5);
+            w = w < 1 ? 1 : (w > mine ? mine : w);
+            for (long long i = 0; i < w; ++i)
+                work[cls].push_back(PrimeWork{(int)k, (int)i, (int)w, cand_item0[k], (int)by_cand[k].size()});
+        }
+    }
+    const size_t work_bytes = (work[0].size() + work[1].size() + work[2].size()) * sizeof(PrimeWork);
+    if ((rc = ensure(ctx, ctx->d_ws1, work_bytes + 64))) return rc;
+    {
+        size_t woff = 0;
+        for (int cls = 0; cls < 3; ++cls) {
+            const size_t bytes = work[cls].size() * sizeof(PrimeWork);
+            if (bytes) MPX_HIP(ctx, hipMemcpyAsync((char*)ctx->d_ws1.p + woff, work[cls].data(), bytes, hipMemcpyHostToDevice, st));
+            woff += bytes;
+        }
+    }
+    if (dev_io) MPX_HIP(ctx, hipStreamSynchronize(st));   // seg, items and work are host vectors of this call
     off = 0;
+    size_t woff = 0;
     prof_mark(ctx, st, "prime_kernel");
     for (int cls = 0; cls < 4; ++cls) {
         const size_t bytes = items[cls].size() * sizeof(PrimeItem);
         const PrimeItem* di = (const PrimeItem*)(d_items + off);
-        const int per_clip = uniform ? (int)items[cls].size() : 0;
-        const size_t count = uniform ? items[cls].size() * (size_t)num_clips : items[cls].size();
-        if (cls == 0) prime_launch<1024, 128>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 1) prime_launch<2048, 256>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 2) prime_launch<4096, 512>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
-        if (cls == 3) prime_launch<8192, 512>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        const int uclips = uniform ? num_clips : 0;
+        if (cls < 3) {
+            const PrimeWork* dw = (const PrimeWork*)((char*)ctx->d_ws1.p + woff);
+            const size_t groups = work[cls].size();
+            if (cls == 0) rc = prime_pers_launch<1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 1) rc = prime_pers_launch<2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 2) rc = prime_pers_launch<4096>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (rc) return rc;
+            woff += groups * sizeof(PrimeWork);
+        } else {   // chirp-z on 8192 points (frames above 3277 samples: input rates above 53 kHz): a workgroup per item, Stockham engine
+            const int per_clip = uniform ? (int)items[cls].size() : 0;
+            const size_t count = uniform ? items[cls].size() * (size_t)num_clips : items[cls].size();
+            prime_launch<8192, 512>(d_in, di, count, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, per_clip, clip_len, clip_slots);
+        }
         off += bytes;
     }
     prof_mark(ctx, st, "prime_sum_kernel");

@@ -56,6 +56,11 @@ typedef enum mpx_status {
 typedef struct mpx_ctx mpx_ctx;
 
 int mpx_abi_version(void);
+/* 1 when the library was built with -DMPX_DEV_KNOBS (`make dev` -> libmpx_hip_dev.so): only such a build reads the
+ * development switches of csrc/ (MPX_SACF_ABLATE, MPX_FIT_MAXFEV, MPX_SACF_PAIR, MPX_FIT_*, MPX_HE_WG, ...) from the
+ * environment, some of which change results.  The release library returns 0 and never looks at them; bench.py refuses
+ * to report numbers from a library that returns 1. */
+int mpx_dev_knobs(void);
 int mpx_device_count(void);
 /* NULL on failure; mpx_last_error(NULL) then holds the reason.
  * A context owns ONE set of grow-only device workspaces and reduction counters: it is neither thread-safe nor

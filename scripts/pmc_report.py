@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Per-kernel medians of the counters collected by scripts/pmc_collect.sh (<dir>/pass*.csv, <dir>/kernel_stats.csv) ->
+<dir>/pmc.json and <dir>/pmc.txt.  Kernels are keyed by their short name plus the grid (a kernel that runs in several
+workloads shows up once per launch shape).  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both in KB; the x2 is
+MI355X_MICROARCH.md's gfx950 correction for wide coalesced reads, calibrated on known bytes in round 2: 1.9946)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+d = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("mpx::", "")
+
+
+for path in sorted(glob.glob(os.path.join(d, "pass*.csv"))):
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            k = short(r["Kernel_Name"])
+            if k.startswith("at::") or "elementwise" in k or "Memset" in k or k.startswith("__amd"):
+                continue
+            key = "%s grid=%s wg=%s" % (k, r.get("Grid_Size", "?"), r.get("Workgroup_Size", "?"))
+            acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+stats = {}
+sp = os.path.join(d, "kernel_stats.csv")
+if os.path.exists(sp):
+    with open(sp) as fh:
+        for r in csv.DictReader(fh):
+            stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6}
+out = {}
+lines = []
+for key in sorted(acc):
+    cs = {c: sorted(v)[len(v) // 2] for c, v in acc[key].items()}
+    n = max(len(v) for v in acc[key].values())
+    rec = {"launches_seen": n, "counters": cs}
+    if "FETCH_SIZE" in cs:
+        rec["hbm_bytes_per_launch"] = 2.0 * cs["FETCH_SIZE"] * 1024.0 + cs.get("WRITE_SIZE", 0.0) * 1024.0
+    wc = cs.get("SQ_WAVE_CYCLES")
+    if wc:
+        for a, b in (("valu_active_frac", "SQ_ACTIVE_INST_VALU"), ("wait_any_frac", "SQ_WAIT_ANY"), ("wait_inst_any_frac", "SQ_WAIT_INST_ANY"),
+                     ("active_any_frac", "SQ_ACTIVE_INST_ANY")):
+            if b in cs:
+                rec[a] = cs[b] / wc
+    if cs.get("SQ_LDS_IDX_ACTIVE"):
+        rec["lds_bank_conflict_frac"] = cs.get("SQ_LDS_BANK_CONFLICT", 0.0) / cs["SQ_LDS_IDX_ACTIVE"]
+    if cs.get("SQ_INSTS_VALU") and cs.get("SQ_THREAD_CYCLES_VALU") and cs.get("SQ_ACTIVE_INST_VALU"):
+        rec["valu_lane_utilisation"] = cs["SQ_THREAD_CYCLES_VALU"] / (64.0 * cs["SQ_ACTIVE_INST_VALU"])
+    kshort = key.split(" grid=")[0]
+    if kshort in stats:
+        rec["kernel_stats"] = stats[kshort]
+    out[key] = rec
+    lines.append(key)
+    for c in sorted(cs):
+        lines.append("    %-26s %.5g" % (c, cs[c]))
+    for c in ("hbm_bytes_per_launch", "valu_active_frac", "wait_any_frac", "wait_inst_any_frac", "lds_bank_conflict_frac", "valu_lane_utilisation"):
+        if c in rec:
+            lines.append("    => %-23s %.5g" % (c, rec[c]))
+json.dump(out, open(os.path.join(d, "pmc.json"), "w"), indent=1, sort_keys=True)
+open(os.path.join(d, "pmc.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:400]))
