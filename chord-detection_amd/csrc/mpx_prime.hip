@@ -40,6 +40,8 @@ struct PrimeItem {
     int valid;              // samples that exist (rest is frame_cutter's zero padding)
     int cand;
     long long slot;         // output slot (clip-major, reference loop order)
+    int valid_b, pad;       // prime_pers_kernel: the NEXT frame of the same clip and candidate rides along (0: there is none);
+                            // it starts N samples later and its slot is slot + 1
 };
 
 constexpr int PRIME_MAX_RUNS = 4;
@@ -186,12 +188,15 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
     static_assert(T % 64 == 0, "whole waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
-    __shared__ double red_v[2][NW];
-    __shared__ int red_i[2][NW];
+    __shared__ cx<double> exch[2 * T];   // y[6T .. 8T): the negative output indices of the chirp-z, for the split below
+    __shared__ double red_v[2][2][NW];
+    __shared__ int red_i[2][2][NW];
+    __shared__ int nonzero[2][2];        // [parity][frame]: some sample of the frame is not zero
     const int tid = threadIdx.x;
     const PrimeWork wk = work[blockIdx.x];
     const PrimeCand c = cands[wk.cand];
     const int N = c.N, half = c.half;
+    if (tid < 4) nonzero[tid >> 1][tid & 1] = 0;
     // what depends on the candidate only, once per workgroup
     cx<double> wc[8], bh[8], oc[2];
 #pragma unroll
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
     }
     const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(c.tw, tid);
     const long long total = uniform_clips ? (long long)wk.count * uniform_clips : wk.count;
+    __syncthreads();
 
     auto item_at = [&](long long i) -> PrimeItem {
         PrimeItem it;
@@ -229,104 +235,135 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
         }
         return it;
     };
-    auto fetch = [&](const PrimeItem& it, float* xs) {
+    // the two frames of an item follow each other in the clip: frame b starts N samples after frame a
+    auto fetch = [&](const PrimeItem& it, float* xa, float* xb) {
         const float* __restrict__ x = sig + it.start;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int n = tid + r * T;
-            xs[r] = n < it.valid ? x[n] : 0.0f;
+            xa[r] = n < it.valid ? x[n] : 0.0f;
+            xb[r] = n < it.valid_b ? x[N + n] : 0.0f;
         }
     };
 
     long long i = wk.worker;
     if (i >= total) return;
     PrimeItem it = item_at(i);
-    float xs[8];
-    fetch(it, xs);
-    int par = 0;
+    float xa[8], xb[8];
+    fetch(it, xa, xb);
+    int par = 0, fpar = 0;   // parity of the argmax slots (per round) and of the zero-frame flags (per item)
     for (; i < total; i += wk.workers) {
         int t = tid;
-        asm volatile("" : "+v"(t));   // addresses are rebuilt per frame: hoisted, they cost more registers than they save
+        asm volatile("" : "+v"(t));   // addresses are rebuilt per item: hoisted, they cost more registers than they save
+        // TWO real frames per transform: u = (a + i b) x window x conj(chirp); their spectra are separated afterwards by
+        // the conjugate symmetry of a real frame's spectrum, X_a[k] = (X[k] + conj X[-k]) / 2, X_b[k] = (X[k] - conj X[-k]) / 2i
         cx<double> regs[8];
+        bool nza = false, nzb = false;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const double s = (double)xs[r];
-            regs[r] = {s * wc[r].x, s * wc[r].y};
+            const double a = (double)xa[r], b = (double)xb[r];
+            nza |= xa[r] != 0.0f;
+            nzb |= xb[r] != 0.0f;
+            regs[r] = {a * wc[r].x - b * wc[r].y, a * wc[r].y + b * wc[r].x};
         }
-        // the next frame's samples travel under this frame's transforms
+        // An all-zero frame has an all-zero spectrum in the reference; next to a loud partner it would come out as that
+        // partner's rounding noise (1e-17), so such a frame is flagged and its magnitudes are set to the exact zeros.
+        if (nza) nonzero[fpar][0] = 1;
+        if (nzb) nonzero[fpar][1] = 1;
+        // the next item's samples travel under this item's transforms
         const long long inext = i + wk.workers;
         const PrimeItem itn = item_at(inext < total ? inext : i);
-        fetch(itn, xs);
-        dif_fft_keep_last<L, double>(buf, twd, regs, t);
+        fetch(itn, xa, xb);
+        dif_fft_keep_last<L, double>(buf, twd, regs, t);     // (one workgroup barrier inside: the flags are visible after it)
+        const bool live_a = nonzero[fpar][0] != 0, live_b = nonzero[fpar][1] != 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) regs[e] = cmul(regs[e], bh[e]);
-        idit_fft_from_last<L, double>(buf, twd, regs, t);
-        // X[k] = conj(chirp[k]) * y[k], k = tid and tid + T (half <= L / 5 < 2 T); mlab: np.abs(result) / window.sum()
-        double m[2];
+        idit_fft_from_last<L, double>(buf, twd, regs, t);     // regs[r] = y[tid + r T]
+        if (tid < 2) nonzero[fpar][tid] = 0;                  // everybody has read them (barrier inside the inverse transform)
+        fpar ^= 1;
+        exch[t] = regs[6];
+        exch[t + T] = regs[7];
+        __syncthreads();
+        // y[-k] for k = tid (r = 0) and k = tid + T (r = 1): positions L - k
+        const cx<double> ym0 = t == 0 ? regs[0] : exch[2 * T - t];
+        const cx<double> ym1 = t == 0 ? exch[T] : exch[T - t];
+        // X[k] = conj(chirp[k]) y[k], X[-k] = conj(chirp[k]) y[-k] (the chirp is even); mlab: np.abs(result) / window.sum()
+        double ma[2], mb[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const cx<double> z = cmul(regs[r], oc[r]);
-            m[r] = hypot(z.x, z.y) / c.wsum;
+            const cx<double> xp = cmul(regs[r], oc[r]), xm = cmul(r == 0 ? ym0 : ym1, oc[r]);
+            const cx<double> sa = {0.5 * (xp.x + xm.x), 0.5 * (xp.y - xm.y)};    // X_a = (X[k] + conj X[-k]) / 2
+            const cx<double> sb = {0.5 * (xp.y + xm.y), 0.5 * (xm.x - xp.x)};    // X_b = (X[k] - conj X[-k]) / 2i
+            ma[r] = live_a ? hypot(sa.x, sa.y) / c.wsum : 0.0;
+            mb[r] = live_b ? hypot(sb.x, sb.y) / c.wsum : 0.0;
         }
         const bool has1 = tid + T < half, has0 = tid < half;
-        if (runs == 0) __syncthreads();   // the next frame's first pass overwrites what other waves may still be reading
+        const bool two = it.valid_b > 0;
         for (int run = 0; run < runs; ++run) {
-            // numpy argmax: first index of the maximum (NaN never wins, as before)
-            double bv = -INFINITY;
-            if (has0 && m[0] > bv) bv = m[0];
-            if (has1 && m[1] > bv) bv = m[1];
-            const double wmax = prime_wave_max(bv);
-            const unsigned long long b0 = __ballot(has0 && m[0] == wmax), b1 = __ballot(has1 && m[1] == wmax);
-            const int wbase = tid & ~63;
-            int widx = 0x7fffffff;
-            if (wmax > -INFINITY) widx = b0 ? wbase + __builtin_ctzll(b0) : wbase + T + __builtin_ctzll(b1);
-            if ((tid & 63) == 0) {
-                red_v[par][tid >> 6] = wmax;
-                red_i[par][tid >> 6] = widx;
+            // numpy argmax: first index of the maximum (NaN never wins, as before); both frames through the same barrier
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const double* m = f ? mb : ma;
+                double bv = -INFINITY;
+                if (has0 && m[0] > bv) bv = m[0];
+                if (has1 && m[1] > bv) bv = m[1];
+                const double wmax = prime_wave_max(bv);
+                const unsigned long long b0 = __ballot(has0 && m[0] == wmax), b1 = __ballot(has1 && m[1] == wmax);
+                const int wbase = tid & ~63;
+                int widx = 0x7fffffff;
+                if (wmax > -INFINITY) widx = b0 ? wbase + __builtin_ctzll(b0) : wbase + T + __builtin_ctzll(b1);
+                if ((tid & 63) == 0) {
+                    red_v[par][f][tid >> 6] = wmax;
+                    red_i[par][f][tid >> 6] = widx;
+                }
             }
             __syncthreads();
-            double best = red_v[par][0];
-            int idx = red_i[par][0];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const double ov = red_v[par][w];
-                const int oi = red_i[par][w];
-                if (ov > best || (ov == best && oi < idx)) {
-                    best = ov;
-                    idx = oi;
+            for (int f = 0; f < 2; ++f) {
+                double* m = f ? mb : ma;
+                double best = red_v[par][f][0];
+                int idx = red_i[par][f][0];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) {
+                    const double ov = red_v[par][f][w];
+                    const int oi = red_i[par][f][w];
+                    if (ov > best || (ov == best && oi < idx)) {
+                        best = ov;
+                        idx = oi;
+                    }
+                }
+                int pc = -1;
+                double val = 0.0;
+                if (half > 0) {
+                    const bool none = idx == 0x7fffffff;   // nothing compared greater than -inf: every magnitude is NaN
+                    if (none) idx = 0;
+                    const double max_f = (double)idx * c.val;
+                    const double midi = 12.0 * (log2(max_f) - log2(440.0)) + 69.0;
+                    // hz_to_note raises on NaN (ValueError) and on +-inf (OverflowError, e.g. the DC bin): the
+                    // reference `continue`s: nothing is added and nothing is eliminated (prime_multif0.py:73-74)
+                    if (midi == midi && !isinf(midi)) {
+                        const long long note = (long long)nearbyint(midi);
+                        pc = (int)(((note % 12) + 12) % 12);
+                        val = none ? __builtin_nan("") : best;
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            const int j = tid + r * T;
+                            for (int k = 1; k < elim; ++k) {   // f == k * max_f, exact comparison (:80), among bins k idx - 1 .. k idx + 1
+                                const int d = j - k * idx;
+                                if (j < half && d >= -1 && d <= 1 && (double)j * c.val == (double)k * max_f) m[r] = 0.0;
+                            }
+                        }
+                        // unicode-sharp quirk A.18 (MPX_NOTES_UNICODE): sharps land in a stray key and are lost, but the
+                        // elimination above has happened; ASCII note names (librosa < 0.8) keep every pitch class
+                        if (note_names == MPX_NOTES_UNICODE && (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) pc = -1;
+                    }
+                }
+                if (tid == 0 && (f == 0 || two)) {
+                    out_pc[(it.slot + f) * PRIME_MAX_RUNS + run] = pc;
+                    out_val[(it.slot + f) * PRIME_MAX_RUNS + run] = val;
                 }
             }
             par ^= 1;
-            int pc = -1;
-            double val = 0.0;
-            if (half > 0) {
-                const bool none = idx == 0x7fffffff;   // nothing compared greater than -inf: every magnitude is NaN
-                if (none) idx = 0;
-                const double max_f = (double)idx * c.val;
-                const double midi = 12.0 * (log2(max_f) - log2(440.0)) + 69.0;
-                // hz_to_note raises on NaN (ValueError) and on +-inf (OverflowError, e.g. the DC bin): the
-                // reference `continue`s: nothing is added and nothing is eliminated (prime_multif0.py:73-74)
-                if (midi == midi && !isinf(midi)) {
-                    const long long note = (long long)nearbyint(midi);
-                    pc = (int)(((note % 12) + 12) % 12);
-                    val = none ? __builtin_nan("") : best;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const int j = tid + r * T;
-                        for (int k = 1; k < elim; ++k) {   // f == k * max_f, exact comparison (:80), among bins k idx - 1 .. k idx + 1
-                            const int d = j - k * idx;
-                            if (j < half && d >= -1 && d <= 1 && (double)j * c.val == (double)k * max_f) m[r] = 0.0;
-                        }
-                    }
-                    // unicode-sharp quirk A.18 (MPX_NOTES_UNICODE): sharps land in a stray key and are lost, but the
-                    // elimination above has happened; ASCII note names (librosa < 0.8) keep every pitch class
-                    if (note_names == MPX_NOTES_UNICODE && (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) pc = -1;
-                }
-            }
-            if (tid == 0) {
-                out_pc[it.slot * PRIME_MAX_RUNS + run] = pc;
-                out_val[it.slot * PRIME_MAX_RUNS + run] = val;
-            }
         }
         it = itn;
     }
@@ -385,7 +422,7 @@ struct PrimePlan {
 // Plans live in the context (host copy of the candidate records in ctx->host_blobs, device tables in
 // ctx->owned) and die with it.
 static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan& plan) {
-    const std::string key = "prime_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
+    const std::string key = "prime2_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
                             std::to_string(p.num_octave);
     auto bit = ctx->host_blobs.find(key);
     if (bit != ctx->host_blobs.end()) {
@@ -404,17 +441,20 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                 const double f = note * oct * h;
                 const int N = (int)((8 / f) * fs);  // prime_multif0.py:53
                 // Only the lower half of the one-sided spectrum is looked at (prime_multif0.py:59-61): K = half outputs.  The
-                // chirp-z convolution then spans chirp[-(N-1) .. K-1], a circular length of N + K - 1 ~ 1.25 N does, not the
-                // 2 N - 1 of a full transform: most candidates run on an FFT of half the size (and frames up to 6553
-                // samples fit the 8192-point class: 96 kHz input).
+                // persistent kernel transforms two real frames at once and separates them by conjugate symmetry, which takes
+                // the outputs -(K-1) .. K-1: the chirp-z convolution then spans chirp[-(N+K-2) .. K-1], a circular length of
+                // N + 2K - 2 ~ 1.5 N (a full transform: 2N - 1).  Frames whose 1.25 N fits 8192 points but whose 1.5 N does
+                // not (5462 .. 6553 samples: input above 67 kHz) stay on the workgroup-per-frame kernel, one frame each.
                 const int half = N >= 2 ? (N / 2 + 1) / 2 : 0;
                 if (N < 2 || N + half - 1 > 8192)
                     return set_error(ctx, MPX_EUNSUPPORTED,
                                      "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..6553)", N, f);
                 PrimeCand c;
                 c.N = N;
-                const int need = N + half - 1;
-                c.L = need <= 1024 ? 1024 : (need <= 2048 ? 2048 : (need <= 4096 ? 4096 : 8192));
+                const int need2 = N + 2 * half - 2;
+                const bool paired = need2 <= 4096;
+                const int need = paired ? need2 : N + half - 1;
+                c.L = !paired ? 8192 : (need <= 1024 ? 1024 : (need <= 2048 ? 2048 : 4096));
                 c.half = half;
                 c.val = 1.0 / (N * (1.0 / fs));
                 std::vector<double> win(N);
@@ -432,8 +472,14 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                     const long double ang = M_PIl * (long double)q / (long double)N;
                     chirp[i] = {(double)cosl(ang), (double)sinl(ang)};
                 }
+                auto chirp_at = [&](long long i) {   // e^{i pi i^2 / N} for any index (phase reduced exactly)
+                    const long long q = (i * i) % (2LL * N);
+                    const long double ang = M_PIl * (long double)q / (long double)N;
+                    return cx<double>{(double)cosl(ang), (double)sinl(ang)};
+                };
                 for (int m = 0; m < (half > 1 ? half : 1); ++m) filt[m] = chirp[m];   // chirp[k - n], k - n = 0 .. K-1
-                for (int m = 1; m < N; ++m) filt[c.L - m] = chirp[m];                 // k - n = -1 .. -(N-1) (the chirp is even)
+                const int neg = paired ? N + half - 2 : N - 1;                        // k - n = -1 .. -neg (the chirp is even)
+                for (int m = 1; m <= neg; ++m) filt[c.L - m] = chirp_at(m);
                 prime_host_fft(filt);
                 for (auto& v : filt) {
                     v.x /= c.L;
@@ -544,13 +590,21 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         for (size_t k = 0; k < plan->cands.size(); ++k) {
             const PrimeCand& c = plan->cands[k];
             const int64_t nf = len <= 0 ? 0 : (len + c.N - 1) / c.N;
-            for (int64_t f = 0; f < nf; ++f) {
+            const int step = c.L <= 4096 ? 2 : 1;   // prime_pers_kernel: frames 2p and 2p + 1 of a clip travel together
+            for (int64_t f = 0; f < nf; f += step) {
                 const int64_t s = f * c.N, left = len - s;
                 PrimeItem it;
                 it.start = offsets[cidx] + s;
                 it.valid = (int)(left >= c.N ? c.N : left);
                 it.cand = (int)k;
-                it.slot = slot++;
+                it.slot = slot;
+                it.valid_b = 0;
+                it.pad = 0;
+                if (step == 2 && f + 1 < nf) {
+                    const int64_t left_b = left - c.N;
+                    it.valid_b = (int)(left_b >= c.N ? c.N : left_b);
+                }
+                slot += it.valid_b ? 2 : 1;
                 by_cand[k].push_back(it);
             }
         }
