@@ -501,8 +501,19 @@ struct If0Plan {
     double* d_window = nullptr;
     cx<double>* d_tw = nullptr;
     cx<double>* d_twn = nullptr;
+    cx<double>* d_twn_r = nullptr;   // [2][8][H/8], H = frame/2: W_{2NF}^(2j+P) in the register order of the DIF engine (if0_split_body)
     If0Wfir wf;
 };
+
+// frequency held by register e of thread t after dif_fft_keep_last<H>
+template <int H>
+static int if0_reg_freq_t(int t, int e) {
+    constexpr int RL = DifPlan<H>::radix(DifPlan<H>::n - 1);
+    return dif_freq<H>(dif_last_pos<H>(t, e / RL, e % RL));
+}
+static int if0_reg_freq(int H, int t, int e) {
+    return H == 512 ? if0_reg_freq_t<512>(t, e) : (H == 1024 ? if0_reg_freq_t<1024>(t, e) : (H == 2048 ? if0_reg_freq_t<2048>(t, e) : if0_reg_freq_t<4096>(t, e)));
+}
 
 // Slowest pole radius of the per-channel chain (2 x resonator 1, 2 x resonator 2: radius A each; the 12 all-pass
 // stages of the warped FIR: |a|; the Butterworth low-pass at the channel frequency: sqrt(a2)), computed from the SAME
@@ -529,7 +540,7 @@ int remez_taps_for(mpx_ctx* ctx, int fs, double* c13);  // mpx_esacf.hip
 
 static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan) {
     char keyb[256];
-    snprintf(keyb, sizeof keyb, "if0_%d_%d_%d_%.17g_%.17g", fs, p.frame_size, p.channels, p.zeta0, p.zeta1);
+    snprintf(keyb, sizeof keyb, "if0r3_%d_%d_%d_%.17g_%.17g", fs, p.frame_size, p.channels, p.zeta0, p.zeta1);
     const std::string key = keyb;
     int rc = remez_taps_for(ctx, fs, plan.wf.c);
     if (rc) return rc;
@@ -540,6 +551,7 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
         plan.d_window = (double*)it->second[1];
         plan.d_tw = (cx<double>*)it->second[2];
         plan.d_twn = (cx<double>*)it->second[3];
+        plan.d_twn_r = (cx<double>*)it->second[4];
         return MPX_OK;
     }
     std::vector<If0ChanCoef> coefs(p.channels);
@@ -590,8 +602,16 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
     plan.d_window = (double*)upload(ctx, win.data(), win.size() * sizeof(double));
     plan.d_tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
     plan.d_twn = (cx<double>*)upload(ctx, twn.data(), twn.size() * sizeof(cx<double>));
-    if (!plan.d_coefs || !plan.d_window || !plan.d_tw || !plan.d_twn) return MPX_ENOMEM;
-    ctx->misc_plans[key] = {plan.d_coefs, plan.d_window, plan.d_tw, plan.d_twn};
+    {
+        const int H = NF / 2, T = H / 8;
+        std::vector<cx<double>> tr((size_t)2 * H);
+        for (int P = 0; P < 2; ++P)
+            for (int e = 0; e < 8; ++e)
+                for (int t = 0; t < T; ++t) tr[((size_t)P * 8 + e) * T + t] = twn[2 * if0_reg_freq(H, t, e) + P];
+        plan.d_twn_r = (cx<double>*)upload(ctx, tr.data(), tr.size() * sizeof(cx<double>));
+    }
+    if (!plan.d_coefs || !plan.d_window || !plan.d_tw || !plan.d_twn || !plan.d_twn_r) return MPX_ENOMEM;
+    ctx->misc_plans[key] = {plan.d_coefs, plan.d_window, plan.d_tw, plan.d_twn, plan.d_twn_r};
     return MPX_OK;
 }
 
@@ -689,6 +709,113 @@ __global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_dif_kernel(const doub
     }
 }
 
+// Round 3: the same transform pair, ONE parity per workgroup.  A workgroup that computes both parities carries 17
+// accumulators across the channel loop next to two transforms' worth of temporaries: under the 128 registers that two
+// workgroups per CU allow, 184 bytes per lane went to scratch, and each parity fetched the frame's samples again -- measured
+// HBM traffic 3.2 x the front end's output.  Split by parity, a workgroup keeps 8 accumulators (+ the Nyquist bin),
+// prefetches the next channel's samples under the current transform and stays in registers; the two workgroups of a frame
+// sit on the same XCD (block ids 8 apart) and start together, so the second read of a frame's samples is an L2 / MALL hit.
+template <int NF, int P, bool POW1, int IF0_PF>
+__device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __restrict__ yc, const If0Frame fr, int channels,
+                                               double power, const double* __restrict__ window, const cx<double>* __restrict__ twNF,
+                                               const cx<double>* __restrict__ twn, const cx<double>* __restrict__ twn_r,
+                                               double* __restrict__ row) {
+    constexpr int H = NF / 2, T = H / 8;
+    using PL = DifPlan<H>;
+    constexpr int RL = PL::radix(PL::n - 1);
+    const int tid0 = threadIdx.x;
+    DifTwiddles<H, double> twd;
+#pragma unroll
+    for (int i = 0; i < PL::n - 1; ++i) twd.w[i] = twNF[2 * ((tid0 & (PL::stride(i) - 1)) * (H / PL::block(i)))];  // W_H = W_NF^2
+    double acc[8], acc_nyq = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    // samples 2m, 2m + 1 of the frame, m = tid + r T.  The front end writes whole frames (the filters ring on past the end
+    // of a clip), the reference pads the FILTERED signal with zeros: loads are unconditional, samples from `valid` on are
+    // replaced by zeros (selects, no branches).
+    const double* src = yc + fr.yc_base;
+    cx<double> xn[8];
+    auto fetch = [&](const double* __restrict__ p, int tid) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xn[r] = *reinterpret_cast<const cx<double>*>(p + 2 * (tid + r * T));
+    };
+    fetch(src, tid0);
+    for (int ch = 0; ch < channels; ++ch) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // nothing below may be hoisted out of the channel loop (registers)
+        cx<double> regs[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int m = tid + r * T;
+            const cx<double> w = *reinterpret_cast<const cx<double>*>(window + 2 * m);
+            // (the select sits on the sample, not on the product: otherwise the compiler makes the WINDOW load conditional,
+            //  a branch and a full wait per point)
+            regs[r] = {(2 * m < fr.valid ? xn[r].x : 0.0) * w.x, (2 * m + 1 < fr.valid ? xn[r].y : 0.0) * w.y};
+            if (P) regs[r] = cmul(regs[r], twNF[m]);
+        }
+        if (IF0_PF == 2)
+        // the next channel's samples travel under this channel's transform (the last channel re-reads itself)
+        fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
+        dif_fft_keep_last<H, double>(buf, twd, regs, tid);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) buf[sigma<H>(dif_last_pos<H>(tid, e / RL, e % RL))] = regs[e];
+        if (IF0_PF == 1)
+        fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = dif_freq<H>(dif_last_pos<H>(tid, e / RL, e % RL));
+            const int jm = P ? H - 1 - j : (H - j) & (H - 1);   // Z[NF - k] lives in the same half-transform
+            const cx<double> A = regs[e];
+            cx<double> B = buf[sigma<H>(dif_pos<H>(jm))];
+            B.y = -B.y;
+            const cx<double> E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
+            const cx<double> D = {0.5 * (A.x - B.x), 0.5 * (A.y - B.y)};
+            // split twiddle W_{2NF}^(2j+P) from the table in register order (by bin it was a 16-byte gather per lane)
+            const cx<double> X = cadd(E, mul_mi(cmul(twn_r[(P * 8 + e) * T + tid], D)));
+            const double mag = sqrt(X.x * X.x + X.y * X.y);  // |X| of audio-range data: no need for hypot's scaling
+            acc[e] += POW1 ? mag : pow(mag, power);
+            if (!P && j == 0) {  // bin NF pairs Z[0] with itself
+                const cx<double> Xn = cadd(E, mul_mi(cmul(twn[NF], D)));
+                const double mn = sqrt(Xn.x * Xn.x + Xn.y * Xn.y);
+                acc_nyq += POW1 ? mn : pow(mn, power);
+            }
+        }
+        if (IF0_PF == 0)
+        fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
+        __syncthreads();  // the mirror reads are done before the next transform writes buf
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int j = dif_freq<H>(dif_last_pos<H>(tid0, e / RL, e % RL));
+        const int k = 2 * j + P;
+        row[k] = acc[e];
+        if (k > 0) row[2 * NF - k] = acc[e];  // |X[N-k]| = |X[k]| for a real frame
+        if (!P && j == 0) row[NF] = acc_nyq;
+    }
+}
+
+template <int NF, bool POW1, int PF>
+__global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_split_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
+                                                                       long long nframes, int channels, double power,
+                                                                       const double* __restrict__ window,
+                                                                       const cx<double>* __restrict__ twNF,  // W_NF^j, j < NF
+                                                                       const cx<double>* __restrict__ twn,   // W_{2NF}^k, k <= NF
+                                                                       const cx<double>* __restrict__ twn_r, // the same, register order
+                                                                       double* __restrict__ ut) {            // [F, 2*NF]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    // block b = 16 q + 8 P + r  ->  frame 8 q + r, parity P: the two workgroups of a frame are 8 block ids apart (same XCD)
+    const long long b = blockIdx.x;
+    const long long f = (b >> 4) * 8 + (b & 7);
+    const int P = (int)(b >> 3) & 1;
+    if (f >= nframes) return;
+    const If0Frame fr = frames[f];
+    double* row = ut + (size_t)f * 2 * NF;
+    if (P) if0_split_body<NF, 1, POW1, PF>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+    else if0_split_body<NF, 0, POW1, PF>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+}
+
 template <int NF, int T>
 static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int channels,
                                double power, const If0Plan& plan, double* ut, hipStream_t st) {
@@ -699,13 +826,23 @@ static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* f
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, channels, power, plan.d_window, plan.d_tw,
                            plan.d_twn, ut);
-    } else {
+    } else if (dev_env("MPX_IF0_BOTH_PARITIES")) {   // round 2: one workgroup per frame computes both parities
         const size_t lds = sizeof(cx<double>) * (NF / 2);
         auto kern = if0_spectrum_dif_kernel<NF>;
         if (lds > 48 * 1024)
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(NF / 16), lds, st, yc, frames, channels, power, plan.d_window,
                            plan.d_tw, plan.d_twn, ut);
+    } else {
+        const size_t lds = sizeof(cx<double>) * (NF / 2);
+        const int pf = dev_env_int("MPX_IF0_PF", 1);
+        auto kern = power == 1.0 ? (pf == 2 ? if0_spectrum_split_kernel<NF, true, 2> : (pf == 1 ? if0_spectrum_split_kernel<NF, true, 1> : if0_spectrum_split_kernel<NF, true, 0>))
+                                 : if0_spectrum_split_kernel<NF, false, 0>;
+        if (lds > 48 * 1024)
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const long long groups = ((nf + 7) / 8) * 16;
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(NF / 16), lds, st, yc, frames, nf, channels, power, plan.d_window,
+                           plan.d_tw, plan.d_twn, plan.d_twn_r, ut);
     }
     MPX_HIP(ctx, hipGetLastError());
     return MPX_OK;
