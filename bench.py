@@ -318,16 +318,79 @@ def kernel_models(n, mh, channels=70, nf=8192):
         "peakpick_kernel": (8 * mh, 4 * mh, "frame"),
         "scatter_kernel": (96, 0, "frame"),
         # Iterative-F0, unit = sample (front end) or frame (spectra, search)
-        "if0_frontend_kernel": (4 + 8 * channels, 110 * channels, "sample"),   # 17 IIR stages + 13-tap FIR per channel and sample
-        "if0_spectrum_kernel": (8 * nf * channels + 16 * nf, channels * (2.5 * 2 * nf * math.log2(2 * nf) + nf), "frame"),
-        "if0_periodicity_kernel": (3 * 16 * nf, 0, "frame"),
+        # COMPULSORY bytes: the samples in once (4 B) and 12 doubles out per frame; what the three kernels hand
+        # each other through HBM -- 8 B x channels per sample from the front end to the spectra, the 2 nf-bin summary
+        # spectrum to the period search -- is INTERMEDIATE traffic and listed separately (INTERMEDIATE_BYTES below)
+        "if0_frontend_kernel": (4, 110 * channels, "sample"),   # 17 IIR stages + 13-tap FIR per channel and sample
+        "if0_spectrum_kernel": (0, channels * (2.5 * 2 * nf * math.log2(2 * nf) + nf), "frame"),
+        "if0_periodicity_kernel": (96, 0, "frame"),
     }
+
+
+# profile marks of the library (mpx_profile_*) -> kernels they cover, as the profiler names them
+MARK_KERNELS = {"prime_kernel": ("prime_pers_kernel", "prime_kernel"),
+                "if0_spectrum_kernel": ("if0_spectrum_split_kernel", "if0_spectrum_dif_kernel", "if0_spectrum_kernel"),
+                "he_kernel": ("he_wave_kernel", "he_kernel", "he_blue_kernel")}
+_TRAFFIC = None
+
+
+def measured_traffic(pmc_workload, mark):
+    """HBM bytes of the launches one profile mark covers, inside one workload of scripts/pmc_workloads.py, from the last
+    PMC collection (profiles/traffic_latest.json; bench.py cannot run rocprofv3 on itself).  (bytes, note) or (None, None)."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
+                _TRAFFIC = json.load(fh)
+        except Exception:
+            _TRAFFIC = {}
+    ks = _TRAFFIC.get("kernels", {}).get(pmc_workload, {})
+    total, hit = 0.0, []
+    for name, shapes in ks.items():
+        base = name.split("<")[0]
+        if any(base == p for p in MARK_KERNELS.get(mark, (mark,))):
+            # a mark covers every launch shape of its kernels in the call (Prime-multiF0: one launch per chirp-z class)
+            total += sum(sh["bytes_per_launch"] for sh in shapes)
+            hit.append(name)
+    if not hit:
+        return None, None
+    return total, "round %s PMC, %s: %s" % (_TRAFFIC.get("round"), pmc_workload, ", ".join(sorted(hit)))
+
+
+def with_traffic(r, pmc_workload, mark, launches=1):
+    """Fill roofline.traffic (bytes per call of the marked kernels x launches) and the ratio to the compulsory bytes."""
+    if r is None:
+        return r
+    marks = mark.split("+")
+    tot, notes = 0.0, []
+    for m in marks:
+        b, note = measured_traffic(pmc_workload, m)
+        if b is None:
+            return r
+        tot += b
+        notes.append(note)
+    r["traffic"] = tot * launches
+    r["traffic_note"] = "HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of these launches; " + "; ".join(notes)
+    comp = r.get("bytes_per_unit", 0) * r.get("units_per_launch", 0)
+    if r.get("compulsory_bytes"):
+        comp = r["compulsory_bytes"]
+    if comp:
+        r["compulsory_bytes"] = comp
+        r["wasted_traffic_ratio"] = r["traffic"] / comp
+    return r
 
 
 def he_kernel_name(f32):
     """The dominant kernel of the headline step: fp64 4096-sample frames run the wave-per-frame kernel (csrc/mpx_he_wave.hpp),
     fp32 the workgroup-per-frame one."""
     return "he_kernel<4096,256,float>" if f32 else "he_wave_kernel<8,4>"
+
+
+def intermediate_bytes(name, channels=70, nf=8192):
+    """Bytes per unit a kernel moves through HBM that are NOT compulsory: hand-offs between the kernels of one method."""
+    return {"if0_frontend_kernel": 8 * channels,                      # writes [channel][t] fp64 for the spectra
+            "if0_spectrum_kernel": 8 * nf * channels + 16 * nf,        # reads it back, writes the 2 nf-bin summary spectrum
+            "if0_periodicity_kernel": 3 * 16 * nf}.get(name, 0)        # summary spectrum in, residual / detected spectra
 
 
 def roofline_of(name, ms, units, model):
@@ -343,6 +406,10 @@ def roofline_of(name, ms, units, model):
     r.update({"kernel": name, "kernel_ms": ms, "units_per_launch": units, "unit_of_work": unit,
               "bytes_per_unit": b, "flops_per_unit": f, "hbm_frac": hbm_frac, "valu_f64_frac": valu_frac,
               "traffic": None})
+    ib = intermediate_bytes(name)
+    if ib:
+        r["intermediate_bytes_per_unit"] = ib
+        r["hbm_frac_with_intermediate"] = (b + ib) * units / (ms * 1e-3) / HBM_PEAK if ms > 0 else 0.0
     return r
 
 
@@ -360,6 +427,7 @@ def fit_roofline(kms, stats):
     return {"bound": "valu_f64", "achieved": fl / 1e12, "peak": F64_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl / F64_PEAK,
             "kernel": "peakfit_kernel+coopfit_kernel", "kernel_ms": ms, "units_per_launch": stats["evaluations"],
             "unit_of_work": "function evaluation", "bytes_per_unit": 0, "flops_per_unit": FLOPS_PER_FIT_EVAL,
+            "compulsory_bytes": stats["fits"] * 180,   # a fit's 21-sample window in (168 B), centre + flag out (12 B)
             "hbm_frac": hbm / HBM_PEAK, "valu_f64_frac": fl / F64_PEAK, "traffic": None, "fits": stats["fits"],
             "evaluations_per_fit": stats["evaluations"] / max(stats["fits"], 1), "fits_finished_cooperatively": stats["parked"]}
 
@@ -383,12 +451,22 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--streams", type=int, default=4,
                     help="batches in flight: step i goes to context/stream i %% S (1 = strictly one launch after the other)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed loop is run this many times, each bracketed by barrier + synchronize; the MEDIAN is "
+                         "reported (the driver's short run, K = 20, is 0.8 ms of GPU time: one sample of it is noise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--workloads", default="esacf_clips_4096,esacf_stft_8192,corpus_4096_all_methods,if0_stream_1h")
     ap.add_argument("--signals", type=int, default=NSIG, help="distinct input signals the steps rotate over")
     ap.add_argument("--f32", action="store_true", help="opt-in fp32 engine (not the headline)")
     args = ap.parse_args()
+
+    # Nothing in the environment may change what is measured: the release library reads no development switches, and this
+    # script refuses to run with any MPX_* variable other than its own two set (MPX_LIB_PATH would swap the library,
+    # MPX_DETERMINISTIC the fit scheduling).
+    foreign = sorted(k for k in os.environ if k.startswith("MPX_") and k not in ("MPX_BENCH_STUB", "MPX_BENCH_CPU_BUDGET"))
+    if foreign:
+        sys.exit("bench.py: unset %s (bench numbers are taken with the default library and defaults only)" % ", ".join(foreign))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -407,6 +485,9 @@ def main():
     import chord_detection_amd as cd
 
     if stub is None:
+        from chord_detection_amd import _lib
+        if _lib.load().mpx_dev_knobs():
+            sys.exit("bench.py: the loaded library was built with -DMPX_DEV_KNOBS (development switches); use the release build")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
         make_engine = lambda: cd.Engine(local_rank, f32=args.f32)
@@ -469,38 +550,46 @@ def main():
     if world > 1:  # the job's one collective, once untimed: RCCL sets its rings up on first use
         sync_engines()
         dist.all_gather([torch.empty_like(d_sums) for _ in range(world)], d_sums)
-    barrier()
-    t0 = time.perf_counter()
-    th0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    host_enqueue_ms = 1e3 * (time.perf_counter() - th0) / max(steps, 1)
-    gathered = None
-    if world > 1:
-        sync_engines()
-        gathered = [torch.empty_like(d_sums) for _ in range(world)]
-        dist.all_gather(gathered, d_sums)          # one RCCL gather of the 12-vectors, at the end
-    else:
-        sync_engines()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    # The timed region, `repeats` times: EXACTLY K steps between barrier + synchronize on both sides, the rank maximum of
+    # each repeat, and the median of the repeats is what `value` is computed from (every repeat is listed in the output).
+    repeats = max(1, args.repeats)
+    rep_s, host_enqueue_ms, gathered = [], 0.0, None
+    for rep in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        th0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        host_enqueue_ms = 1e3 * (time.perf_counter() - th0) / max(steps, 1)
+        if world > 1:
+            sync_engines()
+            gathered = [torch.empty_like(d_sums) for _ in range(world)]
+            dist.all_gather(gathered, d_sums)          # one RCCL gather of the 12-vectors, at the end
+        else:
+            sync_engines()
+        barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rep_s.append(float(t.item()))
+    elapsed = sorted(rep_s)[len(rep_s) // 2]
     sums = d_sums[:steps].cpu().numpy()
 
     # the same K steps strictly one launch after the other on ONE context/stream (what the per-launch roofline describes)
-    barrier()
-    t1 = time.perf_counter()
-    for i in range(steps):
-        step(i, eng)
-    eng.synchronize()
-    barrier()
-    one = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(one, op=dist.ReduceOp.MAX)
-    elapsed_one = float(one.item())
+    one_s = []
+    for rep in range(repeats):
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            step(i, eng)
+        eng.synchronize()
+        barrier()
+        one = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(one, op=dist.ReduceOp.MAX)
+        one_s.append(float(one.item()))
+    elapsed_one = sorted(one_s)[len(one_s) // 2]
 
     # HIP events on that stream: the full step (with the in-kernel reduction) ...
     reps = max(min(steps, 2000), 50)
@@ -532,14 +621,8 @@ def main():
     if steps and not np.allclose(sums[0], d_frames.sum(0).cpu().numpy(), rtol=1e-10):
         sys.exit("bench: fused chroma sum does not match the sum of the per-frame rows")
 
-    traffic, traffic_note = None, None
-    try:  # HBM bytes per launch from the last PMC probe of this kernel (bench.py cannot run rocprofv3 on itself)
-        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as fh:
-            tr = json.load(fh)
-        if tr.get("kernel") == he_kernel_name(args.f32):
-            traffic, traffic_note = tr["bytes_per_launch"], tr.get("method")
-    except Exception:
-        traffic = None
+    # HBM bytes per launch from the last PMC collection of this kernel (bench.py cannot run rocprofv3 on itself)
+    traffic, traffic_note = measured_traffic("he", "he_kernel")
 
     workloads = {}
     if not args.headline_only:
@@ -569,17 +652,22 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if args.f32 else "f64",
             "data": "synthetic",
+            "engine": "hip" if stub is None else "stub",
+            "ms_per_step_repeats": [1e3 * v / max(steps, 1) for v in rep_s],
             "value_one_in_flight": total_frames / elapsed_one,
             "ms_per_step_one_in_flight": 1e3 * elapsed_one / max(steps, 1),
             "config": {"workload": "Harmonic Energy STFT->chromagram, 8192 synthetic 44.1 kHz frames per GPU, "
                                    "4096-pt FFT hop 1024 (BASELINE.json configs[1])",
                        "frames_per_gpu": FRAMES, "fft": N_FFT, "hop": HOP, "fs": FS, "untimed_preheat_ms": PREHEAT_MS,
+                       "repeats": repeats, "repeat_statistic": "median",
                        "batches_in_flight": nstreams, "distinct_input_signals": nsig,
                        "input_bytes_rotated_over": int(nsig * n * 4),
                        "sharding": "frames per rank, no data-path collective; one RCCL all_gather of 12-vectors at the end"},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": traffic,
                          "traffic_note": "bytes/launch; %s; algorithmic = %d" % (traffic_note, B_ALG * FRAMES),
+                         "compulsory_bytes": B_ALG * FRAMES,
+                         "wasted_traffic_ratio": (traffic / (B_ALG * FRAMES)) if traffic else None,
                          "kernel": kname,
                          "kernel_ms": kern_ms, "bytes_per_frame": B_ALG, "frames_per_launch": FRAMES,
                          "step_ms_hip_events": step_ms_events, "host_enqueue_ms_per_step": host_enqueue_ms,
@@ -669,6 +757,9 @@ def wl_esacf_clips(c):
            "rooflines": {k: roofline_of(k, ms, frames, models[k]) for k, ms in kms.items() if k in models}}
     if stats:
         rec["rooflines"]["peakfit_kernel+coopfit_kernel"] = fit_roofline(kms, stats)
+    for k, r in rec["rooflines"].items():
+        with_traffic(r, "esacf_clips", k)
+    with_traffic(rec["roofline"], "esacf_clips", rec["roofline"]["kernel"])
     rec["hbm_frac_whole_path"] = (4 * frame + 48) * rec["value"] / c["world"] / HBM_PEAK
     if _cpu_rec(c, "esacf_clips"):
         rec["cpu_baseline"] = _cpu_rec(c, "esacf_clips")
@@ -733,6 +824,11 @@ def wl_esacf_stft(c):
            "rooflines": {k: roofline_of(k, ms, nf, models[k]) for k, ms in kms.items() if k in models},
            "hbm_frac_whole_path": B_ALG * nf / wall1 / HBM_PEAK,
            "hbm_frac_whole_path_three_in_flight": B_ALG * nf / wall3 / HBM_PEAK}
+    if stats:
+        rec["rooflines"]["peakfit_kernel+coopfit_kernel"] = fit_roofline(kms, stats)
+    for k, r in rec["rooflines"].items():
+        with_traffic(r, "esacf_stft", k)
+    with_traffic(rec["roofline"], "esacf_stft", rec["roofline"]["kernel"])
     if _cpu_rec(c, "esacf_stft"):
         rec["cpu_baseline"] = _cpu_rec(c, "esacf_stft")
     return rec
@@ -804,6 +900,16 @@ def wl_corpus(c):
             rec["roofline"] = roofline_of(dom, ktot[dom], units.get(dom, frames1), models[dom])
         else:
             rec["roofline"] = {"kernel": dom, "kernel_ms": ktot[dom], "bound": "latency", "frac": None, "traffic": None}
+        rec["rooflines"] = {k: roofline_of(k, ms, units.get(k, frames1), models[k]) for k, ms in ktot.items() if k in models}
+        # PMC counters were taken on ONE 1024-clip chunk of the driver (scripts/pmc_workloads.py): x chunks per GPU
+        chunks = -(-per // 1024)
+        pmc_wl = {"prime_kernel": "prime", "if0_frontend_kernel": "if0_clips", "if0_spectrum_kernel": "if0_clips",
+                  "if0_periodicity_kernel": "if0_clips"}
+        for k, r in list(rec["rooflines"].items()) + [(rec["roofline"].get("kernel"), rec["roofline"])]:
+            # (the ESACF side was counted on 4096 clips at once)
+            with_traffic(r, pmc_wl.get(k, "esacf_1023"), k, launches=chunks if k in pmc_wl else per / 4096.0)
+        rec["kernels_ms_note"] = ("sums over the driver's three contexts, whose kernels overlap on the GPU: HIP-event times of "
+                                  "kernels that share the machine (alone, per 1024-clip chunk: scripts/dev/prime_time.py, if0_time.py)")
     if _cpu_rec(c, "corpus"):
         rec["cpu_baseline"] = _cpu_rec(c, "corpus")
     return rec
@@ -855,7 +961,9 @@ def wl_if0_stream(c):
     if rank != 0:
         return None
     assert frames.shape == (total_frames, 12)
-    rec = {"value": secs / wall, "unit": "x real time", "wall_s": wall, "first_pass_wall_s": cold, "scaling": "strong",
+    rec = {"value": secs / wall, "unit": "x real time", "wall_s": wall, "first_pass_wall_s": cold,
+           "value_first_pass": secs / cold, "value_note": "`value` is the second pass of the process (workspaces allocated); "
+           "`value_first_pass` includes the first hipMalloc of the contexts' workspaces (tens of GB)", "scaling": "strong",
            "dtype": "f64", "frames": total_frames,
            "config": {"workload": "Iterative-F0, one %.0f s stream @%d Hz, frames of %d, time-sharded over the GPUs with a "
                                   "65536-sample halo, one all_gather of [frames, 12] (BASELINE.json configs[4]); the stream "
@@ -870,6 +978,9 @@ def wl_if0_stream(c):
         rec["kernels_ms_note"] = "one context, first %.0f s of this rank's shard" % (prof_samples / fs)
         rec["roofline"] = roofline_of(dom, kms[dom], units[dom], models[dom])
         rec["rooflines"] = {k: roofline_of(k, ms, units[k], models[k]) for k, ms in kms.items() if k in units}
+        for k, r in list(rec["rooflines"].items()) + [(dom, rec["roofline"])]:
+            with_traffic(r, "if0_stream", k)
+        rec["hbm_frac_whole_path"] = (4.0 * n + 96.0 * total_frames) / wall / HBM_PEAK   # samples in once, 12 doubles per frame out
     if _cpu_rec(c, "if0"):
         rec["cpu_baseline"] = _cpu_rec(c, "if0")
     return rec

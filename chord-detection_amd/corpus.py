@@ -41,8 +41,9 @@ def clip_notes(clip_id):
 def synth_chunk(clip_ids, fs, seconds, device=None):
     """float32 [len(clip_ids), fs*seconds] polyphonic clips: every note has 8 harmonics decaying by 0.7,
     white noise at 0.003, peak-normalised to 0.9.  Tones are summed in float64 with torch on `device`
-    (CPU when None); the noise stream is seeded by the first clip id of the chunk, so a corpus is
-    reproducible for a fixed chunking and device type."""
+    (CPU when None).  The noise is a counter-based hash of (clip id, sample index) -- no generator state -- so a clip is
+    the same samples whatever chunk, rank or shard it is synthesised in (a sharded corpus equals the unsharded one exactly,
+    for a given device type)."""
     import torch
     dev = torch.device(device) if device is not None else torch.device("cpu")
     n = int(round(fs * seconds))
@@ -60,11 +61,27 @@ def synth_chunk(clip_ids, fs, seconds, device=None):
     for r0 in range(0, len(clip_ids), 32):  # [32 clips, 32 partials, n] float64 at a time
         w = tab_t[r0:r0 + 32]
         out[r0:r0 + 32] = (w[:, :, 2:3] * torch.sin(w[:, :, 0:1] * t + w[:, :, 1:2])).sum(dim=1)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(SEED + int(clip_ids[0]) if len(clip_ids) else SEED)
-    out += 0.003 * torch.randn(out.shape, dtype=torch.float64, device=dev, generator=gen)
+    if len(clip_ids):
+        out += 0.003 * _clip_noise(torch.tensor([int(c) for c in clip_ids], dtype=torch.int64, device=dev), n)
     out *= 0.9 / out.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
     return out.to(torch.float32)
+
+
+def _clip_noise(ids, n):
+    """Approximately normal noise [len(ids), n] as a pure function of (clip id, sample index): the sum of four uniforms
+    from an integer hash (variance 1), float64.  int64 arithmetic wraps identically on every device."""
+    import torch
+    j = torch.arange(n, dtype=torch.int64, device=ids.device)
+    acc = torch.zeros((ids.shape[0], n), dtype=torch.float64, device=ids.device)
+    for k in range(4):
+        h = (ids[:, None] + SEED) * 0x9E3779B1 + j[None, :] * 0x85EBCA77 + (k + 1) * 0xC2B2AE3D
+        h = (h ^ (h >> 15)) & 0xFFFFFFFF
+        h = (h * 0x2C1B3C6D) & 0xFFFFFFFF
+        h = (h ^ (h >> 12)) & 0xFFFFFFFF
+        h = (h * 0x297A2D39) & 0xFFFFFFFF
+        h = (h ^ (h >> 15)) & 0xFFFFFFFF
+        acc += h.to(torch.float64) * (1.0 / 4294967296.0) - 0.5
+    return acc * math.sqrt(3.0)   # four uniforms of variance 1/12 each
 
 
 def _engine_compute(method, clips, fs, device, note_names="unicode"):
@@ -124,7 +141,14 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
 
     def start_ahead(c0):   # host part (the partial tables: Python loops) and enqueueing in a thread of their own:
         box = []           # ctypes releases the GIL while the main thread is inside the engine
-        th = threading.Thread(target=lambda: box.append(synth_ahead(c0)))
+
+        def work():
+            try:
+                box.append(("ok", synth_ahead(c0)))
+            except BaseException as exc:   # handed to the main thread, which re-raises it with its cause
+                box.append(("err", exc))
+
+        th = threading.Thread(target=work)
         th.start()
         return th, box
 
@@ -132,9 +156,9 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
     for ci, c0 in enumerate(starts):
         t_s = time.perf_counter()
         ahead[0].join()
-        if not ahead[1]:
-            raise RuntimeError("corpus synthesis thread failed")
-        ids, clips, ev = ahead[1][0]
+        if not ahead[1] or ahead[1][0][0] != "ok":
+            raise RuntimeError("corpus synthesis of the chunk at clip %d failed" % c0) from (ahead[1][0][1] if ahead[1] else None)
+        ids, clips, ev = ahead[1][0][1]
         if ev is not None:
             ev.synchronize()   # the engines read the chunk through its raw pointer on their own streams
         ahead = start_ahead(starts[ci + 1]) if ci + 1 < len(starts) else None
@@ -186,6 +210,8 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
         if side4 is not None:
             side4.join()
         if failed:
+            if ahead is not None:   # do not leave the next chunk's synthesis running (and allocating) behind the exception
+                ahead[0].join()
             raise failed[0]
     return lo, hi, out, spent
 

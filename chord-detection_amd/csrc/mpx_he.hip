@@ -635,9 +635,15 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
         a.partial = (double*)ctx->d_partials.p;
     }
     const size_t lds = (size_t)hw_shared_bytes(HEW_ROUNDS, plan.nwin) + (size_t)HEW_WAVES * HW_XBUF;
-    auto kern = he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false>;
+    // every frame whole, inside the signal and 8-byte aligned: the instantiation without the ragged loader (no scratch)
+    const bool all_fast = !d_desc && (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0 &&
+                          (num_frames - 1) * (long long)hop + 4096 <= n;
+    auto kern = all_fast ? he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true> : he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false>;
     if (!ctx->occupancy.count("he_wave_lds")) {
-        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->occupancy["he_wave_lds"] = 1;
     }
     prof_mark(ctx, stream, "he_wave_kernel");

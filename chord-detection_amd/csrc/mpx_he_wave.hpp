@@ -200,17 +200,16 @@ __device__ __forceinline__ void hw_load_frame(float2* raw, const float* __restri
     }
 }
 
-#ifdef HW_FAST_ONLY   // tests/tools/he_wave_check.hip: only the branch-free loader, to read the register allocation
-#define HW_SLOW_PATH 0
-#else
-#define HW_SLOW_PATH 1
-#endif
 // shared LDS tables in front of the waves' buffers (bytes): whalf | slots | twnb | ww | wk | theta powers | frame counter
 __host__ __device__ constexpr int hw_shared_bytes(int rounds, int nwin) {
     return 16384 + 8 * 64 * rounds + 16 * 64 * rounds + ((16 * nwin + 15) & ~15) + 5 * 32 * 16 + 16;
 }
 
-template <int WAVES, int ROUNDS, bool DEBUG>
+// FASTONLY: the host has checked that EVERY frame of the launch is whole, inside the signal and 8-byte aligned (one signal,
+// even hop: the headline shape), so the kernel holds the branch-free loader alone.  The general instantiation carries the
+// ragged loader as well, and the register allocation of a kernel is that of its worst path: with both, 24 bytes per lane
+// of scratch are reserved (and set up per wave) that the fast path never touches.
+template <int WAVES, int ROUNDS, bool DEBUG, bool FASTONLY = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx<double>* dbg) {
     constexpr int N = 4096, T = WAVES * 64, NBP = 64 * ROUNDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -519,10 +518,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
         }
         if (pend_f >= 0) finish_tail();
     };
-    if (fast || !HW_SLOW_PATH)
+    if constexpr (FASTONLY) {
         run(std::true_type{});
-    else
-        run(std::false_type{});
+    } else {
+        if (fast)
+            run(std::true_type{});
+        else
+            run(std::false_type{});
+    }
 
     // Which wave computed a frame is decided at run time, so the sum over frames is taken over the rows, in row order:
     // 16 strided sub-sums per bin, combined in a fixed order.  (The rows were stored by this workgroup: the barrier's

@@ -348,27 +348,22 @@ class _Pinned:
             pass
 
 
-def pinned_empty(n, dtype=np.float32):
+def pinned_empty(n, dtype=np.float32, lib=None):
     """A 1-D NumPy array in pinned host memory (mpx_host_alloc): as an input of the host entry points it crosses PCIe
-    in one DMA instead of going through the staging ring (include/mpx.h, "where the samples live")."""
-    lib = _lib.load()
+    in one DMA from the caller's pages (include/mpx.h, "where the samples live").
+
+    Lifetime: the memory is freed (mpx_host_free) when the LAST array that looks at it dies.  The object that frees it hangs
+    on the ctypes buffer NumPy keeps as the base of every view -- plain-ndarray views (np.asarray, slices, .view(np.ndarray))
+    included -- not on an attribute of the returned array, which such views do not carry."""
+    lib = lib or _lib.load()
     dtype = np.dtype(dtype)
     nbytes = int(n) * dtype.itemsize
     ptr = lib.mpx_host_alloc(nbytes)
     if not ptr:
         raise MemoryError("mpx_host_alloc(%d) failed" % nbytes)
-    owner = _Pinned(lib, ptr)
     buf = (C.c_char * nbytes).from_address(ptr)
-    arr = np.frombuffer(buf, dtype=dtype, count=int(n))
-    arr = arr.view(_PinnedArray)
-    arr._mpx_owner = (owner, buf)
-    return arr
-
-
-class _PinnedArray(np.ndarray):
-    def __array_finalize__(self, obj):
-        self._mpx_owner = getattr(obj, "_mpx_owner", None)
-
+    buf._mpx_owner = _Pinned(lib, ptr)   # dies with the buffer, i.e. after every array built on it
+    return np.frombuffer(buf, dtype=dtype, count=int(n))
 
 
 def get_engine(device=0, f32=False, deterministic=False):

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rates of the host entry points (DESIGN.md "Host <-> device"): the headline Harmonic-Energy signal
-(8192 frames, 33.5 MB) handed over as pageable host memory (staging ring on / off), as pinned host memory, as device
-memory through the host entry point, and resident through the _dev entry point; and a 4096-clip ESACF batch (1.44 GB)."""
+(8192 frames, 33.5 MB) handed over as pageable host memory, as pinned host memory, as device memory through the host entry
+point, and resident through the _dev entry point; and a 4096-clip ESACF batch (1.44 GB) from host memory in ONE piece and in
+2 / 4 / 7 pieces whose copies overlap the kernels of the piece before (bit-equal results asserted).  The piece count is a
+development switch read at mpx_create: run with MPX_LIB_PATH=chord-detection_amd/libmpx_hip_dev.so (`make dev`); with the
+release library every row of the piece sweep is the default (4 pieces) and says so."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -29,14 +32,10 @@ def timed(fn, reps=10):
 
 out = {"signal_MB": mb, "pcie_floor_ms_at_63GBps": mb / 63e3 * 1e3}
 ref = eng.harmonic_energy(x_host, FS, N, HOP)
-for label, src, env in (("pageable_staged", x_host, {}), ("pageable_plain_hipMemcpy", x_host, {"MPX_NO_STAGING": "1"}),
-                        ("pinned", x_pin, {}), ("device_through_host_entry", x_dev, {})):
-    os.environ.pop("MPX_NO_STAGING", None)
-    os.environ.update(env)
+for label, src in (("pageable", x_host), ("pinned", x_pin), ("device_through_host_entry", x_dev)):
     s, r = timed(lambda: eng.harmonic_energy(src, FS, N, HOP))
     assert np.array_equal(r, ref), label
     out[label] = {"ms": 1e3 * s, "frames_per_s": 8192 / s, "GB_per_s": mb / 1e3 / s}
-os.environ.pop("MPX_NO_STAGING", None)
 d_sum = torch.zeros(12, dtype=torch.float64, device=dev)
 def resident():
     eng.harmonic_energy_dev(x_dev.data_ptr(), n, FS, N, HOP, None, d_sum.data_ptr())
@@ -50,11 +49,18 @@ clips_dev = corpus.synth_chunk(list(range(64)), 44100, 2.0, dev).repeat(64, 1).c
 clips_host = clips_dev.cpu().numpy()
 frame = int(44100 * 46.4 / 1000)
 want = eng.esacf_batch(clips_dev, 44100, frame)
-for label, src, env in (("esacf_batch_pageable_staged", clips_host, {}), ("esacf_batch_pageable_plain", clips_host, {"MPX_NO_STAGING": "1"}),
-                        ("esacf_batch_device", clips_dev, {})):
-    os.environ.pop("MPX_NO_STAGING", None)
-    os.environ.update(env)
-    s, r = timed(lambda: eng.esacf_batch(src, 44100, frame), 3)
-    assert np.array_equal(r, want), label
-    out[label] = {"ms": 1e3 * s, "clips_per_s": 4096 / s, "input_GB_per_s": clips_host.nbytes / 1e9 / s}
+from chord_detection_amd import _lib
+dev_build = bool(_lib.load().mpx_dev_knobs())
+out["library_has_dev_knobs"] = dev_build
+s, r = timed(lambda: eng.esacf_batch(clips_dev, 44100, frame), 3)
+out["esacf_batch_device"] = {"ms": 1e3 * s, "clips_per_s": 4096 / s}
+for pieces in (1, 2, 4, 7):
+    os.environ["MPX_COPY_PIECES"] = str(pieces)   # read once, at mpx_create, by the development build only
+    e = cd.Engine(0)
+    s, r = timed(lambda: e.esacf_batch(clips_host, 44100, frame), 3)
+    assert np.array_equal(r, want), pieces
+    out["esacf_batch_pageable_pieces_%d" % pieces] = {"ms": 1e3 * s, "clips_per_s": 4096 / s, "input_GB_per_s": clips_host.nbytes / 1e9 / s,
+                                                       "pieces_in_effect": pieces if dev_build else 4}
+    e.close()
+os.environ.pop("MPX_COPY_PIECES", None)
 print(json.dumps(out, indent=1))

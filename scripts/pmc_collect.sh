@@ -7,6 +7,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/pw_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw_stats -- python3 $GRAFT_REPO_ROOT/scripts/pmc_workloads.py $WL > $OUT/stats.log 2>&1
 cp $(find /tmp/pw_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+cp $(find /tmp/pw_stats -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace.csv
+grep "pmc_workloads order:" $OUT/stats.log | sed "s/.*order: //" > $OUT/order.txt
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
@@ -18,4 +20,4 @@ for C in "FETCH_SIZE" "WRITE_SIZE" \
 done
 cd $GRAFT_REPO_ROOT
 python3 scripts/pmc_report.py $OUT
-rm -f $OUT/pass*.csv
+rm -f $OUT/pass*.csv $OUT/kernel_trace.csv

@@ -38,18 +38,18 @@ def _oracle_sum(x, fs, **kw):
         return o_esacf.esacf_compute(x, fs, **kw)
 
 
-# Ill-conditioned frames SEEN by each check (fixed seeds and a deterministic engine => fixed numbers; measured on MI355X,
-# asserted as "<= measured + 1" so that a change in the last bits of an upstream kernel does not fail the suite):
-#   key -> (frames, fragile, loose): `fragile` = frames on which the reference algorithm itself is ill-conditioned
+# Ill-conditioned frames SEEN by each check (fixed seeds and a deterministic engine => fixed numbers): the table lives in
+# tests/golden/esacf_fragile_frames.json, measured on MI355X (gfx950), and is asserted EXACTLY:
+#   key -> [frames, fragile, loose]: `fragile` = frames on which the reference algorithm itself is ill-conditioned
 #   (oracle.frame_fragility: a 1e-12 relative perturbation of the ESACF row changes its chroma), compared with the oracle
 #   fed the GPU's own ESACF row; `loose` = the ones among them that differ EVEN THEN, which is only accepted in bins an
-#   escaped gaussian fit feeds (oracle.runaway_fit_bins).
-MEASURED = {   # MI355X, round 2 (deterministic engine, default mode): 13 checks, 193 frames, 2 fragile, 1 loose
-    "full_frames/piano_like_Cmaj": (44, 0, 0), "full_frames/poly_seed2": (44, 2, 1),
-    "44100/2046": (7, 0, 0), "44100/2046/params": (7, 0, 0), "44100/2046/noop": (7, 0, 0),
-    "44100/2048/hop1024": (12, 0, 0), "16000/742": (11, 0, 0), "48000/2227": (4, 0, 0), "48000/3000/noop": (3, 0, 0),
-    "48000/4095/noop": (2, 0, 0), "44100/4096/hop1024": (6, 0, 0), "44100/4096/hop1024/elim3": (6, 0, 0),
-}
+#   escaped gaussian fit feeds (oracle.runaway_fit_bins), and within one peak height of the frame's energy.
+# MPX_TEST_FRAGILE_SLACK=n in the environment widens the assertion to "<= measured + n" (another GPU generation, or while
+# re-measuring after a kernel changed the last bits of the ESACF rows); every check also reports its counts as a warning,
+# which `pytest -q` keeps in its summary.
+FRAGILE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "esacf_fragile_frames.json")
+MEASURED = {k: tuple(v) for k, v in json.load(open(FRAGILE_TABLE))["checks"].items()}
+SLACK = int(os.environ.get("MPX_TEST_FRAGILE_SLACK", "0"))
 SEEN = {}
 E2E_FRAGILE_CLIPS = {"poly_seed2"}   # the one golden clip with an ill-conditioned frame (2 of its 44): 8 of 9 clips are strict
 
@@ -79,16 +79,24 @@ def _check_frames(eng, x, fs, frame, per, hop=None, key=None, **kw):
                 continue
             loose += 1
             shifted, bins = o_esacf.runaway_fit_bins(e_gpu[f], fs, **okw)
-            # a failed fit shifts the pairing of all later peaks (quirk A.8); otherwise every escaped fit moves ONE peak
-            # height out of the bin the oracle's rounding put it in, into one other bin
+            # Whatever moved, it is peak heights changing bins: the frame's total changes by at most ONE peak height (a
+            # failed fit drops the last pairing, quirk A.8) -- this bound holds in the shifted case too, where the bins
+            # themselves cannot be predicted without the GPU's own fit centres.
+            peak_cap = float(np.max(e_gpu[f])) * (1.0 + 1e-9) + 1e-12
+            assert abs(float(per[f].sum()) - float(same_input.sum())) <= peak_cap, (key, f, per[f], same_input)
+            assert np.all(per[f] >= 0) and float(np.max(np.abs(per[f] - same_input))) <= peak_cap * max(1, differ.size), (key, f)
+            # otherwise every escaped fit moves ONE peak height out of the bin the oracle's rounding put it in, into one other
             assert shifted or (bins and differ.size <= 2 * len(bins) and set(bins) & set(differ.tolist())), \
                 (key, f, differ.tolist(), bins, per[f], same_input)
     if key is not None:
         SEEN[key] = (int(per.shape[0]), fragile, loose)
-        print("esacf ill-conditioned frames  %-28s frames %4d  fragile %3d  loose %3d  (measured %s)"
-              % (key, per.shape[0], fragile, loose, MEASURED.get(key)))
+        warnings.warn("esacf ill-conditioned frames  %-28s frames %4d  fragile %3d  loose %3d  (table %s)"
+                      % (key, per.shape[0], fragile, loose, MEASURED.get(key)))
         assert key in MEASURED, key
-        assert fragile <= MEASURED[key][1] + 1 and loose <= MEASURED[key][2] + 1, (key, fragile, loose, MEASURED[key])
+        if SLACK:
+            assert fragile <= MEASURED[key][1] + SLACK and loose <= MEASURED[key][2] + SLACK, (key, fragile, loose, MEASURED[key])
+        else:
+            assert (int(per.shape[0]), fragile, loose) == MEASURED[key], (key, (int(per.shape[0]), fragile, loose), MEASURED[key])
     return fragile
 
 
@@ -165,6 +173,30 @@ def test_end_to_end_golden_strings_and_keys(eng, clips, golden_dir):
             if name in expected:
                 print("esacf  %-8s %-20s engine %s  tests/test.py expects %s" % (mode, name, repr(c), expected[name]))
             if fragile:
+                # A clip with an ill-conditioned frame is compared with its fixture bin by bin: bins that no escaped fit of
+                # a fragile frame feeds must match the fixture like everywhere else; the others are reported, and may
+                # differ by at most the peak heights of those frames.
+                want_sum = d[name + "/sum" + sfx]
+                excused, cap = set(), 0.0
+                for r in e_gpu:
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        if not o_esacf.frame_fragility(r, FS):
+                            continue
+                        shifted, bins = o_esacf.runaway_fit_bins(r, FS)
+                    cap += float(np.max(r))
+                    excused |= set(range(12)) if shifted else {b for b in bins if b >= 0}
+                got = c.as_array()
+                differ = [b for b in range(12) if not np.isclose(got[b], want_sum[b], rtol=RTOL_CHROMA, atol=1e-9)]
+                warnings.warn("esacf e2e %-8s %-12s engine %s fixture %s | bins differing from the fixture %s, bins an escaped "
+                              "fit may move %s | engine-fixture per bin %s"
+                              % (mode, name, repr(c), str(d[name + "/repr" + sfx]), differ, sorted(excused),
+                                 np.array2string(got - want_sum, precision=3)))
+                # a peak that changes bins also leaves the bin the fixture had it in: allow that bin too, but bound the move
+                assert len(differ) <= 2 * max(1, len(excused)), (name, mode, differ, sorted(excused))
+                assert not differ or (excused & set(differ)) or excused == set(), (name, mode, differ, sorted(excused))
+                assert float(np.max(np.abs(got - want_sum))) <= cap * (1.0 + 1e-9) + 1e-9, (name, mode, got, want_sum)
+                assert abs(float(got.sum() - want_sum.sum())) <= cap * (1.0 + 1e-9) + 1e-9
                 continue
             np.testing.assert_allclose(c.as_array(), d[name + "/sum" + sfx], rtol=RTOL_CHROMA, atol=1e-9)
             assert repr(c) == str(d[name + "/repr" + sfx])

@@ -1,0 +1,64 @@
+"""CPU: register / scratch budget of the hot kernels, read from hipcc's own resource remarks for gfx950
+(scripts/kernel_resources.py compiles csrc/*.hip device-only with -Rpass-analysis=kernel-resource-usage, ~15 s).
+
+A kernel that DESIGN.md calls scratch-free must stay scratch-free: a spill in a frame loop is reloaded behind the
+prefetch of the next frame (round 2 shipped he_wave_kernel with 24 B/lane that came from its ragged-frame path, and
+if0_spectrum_dif_kernel with 184 B/lane, unnoticed)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+@pytest.fixture(scope="module")
+def table():
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    import kernel_resources
+    return kernel_resources.all_resources()
+
+
+SCRATCH_FREE = [
+    "mpx::he_wave_kernel<8, 4, false, true>",          # headline: every frame whole and aligned
+    "mpx::he_kernel<4096, 256, double>",
+    "mpx::sacf_pfa_kernel<1>", "mpx::sacf_pfa_kernel<2>",
+    "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
+    "mpx::bandsplit_kernel<false>", "mpx::bandsplit_kernel<true>",
+    "mpx::coopfit_kernel", "mpx::pv_enhance_kernel", "mpx::scatter_kernel",
+    "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
+    "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
+    "mpx::if0_frontend_kernel", "mpx::if0_periodicity_kernel",
+]
+# kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
+SCRATCH_CEILING = {
+    "mpx::peakfit_kernel": 40,
+    "mpx::he_wave_kernel<8, 4, false, false>": 24,     # ragged / unaligned frames: the loader with per-sample guards
+}
+# occupancy (waves per SIMD) the launch geometry of the host code counts on
+OCCUPANCY = {
+    "mpx::he_wave_kernel<8, 4, false, true>": 2,
+    "mpx::sacf_pfa_kernel<2>": 4,
+    "mpx::if0_spectrum_split_kernel<8192, true, 1>": 4,
+    "mpx::prime_pers_kernel<1024>": 2,
+    "mpx::peakfit_kernel": 2,
+}
+
+
+def test_hot_kernels_stay_scratch_free(table):
+    missing = [k for k in SCRATCH_FREE + list(SCRATCH_CEILING) + list(OCCUPANCY) if k not in table]
+    assert not missing, "kernels not found in the compile remarks (renamed?): %s" % missing
+    spilled = {k: table[k]["scratch"] for k in SCRATCH_FREE if table[k]["scratch"] != 0}
+    assert not spilled, "scratch in kernels documented as scratch-free: %s" % spilled
+
+
+def test_known_spills_do_not_grow(table):
+    for k, cap in SCRATCH_CEILING.items():
+        assert table[k]["scratch"] <= cap, (k, table[k])
+
+
+def test_occupancy_assumptions(table):
+    for k, occ in OCCUPANCY.items():
+        assert table[k]["occupancy"] >= occ, (k, table[k])

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
     printf("grid %lld x %d, LDS %zu B\n", G, WAVES * 64, lds);
     const long long FD = std::min<long long>(F, 24);
     cx<double>* d_dbg; CK(hipMalloc(&d_dbg, (size_t)F * M * 16));
-    auto kd = he_wave_kernel<WAVES, 4, true>; auto kr = he_wave_kernel<WAVES, 4, false>;
+    auto kd = he_wave_kernel<WAVES, 4, true, true>; auto kr = he_wave_kernel<WAVES, 4, false, true>;
     CK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kd, dim3((unsigned)G), dim3(WAVES * 64), lds, 0, a, d_dbg);
