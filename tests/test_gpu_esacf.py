@@ -48,9 +48,21 @@ def _oracle_sum(x, fs, **kw):
 # re-measuring after a kernel changed the last bits of the ESACF rows); every check also reports its counts as a warning,
 # which `pytest -q` keeps in its summary.
 FRAGILE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "esacf_fragile_frames.json")
-MEASURED = {k: tuple(v) for k, v in json.load(open(FRAGILE_TABLE))["checks"].items()}
+with open(FRAGILE_TABLE) as _fh:
+    MEASURED = {k: tuple(v) for k, v in json.load(_fh)["checks"].items()}
 SLACK = int(os.environ.get("MPX_TEST_FRAGILE_SLACK", "0"))
 SEEN = {}
+RECORD = os.environ.get("MPX_TEST_FRAGILE_RECORD")   # re-measuring: path of a JSON that receives what this run saw
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _record_seen():
+    yield
+    if RECORD:
+        with open(RECORD, "w") as fh:
+            json.dump({"checks": {k: list(v) for k, v in sorted(SEEN.items())}}, fh, indent=1)
+
+
 E2E_FRAGILE_CLIPS = {"poly_seed2"}   # the one golden clip with an ill-conditioned frame (2 of its 44): 8 of 9 clips are strict
 
 
@@ -93,7 +105,9 @@ def _check_frames(eng, x, fs, frame, per, hop=None, key=None, **kw):
         warnings.warn("esacf ill-conditioned frames  %-28s frames %4d  fragile %3d  loose %3d  (table %s)"
                       % (key, per.shape[0], fragile, loose, MEASURED.get(key)))
         assert key in MEASURED, key
-        if SLACK:
+        if RECORD:
+            pass
+        elif SLACK:
             assert fragile <= MEASURED[key][1] + SLACK and loose <= MEASURED[key][2] + SLACK, (key, fragile, loose, MEASURED[key])
         else:
             assert (int(per.shape[0]), fragile, loose) == MEASURED[key], (key, (int(per.shape[0]), fragile, loose), MEASURED[key])
