@@ -105,11 +105,26 @@ def _second_engine(device):
     return _SECOND_ENGINE[device]
 
 
+def synth_block(n_clips, fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, synth_device=None):
+    """This rank's clips, synthesised up front: {first clip id of a chunk: (ids, clips)} for run_corpus(resident=...) --
+    a corpus that is already in HBM when the clock starts (bench.py; 4096 two-second clips are 0.7 GB)."""
+    lo, hi = partition(n_clips, world, rank)
+    out = {}
+    for c0 in range(lo, hi, chunk):
+        ids = list(range(c0, min(c0 + chunk, hi)))
+        out[c0] = (ids, synth_chunk(ids, fs, seconds, synth_device))
+    if synth_device is not None and str(synth_device).startswith("cuda"):
+        import torch
+        torch.cuda.synchronize()
+    return out
+
+
 def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, device=0,
-               compute=None, synth_device=None, overlap=True, note_names="unicode"):
+               compute=None, synth_device=None, overlap=True, note_names="unicode", resident=None):
     """Process this rank's block.  Returns (lo, hi, chroma[hi-lo, len(methods), 12] float64, seconds per method).
     `compute(method, clips, fs, device) -> [n,12]` defaults to the HIP engine's batch entry points; tests
-    substitute a CPU function to exercise the sharding logic without a GPU."""
+    substitute a CPU function to exercise the sharding logic without a GPU.  `resident`: the chunks of synth_block()
+    (same n_clips / chunk / rank / world) -- nothing is synthesised inside the call then."""
     if compute is None:
         compute = _engine_compute
         engine_path = True
@@ -131,6 +146,8 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
         side_stream = torch.cuda.Stream(device=synth_device)
 
     def synth_ahead(c0):
+        if resident is not None:
+            return resident[c0][0], resident[c0][1], None
         ids = list(range(c0, min(c0 + chunk, hi)))
         if side_stream is None:
             return ids, synth_chunk(ids, fs, seconds, synth_device), None
