@@ -81,24 +81,66 @@ __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__
         row_valid[lane] = valid;
     }
     __syncthreads();
-    double z[12];
+    // The chain of a sample is 12 all-pass stages deep plus the band filters: evaluated sample by sample it is ONE
+    // dependent chain of ~30 fp64 operations, and a lone wave (8192 frames are 128 waves on 1024 SIMDs) pays the full
+    // latency on each -- 516 clocks per sample for 240 clocks of issue.  Software pipelining across samples removes that
+    // (the Iterative-F0 front end does the same): in iteration tau all-pass stage i works on sample tau - i, reading what
+    // stage i - 1 produced one iteration earlier, and the band filters on sample tau - 12.  All 13 stage updates of an
+    // iteration are then independent of each other (stages are walked in reverse, so an input is consumed before it is
+    // overwritten).  Every stage performs the operations of the sequential form on the same operands; which product of
+    // a sum of two products the compiler fuses is its choice here as it was there (results agree to an ulp).
+    double z[12], pin[12], pxh[12];   // all-pass state; pipeline registers feeding all-pass i (its input, the partial x_hat)
 #pragma unroll
-    for (int i = 0; i < 12; ++i) z[i] = 0.0;
+    for (int i = 0; i < 12; ++i) z[i] = pin[i] = pxh[i] = 0.0;
     double h1 = 0, h2 = 0, g1 = 0, g2 = 0, l1 = 0, l2 = 0;
+    double fxh = 0.0;                 // x_hat of the sample the band filters take next
+    float xr[BS_TILE];                // the last 16 raw samples (a sample waits 12 iterations for its x_hat)
+#pragma unroll
+    for (int q = 0; q < BS_TILE; ++q) xr[q] = 0.f;
     // The workgroup is ONE wave: its LDS operations execute in program order, so the tiles need no
     // s_barrier -- and above all no __syncthreads(), whose release fence would make every tile wait for its
     // own 16 KB of global stores to retire.  The input of tile t+1 is fetched into registers while tile t runs.
+    // (loads are unconditional, from a clamped address, and the zero padding is a select: with a conditional load the
+    //  compiler branches per element and waits for each row-table read -- 32 LDS round trips per tile, half the time of
+    //  a small batch)
     float nxt[BS_TILE];
     auto fetch = [&](int t0) {
+        long long st[BS_TILE];
+        int vl[BS_TILE];
+#pragma unroll
+        for (int q = 0; q < BS_TILE; ++q) {
+            const int r = (q * 64 + lane) >> 4;
+            st[q] = row_start[r];
+            vl[q] = row_valid[r];
+        }
+#pragma unroll
+        for (int q = 0; q < BS_TILE; ++q) {
+            const int t = t0 + (lane & 15);
+            const bool ok = t < vl[q];
+            const float v = sig[ok ? st[q] + t : 0];
+            nxt[q] = ok ? v : 0.f;
+        }
+    };
+    const int ntiles = (N + BS_TILE - 1) / BS_TILE;
+    // stage out: a tile goes out exactly as it lies, (x_lo, x_hi) pairs, 16 KB contiguous per wave:
+    // band layout [block of 64 frames][tile of 16 samples][frame][sample] (band_index above)
+    auto flush = [&](int tile) {
+        cx<double>* dst = xb + ((size_t)blockIdx.x * ntiles + tile) * (64 * BS_TILE);
 #pragma unroll
         for (int q = 0; q < BS_TILE; ++q) {
             const int e = q * 64 + lane, r = e >> 4, c = e & 15;
-            const int t = t0 + c;
-            nxt[q] = t < row_valid[r] ? sig[row_start[r] + t] : 0.f;
+            dst[e] = {tlo[r][c], thi[r][c]};
+            if (XW) {
+                const int t = tile * BS_TILE + c;
+                if (t < N && lf0 + r < num_frames) xw[(lf0 + r) * (long long)N + t] = twf[r][c];
+            }
         }
     };
     fetch(0);
-    for (int t0 = 0; t0 < N; t0 += BS_TILE) {
+    // block tb runs iterations tau = tb .. tb + 15: it takes in the samples tb .. tb + 15 and puts out the samples
+    // tb - 12 .. tb + 3, i.e. columns 4 .. 15 of output tile tb / 16 - 1 (complete after iteration tb + 11: flushed there)
+    // and columns 0 .. 3 of the next one.  One block past the last input tile drains the pipeline (its input is zeros).
+    for (int tb = 0; tb <= ntiles * BS_TILE; tb += BS_TILE) {
         // ---- stage in: 4 frame rows x 16 samples per instruction
 #pragma unroll
         for (int q = 0; q < BS_TILE; ++q) {
@@ -106,48 +148,59 @@ __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__
             tin[e >> 4][e & 15] = nxt[q];
         }
         wave_lds_fence();
-        if (t0 + BS_TILE < N) fetch(t0 + BS_TILE);
-        // ---- this lane's frame: BS_TILE samples of the chain
-#pragma unroll 4
-        for (int j = 0; j < BS_TILE; ++j) {
-            const double xt = (double)tin[lane][j];
-            double xhat = k.c[0] * xt;
-            double in = xt;
+        if (tb + BS_TILE < N) fetch(tb + BS_TILE);
+        else {
 #pragma unroll
-            for (int i = 0; i < 12; ++i) {
-                const double y = -k.a * in + z[i];  // b0*x + z
-                z[i] = in + k.a * y;                // b1*x - a1*y with b1 = 1, a1 = -a
-                in = y;
-                xhat += k.c[i + 1] * y;
-            }
-            const double r = xt - xhat;
-            const double yh = k.hpb[0] * r + h1;
-            h1 = (h2 + k.hpb[1] * r) - k.hpa[1] * yh;
-            h2 = k.hpb[2] * r - k.hpa[2] * yh;
-            const double rect = yh < 0.0 ? 0.0 : yh;
-            const double yhl = k.lpb[0] * rect + g1;
-            g1 = (g2 + k.lpb[1] * rect) - k.lpa[1] * yhl;
-            g2 = k.lpb[2] * rect - k.lpa[2] * yhl;
-            const double yl = k.lpb[0] * r + l1;
-            l1 = (l2 + k.lpb[1] * r) - k.lpa[1] * yl;
-            l2 = k.lpb[2] * r - k.lpa[2] * yl;
-            tlo[lane][j] = yl;
-            thi[lane][j] = yhl;
-            if (XW) twf[lane][j] = r;
+            for (int q = 0; q < BS_TILE; ++q) nxt[q] = 0.f;
         }
-        wave_lds_fence();
-        // ---- stage out: the tile goes out exactly as it lies, (x_lo, x_hi) pairs, 16 KB contiguous per wave:
-        // band layout [block of 64 frames][tile of 16 samples][frame][sample] (band_index above)
-        {
-            cx<double>* dst = xb + ((size_t)blockIdx.x * ((N + BS_TILE - 1) / BS_TILE) + t0 / BS_TILE) * (64 * BS_TILE);
 #pragma unroll
-            for (int q = 0; q < BS_TILE; ++q) {
-                const int e = q * 64 + lane, r = e >> 4, c = e & 15;
-                dst[e] = {tlo[r][c], thi[r][c]};
-                if (XW) {
-                    const int t = t0 + c;
-                    if (t < N && lf0 + r < num_frames) xw[(lf0 + r) * (long long)N + t] = twf[r][c];
-                }
+        for (int q = 0; q < BS_TILE; ++q) {
+            // ---- band filters (sample tau - 12): residual, high-pass / rectifier / low-pass, low-pass
+            {
+                const double xs = (double)xr[(q + 4) & 15];   // written 12 iterations ago
+                const double r = xs - fxh;
+                const double yh = k.hpb[0] * r + h1;
+                h1 = (h2 + k.hpb[1] * r) - k.hpa[1] * yh;
+                h2 = k.hpb[2] * r - k.hpa[2] * yh;
+                const double rect = yh < 0.0 ? 0.0 : yh;
+                const double yhl = k.lpb[0] * rect + g1;
+                g1 = (g2 + k.lpb[1] * rect) - k.lpa[1] * yhl;
+                g2 = k.lpb[2] * rect - k.lpa[2] * yhl;
+                const double yl = k.lpb[0] * r + l1;
+                l1 = (l2 + k.lpb[1] * r) - k.lpa[1] * yl;
+                l2 = k.lpb[2] * r - k.lpa[2] * yl;
+                tlo[lane][(q + 4) & 15] = yl;
+                thi[lane][(q + 4) & 15] = yhl;
+                if (XW) twf[lane][(q + 4) & 15] = r;
+            }
+            // ---- all-pass stages 11 .. 1 (samples tau - 11 .. tau - 1), dsp/wfir.py:25-43
+            {
+                const double o = -k.a * pin[11] + z[11];   // b0*x + z
+                z[11] = pin[11] + k.a * o;                  // b1*x - a1*y with b1 = 1, a1 = -a
+                fxh = pxh[11] + k.c[12] * o;
+            }
+#pragma unroll
+            for (int i = 10; i >= 1; --i) {
+                const double o = -k.a * pin[i] + z[i];
+                z[i] = pin[i] + k.a * o;
+                pin[i + 1] = o;
+                pxh[i + 1] = pxh[i] + k.c[i + 1] * o;
+            }
+            // ---- all-pass stage 0 on the new sample tau
+            {
+                const float xf = tin[lane][q];
+                const double xt = (double)xf;
+                const double xhat0 = k.c[0] * xt;
+                const double o = -k.a * xt + z[0];
+                z[0] = xt + k.a * o;
+                pin[1] = o;
+                pxh[1] = xhat0 + k.c[1] * o;
+                xr[q] = xf;
+            }
+            if (q == 11 && tb >= BS_TILE) {   // output tile tb / 16 - 1 is complete
+                wave_lds_fence();
+                flush(tb / BS_TILE - 1);
+                wave_lds_fence();
             }
         }
         wave_lds_fence();
