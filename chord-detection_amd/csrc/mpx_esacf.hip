@@ -1112,6 +1112,16 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a) {
         __syncthreads();
         const int len_out = (int)nearbyint((double)Mh / (double)r);          // int(round(len/rate)), half-to-even
         const int nsteps = (n_frames + r - 1) / r;                            // len(arange(0, n_frames, r)) <= 2
+        if (nsteps < 2) {
+            // ONE output frame: the vocoder passes STFT column 0 through unchanged, and the ISTFT of a single frame
+            // divides out the window it was analysed with -- time_stretch returns x[:len_out] itself (to the rounding of
+            // its own two FFTs, 1e-16 of the row maximum; the window is >= 0.25 over these samples), so the subtraction
+            // leaves zeros there.  The same identity sacf_kernel uses for rows below 1024 lags; two 2048-point
+            // transforms per rate saved (rates 4, 5, 6 of the default six at Mh = 2047: half of this kernel's transforms).
+            for (int i = tid; i < len_out && i < Mh; i += PV_T) x[i] = 0.0;
+            __syncthreads();
+            continue;
+        }
         for (int t = 0; t < nsteps; ++t) {
             const int c0 = t * r, c1 = c0 + 1;                                // STFT columns int(step), int(step)+1
             // analysis: frame c covers xpad[c*512 + n], xpad = [1024 zeros | x | 1024 zeros]
