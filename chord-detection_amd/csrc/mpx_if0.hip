@@ -117,10 +117,16 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
     constexpr int PF = 16;                     // = the tile width = DEPTH: block tb produces outputs tb-16 .. tb-1
     // the samples of block tb + PF are fetched while block tb runs: a chunk's lanes are often alone on their SIMD
     // (256 two-second clips x 70 channels are 280 waves on 1024 SIMDs), so nothing else hides the load latency
+    // (unconditional loads from a clamped position, the zero padding a select: a conditional load is a branch per sample)
     float nx[PF];
+    const int x_lim = c.clip_left < c_len ? c.clip_left : c_len;   // samples from x on that exist and are wanted
     auto fetch = [&](int tb) {
 #pragma unroll
-        for (int q = 0; q < PF; ++q) nx[q] = (tb + q < c.clip_left && tb + q < c_len) ? x[tb + q] : 0.f;
+        for (int q = 0; q < PF; ++q) {
+            const bool ok = tb + q < x_lim;
+            const float v = x[ok ? tb + q : -c_warm];   // x[-warm] is the first sample of the run-in: always inside the clip
+            nx[q] = ok ? v : 0.f;
+        }
     };
     fetch(-c_warm);
     for (int tb = -c_warm; tb < c_len + DEPTH; tb += PF) {
@@ -185,14 +191,23 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         const int t0 = tb - DEPTH;
         if (t0 >= 0 && t0 < c_len) {   // uniform: warm-up and length are multiples of 16
             wave_lds_fence();
+            // (the tile is read unconditionally, all sixteen rows at once, and only the stores are predicated: with the read
+            //  inside the condition every element was a branch and two waits for the LDS)
+            double tv[PF];
+            long long rbv[PF];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int e = q * 64 + lane, r = e >> 4, cc = e & 15;
+                tv[q] = tile[r][cc];
+                if (TAIL) rbv[q] = rowbase[r];
+            }
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 const int e = q * 64 + lane, r = e >> 4, cc = e & 15;
                 if (TAIL) {
-                    const long long rb = rowbase[r];
-                    if (rb >= 0) yc[rb + t0 + cc] = tile[r][cc];
+                    if (rbv[q] >= 0) yc[rbv[q] + t0 + cc] = tv[q];
                 } else if (r < nch_u) {
-                    out[(size_t)r * c_len + t0 + cc] = tile[r][cc];
+                    out[(size_t)r * c_len + t0 + cc] = tv[q];
                 }
             }
             wave_lds_fence();
@@ -204,17 +219,21 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                                                           long long num_chunks, int channels,
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc, const int* __restrict__ tail_list,
-                                                          const If0TailGroup* __restrict__ tail_groups) {
+                                                          const If0TailGroup* __restrict__ tail_groups, int num_tail_groups) {
     __shared__ double tile[64][17];
     __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
-    if ((long long)blockIdx.x < num_chunks * full) {
+    // The waves of leftover channels come FIRST in the grid: they are the slower ones per step (per-lane streams), and a
+    // launch that needs more than one round of waves (1024 two-second clips: 1127 waves on 1024 one-wave SIMDs) should
+    // end on the fast kind.
+    if ((long long)blockIdx.x >= num_tail_groups) {
+        const long long b = (long long)blockIdx.x - num_tail_groups;
         if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 blockIdx.x / full, (int)(blockIdx.x % full) * 64, 64, g);
+                                 b / full, (int)(b % full) * 64, 64, g);
         return;
     }
-    g = tail_groups[blockIdx.x - num_chunks * full];
+    g = tail_groups[blockIdx.x];
     if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
         if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
                                  tail_list[g.first], 64 * full, channels & 63, g);
@@ -1025,7 +1044,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     prof_mark(ctx, st, "if0_frontend_kernel");
     hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
                        d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                       d_tail_groups);
+                       d_tail_groups, (int)tail_groups.size());
     MPX_HIP(ctx, hipGetLastError());
     prof_mark(ctx, st, "if0_spectrum_kernel");
     if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);

@@ -19,7 +19,8 @@ for rep in range(2):
     prof = eng.profile_end()
 print(tag, "stream600 wall %.1f ms" % (1e3 * dt), {k: round(v[1], 2) for k, v in prof.items()}, "same", bool(np.array_equal(r, r0)), "sum %.12g" % float(np.nansum(r)))
 del x
-c = corpus.synth_chunk(list(range(1024)), 22050, 2.0, dev)
+NCL = int(os.environ.get("IF0_CLIPS", "1024"))
+c = corpus.synth_chunk(list(range(NCL)), 22050, 2.0, dev)
 r0 = eng.iterative_f0_batch(c, 22050)
 for rep in range(2):
     eng.profile_begin()
@@ -27,4 +28,4 @@ for rep in range(2):
     r = eng.iterative_f0_batch(c, 22050)
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
-print(tag, "clips1024 wall %.1f ms" % (1e3 * dt), {k: round(v[1], 2) for k, v in prof.items()}, "same", bool(np.array_equal(r, r0)), "sum %.12g" % float(np.nansum(r)))
+print(tag, NCL, "clips wall %.1f ms" % (1e3 * dt), {k: round(v[1], 2) for k, v in prof.items()}, "same", bool(np.array_equal(r, r0)), "sum %.12g" % float(np.nansum(r)))

@@ -7,6 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/pw_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw_stats -- python3 $GRAFT_REPO_ROOT/scripts/pmc_workloads.py $WL > $OUT/stats.log 2>&1
 cp $(find /tmp/pw_stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+find /tmp/pw_stats -type f | head -20 >> $OUT/stats.log
 cp $(find /tmp/pw_stats -name "*kernel_trace.csv" | head -1) $OUT/kernel_trace.csv
 grep "pmc_workloads order:" $OUT/stats.log | sed "s/.*order: //" > $OUT/order.txt
 i=0

@@ -43,7 +43,7 @@ def walk(path, name_col, handler):
                 last = did
             continue
         k = short(raw)
-        if k.startswith("at::") or "elementwise" in k or "Memset" in k or k.startswith("__amd") or "rocprim" in k or "hipcub" in k:
+        if not k or k.startswith("at::") or "elementwise" in k or "Memset" in k or k.startswith("__amd") or "rocprim" in k or "hipcub" in k:
             continue
         handler(wl, k, r)
 
@@ -59,7 +59,10 @@ durs = collections.defaultdict(list)
 
 
 def on_trace(wl, k, r):
-    key = "%s/%s grid=%s wg=%s" % (wl, k, r.get("Grid_Size", "?"), r.get("Workgroup_Size", "?"))
+    # (the trace CSV spells the launch shape per dimension)
+    grid = r.get("Grid_Size") or str(int(r.get("Grid_Size_X", 1)) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1))
+    wg = r.get("Workgroup_Size") or str(int(r.get("Workgroup_Size_X", 1)) * int(r.get("Workgroup_Size_Y", 1) or 1) * int(r.get("Workgroup_Size_Z", 1) or 1))
+    key = "%s/%s grid=%s wg=%s" % (wl, k, grid, wg)
     durs[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 
 
