@@ -26,6 +26,7 @@ namespace mpx {
 
 struct PrimeCand {          // per candidate frequency, device resident
     int N, L, half;         // frame length, Bluestein FFT length, bins kept = int((N//2+1)/2)
+    int paired;             // prime_pers_kernel: two frames per transform (the filter then covers the outputs -(half-1) .. half-1)
     double val;             // frequency step: 1.0/(N*(1/fs)) exactly as numpy.fft.fftfreq builds it
     double wsum;            // sum(numpy.hanning(N))
     const double* win;      // [N]
@@ -292,7 +293,9 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const cx<double> xp = cmul(regs[r], oc[r]), xm = cmul(r == 0 ? ym0 : ym1, oc[r]);
-            const cx<double> sa = {0.5 * (xp.x + xm.x), 0.5 * (xp.y - xm.y)};    // X_a = (X[k] + conj X[-k]) / 2
+            // (a candidate whose 1.5 N does not fit 4096 points runs one frame per transform: b = 0 and X_a = X[k] itself;
+            //  its filter does not cover the negative outputs, xm is then meaningless and unused)
+            const cx<double> sa = c.paired ? cx<double>{0.5 * (xp.x + xm.x), 0.5 * (xp.y - xm.y)} : xp;    // X_a = (X[k] + conj X[-k]) / 2
             const cx<double> sb = {0.5 * (xp.y + xm.y), 0.5 * (xm.x - xp.x)};    // X_b = (X[k] - conj X[-k]) / 2i
             ma[r] = live_a ? hypot(sa.x, sa.y) / c.wsum : 0.0;
             mb[r] = live_b ? hypot(sb.x, sb.y) / c.wsum : 0.0;
@@ -422,7 +425,7 @@ struct PrimePlan {
 // Plans live in the context (host copy of the candidate records in ctx->host_blobs, device tables in
 // ctx->owned) and die with it.
 static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan& plan) {
-    const std::string key = "prime2_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
+    const std::string key = "prime3_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
                             std::to_string(p.num_octave);
     auto bit = ctx->host_blobs.find(key);
     if (bit != ctx->host_blobs.end()) {
@@ -443,18 +446,20 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                 // Only the lower half of the one-sided spectrum is looked at (prime_multif0.py:59-61): K = half outputs.  The
                 // persistent kernel transforms two real frames at once and separates them by conjugate symmetry, which takes
                 // the outputs -(K-1) .. K-1: the chirp-z convolution then spans chirp[-(N+K-2) .. K-1], a circular length of
-                // N + 2K - 2 ~ 1.5 N (a full transform: 2N - 1).  Frames whose 1.25 N fits 8192 points but whose 1.5 N does
-                // not (5462 .. 6553 samples: input above 67 kHz) stay on the workgroup-per-frame kernel, one frame each.
+                // N + 2K - 2 ~ 1.5 N (a full transform: 2N - 1).  Frames whose 1.5 N does not fit 4096 points but whose 1.25 N
+                // does (2731 .. 3277 samples: the lowest candidates of 48 kHz input) run on the same kernel one frame at a
+                // time; longer ones (up to 6553 samples, input above 53 kHz) on the workgroup-per-frame kernel.
                 const int half = N >= 2 ? (N / 2 + 1) / 2 : 0;
                 if (N < 2 || N + half - 1 > 8192)
                     return set_error(ctx, MPX_EUNSUPPORTED,
                                      "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..6553)", N, f);
                 PrimeCand c;
                 c.N = N;
-                const int need2 = N + 2 * half - 2;
+                const int need2 = N + 2 * half - 2, need1 = N + half - 1;
                 const bool paired = need2 <= 4096;
-                const int need = paired ? need2 : N + half - 1;
-                c.L = !paired ? 8192 : (need <= 1024 ? 1024 : (need <= 2048 ? 2048 : 4096));
+                const int need = paired ? need2 : need1;
+                c.paired = paired ? 1 : 0;
+                c.L = need > 4096 ? 8192 : (need <= 1024 ? 1024 : (need <= 2048 ? 2048 : 4096));
                 c.half = half;
                 c.val = 1.0 / (N * (1.0 / fs));
                 std::vector<double> win(N);
@@ -590,7 +595,7 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         for (size_t k = 0; k < plan->cands.size(); ++k) {
             const PrimeCand& c = plan->cands[k];
             const int64_t nf = len <= 0 ? 0 : (len + c.N - 1) / c.N;
-            const int step = c.L <= 4096 ? 2 : 1;   // prime_pers_kernel: frames 2p and 2p + 1 of a clip travel together
+            const int step = c.paired ? 2 : 1;      // prime_pers_kernel: frames 2p and 2p + 1 of a clip travel together
             for (int64_t f = 0; f < nf; f += step) {
                 const int64_t s = f * c.N, left = len - s;
                 PrimeItem it;

@@ -23,7 +23,15 @@ def _run_bench(*extra, cpu_budget="1"):
 
 def _check_roofline(r):
     assert r["bound"] in ("hbm", "valu_f64") and r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9)
-    assert 0.0 < r["frac"] < 1.0 and 0.0 < r["hbm_frac"] < 1.0 and r["kernel_ms"] > 0
+    assert 0.0 < r["frac"] < 1.0 and r["kernel_ms"] > 0
+    if r["bytes_per_unit"] == 0 and "intermediate_bytes_per_unit" in r:
+        # a kernel between two others of its method: no compulsory bytes of its own, its hand-off traffic is
+        # listed as intermediate and has a fraction of its own
+        assert r["hbm_frac"] == 0.0 and r["intermediate_bytes_per_unit"] > 0 and 0.0 < r["hbm_frac_with_intermediate"] < 1.0
+    else:
+        assert 0.0 < r["hbm_frac"] < 1.0
+    if r.get("traffic") is not None:   # measured HBM bytes of the launch (PMC) next to the compulsory ones
+        assert r["traffic"] > 0 and r["wasted_traffic_ratio"] == pytest.approx(r["traffic"] / r["compulsory_bytes"], rel=1e-9)
     if r["bound"] == "hbm":
         assert r["unit"] == "GB/s" and r["peak"] == 8000.0
         assert r["achieved"] == pytest.approx(r["bytes_per_unit"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9, rel=1e-6)
@@ -38,6 +46,8 @@ def test_bench_line_has_the_contract_fields():
     assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 60, 6)
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "model" not in d["config"]
+    assert d["engine"] == "hip" and d["config"]["repeats"] == 5 and len(d["ms_per_step_repeats"]) == 5
+    assert sorted(d["ms_per_step_repeats"])[2] == pytest.approx(d["ms_per_step"], rel=1e-9)     # the median of the repeats
     assert "configs[1]" in d["config"]["workload"] and d["config"]["frames_per_gpu"] == 8192
     assert d["value"] == pytest.approx(8192 / (d["ms_per_step"] * 1e-3), rel=1e-6)
     assert d["value_one_in_flight"] == pytest.approx(8192 / (d["ms_per_step_one_in_flight"] * 1e-3), rel=1e-6)
@@ -51,7 +61,7 @@ def test_bench_line_has_the_contract_fields():
     assert 0.0 < r["kernel_ms"] <= r["step_ms_hip_events"] * 1.05     # the kernel is inside the (one-at-a-time) step
     assert d["config"]["batches_in_flight"] == 4 and r["in_flight"]["batches"] == 4   # bench.py --streams default
     assert r["in_flight"]["frac"] == pytest.approx(4144 * 8192 / (d["ms_per_step"] * 1e-3) / 8.0e12, rel=1e-6)
-    assert r["traffic"] is None or r["traffic"] >= 0.9 * 4144 * 8192
+    assert r["traffic"] is None or (r["traffic"] >= 0.9 * 4144 * 8192 and r["wasted_traffic_ratio"] == pytest.approx(r["traffic"] / (4144 * 8192), rel=1e-9))
     assert r["secondary"]["bound"] == "valu_f64" and 0.0 < r["secondary"]["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "frames/s" and c["value"] > 0 and "sample" in c
@@ -67,6 +77,9 @@ def test_bench_line_has_the_contract_fields():
     assert w["esacf_stft_8192"]["value_three_in_flight"] >= 0.9 * w["esacf_stft_8192"]["value"]
     assert w["corpus_4096_all_methods"]["unit"] == "clips/s" and w["corpus_4096_all_methods"]["nonzero_rows"] > 0.9 * 4 * 4096
     assert w["if0_stream_1h"]["unit"] == "x real time" and w["if0_stream_1h"]["frames"] == 19380
+    assert w["if0_stream_1h"]["value_first_pass"] > 0 and w["corpus_4096_all_methods"]["value_with_streaming_synthesis"] > 0
+    fe = w["if0_stream_1h"]["rooflines"]["if0_frontend_kernel"]
+    assert fe["bytes_per_unit"] == 4 and fe["intermediate_bytes_per_unit"] == 560     # compulsory: the samples once; 70 x 8 B handed on
     for name, rec in w.items():
         assert rec["value"] > 0 and rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["unit"] == rec["unit"], name
         assert "kernel" in rec["roofline"] and rec["roofline"]["kernel_ms"] > 0, name
