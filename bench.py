@@ -377,6 +377,9 @@ def with_traffic(r, pmc_workload, mark, launches=1):
     if comp:
         r["compulsory_bytes"] = comp
         r["wasted_traffic_ratio"] = r["traffic"] / comp
+    ib = r.get("intermediate_bytes_per_unit", 0) * r.get("units_per_launch", 0)
+    if ib:   # a kernel that hands data to the next one of its method: the measured bytes against compulsory + hand-off
+        r["traffic_vs_compulsory_plus_intermediate"] = r["traffic"] / (comp + ib)
     return r
 
 
