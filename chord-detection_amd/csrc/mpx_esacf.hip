@@ -1662,6 +1662,12 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
     count_evals(next_parked + 2, my_evals);   // total[6..7]: function evaluations of the batch (statistics only)
 }
 
+// SAMPLES_IN_LDS = true (batches with enough fits to fill the machine several times over): the lane's 21 samples live in
+// LDS and fvec is recomputed -- no global loads inside the trip loop (10 % faster per 2.1 M fits, 1/31 of the traffic).
+// false (small batches, where the kernel's time is the number of dependent trips of its longest fits, not throughput): the
+// round-2 arrangement, fvec in LDS and the samples re-read from the ESACF row (L2) -- 21 exponentials less per trip.
+// The two compute the SAME BITS (fvec recomputed is fvec stored), so the choice is pure scheduling.
+template <bool SAMPLES_IN_LDS>
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
     const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
     int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
@@ -1673,7 +1679,14 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     if (threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double* fvec = sh + (size_t)wave * MAXM * 64 + lane;  // element i at fvec[i * 64]
+    // The 21 samples of the lane's fit live in LDS for the life of the fit (element i at ysl[i * 64]; rows >= m are zeros):
+    // read from the ESACF row ONCE, at fetch time.  Until round 3 this space held MINPACK's fvec and the samples were
+    // re-read from the row twice per trip -- 11.8 GB of HBM/L2 traffic per 2.1 M fits for 0.38 GB of windows, 64 different
+    // cache lines per load instruction, and a wait in front of every evaluation.  fvec is not stored at all now: it is
+    // the residual at the current x, and the OUTER section recomputes it row by row next to the two jacobian evaluations
+    // (the same function of the same inputs: the same bits; three independent exponentials per row instead of two).
+    double* ysl = sh + (size_t)wave * MAXM * 64 + lane;
+    double* fvec = ysl;   // SAMPLES_IN_LDS == false: the same space holds fvec (element i at fvec[i * 64])
     double* rq = sh_rq + (size_t)wave * 9 * 64 + lane;      // R (6) and Q^T f (3) between OUTER and INNER
     const int n_long = total_peaks[0], total = n_long + total_peaks[2];
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
@@ -1717,10 +1730,16 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                 } else {
                     row = y + f * (long long)Mh + (i - 10);
                     x0 = (double)(i - 10);
-                    double ymax = row[0];
+                    double ys0[MAXM];
+                    load_samples(row, m, ys0);
+                    if (SAMPLES_IN_LDS) {
+#pragma unroll
+                        for (int q = 0; q < MAXM; ++q) ysl[q * 64] = ys0[q];
+                    }
+                    double ymax = ys0[0];
 #pragma unroll
                     for (int q = 1; q < MAXM; ++q)
-                        if (q < m) ymax = row[q] > ymax ? row[q] : ymax;
+                        if (q < m) ymax = ys0[q] > ymax ? ys0[q] : ymax;
                     x[0] = ymax;  // peakutils initial guess: [max(y), x[0], 5*(x[1]-x[0])]
                     x[1] = x0;
                     x[2] = 5.0;
@@ -1771,46 +1790,41 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         // ---------------- OUTER: jacobian, QR, Q^T f
         if (phase == FIT_OUTER) {
             double a[MAXM][NP], r[NP * NP], qtf[NP];
+            double w[MAXM];  // fvec (the residuals at x) here, Q^T fvec after the factorisation
             {
-                double ys[MAXM];
-                load_samples(row, m, ys);
                 // column 0 (amplitude): ((A+h) e_i - y_i - f_i)/h with f_i = A e_i - y_i is e_i itself up to the
-                // rounding noise of the difference; e_i = (f_i + y_i)/A is read off the stored residuals instead
+                // rounding noise of the difference; e_i = (f_i + y_i)/A is read off the residuals instead
                 // of 21 more exponentials (exact path kept for A == 0)
-                if (x[0] != 0.0) {
-                    const double inv_a = 1.0 / x[0];
+                double ys_g[MAXM];
+                if (!SAMPLES_IN_LDS) load_samples(row, m, ys_g);
+                const GaussEval g0 = gauss_prep(x, exp_tab);   // (dead code without SAMPLES_IN_LDS)
+                const bool a_nonzero = x[0] != 0.0;
+                const double inv_a = a_nonzero ? 1.0 / x[0] : 0.0;
+                double xa[NP] = {eps, x[1], x[2]};
+                const GaussEval ga = gauss_prep(xa, exp_tab);   // only used when A == 0
+                double h1 = eps * fabs(x[1]), h2 = eps * fabs(x[2]);
+                if (h1 == 0.0) h1 = eps;
+                if (h2 == 0.0) h2 = eps;
+                double x1[NP] = {x[0], x[1] + h1, x[2]}, x2[NP] = {x[0], x[1], x[2] + h2};
+                const GaussEval g1 = gauss_prep(x1, exp_tab), g2 = gauss_prep(x2, exp_tab);
+                const double inv_h1 = 1.0 / h1, inv_h2 = 1.0 / h2, inv_ha = 1.0 / eps;
 #pragma unroll
-                    for (int i = 0; i < MAXM; ++i) a[i][0] = keep_if(i < m, (fvec[i * 64] + ys[i]) * inv_a);
-                } else {
-                    x[0] = eps;
-                    const GaussEval g = gauss_prep(x, exp_tab);
-                    const double inv_h = 1.0 / eps;
-#pragma unroll
-                    for (int i = 0; i < MAXM; ++i)
-                        a[i][0] = i < m ? (gauss_resid(g, x0 + (double)i, ys[i]) - fvec[i * 64]) * inv_h : 0.0;
-                    x[0] = 0.0;
-                }
-#pragma unroll
-                for (int j = 1; j < NP; ++j) {
-                    const double temp = x[j];
-                    double h = eps * fabs(temp);
-                    if (h == 0.0) h = eps;
-                    x[j] = temp + h;
-                    const GaussEval g = gauss_prep(x, exp_tab);
-                    const double inv_h = 1.0 / h;
-#pragma unroll
-                    for (int i = 0; i < MAXM; ++i)
-                        a[i][j] = keep_if(i < m, (gauss_resid(g, x0 + (double)i, ys[i]) - fvec[i * 64]) * inv_h);
-                    x[j] = temp;
+                for (int i = 0; i < MAXM; ++i) {
+                    const double yi = SAMPLES_IN_LDS ? ysl[i * 64] : ys_g[i], xi = x0 + (double)i;
+                    const double fi = SAMPLES_IN_LDS ? gauss_resid(g0, xi, yi) : fvec[i * 64];
+                    if (a_nonzero)
+                        a[i][0] = keep_if(i < m, (fi + yi) * inv_a);
+                    else
+                        a[i][0] = i < m ? (gauss_resid(ga, xi, yi) - fi) * inv_ha : 0.0;
+                    a[i][1] = keep_if(i < m, (gauss_resid(g1, xi, yi) - fi) * inv_h1);
+                    a[i][2] = keep_if(i < m, (gauss_resid(g2, xi, yi) - fi) * inv_h2);
+                    w[i] = keep_if(i < m, fi);
                 }
             }
             nfev += NP;
             ipvt[0] = 0;
             ipvt[1] = 1;
             ipvt[2] = 2;
-            double w[MAXM];  // becomes Q^T fvec
-#pragma unroll
-            for (int i = 0; i < MAXM; ++i) w[i] = keep_if(i < m, fvec[i * 64]);
             double acnorm[NP], rdiag[NP], wa[NP];
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -1961,17 +1975,20 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             for (int j = 0; j < NP; ++j) xnew[j] = x[j] + p[j];
             double rn[MAXM];  // residuals at the trial point (MINPACK's wa4)
             {
-                double ys[MAXM];
-                load_samples(row, m, ys);
+                double ys_g[MAXM];
+                if (!SAMPLES_IN_LDS) load_samples(row, m, ys_g);
                 const GaussEval g = gauss_prep(xnew, exp_tab);
 #pragma unroll
-                for (int i = 0; i < MAXM; ++i) rn[i] = keep_if(i < m, gauss_resid(g, x0 + (double)i, ys[i]));
+                for (int i = 0; i < MAXM; ++i)
+                    rn[i] = keep_if(i < m, gauss_resid(g, x0 + (double)i, SAMPLES_IN_LDS ? ysl[i * 64] : ys_g[i]));
             }
             const double s1 = dot_rows(0, [&](int i) { return rn[i]; }, [&](int i) { return rn[i]; });
-            if (fresh) {  // lmdif's prologue: fvec at the initial point
+            if (fresh) {  // lmdif's prologue: fvec at the initial point and its norm
+                if (!SAMPLES_IN_LDS) {
 #pragma unroll
-                for (int i = 0; i < MAXM; ++i)
-                    if (i < m) fvec[i * 64] = rn[i];
+                    for (int i = 0; i < MAXM; ++i)
+                        if (i < m) fvec[i * 64] = rn[i];
+                }
                 nfev = 1;
                 fnorm = sqrt(s1);
                 par = 0.0;
@@ -2016,9 +2033,11 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     x[j] = xnew[j];
                     wa3[j] = diag[j] * x[j];
                 }
+                if (!SAMPLES_IN_LDS) {
 #pragma unroll
-                for (int i = 0; i < MAXM; ++i)
-                    if (i < m) fvec[i * 64] = rn[i];
+                    for (int i = 0; i < MAXM; ++i)
+                        if (i < m) fvec[i * 64] = rn[i];
+                }
                 xnorm = enorm3(wa3);
                 fnorm = fnorm1;
                 ++it;
@@ -2510,7 +2529,11 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const int maxfev = dev_env_int("MPX_FIT_MAXFEV", 200 * (lm::NP + 1));
             const bool park = !deterministic && !dev_env_on("MPX_FIT_NOPARK");
             prof_mark(ctx, st, "peakfit_kernel");
-            hipLaunchKernelGGL(peakfit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
+            // samples in LDS when the fits fill the 131 072 resident lanes about four times over (12 .. 25 fits per frame): the
+            // kernel is then throughput-bound; below that its time is the trip count of its longest fits (bit-identical either way)
+            const bool in_lds = dev_env("MPX_FIT_SAMPLES") ? dev_env_on("MPX_FIT_SAMPLES") : nf >= 32768;
+            auto fit_kernel = in_lds ? peakfit_kernel<true> : peakfit_kernel<false>;
+            hipLaunchKernelGGL(fit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, dev_env_int("MPX_FIT_PARK_NFEV", nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
                                dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),

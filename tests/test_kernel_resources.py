@@ -28,13 +28,14 @@ SCRATCH_FREE = [
     "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
     "mpx::bandsplit_kernel<false>", "mpx::bandsplit_kernel<true>",
     "mpx::coopfit_kernel", "mpx::pv_enhance_kernel", "mpx::scatter_kernel",
+    "mpx::peakfit_kernel<true>",                      # large batches: samples in LDS, fvec recomputed
     "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
     "mpx::if0_frontend_kernel", "mpx::if0_periodicity_kernel",
 ]
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
-    "mpx::peakfit_kernel": 40,
+    "mpx::peakfit_kernel<false>": 40,                  # small batches: the round-2 arrangement
     "mpx::he_wave_kernel<8, 4, false, false>": 24,     # ragged / unaligned frames: the loader with per-sample guards
 }
 # occupancy (waves per SIMD) the launch geometry of the host code counts on
@@ -43,7 +44,7 @@ OCCUPANCY = {
     "mpx::sacf_pfa_kernel<2>": 4,
     "mpx::if0_spectrum_split_kernel<8192, true, 1>": 4,
     "mpx::prime_pers_kernel<1024>": 2,
-    "mpx::peakfit_kernel": 2,
+    "mpx::peakfit_kernel<true>": 2,
 }
 
 
