@@ -910,7 +910,9 @@ def wl_corpus(c):
                 nfr = -(-ncl // nc)
                 pf += nfr * 2.5 * nc * math.log2(nc)
                 pb += nfr * 4 * nc
-        models["prime_kernel"] = (pb, pf, "clip")
+        # compulsory: the clip's samples in ONCE and 12 doubles out; every candidate frequency cuts the same
+        # clip into its own frames, so the kernel READS it once per candidate (pb): listed as re-read bytes, mostly L2 / MALL hits
+        models["prime_kernel"] = (4 * ncl + 96, pf, "clip")
         units["prime_kernel"] = per
         if dom in models:
             rec["roofline"] = roofline_of(dom, ktot[dom], units.get(dom, frames1), models[dom])
@@ -924,6 +926,10 @@ def wl_corpus(c):
         for k, r in list(rec["rooflines"].items()) + [(rec["roofline"].get("kernel"), rec["roofline"])]:
             # (the ESACF side was counted on 4096 clips at once)
             with_traffic(r, pmc_wl.get(k, "esacf_1023"), k, launches=chunks if k in pmc_wl else per / 4096.0)
+        if "prime_kernel" in rec["rooflines"]:
+            rec["rooflines"]["prime_kernel"]["reread_bytes_per_unit"] = pb
+        if rec["roofline"].get("kernel") == "prime_kernel":
+            rec["roofline"]["reread_bytes_per_unit"] = pb
         rec["kernels_ms_note"] = ("sums over the driver's three contexts, whose kernels overlap on the GPU: HIP-event times of "
                                   "kernels that share the machine (alone, per 1024-clip chunk: scripts/dev/prime_time.py, if0_time.py)")
     if _cpu_rec(c, "corpus"):

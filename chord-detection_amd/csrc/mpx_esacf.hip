@@ -906,7 +906,10 @@ template <int A0>
 __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
     constexpr int T = PFA_T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = a.N, Mh = a.Mh;
+    // The frame length is a compile-time constant of the instantiation (the host launches <A0> for N = A0 * 1023 only): the
+    // gather, pair and lag loops below unroll, so that their table loads, sample loads and LDS reads are all in flight
+    // together instead of one dependent global round trip per iteration.
+    constexpr int N = A0 * 3 * 11 * 31, Mh = (N - 1) / 2;
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                      // [A0][3][11][31]
     double* yv = reinterpret_cast<double*>(smem + PFA_YV_OFF(Mh));              // Mh + 2 doubles, inside the dead buf
     const unsigned short* __restrict__ pos = a.pfa_pos;                         // [N] position of index n (L2-resident)
@@ -926,20 +929,46 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
         const long long f = blockIdx.x;
         const int tid = threadIdx.x;
         const cx<double>* xin = a.xb + band_index(f, 0, N);
-        for (int n = tid; n < N; n += T) buf[pos[n]] = xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)];
+        {
+            constexpr int PER = (N + T - 1) / T;
+            cx<double> xv[PER];
+            int pv[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int n = tid + r * T, nc = n < N ? n : 0;
+                pv[r] = pos[nc];
+                xv[r] = xin[(size_t)(nc >> 4) * (64 * BS_TILE) + (nc & 15)];
+            }
+#pragma unroll
+            for (int r = 0; r < PER; ++r)
+                if (tid + r * T < N) buf[pv[r]] = xv[r];
+        }
         __syncthreads();
         if (!(a.ablate & 8)) pfa_dft<A0, false>(buf, cs31, cs11, tid);
         // S[k] = |X_lo[k]|^0.67 + |X_hi[k]|^0.67 from Z[k] and its mirror bin Z[N-k]: one thread per pair, both positions
         // get the (real, even) value; nobody else touches the pair
-        for (int i = tid; i < a.pfa_npairs; i += T) {
-            const int p = a.pfa_pairs[2 * i], q = a.pfa_pairs[2 * i + 1];
-            const cx<double> A = buf[p];
-            const cx<double> B = cconj(buf[q]);
-            const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
-            const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-            const double sv = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);
-            buf[p] = {sv, 0.0};
-            buf[q] = {sv, 0.0};
+        {
+            constexpr int NPAIRS = N / 2 + 1, PER = (NPAIRS + T - 1) / T;   // k <= N - k: k = 0 .. N/2 (host: pfa_npairs)
+            int pp[PER], qq[PER];
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const int i = tid + r * T, ic = i < NPAIRS ? i : 0;
+                const ushort2 pq = reinterpret_cast<const ushort2*>(a.pfa_pairs)[ic];
+                pp[r] = pq.x;
+                qq[r] = pq.y;
+            }
+#pragma unroll
+            for (int r = 0; r < PER; ++r) {
+                const cx<double> A = buf[pp[r]];
+                const cx<double> B = cconj(buf[qq[r]]);
+                const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+                const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+                const double sv = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);
+                if (tid + r * T < NPAIRS) {
+                    buf[pp[r]] = {sv, 0.0};
+                    buf[qq[r]] = {sv, 0.0};
+                }
+            }
         }
         __syncthreads();
         if (!(a.ablate & 4)) pfa_dft<A0, true>(buf, cs31, cs11, tid);
