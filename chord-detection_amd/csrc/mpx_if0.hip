@@ -942,15 +942,33 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             worst = std::max<long long>(worst, std::min<long long>(t0, warmup) + std::min<long long>(chunk, longest - t0));
         return worst;
     };
-    long long chunk = IF0_CHUNK;
-    while (chunk > IF0_CHUNK_MIN) {
-        long long waves = 0;
+    // The front end runs ONE wave per SIMD (320 registers), so a launch takes ceil(waves / SIMDs) rounds of its busiest
+    // lane's steps: the chunk length that minimises rounds x steps wins, the longer one on a tie (less run-in work in
+    // total).  (Until round 3: "halve while there are fewer waves than SIMDs", which turned 934 chunks = 1028 waves into two
+    // rounds of 98 304 steps where 467 chunks take one round of 131 072.)
+    const long long simds = 4LL * ctx->num_cus;
+    const int nt_ch = p.channels % 64, full_ch = p.channels / 64;
+    long long chunk = IF0_CHUNK, best_cost = -1;
+    for (long long cand = IF0_CHUNK; cand >= IF0_CHUNK_MIN; cand >>= 1) {
+        long long chunks_total = 0;
         for (int c = 0; c < num_clips; ++c) {
             const int64_t len = offsets[c + 1] - offsets[c];
-            if (len > 0) waves += ((len + chunk - 1) / chunk) * ((p.channels + 63) / 64);  // (before leftovers are packed)
+            if (len > 0) chunks_total += (len + cand - 1) / cand;
         }
-        if (waves >= 4LL * ctx->num_cus || 10 * lane_steps(chunk / 2) > 9 * lane_steps(chunk)) break;
-        chunk >>= 1;
+        // waves: one per chunk and 64 channels, the leftover channels of up to 64 / nt chunks packed into one when that
+        // saves a round (the same rule as below)
+        long long waves = chunks_total * full_ch;
+        if (nt_ch) {
+            const long long pw = 64 / nt_ch;
+            const long long unpacked = chunks_total * (full_ch + 1), packed = chunks_total * full_ch + (chunks_total + pw - 1) / pw;
+            waves = (unpacked + simds - 1) / simds > (packed + simds - 1) / simds ? packed : unpacked;
+        }
+        const long long rounds = (waves + simds - 1) / simds;
+        const long long cost = (rounds > 0 ? rounds : 1) * lane_steps(cand);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            chunk = cand;
+        }
     }
     for (int c = 0; c < num_clips; ++c) {
         const int64_t len = offsets[c + 1] - offsets[c];
