@@ -356,13 +356,34 @@ __device__ __forceinline__ double wave_range_max(const double* __restrict__ ur, 
     return m;
 }
 
+// maximum over the wave of values that are never NaN, in every lane: four DPP row steps and four v_readlane -- no LDS
+// round trips (a shuffle-based reduction of a double is twelve ds_bpermute with a wait each)
+template <int CTRL>
+__device__ __forceinline__ double if0_dpp(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double if0_readlane(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ double if0_wave_max(double v) {
+    v = fmax(v, if0_dpp<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmax(v, if0_dpp<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmax(v, if0_dpp<0x141>(v));   // row_half_mirror
+    v = fmax(v, if0_dpp<0x140>(v));   // row_mirror: all 16 lanes of a row agree
+    return fmax(fmax(if0_readlane(v, 0), if0_readlane(v, 16)), fmax(if0_readlane(v, 32), if0_readlane(v, 48)));
+}
+
 __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     __shared__ double tau_low[32], tau_up[32], smax[32];
-    __shared__ double umax[64];
+    __shared__ double umax2[2][128];   // [parity][interval * 64 + harmonic]: range maxima of smax_pair
     __shared__ double bmax[256];  // maxima of the 64-bin blocks of ur (n <= 16384)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long f = blockIdx.x;
     const int n = a.n;
+    int upar = 0;
     const double* __restrict__ uk = a.ut + f * (long long)n;
     double* __restrict__ ur = a.ur + f * (long long)n;
     double* __restrict__ ud = a.ud + f * (long long)n;
@@ -386,25 +407,65 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     __threadfence_block();
     build_bmax();
 
-    // periodicity.py:144-163; executed by every thread with identical (uniform) results
-    auto smax_fn = [&](int q) -> double {
-        const double tl = tau_low[q], tu = tau_up[q];
-        const double tau = 0.5 * (tl + tu);
-        const double deltatau = tu - tl;
-        // one wave per harmonic m: range maxima without workgroup barriers
-        for (int m = 1 + wave; m < a.M; m += PER_T / 64) {
-            const int lowk = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
-            int highk = (int)(m * a.K / (tau - 0.5 * deltatau) + 0.5);
-            if (highk > n - 1) highk = n - 1;  // numpy slicing clips silently
-            const double mx = wave_range_max(ur, bmax, lowk, highk, lane);
-            if (lane == 0) umax[m] = mx;
+    // periodicity.py:144-163 for TWO intervals at once (a halving step of min_search evaluates the new interval and the
+    // best one so far); executed by every thread with identical (uniform) results.  One wave per harmonic m for the range
+    // maxima; a wave takes PER_G harmonics x both intervals per pass: their loads -- the ragged ends from ur, the whole
+    // 64-bin blocks from bmax -- are issued unconditionally (clamped positions, -inf by select) before the first of them
+    // is used, and the wave maxima are DPP row steps + v_readlane (no LDS round trips; the shuffle form was twelve
+    // ds_bpermute with a wait each per range).  Half the barriers of the one-interval-at-a-time form.  A maximum does not
+    // depend on the order: the results are the same bits.
+    constexpr int PER_G = 1;   // harmonics per wave and pass (measured 1 / 2 / 3 / 5: 4.75 / 5.5 / 6.8 / 6.6 ms per 3230 frames --
+                               // registers, i.e. resident workgroups, are worth more here than loads in flight per wave)
+    auto smax_pair = [&](int qa, int qb, double& sal_a, double& sal_b) {
+        double tl[2] = {tau_low[qa], tau_low[qb]}, tu[2] = {tau_up[qa], tau_up[qb]};
+        double* um = umax2[upar];
+        for (int m0 = 1 + wave; m0 < a.M; m0 += PER_G * (PER_T / 64)) {
+            double mx[2 * PER_G];
+#pragma unroll
+            for (int g = 0; g < 2 * PER_G; ++g) {
+                const int w = g & 1, m = m0 + (g >> 1) * (PER_T / 64);
+                const double tau = 0.5 * (tl[w] + tu[w]), deltatau = tu[w] - tl[w];
+                const int lo = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
+                int hi = (int)(m * a.K / (tau - 0.5 * deltatau) + 0.5);
+                if (hi > n - 1) hi = n - 1;  // numpy slicing clips silently
+                const bool live = m < a.M;
+                const bool wide = hi - lo >= 192;
+                const int b0 = (lo + 63) >> 6, b1 = (hi + 1) >> 6;  // whole blocks [b0, b1) of a wide range
+                // three positions in ur: a narrow range is lo + lane + 64 j; a wide one its two ragged ends
+                const int i0 = lo + lane, i1 = wide ? b1 * 64 + lane : lo + lane + 64, i2 = lo + lane + 128;
+                const bool ok0 = live && (wide ? i0 < b0 * 64 : i0 <= hi), ok1 = live && i1 <= hi, ok2 = live && !wide && i2 <= hi;
+                const double v0 = ur[ok0 ? i0 : 0], v1 = ur[ok1 ? i1 : 0], v2 = ur[ok2 ? i2 : 0];
+                double mm = ok0 ? v0 : -INFINITY;
+                mm = ok1 && v1 > mm ? v1 : mm;
+                mm = ok2 && v2 > mm ? v2 : mm;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // n <= 16384: at most 256 blocks
+                    const int b = b0 + lane + 64 * j;
+                    const bool okb = live && wide && b < b1;
+                    const double vb = bmax[okb ? b : 0];
+                    mm = okb && vb > mm ? vb : mm;
+                }
+                mx[g] = mm;
+            }
+#pragma unroll
+            for (int g = 0; g < 2 * PER_G; ++g) mx[g] = if0_wave_max(mx[g]);
+            if (lane == 0) {
+#pragma unroll
+                for (int g = 0; g < 2 * PER_G; ++g) {
+                    const int m = m0 + (g >> 1) * (PER_T / 64);
+                    if (m < a.M) um[(g & 1) * 64 + m] = mx[g];
+                }
+            }
         }
         __syncthreads();
-        double salience = 0.0;
-        for (int m = 1; m < a.M; ++m) salience += (m * a.fs / tu + a.epsilon2) * umax[m];
-        salience *= a.fs / tl + a.epsilon1;
-        __syncthreads();
-        return salience;
+        double s0 = 0.0, s1 = 0.0;
+        for (int m = 1; m < a.M; ++m) {
+            s0 += (m * a.fs / tu[0] + a.epsilon2) * um[m];
+            s1 += (m * a.fs / tu[1] + a.epsilon2) * um[64 + m];
+        }
+        sal_a = s0 * (a.fs / tl[0] + a.epsilon1);
+        sal_b = s1 * (a.fs / tl[1] + a.epsilon1);
+        upar ^= 1;   // the next call writes the other buffer: no second barrier (a barrier separates any two calls' reads)
     };
 
     double voice_sal[8], voice_per[8];
@@ -429,8 +490,8 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
                 tau_up[qbest] = tau_low[q];
             }
             __syncthreads();
-            const double sq = smax_fn(q);
-            const double sb = smax_fn(qbest);
+            double sq, sb;
+            smax_pair(q, qbest, sq, sb);
             if (tid == 0) {
                 smax[q] = sq;
                 smax[qbest] = sb;
