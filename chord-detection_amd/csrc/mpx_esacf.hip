@@ -1410,12 +1410,13 @@ __device__ __forceinline__ double row_sum(double v) {
     v += dpp_f64<0x140>(v);   // row_mirror
     return v;
 }
-// value of lane J of the caller's 16-lane row (ds_swizzle, bit-mask mode: lane' = (lane & 0x10) | J)
+// value of lane J of the caller's 16-lane row: DPP row_newbcast, register to register.  (Until round 3: ds_swizzle in
+// bit-mask mode, a round trip through the LDS crossbar with a wait, thirty of them on the dependent path of a trip.)
 template <int J>
 __device__ __forceinline__ double row_bcast_c(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_ds_swizzle(lo, 0x10 | (J << 5));
-    hi = __builtin_amdgcn_ds_swizzle(hi, 0x10 | (J << 5));
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + J, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + J, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double row_bcast(double v, int j) {  // j in 0..2, a constant after unrolling
