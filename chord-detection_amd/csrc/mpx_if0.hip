@@ -9,7 +9,8 @@
 //                           sequentially; every stage is stable, so a chunk that starts from zero state W
 //                           samples early reproduces the sequential result to fp64 rounding and chunks run in
 //                           parallel.  W comes from the slowest pole of the chain the parameters produce
-//                           (if0_warmup: rho^W W^3 <= 1e-15; the defaults give rho = 0.99893 and W = 65536).
+//                           (if0_warmup: the part of the chain's n^3 rho^n response beyond W is <= 1e-13 of the whole;
+//                           the defaults give rho = 0.99893 and W = 40960).
 //  2. if0_spectrum_kernel   one workgroup per frame: for every channel, Hamming x frame, zero-pad to
 //                           2*frame (iterative_f0.py:72-77), real FFT as a frame-point complex LDS FFT,
 //                           |X|^power accumulated over channels in registers (iterative_f0.py:80-85).
@@ -29,7 +30,7 @@ namespace mpx {
 constexpr int IF0_MAXCH = 128;
 constexpr long long IF0_CHUNK = 262144;   // largest front-end chunk (samples; multiple of every frame size)
 constexpr long long IF0_CHUNK_MIN = 16384;
-constexpr long long IF0_WARMUP = 65536;   // SHORTEST zero-state run-in before a chunk that does not start a clip (if0_warmup)
+constexpr long long IF0_WARMUP = 16384;   // SHORTEST zero-state run-in before a chunk that does not start a clip (if0_warmup)
 constexpr long long IF0_WARMUP_MAX = 1 << 22;
 
 struct If0ChanCoef {   // per channel, built on the host in double
@@ -597,9 +598,16 @@ static int if0_reg_freq(int H, int t, int e) {
 
 // Slowest pole radius of the per-channel chain (2 x resonator 1, 2 x resonator 2: radius A each; the 12 all-pass
 // stages of the warped FIR: |a|; the Butterworth low-pass at the channel frequency: sqrt(a2)), computed from the SAME
-// closed forms if0_plan uses, and the run-in it needs: the zero-input response of four cascaded sections of radius
-// rho decays like n^3 rho^n, so W is the smallest multiple of 8192 (a multiple of every frame size), at least
-// IF0_WARMUP, with rho^W W^3 <= 1e-15.  0 when the chain is too slow for IF0_WARMUP_MAX (or unstable).
+// closed forms if0_plan uses, and the run-in it needs.  The four resonator sections of a channel have (to 1e-6) the same
+// pole pair, so the response to what happened n samples ago is enveloped by n^3 rho^n, whose total is 6 / (1 - rho)^4; the
+// part of it beyond W samples, relative to the whole, is the incomplete gamma ratio Q(4, u) = e^-u (u^3 + 3u^2 + 6u + 6) / 6
+// at u = W (1 - rho).  W is the smallest multiple of 8192 (a multiple of every frame size), at least IF0_WARMUP, with
+// Q(4, u) <= 1e-13: 40960 samples for the default chain (u = 43.8).  Measured on the restated reference (oracle,
+// slowest channel, 22.05 and 44.1 kHz): starting 32768 samples early leaves 3e-12 .. 6e-12 of the sequential result,
+// 40960 leaves 3e-15 .. 6e-15 -- the level at which the other channels differ between ANY two chunkings (5e-14: rounding
+// through the rectifier).  (Rounds 1-2 bounded the ABSOLUTE envelope, rho^W W^3 <= 1e-15, which ignores the 1e-12 gain
+// of the four sections and asked for 65536 samples: a third more front-end work per chunk.)
+// 0 when the chain is too slow for IF0_WARMUP_MAX (or unstable).
 static long long if0_warmup(int fs, const mpx_if0_params& p, double* rho_out) {
     double rho = std::fabs(1.0674 * std::sqrt((2.0 / M_PI) * std::atan(0.06583 * fs / 1000.0)) - 0.1916);
     for (int c = 0; c < p.channels; ++c) {
@@ -611,8 +619,10 @@ static long long if0_warmup(int fs, const mpx_if0_params& p, double* rho_out) {
     }
     if (rho_out) *rho_out = rho;
     if (!(rho < 1.0)) return 0;
-    for (long long w = IF0_WARMUP; w <= IF0_WARMUP_MAX; w += 8192)
-        if (w * std::log(rho) + 3.0 * std::log((double)w) <= std::log(1e-15)) return w;
+    for (long long w = IF0_WARMUP; w <= IF0_WARMUP_MAX; w += 8192) {
+        const double u = (double)w * (1.0 - rho);
+        if (-u + std::log((u * u * u + 3.0 * u * u + 6.0 * u + 6.0) / 6.0) <= std::log(1e-13)) return w;
+    }
     return 0;
 }
 

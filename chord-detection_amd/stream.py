@@ -19,7 +19,7 @@ import numpy as np
 from .chromagram import Chromagram
 from .corpus import gather_blocks, partition
 
-WARMUP = 65536  # samples; the run-in of the DEFAULT filter chain, a multiple of every Iterative-F0 frame size (1024 ... 8192)
+WARMUP = 65536  # samples: the halo of a SUBSTITUTED compute function (CPU tests); the engine asks the library, which needs 40960 for the default chain
 SEED = 20260103  # + segment id
 SEGMENT_SECONDS = 0.5
 
@@ -31,7 +31,7 @@ def num_frames(n, frame_size):
 
 def engine_warmup(fs, device=0, **kw):
     """Run-in samples the LIBRARY asks for with these filter-bank parameters (mpx_iterative_f0_warmup: from the slowest
-    pole of the chain; 65536 for the defaults, more for channel sets that reach higher or lower).  ValueError when the
+    pole of the chain; 40960 for the defaults, more for channel sets that reach higher or lower).  ValueError when the
     chain cannot be cut into shards at all."""
     from .engine import get_engine
     keys = ("frame_size", "power", "channels", "zeta0", "zeta1")

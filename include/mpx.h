@@ -197,7 +197,7 @@ int mpx_prime_multif0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs
  * frames of `frame_size` (1024/2048/4096/8192) x Hamming zero-padded to 2*frame_size, sum over channels of
  * |FFT|^power, then the iterative period search / harmonic cancellation per frame.
  * Long signals are filtered in chunks of up to 262144 samples, each with a zero-state run-in of
- * mpx_iterative_f0_warmup samples (65536 for the defaults: the chain has decayed to fp64 rounding by then), so
+ * mpx_iterative_f0_warmup samples (40960 for the defaults: the chain has decayed to fp64 rounding by then), so
  * chunks run in parallel and shard across GPUs. */
 typedef struct mpx_if0_params {
     int frame_size;      /* default 8192 */
@@ -229,9 +229,11 @@ int mpx_iterative_f0_batch(mpx_ctx* ctx, const float* signals, const int64_t* of
 int mpx_iterative_f0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_if0_params* params,
                          double* d_chroma_frames, double* d_chroma_sum, void* stream);
 
-/* Zero-state run-in (samples, a multiple of 8192, >= 65536) after which this parameter set's filter chain has
- * forgotten its start to fp64 rounding: rho^W W^3 <= 1e-15 for the slowest pole radius rho of the chain (also returned
- * when pole_radius != NULL; 0.99893 and 65536 for the defaults at any sample rate).  The library uses it for its own
+/* Zero-state run-in (samples, a multiple of 8192, >= 16384) after which this parameter set's filter chain has
+ * forgotten its start to fp64 rounding: the part of its n^3 rho^n response older than W samples is <= 1e-13 of the whole,
+ * e^-u (u^3 + 3u^2 + 6u + 6) / 6 at u = W (1 - rho), for the slowest pole radius rho of the chain (also returned when
+ * pole_radius != NULL; 0.99893 and 40960 for the defaults at any sample rate; until round 3 the bound was the absolute
+ * rho^W W^3 <= 1e-15: 65536).  The library uses it for its own
  * chunks; a caller that shards one stream over GPUs starts each shard this many samples early (stream.py).
  * MPX_EINVAL when the chain is unstable or would need more than 4 M samples: mpx_iterative_f0* then refuse too. */
 int mpx_iterative_f0_warmup(mpx_ctx* ctx, int fs, const mpx_if0_params* params, int64_t* samples, double* pole_radius);

@@ -100,3 +100,17 @@ def test_bench_without_cpu_leg_and_smoke():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_scale_script_one_gpu():
+    """scripts/scale_1to8.sh at N = 1 (all this box has): the launcher path (torch.distributed.run, one rank) prints the
+    driver's fields and agrees with the plain bench.py value; larger N are reported as skipped, not failed."""
+    out = subprocess.run(["bash", os.path.join(ROOT, "scripts", "scale_1to8.sh"), "--steps", "300", "--warmup", "30", "--gpus", "1 2"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(l) for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 2
+    one = lines[0]
+    assert one["n_gpus"] == 1 and one["value"] > 1e7 and one["scaling"] == "weak" and len(one["ms_per_step_repeats"]) == 5
+    assert one["plain_bench_value"] > 0 and abs(one["plain_bench_value"] - one["value"]) < 0.15 * one["value"]
+    assert lines[1]["n_gpus"] == 2 and ("skipped" in lines[1] or lines[1].get("value", 0) > 0)

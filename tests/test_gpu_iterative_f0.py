@@ -82,7 +82,7 @@ def test_spectra_and_batch_vs_oracle(eng, clips):
 
 
 def test_chunked_front_end_matches_sequential_filtering(eng):
-    """A signal longer than one 262144-sample chunk: chunks start from zero state 65536 samples early.
+    """A signal longer than one 262144-sample chunk: chunks start from zero state mpx_iterative_f0_warmup (40960) samples early.
     The reference filters sequentially; the oracle does too.  Agreement shows the run-in is long enough."""
     from oracle import iterative_f0 as o_if0
     rng = np.random.default_rng(11)

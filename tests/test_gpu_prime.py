@@ -93,6 +93,49 @@ def test_batch_edge_cases_vs_oracle(eng, clips):
         eng.prime_multif0(np.zeros((2, 2), dtype=np.float32), FS)
 
 
+def test_frame_pairs_silence_and_one_frame_mode(eng):
+    """Round 3: prime_pers_kernel transforms two consecutive real frames of a clip at once and separates them by conjugate
+    symmetry.  (a) A frame of digital silence next to a loud one must contribute the reference's exact nothing (its spectrum
+    is all zeros: the argmax lands on the DC bin, hz_to_note raises, `continue`), not the partner's rounding noise;
+    (b) clips whose frame counts per candidate are odd, even and 1; (c) 48 kHz: the lowest candidates (2731..3277
+    samples) run one frame per transform on the same kernel, the others in pairs."""
+    from oracle import prime_multif0 as o_prime
+    rng = np.random.default_rng(7)
+    t = np.arange(9000) / FS
+    tone = (0.5 * np.sin(2 * np.pi * 329.63 * t) + 0.25 * np.sin(2 * np.pi * 659.26 * t)).astype(np.float32)
+    cases = {
+        "tone_then_silence": np.concatenate([tone, np.zeros(9000, dtype=np.float32)]),
+        "silence_then_tone": np.concatenate([np.zeros(9000, dtype=np.float32), tone]),
+        "alternating": np.concatenate([tone[:1348], np.zeros(1348, dtype=np.float32)] * 4),
+        "one_frame_each": tone[:300],
+        "exactly_two_frames_of_the_longest": tone[:2 * 1348],
+        "all_silence": np.zeros(5000, dtype=np.float32),
+    }
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, x in cases.items():
+            for mode in ("unicode", "ascii"):
+                got = eng.prime_multif0(x, FS, note_names=mode)
+                want = o_prime.prime_compute(x.astype(np.float64), FS, note_names=mode)
+                np.testing.assert_allclose(got, want, rtol=RTOL, atol=1e-12, err_msg=name)
+                if name == "all_silence":
+                    assert not got.any()
+        # silence contributes NOTHING: the clip with silence appended equals the clip alone wherever the frames line up
+        # (candidate by candidate the tone's frames are the same samples; the extra frames are silent)
+        a = eng.prime_multif0(cases["tone_then_silence"], FS, note_names="ascii")
+        b = o_prime.prime_compute(cases["tone_then_silence"].astype(np.float64), FS, note_names="ascii")
+        assert np.array_equal(a == 0, b == 0)   # exactly the oracle's empty pitch classes: no 1e-17 leak from a loud partner
+        # 48 kHz, a chord with noise, against the oracle
+        t48 = np.arange(30000) / 48000.0
+        x48 = (0.3 * np.sin(2 * np.pi * 196.0 * t48) + 0.2 * np.sin(2 * np.pi * 246.94 * t48) + 0.1 * np.sin(2 * np.pi * 392.0 * t48)
+               + 1e-3 * rng.standard_normal(t48.shape[0])).astype(np.float32)
+        np.testing.assert_allclose(eng.prime_multif0(x48, 48000), o_prime.prime_compute(x48.astype(np.float64), 48000),
+                                   rtol=RTOL, atol=1e-7)
+        batch = eng.prime_multif0_batch([x48, x48[:12345], np.zeros(4000, dtype=np.float32)], 48000)
+        np.testing.assert_array_equal(batch[0], eng.prime_multif0(x48, 48000))
+        assert not batch[2].any()
+
+
 def test_equal_length_clips_share_one_item_list(eng, clips):
     """A batch of equal-length clips takes the path where the host builds ONE clip's item list and the kernel derives
     the others: every clip must come out exactly as on its own, and as in a ragged batch (the general path)."""

@@ -162,7 +162,7 @@ def test_iterative_f0_at_44100_across_chunk_and_piece_boundaries(monkeypatch):
     assert want.shape == (41, 12) and np.abs(want).sum() > 0
     eng = cd.get_engine(0)
     w, rho = eng.iterative_f0_warmup(fs)
-    assert w == 65536 and 0.99892 < rho < 0.99894          # the default chain: what DESIGN.md and stream.WARMUP assume
+    assert w == 40960 and 0.99892 < rho < 0.99894          # the default chain; stream.WARMUP, the CPU tests' halo, is larger
     total, got = eng.iterative_f0(x, fs, return_frames=True)
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=0)
     ut = eng.iterative_f0_spectra(x, fs)
@@ -185,8 +185,9 @@ def test_run_in_follows_the_slowest_pole():
     eng = cd.get_engine(0)
     w0, r0 = eng.iterative_f0_warmup(22050)
     w1, r1 = eng.iterative_f0_warmup(44100, channels=80, zeta1=0.45)        # top channel near 20 kHz
-    assert w0 == 65536 and r1 > r0 and w1 > w0 and w1 % 8192 == 0
-    assert r1 ** w1 * float(w1) ** 3 <= 1e-15 < r1 ** (w1 - 8192) * float(w1 - 8192) ** 3
+    assert w0 == 40960 and r1 > r0 and w1 > w0 and w1 % 8192 == 0
+    tail = lambda w: np.exp(-w * (1 - r1)) * ((w * (1 - r1)) ** 3 + 3 * (w * (1 - r1)) ** 2 + 6 * w * (1 - r1) + 6) / 6   # Q(4, u)
+    assert tail(w1) <= 1e-13 < tail(w1 - 8192)
     n = w1 + 5 * FRAME
     x = stream.synth_stream(0, n, 44100, "cuda:0").cpu().numpy()
     kw = dict(channels=80, zeta1=0.45)
@@ -195,17 +196,19 @@ def test_run_in_follows_the_slowest_pole():
         rows = [stream.run_stream_shard(lambda a, b: x[a:b], n, 44100, r, world, FRAME, **kw)[2] for r in range(world)]
         np.testing.assert_allclose(np.concatenate(rows), whole, rtol=1e-9, atol=1e-12)
     with pytest.raises(ValueError):
-        eng.iterative_f0_warmup(768000, channels=100, zeta1=0.65)           # top channel at 298 kHz: pole radius 0.99998,
-                                                                            # 4.4 M samples of run-in: refused
+        eng.iterative_f0_warmup(2000000, channels=100, zeta1=0.75)          # top channel at 865 kHz: pole radius 0.999994,
+                                                                            # 6.4 M samples of run-in (> 4 M): refused
+    w2, r2 = eng.iterative_f0_warmup(768000, channels=100, zeta1=0.65)      # 298 kHz: radius 0.99998 -> 2.2 M samples: accepted
+    assert 2_000_000 < w2 < 2_400_000 and w2 % 8192 == 0 and 0.99998 < r2 < 0.99999
     with pytest.raises(ValueError):
-        eng.iterative_f0(np.zeros(9000, dtype=np.float32), 768000, channels=100, zeta1=0.65)
+        eng.iterative_f0(np.zeros(9000, dtype=np.float32), 2000000, channels=100, zeta1=0.75)
 
 
 @pytest.mark.gpu
 def test_one_hour_stream_shard_count_invariance():
     """BASELINE configs[4] at full size: Iterative-F0 over ONE 1 h stream @44.1 kHz (19 380 frames).  Size-independent
     property: the frames do not depend on how many time shards (GPUs) the stream was cut into -- 1, 2, 3 and 8 shards,
-    each started 65536 samples early from zero state, agree to 1e-9, and the run is reproducible."""
+    each started the run-in (40960 samples for this chain) early from zero state, agree to 1e-9, and the run is reproducible."""
     import time
     fs, secs = 44100, 3600.0
     n = int(round(secs * fs))
