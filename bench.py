@@ -959,7 +959,7 @@ def wl_if0_stream(c):
 
     def compute_block():
         if c["stub"] is None:
-            return stream.run_stream_rank(lambda a, b: x[a - s0:b - s0], n, fs, rank, world, nf_size, local, sub=3)[2]
+            return stream.run_stream_rank(lambda a, b: x[a - s0:b - s0], n, fs, rank, world, nf_size, local)[2]
         return stream.run_stream_shard(lambda a, b: x.numpy(), n, fs, rank, world, nf_size, local, **kw)[2]
 
     t0 = time.perf_counter()
@@ -989,7 +989,9 @@ def wl_if0_stream(c):
            "dtype": "f64", "frames": total_frames,
            "config": {"workload": "Iterative-F0, one %.0f s stream @%d Hz, frames of %d, time-sharded over the GPUs with a "
                                   "65536-sample halo, one all_gather of [frames, 12] (BASELINE.json configs[4]); the stream "
-                                  "is resident in HBM" % (secs, fs, nf_size), "shards_in_flight_per_gpu": 3}}
+                                  "is resident in HBM" % (secs, fs, nf_size),
+                      "engine_calls_per_gpu": "one call over the rank's share when its front-end output fits 90 GiB "
+                                              "(the 1 h stream on one GPU: 83 GiB), else three time shards in flight"}}
     if prof:
         kms = {k: v[1] for k, v in prof.items()}
         dom = max(kms, key=kms.get)

@@ -1019,8 +1019,11 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     // rounds of 98 304 steps where 467 chunks take one round of 131 072.)
     const long long simds = 4LL * ctx->num_cus;
     const int nt_ch = p.channels % 64, full_ch = p.channels / 64;
+    // Candidates: every multiple of 8192 samples (a multiple of every frame size) up to IF0_CHUNK, not only the powers of
+    // two: the hour of 44.1 kHz audio is 923 chunks of 172 032 samples = 1015 waves, ONE round of 212 992 steps, where
+    // 262 144-sample chunks fill 65 % of the SIMDs for 303 104 steps.
     long long chunk = IF0_CHUNK, best_cost = -1;
-    for (long long cand = IF0_CHUNK; cand >= IF0_CHUNK_MIN; cand >>= 1) {
+    for (long long cand = IF0_CHUNK; cand >= IF0_CHUNK_MIN; cand -= 8192) {
         long long chunks_total = 0;
         for (int c = 0; c < num_clips; ++c) {
             const int64_t len = offsets[c + 1] - offsets[c];
@@ -1162,6 +1165,10 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     a.epsilon2 = p.epsilon2;
     a.gamma = p.gamma;
     a.chroma = (dev_io && chroma_frames) ? chroma_frames : (double*)ctx->d_frames_out.p;
+    // (Measured and rejected at the end of round 3: the period search of one group of 2048 frames on a second stream next to
+    //  the summary spectra of the next group -- it fits beside them on every CU, but the whole-hour call went from 126.5 to
+    //  135 ms: its re-reads of the spectrum rows (6.9 x their bytes, through L2) slow the LDS/L2-bound spectra down by more
+    //  than its own 25 ms.)
     prof_mark(ctx, st, "if0_periodicity_kernel");
     hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
     prof_mark(ctx, st, nullptr);

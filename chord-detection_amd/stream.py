@@ -103,16 +103,25 @@ def _engine_frames_on(j):
 
 
 PIECE_BYTES = 32 << 30   # front-end output of one piece (560 B per sample at 70 channels): bounds the contexts' workspaces
+ONE_CALL_BYTES = 90 << 30   # a rank's whole share goes through ONE engine call when its front-end output fits this (the
+                            # library refuses beyond 96 GiB): the front end then cuts ONE launch of ~1000 long chunks -- 923
+                            # x 172 032 samples for an hour of 44.1 kHz audio, a run-in per chunk of 24 % instead of 62 % --
+                            # and the whole-hour call takes 0.127 s where three 30 GB pieces in flight took 0.145 s
 
 
-def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=3, channels=70, **kw):
-    """This rank's frames, computed as `sub` time shards IN FLIGHT on the same GPU (one context and one host thread
-    each; ctypes releases the GIL): the front end of one shard runs next to the spectra and the period search of the
-    other.  Same halo logic as between ranks: the rank's block of frames is partitioned once more.
-    Returns (f0, f1, frames[f1-f0, 12])."""
+def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=None, channels=70, **kw):
+    """This rank's frames.  sub=None: one engine call when the share fits ONE_CALL_BYTES of front-end output, else three
+    time shards IN FLIGHT on the same GPU (one context and one host thread each; ctypes releases the GIL): the front end of
+    one shard runs next to the spectra and the period search of the other.  Same halo logic as between ranks: the rank's
+    block of frames is partitioned once more.  Returns (f0, f1, frames[f1-f0, 12])."""
     import threading
     warmup = engine_warmup(fs, device, frame_size=frame_size, channels=channels, **kw)
     F0, F1 = partition(num_frames(n, frame_size), world, rank)
+    if sub is None:
+        sub = 1 if (F1 - F0) * int(frame_size) * int(channels) * 8 <= ONE_CALL_BYTES else 3
+    if sub == 1 and (F1 - F0) * int(frame_size) * int(channels) * 8 <= ONE_CALL_BYTES:
+        return run_stream_shard(read, n, fs, rank, world, frame_size, device, compute=_engine_frames_on(0), frames=(F0, F1),
+                                warmup=warmup, channels=channels, **kw)
     # pieces: a multiple of `sub`, each small enough for PIECE_BYTES of front-end output (a two-hour stream would
     # otherwise ask one context for 180 GB, and the library refuses beyond 96 GiB per call)
     per_frame = int(frame_size) * int(channels) * 8
@@ -197,9 +206,10 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     ap.add_argument("--seconds", type=float, default=3600.0)
     ap.add_argument("--fs", type=int, default=44100)
     ap.add_argument("--frame-size", type=int, default=8192)
-    ap.add_argument("--shards-per-gpu", type=int, default=3,
-                    help="time shards in flight on each GPU, own context each (1 h @44.1 kHz on one MI355X: 18 900x real time "
-                         "with 1, 19 300x with 2, 20 800x with 3, 20 000x with 4)")
+    ap.add_argument("--shards-per-gpu", type=int, default=0,
+                    help="time shards in flight on each GPU, own context each; 0 (default): one engine call over the rank's "
+                         "share when its front-end output fits 90 GiB, else 3 (1 h @44.1 kHz on one MI355X, round 3: "
+                         "0.13-0.14 s in one call, 0.145-0.15 s with 3 shards)")
     args = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -225,7 +235,7 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
         return synth_stream(s0, s1, args.fs, dev)
 
     if compute is None:
-        for j in range(max(1, args.shards_per_gpu)):   # plans, tables, clocks -- of every context
+        for j in range(max(1, args.shards_per_gpu or 3)):   # plans, tables, clocks -- of every context
             _engine_frames_on(j)(read(0, min(n, 4 * args.frame_size)), args.fs, args.frame_size, local)
     if world > 1:
         dist.barrier()
@@ -244,9 +254,9 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
         if compute is not None:    # the CPU tests' checker: one shard per rank, same halo logic
             return run_stream_shard(lambda a, b: x.numpy(), n, args.fs, rank, world, args.frame_size, local,
                                     compute=compute)[2]
-        if args.shards_per_gpu > 1:
+        if args.shards_per_gpu != 1:
             return run_stream_rank(lambda a, b: x[a - s0:b - s0], n, args.fs, rank, world, args.frame_size, local,
-                                   sub=args.shards_per_gpu)[2]
+                                   sub=args.shards_per_gpu or None)[2]
         return run_stream_shard(lambda a, b: x, n, args.fs, rank, world, args.frame_size, local)[2]
 
     # twice: the first pass grows the contexts' workspaces (tens of GB of hipMalloc: 0.1 ... 3 s, whatever state the
@@ -269,7 +279,7 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
                           "n_gpus": world, "frames": total_frames, "frames_per_rank": f1 - f0,
                           "synthesis_seconds_rank_max": synth_s, "compute_seconds_rank_max": compute_s,
                           "x_realtime_compute": args.seconds / compute_s if compute_s > 0 else None,
-                          "compute_seconds_first_pass": cold_s, "shards_in_flight_per_gpu": args.shards_per_gpu,
+                          "compute_seconds_first_pass": cold_s, "shards_in_flight_per_gpu": args.shards_per_gpu or "auto (one call when the share fits 90 GiB of front-end output, else 3)",
                           "chroma": repr(c), "key": c.key()}))
     if world > 1:
         dist.destroy_process_group()
