@@ -129,8 +129,14 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             nx[q] = ok ? v : 0.f;
         }
     };
+    // Outputs from the end of the clip on are never looked at: the reference pads the FILTERED signal with zeros, and the
+    // spectrum kernel replaces every sample from `valid` on by zero before it multiplies.  A wave of one chunk therefore
+    // stops at the last real sample (rounded up to a tile) instead of filtering the zero padding up to the whole frame:
+    // 44 112 instead of 49 168 steps for a two-second clip at 22.05 kHz.  (A wave of leftover channels of several chunks
+    // keeps the common bound.)
+    const int c_end = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
     fetch(-c_warm);
-    for (int tb = -c_warm; tb < c_len + DEPTH; tb += PF) {
+    for (int tb = -c_warm; tb < c_end + DEPTH; tb += PF) {
         float xs[PF];
 #pragma unroll
         for (int q = 0; q < PF; ++q) xs[q] = nx[q];
@@ -190,7 +196,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             }
         }
         const int t0 = tb - DEPTH;
-        if (t0 >= 0 && t0 < c_len) {   // uniform: warm-up and length are multiples of 16
+        if (t0 >= 0 && t0 < c_end) {   // uniform: warm-up and length are multiples of 16
             wave_lds_fence();
             // (the tile is read unconditionally, all sixteen rows at once, and only the stores are predicated: with the read
             //  inside the condition every element was a branch and two waits for the LDS)
