@@ -1119,7 +1119,10 @@ __device__ __forceinline__ double pv_hann(const cx<double>* __restrict__ tw, int
     return 0.5 - 0.5 * tw[n & (PV_NFFT - 1)].x;  // periodic Hann: cos(2 pi n / 2048) = Re W_2048^n
 }
 
-__global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a) {
+// PICK: the peak picking of the finished row runs at the end of this kernel, on the LDS copy it already holds (until round 3:
+// a second kernel that read the row back from HBM).
+template <bool PICK>
+__global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a, SacfArgs sa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                       // 2048 complex (padded)
     double* x = reinterpret_cast<double*>(buf + lds_slots(PV_NFFT));             // [Mh] working copy of the SACF
@@ -1235,6 +1238,10 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a) {
         __syncthreads();
     }
     for (int n = tid; n < Mh; n += PV_T) row[n] = x[n];
+    if (PICK) {
+        __syncthreads();   // the transform buffer is dead: it is the picker's scratch
+        peak_pick<PV_T>(sa, f, x, reinterpret_cast<char*>(buf), tid);
+    }
 }
 
 // Peak picking on rows that are already enhanced (phase-vocoder regime).
@@ -2533,12 +2540,17 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             pa.n_peaks_elim = p.n_peaks_elim;
             pa.tw = (const cx<double>*)pit->second[0];
             const size_t pv_lds = sizeof(cx<double>) * lds_slots(PV_NFFT) + sizeof(double) * (size_t)(Mh + 2);
-            MPX_HIP(ctx, hipFuncSetAttribute((const void*)pv_enhance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_lds));
+            static_assert(PV_T == 256, "peak_pick<256> inside pv_enhance_kernel");
+            const bool fused = peak_scratch_bytes(Mh) <= sizeof(cx<double>) * lds_slots(PV_NFFT) && !dev_env_on("MPX_PV_SEPARATE_PICK");
+            auto pvk = fused ? pv_enhance_kernel<true> : pv_enhance_kernel<false>;
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)pvk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_lds));
             prof_mark(ctx, st, "pv_enhance_kernel");
-            hipLaunchKernelGGL(pv_enhance_kernel, dim3((unsigned)nf), dim3(PV_T), pv_lds, st, pa);
-            const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
-            prof_mark(ctx, st, "peakpick_kernel");
-            hipLaunchKernelGGL(peakpick_kernel<256>, dim3((unsigned)nf), dim3(256), pk_lds, st, a);
+            hipLaunchKernelGGL(pvk, dim3((unsigned)nf), dim3(PV_T), pv_lds, st, pa, a);
+            if (!fused) {
+                const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
+                prof_mark(ctx, st, "peakpick_kernel");
+                hipLaunchKernelGGL(peakpick_kernel<256>, dim3((unsigned)nf), dim3(256), pk_lds, st, a);
+            }
             MPX_HIP(ctx, hipGetLastError());
         }
         if (!pv && (a.ablate & 16)) {
