@@ -73,6 +73,7 @@ SIGNATURES = {
     "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_set_remez_taps": (C.c_int, [_vp, C.c_int, _dp]),
     "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),
+    "mpx_test_pow067": (C.c_int, [_dp, C.c_int, _dp]),
     "mpx_timer_begin": (C.c_int, [_vp, _vp]),
     "mpx_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "mpx_host_alloc": (_vp, [C.c_size_t]),

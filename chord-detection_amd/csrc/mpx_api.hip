@@ -5,6 +5,7 @@
 
 #include "mpx_internal.hpp"
 #include "mpx_lm.hpp"
+#include "mpx_pow067.hpp"
 
 static thread_local std::string g_create_error;
 
@@ -594,6 +595,15 @@ int mpx_test_gaussian_fit(const double* xs, const double* ys, int m, double* cen
         pr.ys[i] = ys[i];
     }
     return mpx::lm::gaussian_fit(pr, center);
+}
+
+// host-callable copy of the SACF kernels' |X|^0.67
+int mpx_test_pow067(const double* x, int n, double* out) {
+    if (!x || !out || n < 0) return MPX_EINVAL;
+    double tab[mpx::p067::TAB_DOUBLES];
+    mpx::p067::build_tables(tab);
+    for (int i = 0; i < n; ++i) out[i] = mpx::p067::pow067(x[i], tab);
+    return MPX_OK;
 }
 
 int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int fs,

@@ -22,6 +22,7 @@
 #include "mpx_fft_dif.hpp"
 #include "mpx_internal.hpp"
 #include "mpx_lm.hpp"
+#include "mpx_pow067.hpp"
 
 namespace mpx {
 
@@ -242,6 +243,7 @@ struct SacfArgs {
     int ablate;         // profiling knob (env MPX_SACF_ABLATE): 1 no pow, 2 no peak picking, 4 no 2nd DFT, 8 no 1st DFT
     // prime-factor engine (sacf_pfa_kernel): N = A0 * 3 * 11 * 31
     const unsigned short* pfa_pos;    // [N]   array position of index n (input sample n; output lag n)
+    const double* pow_tab;            // [193] tables of mpx_pow067.hpp (|X|^0.67)
     const unsigned short* pfa_pairs;  // [npairs][2] positions (p, mirror p), p <= mirror p
     const cx<double>* pfa_cs31;       // [16][16] (cos, sin)(2 pi n k / 31), k = 0..15, n = 0..15
     const cx<double>* pfa_cs11;       // [6][5]   (cos, sin)(2 pi n k / 11)
@@ -526,7 +528,14 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
 // audio-range input are far from the overflow/underflow guards of hypot; the result is within ~15 ulp of
 // numpy's (|0.335 ln q| <= 30 amplifies the rounding of log), two orders of magnitude below the rounding
 // noise the FFTs put on the SACF.  |X| = 0 gives exp(-inf) = 0 like 0 ** 0.67.
-__device__ __forceinline__ double mag067(double re, double im) { return exp(0.335 * log(re * re + im * im)); }
+// |X|^0.67 of one band (esacf.py:95-101, k fixed at 0.67) from its real and imaginary part; tab: mpx_pow067.hpp tables in LDS
+__device__ __forceinline__ double mag067(double re, double im, const double* tab) { return p067::pow067(re * re + im * im, tab); }
+// the library form (until round 3 everywhere; still sacf_pfa_kernel<1>, see there)
+__device__ __forceinline__ double mag067_libm(double re, double im) { return exp(0.335 * log(re * re + im * im)); }
+// every SACF kernel keeps the 193-entry table in (static) LDS: filled at the start, first used behind a workgroup barrier
+#define MPX_POW067_LDS(a, tid, nthreads)                                   \
+    __shared__ double pow_tab[p067::TAB_DOUBLES];                           \
+    for (int i_ = (tid); i_ < p067::TAB_DOUBLES; i_ += (nthreads)) pow_tab[i_] = (a).pow_tab[i_]
 
 template <int L, bool BLUE>
 __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                      // L complex, slot sigma<L>(position)
     double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * L);      // Mh + 2 doubles
     const int tid = threadIdx.x;
+    MPX_POW067_LDS(a, tid, T);
     const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(a.tw, tid);
     cx<double> regs[8];
     cx<double> chv[4];  // this thread's chirp values (Bluestein)
@@ -588,8 +598,9 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
                 // X_lo = (A + B)/2 ; X_hi = (A - B)/(2i)
                 const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
                 const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-                sv[e] = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);  // k fixed at 0.67
+                sv[e] = (a.ablate & 1) ? lr + hr : mag067(lr, li, pow_tab) + mag067(hr, hm, pow_tab);  // k fixed at 0.67
             }
+            __builtin_amdgcn_sched_barrier(0);   // one bin (two powers) at a time: interleaved, the eight of them spill
         }
         __syncthreads();  // mirror reads done: buf is free
         if (h == 0 && have_b) {
@@ -915,10 +926,16 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
     const unsigned short* __restrict__ pos = a.pfa_pos;                         // [N] position of index n (L2-resident)
     cx<double>* cs31 = reinterpret_cast<cx<double>*>(smem + PFA_TAB_OFF(N, Mh));   // [16][16]
     cx<double>* cs11 = cs31 + 256;                                                    // [6][5]
+    __shared__ double pow_tab[p067::TAB_DOUBLES];
     {
+        // all three table loads are issued before the first of them is stored: one L2 round trip, not three
         const int tid = threadIdx.x;
-        cs31[tid] = a.pfa_cs31[tid];
-        if (tid < 30) cs11[tid] = a.pfa_cs11[tid];
+        const cx<double> v31 = a.pfa_cs31[tid];
+        const cx<double> v11 = a.pfa_cs11[tid < 30 ? tid : 0];
+        const double vp = A0 == 1 ? 0.0 : a.pow_tab[tid < p067::TAB_DOUBLES ? tid : 0];
+        cs31[tid] = v31;
+        if (tid < 30) cs11[tid] = v11;
+        if (A0 != 1 && tid < p067::TAB_DOUBLES) pow_tab[tid] = vp;
     }
     __syncthreads();
     const double inv_n = 1.0 / (double)N;
@@ -963,7 +980,11 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
                 const cx<double> B = cconj(buf[qq[r]]);
                 const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
                 const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-                const double sv = (a.ablate & 1) ? lr + hr : mag067(lr, li) + mag067(hr, hm);
+                // N = 1023 (two pairs per thread: four powers in flight) is FASTER on the library's log / exp, which never
+                // wait for a table read (3.9 against 4.3 ms per 176 k frames); N = 2046 (eight in flight) on the tables
+                // (6.0 -> 5.6 ms).  Both are within their error of the true power (4e-15 / 3e-16): a per-size choice.
+                const double sv = (a.ablate & 1) ? lr + hr
+                                  : (A0 == 1 ? mag067_libm(lr, li) + mag067_libm(hr, hm) : mag067(lr, li, pow_tab) + mag067(hr, hm, pow_tab));
                 if (tid + r * T < NPAIRS) {
                     buf[pp[r]] = {sv, 0.0};
                     buf[qq[r]] = {sv, 0.0};
@@ -1042,6 +1063,7 @@ __global__ __launch_bounds__(T) void sacf_big_kernel(SacfArgs a) {
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                                  // L complex, padded
     double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));       // Mh + 2 doubles
     const int tid = threadIdx.x;
+    MPX_POW067_LDS(a, tid, T);
     const long long f = blockIdx.x;
     cx<double> regs[L / T];
     const cx<double>* xin = a.xb + band_index(f, 0, N);
@@ -1059,7 +1081,7 @@ __global__ __launch_bounds__(T) void sacf_big_kernel(SacfArgs a) {
             const cx<double> B = cconj(buf[lds_slot(k == 0 ? 0 : N - k)]);
             const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
             const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
-            sv[e] = mag067(lr, li) + mag067(hr, hm);
+            sv[e] = mag067(lr, li, pow_tab) + mag067(hr, hm, pow_tab);
         }
     }
     __syncthreads();
@@ -2486,6 +2508,17 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         // measured, not adopted: pairing saves 0.85 ms per 176 k frames, but the rounding-level cross-talk between the
         // two frames makes results depend on the batch neighbour and flips 0.075 % of the frames (ill-conditioned fits)
         a.pair = !deterministic && dev_env_on("MPX_SACF_PAIR") ? 1 : 0;
+        {
+            auto pt = ctx->misc_plans.find("pow067_tab");
+            if (pt == ctx->misc_plans.end()) {
+                double tab[p067::TAB_DOUBLES];
+                p067::build_tables(tab);
+                void* d = upload(ctx, tab, sizeof tab);
+                if (!d) return MPX_ENOMEM;
+                pt = ctx->misc_plans.emplace("pow067_tab", std::vector<void*>{d}).first;
+            }
+            a.pow_tab = (const double*)pt->second[0];
+        }
         a.ablate = dev_env_int("MPX_SACF_ABLATE", 0);
         prof_mark(ctx, st, use_pfa ? "sacf_pfa_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel"));
         if (use_pfa) {

@@ -268,6 +268,10 @@ int mpx_set_remez_taps(mpx_ctx* ctx, int fs, const double* taps13);
  * negative mpx_status; m in [3, 21]. */
 int mpx_test_gaussian_fit(const double* xs, const double* ys, int m, double* center);
 
+/* Host-callable copy of the device code for |X|^0.67 (esacf.py:95-101) from x = |X|^2: out[i] = x[i]^(0.67/2) by the table
+ * form the SACF kernels use (csrc/mpx_pow067.hpp), so its accuracy can be checked against long-double pow without a GPU. */
+int mpx_test_pow067(const double* x, int n, double* out);
+
 /* ---- timing helper (HIP events on the stream the kernels run on) ----------
  * mpx_timer_begin records an event on `stream` (NULL = context stream);
  * mpx_timer_end records the closing event, waits for it and returns the
