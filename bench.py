@@ -370,7 +370,7 @@ def with_traffic(r, pmc_workload, mark, launches=1):
         tot += b
         notes.append(note)
     r["traffic"] = tot * launches
-    r["traffic_note"] = "HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) of these launches; " + "; ".join(notes)
+    r["traffic_note"] = "HBM-side bytes (calibrated factor x FETCH_SIZE + WRITE_SIZE, scripts/pmc_to_traffic.py) of these launches; " + "; ".join(notes)
     comp = r.get("bytes_per_unit", 0) * r.get("units_per_launch", 0)
     if r.get("compulsory_bytes"):
         comp = r["compulsory_bytes"]

@@ -1740,7 +1740,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // The 21 samples of the lane's fit live in LDS for the life of the fit (element i at ysl[i * 64]; rows >= m are zeros):
     // read from the ESACF row ONCE, at fetch time.  Until round 3 this space held MINPACK's fvec and the samples were
-    // re-read from the row twice per trip -- 11.8 GB of HBM/L2 traffic per 2.1 M fits for 0.38 GB of windows, 64 different
+    // re-read from the row twice per trip -- 6.4 GB of L2-miss traffic per 2.1 M fits for 0.38 GB of windows, 64 different
     // cache lines per load instruction, and a wait in front of every evaluation.  fvec is not stored at all now: it is
     // the residual at the current x, and the OUTER section recomputes it row by row next to the two jacobian evaluations
     // (the same function of the same inputs: the same bits; three independent exponentials per row instead of two).
