@@ -225,6 +225,7 @@ struct SacfArgs {
     const cx<double>* tw;     // W_L
     const cx<double>* chirp;  // b[n] = exp(i*pi*n^2/N), n < N   (Bluestein only)
     const cx<double>* bhat;   // FFT_L(chirp filter) / L         (Bluestein only)
+    const cx<double>* twn;    // W_N^k, k <= N/2                 (sacf_split_kernel only; chirp / bhat are those of N/2 there)
     int n_peaks_elim;
     double peak_thresh;
     int peak_min_dist;
@@ -311,7 +312,7 @@ __device__ __forceinline__ void block_minmax(double* sh, double& mx, double& mn)
 }
 
 // peakutils.indexes(y, thres, min_dist) on the Mh values in yv (LDS) + publication of the kept peaks.
-// `scratch` is >= PEAK_WORDS*32 + (Mh/2 + 2)*8 bytes of LDS that nobody else uses any more.
+// `scratch` is >= peak_scratch_bytes(Mh) = peak_words(Mh)*32 + (Mh/2 + 2)*8 bytes of LDS that nobody else uses any more.
 //
 // Everything is flag words: position i = tid + e*T of wave w is bit `lane` of word e*T/64 + w, so a
 // __ballot is one word.  "dy != 0" words give the nearest non-zero neighbour of a plateau position
@@ -320,9 +321,10 @@ __device__ __forceinline__ void block_minmax(double* sh, double& mx, double& mn)
 // rule: a candidate is kept iff no HIGHER candidate within min_dist is kept (height, then larger
 // index, decides "higher" -- the visiting order of peakutils), so a candidate can decide as soon as
 // all its higher neighbours have; every round decides at least the highest undecided one.
-constexpr int PEAK_WORDS = 40;  // >= (Mh + T) / 64 for Mh <= 2047, T <= 512
+// flag words per set: >= (Mh + T) / 64 for T <= 512; at most 64, one per lane of the wave that ranks them (Mh <= 4095)
+__host__ __device__ inline int peak_words(int Mh) { return Mh <= 2047 ? 40 : 64; }
 __host__ __device__ inline size_t peak_scratch_bytes(int Mh) {
-    return ((size_t)PEAK_WORDS * 32 + (size_t)(Mh / 2 + 2) * 8 + 15) & ~(size_t)15;
+    return ((size_t)peak_words(Mh) * 32 + (size_t)(Mh / 2 + 2) * 8 + 15) & ~(size_t)15;
 }
 
 template <int T>
@@ -332,10 +334,11 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     const int Mh = a.Mh, D = Mh - 1;  // D = len(dy)
     const int lane = tid & 63, wave = tid >> 6;
     u64* nzw = reinterpret_cast<u64*>(scratch);
-    u64* candw = nzw + PEAK_WORDS;
-    u64* keptw = candw + PEAK_WORDS;
-    u64* longw = keptw + PEAK_WORDS;
-    int* cand = reinterpret_cast<int*>(longw + PEAK_WORDS);  // [Mh/2 + 2]
+    const int PW = peak_words(a.Mh);
+    u64* candw = nzw + PW;
+    u64* keptw = candw + PW;
+    u64* longw = keptw + PW;
+    int* cand = reinterpret_cast<int*>(longw + PW);  // [Mh/2 + 2]
     volatile int* state = cand + (Mh / 2 + 2);               // [Mh/2 + 2]: 0 undecided, 1 kept, 2 removed
     __shared__ double sh_red[2 * NW];
     __shared__ int sh_base[2];
@@ -1120,6 +1123,142 @@ __global__ __launch_bounds__(T) void sacf_big_kernel(SacfArgs a) {
     peak_pick<T>(a, f, yv, smem, tid);
 }
 
+// Even frame lengths above 4096 samples (the reference's 46.4 ms frame above 88.2 kHz: 4454 samples at 96 kHz, 8184 at
+// 176.4 kHz; esacf.py:27 puts no bound on it): a 2N-1 point chirp-z no longer fits LDS, so the N-point transforms are split
+// once by radix 2 around n1 = N/2 point chirp-z transforms of length L = 8192 (2 n1 - 1 <= L):
+//   forward  Z = DFT_N(x_lo + i x_hi):  E = DFT_n1(z[2m]), O = DFT_n1(z[2m+1]);  Z[k] = E[k] + W_N^k O[k],
+//            Z[n1 + k] = E[k] - W_N^k O[k]   (decimation in time; E waits in registers while O is computed)
+//   inverse  r[n] = 1/N sum_k S[k] W_N^{-kn}:  c[j] = S[2j] + i S[2j+1] (two REAL sequences in one transform),
+//            C = IDFT_n1(c);  G0[n] = (C[n] + conj C[n1-n]) / 2,  G1[n] = (C[n] - conj C[n1-n]) / 2i,
+//            r[n] = (G0[n] + W_N^{-n} G1[n]) / N   (decimation in frequency of the input; n < Mh < n1)
+// Three chirp-z transforms per frame instead of two; same padded Stockham engine and the same "correct and complete, not
+// tuned" standing as sacf_big_kernel.  The SACF row and the peak-picking scratch alias the transform buffer (136 KB).
+template <int L, int T>
+__device__ __forceinline__ void chirpz_stockham(cx<double>* buf, int n1, const SacfArgs& a, cx<double>* regs, int tid) {
+    for (int n = tid; n < L; n += T) buf[lds_slot(n)] = n < n1 ? cmulc(buf[lds_slot(n)], a.chirp[n]) : cx<double>{0.0, 0.0};
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+    for (int k = tid; k < L; k += T) buf[lds_slot(k)] = cswap(cmul(buf[lds_slot(k)], a.bhat[k]));
+    __syncthreads();
+    fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+    for (int k = tid; k < n1; k += T) buf[lds_slot(k)] = cmulc(cswap(buf[lds_slot(k)]), a.chirp[k]);
+    __syncthreads();
+}
+
+template <int L, int T>
+__global__ __launch_bounds__(T) void sacf_split_kernel(SacfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(L == 8192 && T == 512, "register shares below are written for 8192 / 512");
+    const int N = a.N, Mh = a.Mh, n1 = N >> 1;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);   // L complex, padded
+    const int tid = threadIdx.x;
+    MPX_POW067_LDS(a, tid, T);
+    const long long f = blockIdx.x;
+    cx<double> regs[L / T];
+    constexpr int PER = 4096 / T;   // n1 <= 4096 points, this thread's share
+    cx<double> ev[PER];
+    const cx<double>* xin = a.xb + band_index(f, 0, N);
+    auto sample = [&](int n) { return xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)]; };
+    for (int m = tid; m < n1; m += T) buf[lds_slot(m)] = sample(2 * m);
+    __syncthreads();
+    chirpz_stockham<L, T>(buf, n1, a, regs, tid);
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int k = tid + e * T;
+        ev[e] = k < n1 ? buf[lds_slot(k)] : cx<double>{0.0, 0.0};
+    }
+    __syncthreads();
+    for (int m = tid; m < n1; m += T) buf[lds_slot(m)] = sample(2 * m + 1);
+    __syncthreads();
+    chirpz_stockham<L, T>(buf, n1, a, regs, tid);
+    cx<double>* E = buf + lds_slot(L / 2);   // upper half: E[k] at E[lds_slot(k)] (lds_slot(L/2 + k) = lds_slot(L/2) + lds_slot(k))
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int k = tid + e * T;
+        if (k < n1) E[lds_slot(k)] = ev[e];
+    }
+    __syncthreads();
+    // S[k] = |X_lo[k]|^0.67 + |X_hi[k]|^0.67 for k = 0 .. n1 (S[N-k] = S[k]); thread t takes k = t + 512 e, and k = n1 last
+    double sv[PER + 1];
+#pragma unroll
+    for (int e = 0; e <= PER; ++e) {
+        const int k = tid + e * T;
+        sv[e] = 0.0;
+        if (k <= n1) {
+            const int ka = k < n1 ? k : 0, kb = k == 0 ? 0 : n1 - k;   // Z[k] from (E, O)[ka]; Z[N-k] from (E, O)[kb]
+            const cx<double> wa = a.twn[ka], wb = a.twn[kb];
+            const cx<double> Ea = E[lds_slot(ka)], Oa = cmul(buf[lds_slot(ka)], wa);
+            const cx<double> Eb = E[lds_slot(kb)], Ob = cmul(buf[lds_slot(kb)], wb);
+            const double sa = k < n1 ? 1.0 : -1.0, sb = k == 0 ? 1.0 : -1.0;
+            const cx<double> A = {Ea.x + sa * Oa.x, Ea.y + sa * Oa.y};
+            const cx<double> B = {Eb.x + sb * Ob.x, -(Eb.y + sb * Ob.y)};   // conj Z[N-k]
+            const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+            const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+            sv[e] = mag067(lr, li, pow_tab) + mag067(hr, hm, pow_tab);
+        }
+    }
+    __syncthreads();
+    double* sd = reinterpret_cast<double*>(E);   // S[0 .. n1], read back folded
+#pragma unroll
+    for (int e = 0; e <= PER; ++e) {
+        const int k = tid + e * T;
+        if (k <= n1) sd[k] = sv[e];
+    }
+    __syncthreads();
+    for (int j = tid; j < n1; j += T) {
+        const int k0 = 2 * j, k1 = 2 * j + 1;
+        // swapped: the forward chirp-z of (im, re) is the swapped inverse transform
+        buf[lds_slot(j)] = {sd[k1 <= n1 ? k1 : N - k1], sd[k0 <= n1 ? k0 : N - k0]};
+    }
+    __syncthreads();
+    chirpz_stockham<L, T>(buf, n1, a, regs, tid);
+    const double inv_n = 1.0 / (double)N;
+    double rv[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int n = tid + e * T;
+        rv[e] = 0.0;
+        if (n < Mh) {
+            const cx<double> C = cswap(buf[lds_slot(n)]);
+            const cx<double> Cc = cconj(cswap(buf[lds_slot(n == 0 ? 0 : n1 - n)]));
+            const cx<double> w = a.twn[n];                                      // W_N^n; its conjugate rotates G1
+            const double g0 = 0.5 * (C.x + Cc.x);
+            const double qx = 0.5 * (C.y - Cc.y), qy = -0.5 * (C.x - Cc.x);    // G1[n]
+            rv[e] = (g0 + (w.x * qx + w.y * qy)) * inv_n;
+        }
+    }
+    __syncthreads();   // buf is dead from here on: the row and the peak-picking scratch alias it
+    double* yv = reinterpret_cast<double*>(smem + peak_scratch_bytes(Mh));
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const int n = tid + e * T;
+        if (n < Mh) {
+            yv[n] = rv[e];
+            if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = rv[e];
+        }
+    }
+    __syncthreads();
+    double* yrow = a.y_out + f * (long long)Mh;
+    if (a.defer_enhance) {
+        for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+        return;
+    }
+    for (int r = 2; r <= a.n_peaks_elim; ++r) {
+        int cut = 0;
+        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+        for (int n = tid; n < Mh; n += T) {
+            double v = yv[n];
+            v = v < 0.0 ? 0.0 : v;
+            if (n < cut) v = v - v;
+            v = v < 0.0 ? 0.0 : v;
+            yv[n] = v;
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+    peak_pick<T>(a, f, yv, smem, tid);
+}
+
 // ------------------------------------------------------------------ kernel 2b / 2c
 // Enhancement when librosa.effects.time_stretch is a REAL phase vocoder, i.e. when the STFT of the
 // Mh-lag SACF has more than two frames (Mh >= 1024: ESACF frames above 2048 samples).  Per rate r
@@ -1143,8 +1282,10 @@ __device__ __forceinline__ double pv_hann(const cx<double>* __restrict__ tw, int
 
 // PICK: the peak picking of the finished row runs at the end of this kernel, on the LDS copy it already holds (until round 3:
 // a second kernel that read the row back from HBM).
-template <bool PICK>
-__global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a, SacfArgs sa) {
+// MAXS: output frames of the vocoder this instantiation can hold (2: rows up to 2047 lags, everything until round 3;
+// 4: rows up to 4095 lags, ESACF frames up to 8192 samples -- the phase is then carried as a unit vector per bin, see there).
+template <bool PICK, int MAXS>
+__global__ __launch_bounds__(PV_T, MAXS > 2 ? 1 : 2) void pv_enhance_kernel(PvArgs a, SacfArgs sa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                       // 2048 complex (padded)
     double* x = reinterpret_cast<double*>(buf + lds_slots(PV_NFFT));             // [Mh] working copy of the SACF
@@ -1158,6 +1299,7 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a, SacfArgs 
     // two workgroups per CU (the spectra in LDS made it 92 KB and one).
     constexpr int NB = (PV_BINS + PV_T - 1) / PV_T;  // 5
     cx<double> d0[NB], d1[NB];
+    cx<double> d2[MAXS > 2 ? NB : 1], d3[MAXS > 2 ? NB : 1], dir[MAXS > 2 ? NB : 1];
     for (int n = tid; n < Mh; n += PV_T) x[n] = row[n];
     __syncthreads();
     const int n_frames = 1 + Mh / PV_HOP;  // centered STFT of Mh samples
@@ -1176,7 +1318,9 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a, SacfArgs 
             __syncthreads();
             continue;
         }
-        for (int t = 0; t < nsteps; ++t) {
+#pragma unroll
+        for (int t = 0; t < MAXS; ++t) {
+            if (t >= nsteps) break;
             const int c0 = t * r, c1 = c0 + 1;                                // STFT columns int(step), int(step)+1
             // analysis: frame c covers xpad[c*512 + n], xpad = [1024 zeros | x | 1024 zeros]
             for (int n = tid; n < PV_NFFT; n += PV_T) {
@@ -1208,56 +1352,129 @@ __global__ __launch_bounds__(PV_T, 2) void pv_enhance_kernel(PvArgs a, SacfArgs 
                         const double nb = sqrt(B.x * B.x + B.y * B.y);
                         const double inb = nb > 0.0 ? 1.0 / nb : 0.0;
                         d1[j] = nb > 0.0 ? cx<double>{B.x * inb, B.y * inb} : cx<double>{1.0, 0.0};   // direction for t = 1
-                    } else {
+                    } else if (MAXS <= 2) {
                         const double mag = sqrt(A.x * A.x + A.y * A.y);
                         d1[j] = {mag * d1[j].x, mag * d1[j].y};
+                    } else {
+                        // more than two output frames: e^{i phase_acc} of frame t+1 is that of frame t turned by
+                        // angle(c1) - angle(c0) (phi + wrap(dphase - phi) is dphase up to a multiple of 2 pi), i.e. times
+                        // u(B) conj(u(A)) with u(z) = z / |z| and u(0) = 1 (np.angle(0) = 0): still no angle, one more
+                        // square root and division per bin and step
+                        const cx<double> dcur = t == 1 ? d1[j] : dir[j];
+                        const double mag = sqrt(A.x * A.x + A.y * A.y);
+                        const cx<double> val = {mag * dcur.x, mag * dcur.y};
+                        if (t == 1) d1[j] = val;
+                        else if (t == 2) d2[j] = val;
+                        else d3[j] = val;
+                        if (t + 1 < nsteps) {
+                            const double ia = mag > 0.0 ? 1.0 / mag : 0.0;
+                            const cx<double> ua = mag > 0.0 ? cx<double>{A.x * ia, A.y * ia} : cx<double>{1.0, 0.0};
+                            const double nb = sqrt(B.x * B.x + B.y * B.y);
+                            const double inb = nb > 0.0 ? 1.0 / nb : 0.0;
+                            const cx<double> ub = nb > 0.0 ? cx<double>{B.x * inb, B.y * inb} : cx<double>{1.0, 0.0};
+                            const cx<double> turn = cmulc(ub, ua);   // ub * conj(ua)
+                            dir[j] = cmul(dcur, turn);
+                        }
                     }
                 }
             }
             __syncthreads();
         }
-        if (nsteps < 2) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) d1[j] = {0.0, 0.0};   // (held the direction of column 1 so far)
-        }
-        // synthesis: irfft of both output frames through one complex inverse FFT (swap trick); every thread
-        // writes its bins and their Hermitian mirrors
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int k = tid + j * PV_T;
-            if (k < PV_BINS) {
-                cx<double> e0 = d0[j], e1 = d1[j];
-                if (k == 0 || k == PV_NFFT / 2) e0.y = e1.y = 0.0;    // irfft ignores the imaginary part there
-                buf[lds_slot(k & (PV_NFFT - 1))] = cswap(cx<double>{e0.x - e1.y, e0.y + e1.x});  // D0 + i*D1
-                if (k != 0 && k != PV_NFFT / 2)                         // conj(D0) + i*conj(D1) at 2048-k
-                    buf[lds_slot(PV_NFFT - k)] = cswap(cx<double>{e0.x + e1.y, -e0.y + e1.x});
-            }
-        }
-        __syncthreads();
-        fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
-        // overlap-add, normalise by the window sum-square, drop the 1024-sample centre pad, subtract, clip
-        const double inv = 1.0 / (double)PV_NFFT;
-        for (int i = tid; i < Mh; i += PV_T) {
-            double v = x[i];
-            if (i < len_out) {
-                const int n = i + PV_NFFT / 2;  // position in the overlap-add buffer
-                double acc = 0.0, wss = 0.0;
-                if (n < PV_NFFT) {
-                    const double w = pv_hann(a.tw, n);
-                    acc += w * (cswap(buf[lds_slot(n)]).x * inv);
-                    wss += w * w;
+        if constexpr (MAXS <= 2) {
+            // synthesis: irfft of both output frames through one complex inverse FFT (swap trick); every thread
+            // writes its bins and their Hermitian mirrors
+    #pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int k = tid + j * PV_T;
+                if (k < PV_BINS) {
+                    cx<double> e0 = d0[j], e1 = d1[j];
+                    if (k == 0 || k == PV_NFFT / 2) e0.y = e1.y = 0.0;    // irfft ignores the imaginary part there
+                    buf[lds_slot(k & (PV_NFFT - 1))] = cswap(cx<double>{e0.x - e1.y, e0.y + e1.x});  // D0 + i*D1
+                    if (k != 0 && k != PV_NFFT / 2)                         // conj(D0) + i*conj(D1) at 2048-k
+                        buf[lds_slot(PV_NFFT - k)] = cswap(cx<double>{e0.x + e1.y, -e0.y + e1.x});
                 }
-                if (nsteps > 1 && n >= PV_HOP && n - PV_HOP < PV_NFFT) {
-                    const double w = pv_hann(a.tw, n - PV_HOP);
-                    acc += w * (cswap(buf[lds_slot(n - PV_HOP)]).y * inv);
-                    wss += w * w;
-                }
-                if (wss > 2.2250738585072014e-308) acc /= wss;
-                v -= acc;
             }
-            x[i] = v < 0.0 ? 0.0 : v;
+            __syncthreads();
+            fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
+            // overlap-add, normalise by the window sum-square, drop the 1024-sample centre pad, subtract, clip
+            const double inv = 1.0 / (double)PV_NFFT;
+            for (int i = tid; i < Mh; i += PV_T) {
+                double v = x[i];
+                if (i < len_out) {
+                    const int n = i + PV_NFFT / 2;  // position in the overlap-add buffer
+                    double acc = 0.0, wss = 0.0;
+                    if (n < PV_NFFT) {
+                        const double w = pv_hann(a.tw, n);
+                        acc += w * (cswap(buf[lds_slot(n)]).x * inv);
+                        wss += w * w;
+                    }
+                    if (nsteps > 1 && n >= PV_HOP && n - PV_HOP < PV_NFFT) {
+                        const double w = pv_hann(a.tw, n - PV_HOP);
+                        acc += w * (cswap(buf[lds_slot(n - PV_HOP)]).y * inv);
+                        wss += w * w;
+                    }
+                    if (wss > 2.2250738585072014e-308) acc /= wss;
+                    v -= acc;
+                }
+                x[i] = v < 0.0 ? 0.0 : v;
+            }
+            __syncthreads();
+        } else {
+            // up to four output frames: two packed inverse transforms; the overlap-add of a thread's samples
+            // (i = tid + 256 q < len_out <= 2048) is carried in registers between them, frames in ascending order
+            constexpr int NQ = PV_NFFT / PV_T;
+            const double inv = 1.0 / (double)PV_NFFT;
+            double acc[NQ], wss[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc[q] = wss[q] = 0.0;
+#pragma unroll
+            for (int pr = 0; pr < MAXS / 2; ++pr) {
+                if (2 * pr >= nsteps) break;
+                const bool second = 2 * pr + 1 < nsteps;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int k = tid + j * PV_T;
+                    if (k < PV_BINS) {
+                        cx<double> e0 = pr == 0 ? d0[j] : d2[j], e1 = pr == 0 ? d1[j] : d3[j];
+                        if (!second) e1 = {0.0, 0.0};
+                        if (k == 0 || k == PV_NFFT / 2) e0.y = e1.y = 0.0;
+                        buf[lds_slot(k & (PV_NFFT - 1))] = cswap(cx<double>{e0.x - e1.y, e0.y + e1.x});
+                        if (k != 0 && k != PV_NFFT / 2)
+                            buf[lds_slot(PV_NFFT - k)] = cswap(cx<double>{e0.x + e1.y, -e0.y + e1.x});
+                    }
+                }
+                __syncthreads();
+                fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int i = tid + q * PV_T;
+                    if (i < len_out) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int m = i + PV_NFFT / 2 - (2 * pr + h) * PV_HOP;   // sample of output frame 2 pr + h
+                            if ((h == 0 || second) && m >= 0 && m < PV_NFFT) {
+                                const double w = pv_hann(a.tw, m);
+                                const cx<double> z = cswap(buf[lds_slot(m)]);
+                                acc[q] += w * ((h == 0 ? z.x : z.y) * inv);
+                                wss[q] += w * w;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int i = tid + q * PV_T;
+                if (i < len_out && i < Mh) {
+                    double t = acc[q];
+                    if (wss[q] > 2.2250738585072014e-308) t /= wss[q];
+                    const double v = x[i] - t;
+                    x[i] = v < 0.0 ? 0.0 : v;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     for (int n = tid; n < Mh; n += PV_T) row[n] = x[n];
     if (PICK) {
@@ -2209,10 +2426,10 @@ struct EsacfPlan {
     bool blue = false;
 };
 
-static int esacf_plan(mpx_ctx* ctx, int N, EsacfPlan& plan) {
-    const std::string key = "esacf_N" + std::to_string(N);
+static int esacf_plan(mpx_ctx* ctx, int N, EsacfPlan& plan, bool force_blue = false) {
+    const std::string key = (force_blue ? "esacf_bN" : "esacf_N") + std::to_string(N);
     auto it = ctx->misc_plans.find(key);
-    const bool pow2 = (N & (N - 1)) == 0 && N >= 512;  // smaller frames ride the 512-point Bluestein
+    const bool pow2 = !force_blue && (N & (N - 1)) == 0 && N >= 512;  // smaller frames ride the 512-point Bluestein
     int L = 512;
     if (pow2)
         L = N;
@@ -2417,8 +2634,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     // computing the same bits, for cross-checks.
     const bool deterministic = (ctx->flags & MPX_FLAG_DETERMINISTIC) != 0;
     const int N = frame, Mh = (N - 1) / 2;
-    if (N < 64 || N > 4096)
-        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: frame length %d outside [64, 4096]", N);
+    // above 4096 samples: one radix-2 split around chirp-z transforms of N/2 points (sacf_split_kernel), even N only
+    const bool split = N > 4096;
+    if (N < 64 || N > 8192 || (split && (N & 1)))
+        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: frame length %d (supported: 64 ... 4096, and even lengths up to 8192)", N);
     if (p.enhance_mode != MPX_ENHANCE_LIBROSA010 && p.enhance_mode != MPX_ENHANCE_NOOP)
         return set_error(ctx, MPX_EINVAL, "ESACF: unknown enhance_mode %d", p.enhance_mode);
     if (p.peak_min_dist < 0 || p.n_peaks_elim < 0 || p.n_peaks_elim > 64)
@@ -2434,9 +2653,25 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     int rc = band_coefs(ctx, fs, coef);
     if (rc) return rc;
     EsacfPlan plan;
-    if ((rc = esacf_plan(ctx, N, plan))) return rc;
+    if ((rc = esacf_plan(ctx, split ? N / 2 : N, plan, split))) return rc;
+    const cx<double>* twn = nullptr;
+    if (split) {
+        const std::string key = "esacf_twn" + std::to_string(N);
+        auto it = ctx->misc_plans.find(key);
+        if (it == ctx->misc_plans.end()) {
+            std::vector<cx<double>> w((size_t)N / 2 + 1);
+            for (int k = 0; k <= N / 2; ++k) {
+                const long double ang = -2.0L * M_PIl * k / (long double)N;
+                w[k] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+            void* d = upload(ctx, w.data(), w.size() * sizeof(cx<double>));
+            if (!d) return MPX_ENOMEM;
+            it = ctx->misc_plans.emplace(key, std::vector<void*>{d}).first;
+        }
+        twn = (const cx<double>*)it->second[0];
+    }
     // the reference's own frame lengths (1023, 2046) run on the prime-factor engine; MPX_SACF_BLUESTEIN=1 forces the chirp-z
-    const bool use_pfa = pfa_supported(N) && !dev_env_on("MPX_SACF_BLUESTEIN");
+    const bool use_pfa = !split && pfa_supported(N) && !dev_env_on("MPX_SACF_BLUESTEIN");
     PfaPlan pfa;
     if (use_pfa && (rc = pfa_plan(ctx, N, pfa))) return rc;
     if (plan.L > 8192)
@@ -2491,6 +2726,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.tw = plan.tw;
         a.chirp = plan.chirp;
         a.bhat = plan.bhat;
+        a.twn = twn;
         a.n_peaks_elim = p.n_peaks_elim;
         a.peak_thresh = p.peak_thresh;
         a.peak_min_dist = p.peak_min_dist;
@@ -2520,8 +2756,17 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             a.pow_tab = (const double*)pt->second[0];
         }
         a.ablate = dev_env_int("MPX_SACF_ABLATE", 0);
-        prof_mark(ctx, st, use_pfa ? "sacf_pfa_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel"));
-        if (use_pfa) {
+        prof_mark(ctx, st, split ? "sacf_split_kernel" : (use_pfa ? "sacf_pfa_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel")));
+        if (split) {
+            const size_t lds = sizeof(cx<double>) * lds_slots(8192);
+            if (peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2) > lds)
+                return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", N);
+            a.pair = 0;
+            auto kern = sacf_split_kernel<8192, 512>;
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(512), lds, st, a);
+            MPX_HIP(ctx, hipGetLastError());
+        } else if (use_pfa) {
             a.pfa_pos = pfa.pos;
             a.pfa_pairs = pfa.pairs;
             a.pfa_cs31 = pfa.cs31;
@@ -2575,7 +2820,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const size_t pv_lds = sizeof(cx<double>) * lds_slots(PV_NFFT) + sizeof(double) * (size_t)(Mh + 2);
             static_assert(PV_T == 256, "peak_pick<256> inside pv_enhance_kernel");
             const bool fused = peak_scratch_bytes(Mh) <= sizeof(cx<double>) * lds_slots(PV_NFFT) && !dev_env_on("MPX_PV_SEPARATE_PICK");
-            auto pvk = fused ? pv_enhance_kernel<true> : pv_enhance_kernel<false>;
+            const bool four = (1 + Mh / PV_HOP + 1) / 2 > 2;   // output frames at rate 2 (at most 4: Mh <= 4095)
+            auto pvk = four ? (fused ? pv_enhance_kernel<true, 4> : pv_enhance_kernel<false, 4>)
+                            : (fused ? pv_enhance_kernel<true, 2> : pv_enhance_kernel<false, 2>);
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)pvk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pv_lds));
             prof_mark(ctx, st, "pv_enhance_kernel");
             hipLaunchKernelGGL(pvk, dim3((unsigned)nf), dim3(PV_T), pv_lds, st, pa, a);

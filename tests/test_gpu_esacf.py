@@ -317,6 +317,43 @@ def test_phase_vocoder_enhancement_4096_frames(eng):
     _check_clip(eng, x, 44100, 4096, hop=1024, key="44100/4096/hop1024/elim3", n_peaks_elim=3)
 
 
+def test_frames_above_4096_samples_radix2_split(eng):
+    """esacf.py:27 sizes the frame as int(fs * 46.4 / 1000) without a bound: 4454 samples at 96 kHz, 8184 at 176.4 kHz.
+    Above 4096 samples the N-point transforms are split once by radix 2 around N/2-point chirp-z transforms
+    (sacf_split_kernel), and the 2227 ... 4095-lag SACF gives the phase vocoder up to 8 STFT columns / 4 output frames
+    (pv_enhance_kernel<.., 4>).  SACF and ESACF rows against the oracle's, then whole clips frame by frame."""
+    from oracle import esacf as o_esacf
+    from oracle import dsp as o_dsp
+    assert o_esacf.ham_samples(96000) == 4454 and o_esacf.ham_samples(176400) == 8184
+    for fs, N, nfr, seed in ((96000, 4454, 3, 96), (176400, 8184, 2, 176), (96000, 8192, 2, 81), (96000, 4098, 2, 40)):
+        rng = np.random.default_rng(seed)
+        n = nfr * N - 300
+        t = np.arange(n) / float(fs)
+        x = np.zeros(n)
+        for f0 in (146.83, 220.0, 277.18, 369.99):
+            for h in range(1, 7):
+                x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+        x = (0.25 * x + 0.004 * rng.standard_normal(n)).astype(np.float32)
+        frames = o_dsp.frame_matrix(x, N, N)
+        _, lo, hi = o_esacf.band_split(frames, fs)
+        s = o_esacf.sacf(lo, hi)
+        got = eng.esacf_stage("sacf", x, fs, N)
+        assert got.shape == s.shape == (nfr, (N - 1) // 2)
+        np.testing.assert_allclose(got, s, rtol=0, atol=1e-10 * np.abs(s).max())
+        got = eng.esacf_stage("esacf", x, fs, N)
+        want = np.array([o_esacf.esacf_enhance(r, 6, "librosa010") for r in s])
+        assert not np.allclose(want, np.clip(s, 0, None))
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.abs(s).max())
+        _check_clip(eng, x, fs, N, key="%d/%d" % (fs, N))
+        if N == 4454:
+            _check_clip(eng, x, fs, N, hop=N // 2, key="96000/4454/hop2227/elim3", n_peaks_elim=3)
+            _check_clip(eng, x, fs, N, key="96000/4454/noop", enhance_mode="noop", peak_min_dist=1)
+    # what stays refused says so: odd lengths above 4096 (no radix-2 split) and anything above 8192
+    for bad in (4455, 8194, 8908):
+        with pytest.raises(Exception, match="frame length %d" % bad):
+            eng.esacf(np.zeros(2 * bad, np.float32), 96000, bad)
+
+
 def test_edge_cases_and_batch(eng, clips):
     import chord_detection_amd as cd
     assert np.all(eng.esacf(np.zeros(0, dtype=np.float32), FS, 1023) == 0)
