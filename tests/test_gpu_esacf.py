@@ -104,7 +104,7 @@ def _check_frames(eng, x, fs, frame, per, hop=None, key=None, **kw):
         SEEN[key] = (int(per.shape[0]), fragile, loose)
         warnings.warn("esacf ill-conditioned frames  %-28s frames %4d  fragile %3d  loose %3d  (table %s)"
                       % (key, per.shape[0], fragile, loose, MEASURED.get(key)))
-        assert key in MEASURED, key
+        assert key in MEASURED or RECORD, key
         if RECORD:
             pass
         elif SLACK:
@@ -365,7 +365,7 @@ def test_edge_cases_and_batch(eng, clips):
     with pytest.raises(ValueError):
         eng.esacf(np.zeros(10, dtype=np.float32), FS, 1023, enhance_mode="bogus")
     with pytest.raises(NotImplementedError):
-        eng.esacf(np.zeros(10, dtype=np.float32), FS, 5000)
+        eng.esacf(np.zeros(10, dtype=np.float32), FS, 5001)   # odd and above 4096
     batch = [clips["tone_E4"], clips["short_ragged"], np.zeros(0, dtype=np.float32), clips["poly_seed1"][:1023]]
     got = eng.esacf_batch(batch, FS, 1023)
     for i, x in enumerate(batch):
