@@ -143,7 +143,6 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         fetch(tb + PF);
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
-            const int tau = tb + q;
             // ---- final stage (sample tau-16): residual, full-wave rectifier, low-pass, average
             {
                 double r = sob[(q + 3) & 15] - fxh;   // written 13 steps ago
@@ -220,6 +219,144 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             wave_lds_fence();
         }
     }
+}
+
+// The same chain in its SEQUENTIAL form -- every sample walks the 17 stages one after the other -- for TWO waves per SIMD
+// (<= 256 registers): no pipeline registers between the stages and no 16-slot ring for the residual's input, 88 registers
+// fewer than the pipelined body above.  The dependent chain of a sample is ~21 operations deep against 59 fp64 operations
+// to issue, the state updates fill its latency, and the second wave fills what is left; the 16 samples of a tile are unrolled,
+// so the compiler may still overlap neighbouring samples where registers allow.  Same operations on the same operands.
+template <bool TAIL>
+__device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
+                                                      int channels, const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
+                                                      double* __restrict__ yc, const int* __restrict__ tail_list,
+                                                      double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
+                                                      int nch_u, const If0TailGroup g) {
+    const int lane = threadIdx.x;
+    const int full = channels >> 6, nt = channels & 63;
+    long long ck;
+    int ch, ch0 = 0;
+    bool active = true;
+    if (!TAIL) {
+        ck = ck_u;
+        ch0 = ch0_u;
+        ch = ch0 + (lane < nch_u ? lane : 0);
+    } else {
+        const int sub = lane / nt;
+        active = sub < g.count;
+        ck = tail_list[g.first + (active ? sub : 0)];
+        ch = 64 * full + lane % nt;
+    }
+    const If0Chunk c = chunks[ck];
+    const int c_warm = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
+    const int c_len = TAIL ? __builtin_amdgcn_readfirstlane(c.len) : c.len;
+    const If0ChanCoef k = coefs[ch];
+    if (TAIL) rowbase[lane] = active ? c.yc_row0 * channels + (long long)ch * c_len : -1;
+    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + (size_t)ch0 * c_len;
+    double a1 = 0, a2 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, d1 = 0, d2 = 0, l1 = 0, l2 = 0;
+    double z[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) z[i] = 0.0;
+    const float* __restrict__ x = sig + c.sig_start;
+    constexpr int PF = 16, G = 4;   // tile width; samples per trip of the loop (a real loop: the compiler interleaves at most G samples)
+    float nx[G];
+    const int x_lim = c.clip_left < c_len ? c.clip_left : c_len;
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const bool ok = t + q < x_lim;
+            const float v = x[ok ? t + q : -c_warm];
+            nx[q] = ok ? v : 0.f;
+        }
+    };
+    const int c_end = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
+    const size_t lane_off = (size_t)(lane >> 4) * c_len + (lane & 15);
+    fetch(-c_warm);
+#pragma unroll 1
+    for (int t = -c_warm; t < c_end; t += G) {
+        float xs[G];
+#pragma unroll
+        for (int q = 0; q < G; ++q) xs[q] = nx[q];
+        fetch(t + G);
+        const int col = t & (PF - 1);   // the run-in and the chunk start are multiples of 16
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const double xt = (double)xs[q];
+            const double y = k.r1b0 * xt + a1;
+            a1 = a2 - k.r1a1 * y;
+            a2 = k.r1b2 * xt - k.r1a2 * y;
+            const double u = k.r1b0 * y + b1;
+            b1 = b2 - k.r1a1 * u;
+            b2 = k.r1b2 * y - k.r1a2 * u;
+            const double v = k.r2b0 * u + c1;
+            c1 = c2 - k.r2a1 * v;
+            c2 = -k.r2a2 * v;
+            const double sres = k.r2b0 * v + d1;
+            d1 = d2 - k.r2a1 * sres;
+            d2 = -k.r2a2 * sres;
+            double in = sres, xh = wf.c[0] * sres;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const double o = -wf.a * in + z[i];
+                z[i] = in + wf.a * o;
+                xh = xh + wf.c[i + 1] * o;
+                in = o;
+            }
+            double r = sres - xh;
+            r = r < 0.0 ? -r : r;
+            const double lp = k.lpb0 * r + l1;
+            l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
+            l2 = k.lpb2 * r - k.lpa2 * lp;
+            tile[lane][col + q] = (r + lp) / 2.0;
+        }
+        if (t >= 0 && col == PF - G) {   // uniform; a tile of 16 samples is complete
+            const int tb = t - (PF - G);
+            wave_lds_fence();
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {   // four rows at a time: registers
+                double tv[PF / 4];
+                long long rbv[PF / 4];
+#pragma unroll
+                for (int q = 0; q < PF / 4; ++q) {
+                    const int e = (h * (PF / 4) + q) * 64 + lane, r = e >> 4, cc = e & 15;
+                    tv[q] = tile[r][cc];
+                    if (TAIL) rbv[q] = rowbase[r];
+                }
+#pragma unroll
+                for (int q = 0; q < PF / 4; ++q) {
+                    const int e = (h * (PF / 4) + q) * 64 + lane, r = e >> 4, cc = e & 15;
+                    if (TAIL) {
+                        if (rbv[q] >= 0) yc[rbv[q] + tb + cc] = tv[q];
+                    } else if (r < nch_u) {
+                        // rows e >> 4 = 4 (4 h + q) + (lane >> 4): a wave-uniform base per store, one per-lane offset for all
+                        (out + (size_t)(4 * (h * (PF / 4) + q)) * c_len + tb)[lane_off] = tv[q];
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void if0_frontend2_kernel(
+    const float* __restrict__ sig, const If0Chunk* __restrict__ chunks, long long num_chunks, int channels,
+    const If0ChanCoef* __restrict__ coefs, If0Wfir wf, double* __restrict__ yc, const int* __restrict__ tail_list,
+    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups) {
+    __shared__ double tile[64][17];
+    __shared__ long long rowbase[64];
+    const int full = channels >> 6;
+    If0TailGroup g = {0, 0};
+    if ((long long)blockIdx.x >= num_tail_groups) {
+        const long long b = (long long)blockIdx.x - num_tail_groups;
+        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g);
+        return;
+    }
+    g = tail_groups[blockIdx.x];
+    if (g.count == 1)
+        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 64 * full,
+                                     channels & 63, g);
+    else
+        if0_frontend_seq_body<true>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g);
 }
 
 __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
@@ -1019,37 +1156,55 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             worst = std::max<long long>(worst, std::min<long long>(t0, warmup) + std::min<long long>(chunk, longest - t0));
         return worst;
     };
-    // The front end runs ONE wave per SIMD (320 registers), so a launch takes ceil(waves / SIMDs) rounds of its busiest
-    // lane's steps: the chunk length that minimises rounds x steps wins, the longer one on a tie (less run-in work in
-    // total).  (Until round 3: "halve while there are fewer waves than SIMDs", which turned 934 chunks = 1028 waves into two
+    // Two front-end kernels.  The PIPELINED one (if0_frontend_kernel) runs ONE wave per SIMD (320 registers) at 178 ns per
+    // step; a launch takes ceil(waves / SIMDs) rounds of its busiest lane's steps.  The SEQUENTIAL one
+    // (if0_frontend2_kernel, 165 registers, three waves per SIMD) steps a lone wave every 293 ns and n waves sharing a SIMD
+    // every n x 168 ns each -- the same fp64 issue rate, but no quantisation into rounds: 1024 two-second clips are 2048
+    // waves = two pipelined rounds (17.7 ms) or two sequential waves per SIMD (14.8 ms), while the hour-long stream is ONE
+    // pipelined round of 923 long chunks (the sequential kernel would need twice the chunks, each with its own run-in).
+    // Per kernel the chunk length that minimises the modelled time wins (the longer one on a tie: less run-in work in
+    // total), then the cheaper kernel.  Times measured on MI355X (scripts/dev/if0_time.py), in units of 1/1000 pipelined step.
+    // (Until round 3: "halve while there are fewer waves than SIMDs", which turned 934 chunks = 1028 waves into two
     // rounds of 98 304 steps where 467 chunks take one round of 131 072.)
+    const int fe_force = dev_env_int("MPX_IF0_FE_WAVES", 0);          // development knob: 1 pipelined, 3 sequential, 0 the model's choice
     const long long simds = 4LL * ctx->num_cus;
     const int nt_ch = p.channels % 64, full_ch = p.channels / 64;
     // Candidates: every multiple of 8192 samples (a multiple of every frame size) up to IF0_CHUNK, not only the powers of
     // two: the hour of 44.1 kHz audio is 923 chunks of 172 032 samples = 1015 waves, ONE round of 212 992 steps, where
     // 262 144-sample chunks fill 65 % of the SIMDs for 303 104 steps.
-    long long chunk = IF0_CHUNK, best_cost = -1;
-    for (long long cand = IF0_CHUNK; cand >= IF0_CHUNK_MIN; cand -= 8192) {
-        long long chunks_total = 0;
-        for (int c = 0; c < num_clips; ++c) {
-            const int64_t len = offsets[c + 1] - offsets[c];
-            if (len > 0) chunks_total += (len + cand - 1) / cand;
-        }
-        // waves: one per chunk and 64 channels, the leftover channels of up to 64 / nt chunks packed into one when that
-        // saves a round (the same rule as below)
+    auto waves_for = [&](long long chunks_total) {
+        // one wave per chunk and 64 channels, the leftover channels of up to 64 / nt chunks packed into one when that lowers
+        // the number of waves the busiest SIMD takes (the same rule as below)
         long long waves = chunks_total * full_ch;
         if (nt_ch) {
             const long long pw = 64 / nt_ch;
             const long long unpacked = chunks_total * (full_ch + 1), packed = chunks_total * full_ch + (chunks_total + pw - 1) / pw;
             waves = (unpacked + simds - 1) / simds > (packed + simds - 1) / simds ? packed : unpacked;
         }
-        const long long rounds = (waves + simds - 1) / simds;
-        const long long cost = (rounds > 0 ? rounds : 1) * lane_steps(cand);
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            chunk = cand;
+        return waves;
+    };
+    auto plan_chunk = [&](bool sequential, long long& best_chunk) {
+        long long best_cost = -1;
+        for (long long cand = IF0_CHUNK; cand >= IF0_CHUNK_MIN; cand -= 8192) {
+            long long chunks_total = 0;
+            for (int c = 0; c < num_clips; ++c) {
+                const int64_t len = offsets[c + 1] - offsets[c];
+                if (len > 0) chunks_total += (len + cand - 1) / cand;
+            }
+            const long long per_simd = std::max<long long>(1, (waves_for(chunks_total) + simds - 1) / simds);
+            const long long unit = sequential ? std::max<long long>(1650, 944 * per_simd) : (per_simd > 1 ? 1120 : 1000) * per_simd;
+            const long long cost = unit * lane_steps(cand);
+            if (best_cost < 0 || cost < best_cost) {
+                best_cost = cost;
+                best_chunk = cand;
+            }
         }
-    }
+        return best_cost;
+    };
+    long long chunk_p = IF0_CHUNK, chunk_s = IF0_CHUNK;
+    const long long cost_p = plan_chunk(false, chunk_p), cost_s = plan_chunk(true, chunk_s);
+    const bool fe_sequential = fe_force == 1 ? false : (fe_force == 3 ? true : cost_s < cost_p);
+    const long long chunk = fe_sequential ? chunk_s : chunk_p;
     for (int c = 0; c < num_clips; ++c) {
         const int64_t len = offsets[c + 1] - offsets[c];
         if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
@@ -1089,7 +1244,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         // A packed wave is ~13 % slower per step (per-lane input streams), and the pass is as long as the busiest SIMD:
         // pack exactly when that lowers the number of waves the busiest SIMD has to take (800 chunks: 2 -> 1; one
         // clip: 1 -> 1, 1024 clips: 2 -> 2, where packing would only slow the leftovers down).
-        const long long simds = 4LL * ctx->num_cus, pw = 64 / nt;
+        const long long pw = 64 / nt;
         const long long unpacked = nchunks * (full_groups + 1), packed = nchunks * full_groups + (nchunks + pw - 1) / pw;
         const int per_wave = (unpacked + simds - 1) / simds > (packed + simds - 1) / simds ? (int)pw : 1;
         for (long long i = 0; i < nchunks; ++i) {
@@ -1140,9 +1295,14 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     double* ur = ut + (size_t)nframes * n2;
     double* ud = ur + (size_t)nframes * n2;
     prof_mark(ctx, st, "if0_frontend_kernel");
-    hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
-                       d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                       d_tail_groups, (int)tail_groups.size());
+    if (!fe_sequential)
+        hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
+                           d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
+                           d_tail_groups, (int)tail_groups.size());
+    else
+        hipLaunchKernelGGL(if0_frontend2_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
+                           d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
+                           d_tail_groups, (int)tail_groups.size());
     MPX_HIP(ctx, hipGetLastError());
     prof_mark(ctx, st, "if0_spectrum_kernel");
     if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
