@@ -948,7 +948,24 @@ __global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_dif_kernel(const doub
 // HBM traffic 3.2 x the front end's output.  Split by parity, a workgroup keeps 8 accumulators (+ the Nyquist bin),
 // prefetches the next channel's samples under the current transform and stays in registers; the two workgroups of a frame
 // sit on the same XCD (block ids 8 apart) and start together, so the second read of a frame's samples is an L2 / MALL hit.
-template <int NF, int P, bool POW1, int IF0_PF>
+// sqrt of a sum of squares of audio-range data: zero, or far inside the normal range (>= 2^-767).  The compiler's own
+// expansion of sqrt(double) -- v_rsq_f64 and these Newton steps -- wrapped in a scaling of tiny arguments (a compare, two
+// selects, two v_ldexp) and a class test for 0 / inf: six of its eighteen instructions, eight times per channel and thread.
+// Same steps on the same operands: the same bits wherever the scaling would not have engaged.
+__device__ __forceinline__ double sqrt_sumsq(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;
+}
+
+template <int NF, int P, bool POW1, int IF0_PF, bool FULL>   // FULL: every sample of the frame exists (no zero padding to select)
 __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __restrict__ yc, const If0Frame fr, int channels,
                                                double power, const double* __restrict__ window, const cx<double>* __restrict__ twNF,
                                                const cx<double>* __restrict__ twn, const cx<double>* __restrict__ twn_r,
@@ -960,9 +977,15 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
     DifTwiddles<H, double> twd;
 #pragma unroll
     for (int i = 0; i < PL::n - 1; ++i) twd.w[i] = twNF[2 * ((tid0 & (PL::stride(i) - 1)) * (H / PL::block(i)))];  // W_H = W_NF^2
-    double acc[8], acc_nyq = 0.0;
+    double acc[8];
+    // the Nyquist bin belongs to the one thread that holds bin 0: its sum lives in LDS (touched by that thread alone) instead
+    // of in two registers of every thread
+    __shared__ double nyq_sh;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = 0.0;
+    for (int e = 0; e < 8; ++e) {
+        acc[e] = 0.0;
+        if (!P && dif_freq<H>(dif_last_pos<H>(tid0, e / RL, e % RL)) == 0) nyq_sh = 0.0;
+    }
     // samples 2m, 2m + 1 of the frame, m = tid + r T.  The front end writes whole frames (the filters ring on past the end
     // of a clip), the reference pads the FILTERED signal with zeros: loads are unconditional, samples from `valid` on are
     // replaced by zeros (selects, no branches).
@@ -983,7 +1006,8 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
             const cx<double> w = *reinterpret_cast<const cx<double>*>(window + 2 * m);
             // (the select sits on the sample, not on the product: otherwise the compiler makes the WINDOW load conditional,
             //  a branch and a full wait per point)
-            regs[r] = {(2 * m < fr.valid ? xn[r].x : 0.0) * w.x, (2 * m + 1 < fr.valid ? xn[r].y : 0.0) * w.y};
+            if (FULL) regs[r] = {xn[r].x * w.x, xn[r].y * w.y};
+            else regs[r] = {(2 * m < fr.valid ? xn[r].x : 0.0) * w.x, (2 * m + 1 < fr.valid ? xn[r].y : 0.0) * w.y};
             if (P) regs[r] = cmul(regs[r], twNF[m]);
         }
         if (IF0_PF == 2)
@@ -1006,12 +1030,12 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
             const cx<double> D = {0.5 * (A.x - B.x), 0.5 * (A.y - B.y)};
             // split twiddle W_{2NF}^(2j+P) from the table in register order (by bin it was a 16-byte gather per lane)
             const cx<double> X = cadd(E, mul_mi(cmul(twn_r[(P * 8 + e) * T + tid], D)));
-            const double mag = sqrt(X.x * X.x + X.y * X.y);  // |X| of audio-range data: no need for hypot's scaling
+            const double mag = sqrt_sumsq(X.x * X.x + X.y * X.y);  // |X| of audio-range data: no need for hypot's scaling
             acc[e] += POW1 ? mag : pow(mag, power);
             if (!P && j == 0) {  // bin NF pairs Z[0] with itself
                 const cx<double> Xn = cadd(E, mul_mi(cmul(twn[NF], D)));
-                const double mn = sqrt(Xn.x * Xn.x + Xn.y * Xn.y);
-                acc_nyq += POW1 ? mn : pow(mn, power);
+                const double mn = sqrt_sumsq(Xn.x * Xn.x + Xn.y * Xn.y);
+                nyq_sh += POW1 ? mn : pow(mn, power);
             }
         }
         if (IF0_PF == 0)
@@ -1024,7 +1048,7 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
         const int k = 2 * j + P;
         row[k] = acc[e];
         if (k > 0) row[2 * NF - k] = acc[e];  // |X[N-k]| = |X[k]| for a real frame
-        if (!P && j == 0) row[NF] = acc_nyq;
+        if (!P && j == 0) row[NF] = nyq_sh;
     }
 }
 
@@ -1045,8 +1069,20 @@ __global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_split_kernel(const do
     if (f >= nframes) return;
     const If0Frame fr = frames[f];
     double* row = ut + (size_t)f * 2 * NF;
-    if (P) if0_split_body<NF, 1, POW1, PF>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
-    else if0_split_body<NF, 0, POW1, PF>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+    // (most frames are whole -- all but the last of a stream, five of the six of a two-second clip: their 32 selects and 16
+    //  compares per channel are 8 % of this kernel's vector instructions)
+    // (only for the default frame size, whose instantiation stays scratch-free with four bodies: the others keep one per parity)
+    if (NF != 8192) {
+        if (P) if0_split_body<NF, 1, POW1, PF, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+        else if0_split_body<NF, 0, POW1, PF, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+    } else if (fr.valid >= NF) {
+        if (P) if0_split_body<NF, 1, POW1, PF, true>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+        else if0_split_body<NF, 0, POW1, PF, true>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+    } else {
+        // (the rare kind -- the last frame of a clip -- fetches the next channel after the split: the selects' registers)
+        if (P) if0_split_body<NF, 1, POW1, 0, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+        else if0_split_body<NF, 0, POW1, 0, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+    }
 }
 
 template <int NF, int T>
