@@ -470,36 +470,6 @@ constexpr int PER_T = 256;
 __constant__ double IF0_HAMMING9[9] = {0.0011244659258033, 0.11559343551383, 0.42817348241183, 0.81822361914331, 1.0,
                                        0.81822361914331, 0.42817348241183, 0.11559343551383, 0.0011244659258033};
 
-// max over ur[lo..hi] by ONE wave (no workgroup barrier).  Wide ranges (the first interval-halving steps span
-// thousands of bins) take the maxima of whole 64-bin blocks from `bmax` (LDS, rebuilt whenever ur changes) and
-// read only the two ragged ends from memory; a maximum does not depend on the order, so the result is identical.
-__device__ __forceinline__ double wave_range_max(const double* __restrict__ ur, const double* bmax, int lo, int hi, int lane) {
-    double m = -INFINITY;
-    if (hi - lo < 192) {
-        for (int i = lo + lane; i <= hi; i += 64) {
-            const double v = ur[i];
-            m = v > m ? v : m;
-        }
-    } else {
-        const int b0 = (lo + 63) >> 6, b1 = (hi + 1) >> 6;  // whole blocks [b0, b1)
-        if (lo + lane < b0 * 64) m = ur[lo + lane];
-        if (b1 * 64 + lane <= hi) {
-            const double v = ur[b1 * 64 + lane];
-            m = v > m ? v : m;
-        }
-        for (int b = b0 + lane; b < b1; b += 64) {
-            const double v = bmax[b];
-            m = v > m ? v : m;
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(m, off);
-        m = o > m ? o : m;
-    }
-    return m;
-}
-
 // maximum over the wave of values that are never NaN, in every lane: four DPP row steps and four v_readlane -- no LDS
 // round trips (a shuffle-based reduction of a double is twelve ds_bpermute with a wait each)
 template <int CTRL>
@@ -520,14 +490,24 @@ __device__ __forceinline__ double if0_wave_max(double v) {
     return fmax(fmax(if0_readlane(v, 0), if0_readlane(v, 16)), fmax(if0_readlane(v, 32), if0_readlane(v, 48)));
 }
 
+// One workgroup per frame.  Until the end of round 3 the kernel was bound by VALU ISSUE (3.8 G wave instructions per 6144
+// frames: 85 % of its time at four waves per SIMD), and 40 % of them were every thread of the workgroup repeating the same
+// serial work after each interval halving: the salience sums -- 2 (M - 1) divisions, one after the other -- and the arg-max over the intervals.  Here wave 0
+// does that alone: the weights m fs / tau_up + eps2 of both intervals in ONE parallel step (lane m), the two sums by lane 0
+// as the same fused multiply-adds in the same order, the interval bookkeeping and the arg-max with them; the other waves
+// wait at the barrier (two per halving step instead of four).  The bounds of the 2 (M - 1) bin ranges are computed one pair
+// per lane (two divisions in all instead of two per range) and handed out by v_readlane.  Same operations on the same
+// operands: bit-identical chroma (checked against that kernel on a 600 s stream, 1024 clips and two other parameter sets:
+// scripts/dev/if0_ab.py); 4.75 -> 3.8 ms per 3230 frames, 8.2 -> 6.6 ms per 6144.
 __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     __shared__ double tau_low[32], tau_up[32], smax[32];
-    __shared__ double umax2[2][128];   // [parity][interval * 64 + harmonic]: range maxima of smax_pair
+    __shared__ double um[128];    // [interval * 64 + harmonic]: range maxima
+    __shared__ double wts[128];   // [interval * 64 + harmonic]: m fs / tau_up + epsilon2
     __shared__ double bmax[256];  // maxima of the 64-bin blocks of ur (n <= 16384)
+    __shared__ int qbest_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long f = blockIdx.x;
     const int n = a.n;
-    int upar = 0;
     const double* __restrict__ uk = a.ut + f * (long long)n;
     double* __restrict__ ur = a.ur + f * (long long)n;
     double* __restrict__ ud = a.ud + f * (long long)n;
@@ -551,65 +531,75 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     __threadfence_block();
     build_bmax();
 
-    // periodicity.py:144-163 for TWO intervals at once (a halving step of min_search evaluates the new interval and the
-    // best one so far); executed by every thread with identical (uniform) results.  One wave per harmonic m for the range
-    // maxima; a wave takes PER_G harmonics x both intervals per pass: their loads -- the ragged ends from ur, the whole
-    // 64-bin blocks from bmax -- are issued unconditionally (clamped positions, -inf by select) before the first of them
-    // is used, and the wave maxima are DPP row steps + v_readlane (no LDS round trips; the shuffle form was twelve
-    // ds_bpermute with a wait each per range).  Half the barriers of the one-interval-at-a-time form.  A maximum does not
-    // depend on the order: the results are the same bits.
-    constexpr int PER_G = 1;   // harmonics per wave and pass (measured 1 / 2 / 3 / 5: 4.75 / 5.5 / 6.8 / 6.6 ms per 3230 frames --
-                               // registers, i.e. resident workgroups, are worth more here than loads in flight per wave)
-    auto smax_pair = [&](int qa, int qb, double& sal_a, double& sal_b) {
-        double tl[2] = {tau_low[qa], tau_low[qb]}, tu[2] = {tau_up[qa], tau_up[qb]};
-        double* um = umax2[upar];
-        for (int m0 = 1 + wave; m0 < a.M; m0 += PER_G * (PER_T / 64)) {
-            double mx[2 * PER_G];
+    // periodicity.py:144-163, the range maxima of TWO intervals (a halving step of min_search evaluates the new interval
+    // and the best one so far): one wave per harmonic m and both intervals per pass; the loads -- the ragged ends from ur,
+    // the whole 64-bin blocks from bmax -- are issued unconditionally (clamped positions, -inf by select), the wave maxima
+    // are DPP row steps + v_readlane.  A maximum does not depend on the order: the results are the same bits.
+    auto range_maxima = [&](double tl0, double tl1, double tu0, double tu1) {
+        int plo[2], phi[2];   // pair p = 2 (m - 1) + interval of lane p (and p + 64 when M > 33)
 #pragma unroll
-            for (int g = 0; g < 2 * PER_G; ++g) {
-                const int w = g & 1, m = m0 + (g >> 1) * (PER_T / 64);
-                const double tau = 0.5 * (tl[w] + tu[w]), deltatau = tu[w] - tl[w];
-                const int lo = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
+        for (int h = 0; h < 2; ++h) {
+            plo[h] = phi[h] = 0;
+            if (h == 0 || 2 * (a.M - 1) > 64) {
+                const int pidx = lane + 64 * h, m = 1 + (pidx >> 1);
+                const double tlw = (pidx & 1) ? tl1 : tl0, tuw = (pidx & 1) ? tu1 : tu0;
+                const double tau = 0.5 * (tlw + tuw), deltatau = tuw - tlw;
+                plo[h] = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
                 int hi = (int)(m * a.K / (tau - 0.5 * deltatau) + 0.5);
                 if (hi > n - 1) hi = n - 1;  // numpy slicing clips silently
-                const bool live = m < a.M;
-                const bool wide = hi - lo >= 192;
-                const int b0 = (lo + 63) >> 6, b1 = (hi + 1) >> 6;  // whole blocks [b0, b1) of a wide range
-                // three positions in ur: a narrow range is lo + lane + 64 j; a wide one its two ragged ends
-                const int i0 = lo + lane, i1 = wide ? b1 * 64 + lane : lo + lane + 64, i2 = lo + lane + 128;
-                const bool ok0 = live && (wide ? i0 < b0 * 64 : i0 <= hi), ok1 = live && i1 <= hi, ok2 = live && !wide && i2 <= hi;
-                const double v0 = ur[ok0 ? i0 : 0], v1 = ur[ok1 ? i1 : 0], v2 = ur[ok2 ? i2 : 0];
-                double mm = ok0 ? v0 : -INFINITY;
-                mm = ok1 && v1 > mm ? v1 : mm;
-                mm = ok2 && v2 > mm ? v2 : mm;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {   // n <= 16384: at most 256 blocks
-                    const int b = b0 + lane + 64 * j;
-                    const bool okb = live && wide && b < b1;
-                    const double vb = bmax[okb ? b : 0];
-                    mm = okb && vb > mm ? vb : mm;
-                }
-                mx[g] = mm;
+                phi[h] = hi;
             }
+        }
+        for (int m = 1 + wave; m < a.M; m += PER_T / 64) {
+            double mx[2];
 #pragma unroll
-            for (int g = 0; g < 2 * PER_G; ++g) mx[g] = if0_wave_max(mx[g]);
+            for (int w = 0; w < 2; ++w) {
+                const int pidx = 2 * (m - 1) + w;   // wave-uniform
+                const int lo = __builtin_amdgcn_readlane(pidx < 64 ? plo[0] : plo[1], pidx & 63);
+                const int hi = __builtin_amdgcn_readlane(pidx < 64 ? phi[0] : phi[1], pidx & 63);
+                // lo and hi are wave-uniform (scalar registers): what a range does not need is skipped by a scalar branch --
+                // from the fifth halving step on the ranges are a few bins wide and one load per range is all there is
+                const int span = hi - lo;
+                const bool wide = span >= 192;
+                const int i0 = lo + lane;
+                double mm;
+                if (!wide) {
+                    // a narrow range is lo + lane + 64 j, j < 3
+                    const bool ok0 = i0 <= hi;
+                    const double v0 = ur[ok0 ? i0 : 0];
+                    mm = ok0 ? v0 : -INFINITY;
+                    if (span >= 64) {
+                        const int i1 = i0 + 64, i2 = i0 + 128;
+                        const bool ok1 = i1 <= hi, ok2 = i2 <= hi;
+                        const double v1 = ur[ok1 ? i1 : 0], v2 = ur[ok2 ? i2 : 0];
+                        mm = ok1 && v1 > mm ? v1 : mm;
+                        mm = ok2 && v2 > mm ? v2 : mm;
+                    }
+                } else {
+                    // a wide one: its two ragged ends from ur, the whole 64-bin blocks [b0, b1) from bmax
+                    const int b0 = (lo + 63) >> 6, b1 = (hi + 1) >> 6;
+                    const int i1 = b1 * 64 + lane;
+                    const bool ok0 = i0 < b0 * 64, ok1 = i1 <= hi;
+                    const double v0 = ur[ok0 ? i0 : 0], v1 = ur[ok1 ? i1 : 0];
+                    mm = ok0 ? v0 : -INFINITY;
+                    mm = ok1 && v1 > mm ? v1 : mm;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {   // n <= 16384: at most 256 blocks
+                        const int b = b0 + lane + 64 * j;
+                        const bool okb = b < b1;
+                        const double vb = bmax[okb ? b : 0];
+                        mm = okb && vb > mm ? vb : mm;
+                    }
+                }
+                mx[w] = mm;
+            }
+            mx[0] = if0_wave_max(mx[0]);
+            mx[1] = if0_wave_max(mx[1]);
             if (lane == 0) {
-#pragma unroll
-                for (int g = 0; g < 2 * PER_G; ++g) {
-                    const int m = m0 + (g >> 1) * (PER_T / 64);
-                    if (m < a.M) um[(g & 1) * 64 + m] = mx[g];
-                }
+                um[m] = mx[0];
+                um[64 + m] = mx[1];
             }
         }
-        __syncthreads();
-        double s0 = 0.0, s1 = 0.0;
-        for (int m = 1; m < a.M; ++m) {
-            s0 += (m * a.fs / tu[0] + a.epsilon2) * um[m];
-            s1 += (m * a.fs / tu[1] + a.epsilon2) * um[64 + m];
-        }
-        sal_a = s0 * (a.fs / tl[0] + a.epsilon1);
-        sal_b = s1 * (a.fs / tl[1] + a.epsilon1);
-        upar ^= 1;   // the next call writes the other buffer: no second barrier (a barrier separates any two calls' reads)
     };
 
     double voice_sal[8], voice_per[8];
@@ -619,39 +609,54 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     double prevmix = 0.0, mix = 0.0;
     for (;;) {
         // ---- min_search (periodicity.py:114-142)
-        int q = 0, qbest = 0;
         if (tid == 0) {
             tau_low[0] = a.tau_min;
             tau_up[0] = a.tau_max;
+            qbest_sh = 0;
         }
         __syncthreads();
-        while ((tau_up[qbest] - tau_low[qbest]) > a.tau_prec && q < a.Q - 1) {
+        int q = 0;
+        for (;;) {
+            const int qbest = qbest_sh;
+            const double tlb = tau_low[qbest], tub = tau_up[qbest];
+            if (!((tub - tlb) > a.tau_prec && q < a.Q - 1)) break;
             ++q;
-            __syncthreads();
-            if (tid == 0) {
-                tau_low[q] = (tau_low[qbest] + tau_up[qbest]) * 0.5;
-                tau_up[q] = tau_up[qbest];
-                tau_up[qbest] = tau_low[q];
-            }
-            __syncthreads();
-            double sq, sb;
-            smax_pair(q, qbest, sq, sb);
-            if (tid == 0) {
-                smax[q] = sq;
-                smax[qbest] = sb;
-            }
-            __syncthreads();
-            int whichq = 0;
-            double maxval = smax[0];
-            for (int j = 1; j <= q; ++j) {
-                const double valnow = smax[j];
-                if (valnow > maxval) {
-                    maxval = valnow;
-                    whichq = j;
+            // the new interval q is the upper half of the best one, which keeps its lower half
+            const double tlq = (tlb + tub) * 0.5;
+            range_maxima(tlq, tlb, tub, tlq);
+            __syncthreads();   // the maxima are complete, and everybody has read the interval table
+            if (wave == 0) {
+                if (lane >= 1 && lane < a.M) {
+                    wts[lane] = lane * a.fs / tub + a.epsilon2;        // interval q:     tau_up = tub
+                    wts[64 + lane] = lane * a.fs / tlq + a.epsilon2;   // interval qbest: tau_up = tlq
+                }
+                wave_lds_fence();
+                if (lane == 0) {
+                    double s0 = 0.0, s1 = 0.0;
+                    for (int m = 1; m < a.M; ++m) {
+                        s0 = __builtin_fma(wts[m], um[m], s0);
+                        s1 = __builtin_fma(wts[64 + m], um[64 + m], s1);
+                    }
+                    tau_low[q] = tlq;
+                    tau_up[q] = tub;
+                    tau_up[qbest] = tlq;
+                    smax[q] = s0 * (a.fs / tlq + a.epsilon1);
+                    smax[qbest] = s1 * (a.fs / tlb + a.epsilon1);
+                    int whichq = 0;
+                    double maxval = smax[0];
+                    for (int j = 1; j <= q; ++j) {
+                        const double valnow = smax[j];
+                        if (valnow > maxval) {
+                            maxval = valnow;
+                            whichq = j;
+                        }
+                    }
+                    qbest_sh = whichq;
                 }
             }
-            qbest = whichq;
+            __syncthreads();
         }
+        const int qbest = qbest_sh;
         const double tau = (tau_low[qbest] + tau_up[qbest]) * 0.5;
         const double best = smax[qbest];
         __syncthreads();
