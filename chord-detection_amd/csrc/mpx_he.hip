@@ -869,6 +869,96 @@ __global__ __launch_bounds__(T) void he_blue_kernel(HeBlueArgs a) {
     }
 }
 
+// Frames whose chirp-z does not fit 8192 points (N + highest window bin > 8192: non-powers of two above ~6900 samples,
+// anything above 16384): the input is decimated by R -- X[k] = sum_r W_N^(r k) G_r[k], G_r[k] = sum_m s[R m + r] W_N^(R m k) --
+// and every G_r is a chirp-z transform of ceil(N / R) points with the chirp exp(i pi R j^2 / N) (a zoom: only the K bins below
+// the highest window are evaluated), R passes through the same 8192-point engine; a thread accumulates its (at most two) window
+// bins over the passes, the factors W_N^(r k) conj(chirp[k]) come from a table built with the plan.
+struct HeBlueSplitArgs {
+    HeBlueArgs b;            // chirp: [ceil(N/R)] exp(i pi R j^2 / N); bhat: filter spectrum of that chirp
+    int R, n1;               // decimation, ceil(N / R)
+    const cx<double>* coef;  // [R][nb] W_N^(r k) conj(chirp[k]) at the window bins
+};
+
+template <int L, int T>
+__global__ __launch_bounds__(T) void he_blue_split_kernel(HeBlueSplitArgs sa) {
+    const HeBlueArgs& a = sa.b;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    double* mag = reinterpret_cast<double*>(smem + sizeof(cx<double>) * lds_slots(L));  // [nb] then winmax [nwin]
+    double* winmax = mag + a.nb;
+    const int tid = threadIdx.x, N = a.N, R = sa.R, n1 = sa.n1;
+    const long long f = blockIdx.x;
+    long long start;
+    int valid;
+    if (a.desc) {
+        start = a.desc[f].start;
+        valid = a.desc[f].valid;
+    } else {
+        start = f * (long long)a.hop;
+        const long long left = a.n - start;
+        valid = left >= N ? N : (left > 0 ? (int)left : 0);
+    }
+    const float* __restrict__ x = a.sig + start;
+    cx<double> regs[L / T];
+    constexpr int PB = 2;   // window bins per thread (nb <= PB * T, checked by the host)
+    cx<double> acc[PB];
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc[j] = {0.0, 0.0};
+    for (int r = 0; r < R; ++r) {
+        for (int m = tid; m < L; m += T) {
+            cx<double> v = {0.0, 0.0};
+            const long long n = (long long)R * m + r;
+            if (m < n1 && n < N) {
+                const double s = (n < valid ? (double)x[n] : 0.0) * a.win[n];
+                const cx<double> ch = a.chirp[m];
+                v = {s * ch.x, -s * ch.y};  // s * conj(chirp)
+            }
+            buf[lds_slot(m)] = v;
+        }
+        __syncthreads();
+        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+        for (int k = tid; k < L; k += T) {
+            const cx<double> p = cmul(buf[lds_slot(k)], a.bhat[k]);
+            buf[lds_slot(k)] = {p.y, p.x};  // swapped: the next forward FFT acts as the inverse
+        }
+        __syncthreads();
+        fft_lds<L, T, false, double>(buf, a.tw, regs, tid);
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int i = tid + j * T;
+            if (i < a.nb) {
+                const cx<double> b = buf[lds_slot(a.bins[i])];
+                const cx<double> z = cmul(cx<double>{b.y, b.x}, sa.coef[(size_t)r * a.nb + i]);
+                acc[j] = {acc[j].x + z.x, acc[j].y + z.y};
+            }
+        }
+        __syncthreads();   // the next pass overwrites buf
+    }
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        const int i = tid + j * T;
+        if (i < a.nb) mag[i] = sqrt(sqrt(acc[j].x * acc[j].x + acc[j].y * acc[j].y));  // sqrt(|rfft|), harmonic_energy.py:43
+    }
+    __syncthreads();
+    for (int wi = tid; wi < a.nwin; wi += T) {
+        double m = -INFINITY;
+        for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) m = mag[k] > m ? mag[k] : m;
+        winmax[wi] = m;
+    }
+    __syncthreads();
+    if (tid < 12) {
+        double chroma = 0.0;
+        const int base = tid * a.wins_per_note;
+        for (int o = 0; o < a.wins_per_note; o += a.num_harmonic) {
+            double note_sum = 0.0;
+            for (int h = 0; h < a.num_harmonic; ++h) note_sum += winmax[base + o + h] * a.ww[base + o + h];
+            chroma += note_sum;
+        }
+        a.out[f * 12 + tid] = chroma;
+    }
+}
+
 static void he_host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, forward; plan tables only
     const size_t n = a.size();
     for (size_t i = 1, j = 0; i < n; ++i) {
@@ -930,20 +1020,25 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
         // 8192-point engine with the default windows, and 2049..3500 take the 4096-point one.
         const int K = bins.back() + 1;
         int L = 1024;
-        while (L < N + K - 1) L <<= 1;
-        if (L > 8192)
-            return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d with windows up to bin %d needs a %d-point "
-                             "chirp-z (supported: N + highest bin <= 8192, or a power of two in [1024, 16384])", N, K - 1, L);
+        while (L < N + K - 1 && L < 8192) L <<= 1;
+        // beyond 8192 points: decimate the input by R (he_blue_split_kernel), R passes of ceil(N / R) + K - 1 <= 8192 points
+        int R = 1;
+        while ((N + R - 1) / R + K - 1 > 8192 && R < 64) ++R;
+        if ((N + R - 1) / R + K - 1 > 8192 || (R > 1 && bins.size() > 1024))
+            return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d with %zu window bins up to bin %d does not fit "
+                             "64 passes of the 8192-point chirp-z", N, bins.size(), K - 1);
+        const int n1 = (N + R - 1) / R;
+        const int J = n1 > K ? n1 : K;   // chirp samples needed: inputs m < n1, outputs k < K
         std::vector<double> win(N);
         for (int i = 0; i < N; ++i) win[i] = N == 1 ? 1.0 : 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (double)(N - 1));
-        std::vector<cx<double>> chirp(N), filt(L, cx<double>{0.0, 0.0}), tw(L);
-        for (long long i = 0; i < N; ++i) {
-            const long long q = (i * i) % (2LL * N);
+        std::vector<cx<double>> chirp(J), filt(L, cx<double>{0.0, 0.0}), tw(L);
+        for (long long i = 0; i < J; ++i) {   // exp(i pi R j^2 / N), the phase reduced exactly
+            const long long q = (long long)(((unsigned long long)R * (unsigned long long)(i * i)) % (unsigned long long)(2LL * N));
             const long double ang = M_PIl * (long double)q / (long double)N;
             chirp[i] = {(double)cosl(ang), (double)sinl(ang)};
         }
-        for (int m = 0; m < K && m < N; ++m) filt[m] = chirp[m];     // chirp[k - n], k - n = 0 .. K-1
-        for (int m = 1; m < N; ++m) filt[L - m] = chirp[m];          // k - n = -1 .. -(N-1) (the chirp is even)
+        for (int m = 0; m < K && m < J; ++m) filt[m] = chirp[m];     // chirp[k - n], k - n = 0 .. K-1
+        for (int m = 1; m < n1; ++m) filt[L - m] = chirp[m];         // k - n = -1 .. -(n1-1) (the chirp is even)
         he_host_fft(filt);
         for (auto& v : filt) {
             v.x /= L;
@@ -953,7 +1048,20 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
             const long double ang = -2.0L * M_PIl * j / (long double)L;
             tw[j] = {(double)cosl(ang), (double)sinl(ang)};
         }
-        std::vector<int> meta = {(int)bins.size(), (int)k0.size(), p.num_octave * p.num_harmonic, p.num_harmonic, L};
+        std::vector<int> meta = {(int)bins.size(), (int)k0.size(), p.num_octave * p.num_harmonic, p.num_harmonic, L, R, n1};
+        std::vector<cx<double>> coef;   // R > 1: W_N^(r k) conj(chirp[k]) per pass and window bin
+        if (R > 1) {
+            coef.resize((size_t)R * bins.size());
+            for (int r = 0; r < R; ++r)
+                for (size_t i = 0; i < bins.size(); ++i) {
+                    const long long k = bins[i];
+                    const long double ang = -2.0L * M_PIl * (long double)((r * k) % N) / (long double)N;
+                    const cx<double> w = {(double)cosl(ang), (double)sinl(ang)}, c = chirp[(size_t)k];
+                    coef[(size_t)r * bins.size() + i] = {w.x * c.x + w.y * c.y, w.y * c.x - w.x * c.y};   // w * conj(c)
+                }
+        } else {
+            coef.resize(1);
+        }
         std::vector<void*> d = {upload(ctx, win.data(), win.size() * sizeof(double)),
                                 upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>)),
                                 upload(ctx, filt.data(), filt.size() * sizeof(cx<double>)),
@@ -961,7 +1069,8 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
                                 upload(ctx, bins.data(), bins.size() * sizeof(int)),
                                 upload(ctx, k0.data(), k0.size() * sizeof(int)),
                                 upload(ctx, k1.data(), k1.size() * sizeof(int)),
-                                upload(ctx, ww.data(), ww.size() * sizeof(double))};
+                                upload(ctx, ww.data(), ww.size() * sizeof(double)),
+                                upload(ctx, coef.data(), coef.size() * sizeof(cx<double>))};
         for (void* q : d)
             if (!q) return MPX_ENOMEM;
         std::vector<unsigned char> blob(meta.size() * sizeof(int));
@@ -1008,7 +1117,22 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
         return MPX_OK;
     };
     int rc;
-    if (L == 1024) rc = launch(he_blue_kernel<1024, 64>, 64, sizeof(cx<double>) * lds_slots(1024) + extra);
+    if (meta[5] > 1) {
+        HeBlueSplitArgs sa;
+        sa.b = a;
+        sa.R = meta[5];
+        sa.n1 = meta[6];
+        sa.coef = (const cx<double>*)it->second[8];
+        const size_t lds = sizeof(cx<double>) * lds_slots(8192) + extra;
+        if (lds > 160 * 1024) return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame %d needs %zu B of LDS", N, lds);
+        auto kern = he_blue_split_kernel<8192, 512>;
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        prof_mark(ctx, stream, "he_blue_kernel");
+        hipLaunchKernelGGL(kern, dim3((unsigned)num_frames), dim3(512), lds, stream, sa);
+        prof_mark(ctx, stream, nullptr);
+        MPX_HIP(ctx, hipGetLastError());
+        rc = MPX_OK;
+    } else if (L == 1024) rc = launch(he_blue_kernel<1024, 64>, 64, sizeof(cx<double>) * lds_slots(1024) + extra);
     else if (L == 2048) rc = launch(he_blue_kernel<2048, 128>, 128, sizeof(cx<double>) * lds_slots(2048) + extra);
     else if (L == 4096) rc = launch(he_blue_kernel<4096, 256>, 256, sizeof(cx<double>) * lds_slots(4096) + extra);
     else rc = launch(he_blue_kernel<8192, 512>, 512, sizeof(cx<double>) * lds_slots(8192) + extra);
@@ -1027,9 +1151,8 @@ int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_de
     if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
     if (num_frames == 0) return MPX_OK;
     if (frame < 1024 || frame > 16384 || (frame & (frame - 1))) {
-        if (frame < 2 || frame > 8191)
-            return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d (supported: powers of two in "
-                             "[1024, 16384] and any size whose chirp-z fits 8192 points: frame + highest window bin <= 8192)", frame);
+        if (frame < 2 || frame > (1 << 18))
+            return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d (supported: 2 ... 262144, as far as 64 passes of the 8192-point chirp-z reach)", frame);
         return he_blue_run(ctx, d_signal, n, d_desc, num_frames, fs, p, frame, hop, d_chroma_frames, d_chroma_sum, stream);
     }
     const bool f32 = ctx->flags & MPX_FLAG_F32;

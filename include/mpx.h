@@ -104,8 +104,9 @@ typedef struct mpx_he_params {
 
 /* One signal, host buffers.  replaces harmonic_energy.py:30-73.
  *   signal[n] float32 samples at `fs` Hz; frame = FFT size: a power of two in
- *   1024..16384 (fast path) or any size with frame + highest window bin <= 8192 (chirp-z; ~6900 samples with the
- *   default windows); hop in [1, frame].
+ *   1024..16384 (fast path) or any other size from 2 up (chirp-z on the bins below the highest window: one pass while
+ *   frame + highest window bin <= 8192, ~6900 samples with the default windows; beyond that the input decimated
+ *   by R <= 64, R passes -- ~77 000 samples at 44.1 kHz); hop in [1, frame].
  *   chroma_frames: optional [F,12] per-frame chroma (NULL to skip);
  *   chroma_sum:    [12] sum over frames == compute_pitches() result. */
 int mpx_harmonic_energy(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
