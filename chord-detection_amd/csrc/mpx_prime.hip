@@ -34,6 +34,8 @@ struct PrimeCand {          // per candidate frequency, device resident
     const cx<double>* bhat;   // [L] FFT_L(chirp filter)/L, natural order (8192-point class)
     const cx<double>* bhat_r; // [8][L/8] the same in the register order dif_fft_keep_last<L> leaves (L <= 4096)
     const cx<double>* tw;     // [L] W_L
+    int R, n1;                // prime_kernel, frames whose chirp-z does not fit 8192 points: input decimated by R, n1 = ceil(N / R)
+    const cx<double>* coef;   // [R][half] W_N^(r k) conj(chirp[k]) (R > 1; chirp is then exp(i pi R j^2 / N), j < max(n1, half))
 };
 
 struct PrimeItem {
@@ -73,6 +75,7 @@ __global__ __launch_bounds__(T) void prime_kernel(const float* __restrict__ sig,
     const float* __restrict__ x = sig + it.start;
     cx<double> regs[L / T];
 
+    if (c.R <= 1) {
     for (int n = tid; n < L; n += T) {
         cx<double> v = {0.0, 0.0};
         if (n < N) {
@@ -97,6 +100,51 @@ __global__ __launch_bounds__(T) void prime_kernel(const float* __restrict__ sig,
         mag[k] = hypot(z.x, z.y) / c.wsum;  // mlab: np.abs(result) / window.sum()
     }
     __syncthreads();
+    } else {
+        // Frames above 6553 samples (input above ~107 kHz): N + half - 1 points do not fit the engine.  The input decimated by
+        // R: X[k] = sum_r W_N^(r k) G_r[k], G_r[k] = sum_m s[R m + r] W_N^(R m k) a chirp-z of n1 = ceil(N / R) points with
+        // the chirp exp(i pi R j^2 / N); R passes, a thread accumulates its bins k = tid + j T < half <= 4096 over them.
+        constexpr int PB = 4096 / T;
+        cx<double> acc[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc[j] = {0.0, 0.0};
+        for (int r = 0; r < c.R; ++r) {
+            for (int m = tid; m < L; m += T) {
+                cx<double> v = {0.0, 0.0};
+                const int n = c.R * m + r;
+                if (m < c.n1 && n < N) {
+                    const double s = (n < it.valid ? (double)x[n] : 0.0) * c.win[n];
+                    const cx<double> ch = c.chirp[m];
+                    v = {s * ch.x, -s * ch.y};
+                }
+                buf[lds_slot(m)] = v;
+            }
+            __syncthreads();
+            fft_lds<L, T, false, double>(buf, c.tw, regs, tid);
+            for (int k = tid; k < L; k += T) {
+                const cx<double> p = cmul(buf[lds_slot(k)], c.bhat[k]);
+                buf[lds_slot(k)] = {p.y, p.x};
+            }
+            __syncthreads();
+            fft_lds<L, T, false, double>(buf, c.tw, regs, tid);
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int k = tid + j * T;
+                if (k < half) {
+                    const cx<double> b = buf[lds_slot(k)];
+                    const cx<double> z = cmul(cx<double>{b.y, b.x}, c.coef[(size_t)r * half + k]);
+                    acc[j] = {acc[j].x + z.x, acc[j].y + z.y};
+                }
+            }
+            __syncthreads();   // the next pass (and the magnitudes) overwrite buf
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int k = tid + j * T;
+            if (k < half) mag[k] = hypot(acc[j].x, acc[j].y) / c.wsum;
+        }
+        __syncthreads();
+    }
 
     for (int run = 0; run < runs; ++run) {
         // numpy argmax: first index of the maximum
@@ -425,7 +473,7 @@ struct PrimePlan {
 // Plans live in the context (host copy of the candidate records in ctx->host_blobs, device tables in
 // ctx->owned) and die with it.
 static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan& plan) {
-    const std::string key = "prime3_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
+    const std::string key = "prime4_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
                             std::to_string(p.num_octave);
     auto bit = ctx->host_blobs.find(key);
     if (bit != ctx->host_blobs.end()) {
@@ -450,11 +498,67 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                 // does (2731 .. 3277 samples: the lowest candidates of 48 kHz input) run on the same kernel one frame at a
                 // time; longer ones (up to 6553 samples, input above 53 kHz) on the workgroup-per-frame kernel.
                 const int half = N >= 2 ? (N / 2 + 1) / 2 : 0;
-                if (N < 2 || N + half - 1 > 8192)
+                // frames above 6553 samples (input above ~107 kHz): the input decimated by R, R passes of the 8192-point
+                // chirp-z (prime_kernel); a thread accumulates at most 8 bins: half <= 4096, i.e. frames up to 16 384 samples
+                int R = 1;
+                while (N >= 2 && (N + R - 1) / R + half - 1 > 8192 && R < 64) ++R;
+                if (N < 2 || (N + R - 1) / R + half - 1 > 8192 || (R > 1 && half > 4096))
                     return set_error(ctx, MPX_EUNSUPPORTED,
-                                     "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..6553)", N, f);
+                                     "prime-multiF0: frame of %d samples for candidate %.2f Hz (supported: 2..16384)", N, f);
                 PrimeCand c;
                 c.N = N;
+                c.R = R;
+                c.n1 = (N + R - 1) / R;
+                c.coef = nullptr;
+                if (R > 1) {
+                    c.paired = 0;
+                    c.L = 8192;
+                    c.half = half;
+                    c.val = 1.0 / (N * (1.0 / fs));
+                    std::vector<double> win(N);
+                    double wsum = 0.0;
+                    for (int i = 0; i < N; ++i) win[i] = 0.5 - 0.5 * std::cos(2.0 * M_PI * i / (double)(N - 1));
+                    for (int i = 0; i < N; ++i) wsum += win[i];
+                    c.wsum = wsum;
+                    const int J = c.n1 > half ? c.n1 : half;
+                    std::vector<cx<double>> chirp(J), filt(c.L, cx<double>{0.0, 0.0}), coef((size_t)R * half);
+                    for (long long i = 0; i < J; ++i) {   // exp(i pi R j^2 / N), the phase reduced exactly
+                        const long long q = (long long)(((unsigned long long)R * (unsigned long long)(i * i)) % (unsigned long long)(2LL * N));
+                        const long double ang = M_PIl * (long double)q / (long double)N;
+                        chirp[i] = {(double)cosl(ang), (double)sinl(ang)};
+                    }
+                    for (int m = 0; m < half; ++m) filt[m] = chirp[m];              // k - m = 0 .. half-1
+                    for (int m = 1; m < c.n1; ++m) filt[c.L - m] = chirp[m];        // k - m = -1 .. -(n1-1)
+                    prime_host_fft(filt);
+                    for (auto& v : filt) {
+                        v.x /= c.L;
+                        v.y /= c.L;
+                    }
+                    for (int r = 0; r < R; ++r)
+                        for (int k = 0; k < half; ++k) {
+                            const long double ang = -2.0L * M_PIl * (long double)(((long long)r * k) % N) / (long double)N;
+                            const cx<double> w = {(double)cosl(ang), (double)sinl(ang)}, ch = chirp[k];
+                            coef[(size_t)r * half + k] = {w.x * ch.x + w.y * ch.y, w.y * ch.x - w.x * ch.y};   // w * conj(chirp)
+                        }
+                    if (!twl.count(c.L)) {
+                        std::vector<cx<double>> tw(c.L);
+                        for (int j = 0; j < c.L; ++j) {
+                            const long double ang = -2.0L * M_PIl * j / (long double)c.L;
+                            tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+                        }
+                        twl[c.L] = upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+                        if (!twl[c.L]) return MPX_ENOMEM;
+                    }
+                    c.tw = (const cx<double>*)twl[c.L];
+                    c.win = (const double*)upload(ctx, win.data(), win.size() * sizeof(double));
+                    c.chirp = (const cx<double>*)upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
+                    c.bhat = (const cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
+                    c.coef = (const cx<double>*)upload(ctx, coef.data(), coef.size() * sizeof(cx<double>));
+                    c.bhat_r = nullptr;
+                    if (!c.win || !c.chirp || !c.bhat || !c.coef) return MPX_ENOMEM;
+                    plan.cands.push_back(c);
+                    continue;
+                }
                 const int need2 = N + 2 * half - 2, need1 = N + half - 1;
                 const bool paired = need2 <= 4096;
                 const int need = paired ? need2 : need1;

@@ -174,7 +174,8 @@ int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs,
  * Hann windowed, |FFT|/sum(window), lower half of the one-sided spectrum, and
  * harmonic_elim_runs rounds of (argmax -> pitch class += peak; zero the bins whose
  * frequency EQUALS 1..harmonic_multiples_elim-1 times the peak frequency).
- * Frame lengths up to 6553 samples are supported (fs <= ~107 kHz with the defaults: 88.2 and 96 kHz input). */
+ * Frame lengths up to 16384 samples are supported (fs <= ~268 kHz with the defaults; above 6553 samples, i.e.
+ * ~107 kHz, in decimated chirp-z passes). */
 typedef struct mpx_prime_params {
     int num_harmonic;              /* default 1 */
     int num_octave;                /* default 2 */

@@ -87,8 +87,17 @@ def test_batch_edge_cases_vs_oracle(eng, clips):
         warnings.simplefilter("ignore")
         np.testing.assert_allclose(eng.prime_multif0(x96, 96000), o_prime.prime_compute(x96.astype(np.float64), 96000),
                                    rtol=RTOL, atol=1e-7)
+    # above ~107 kHz the lowest candidates' frames exceed 6553 samples: the input decimated by R, R passes of the 8192-point
+    # chirp-z (192 kHz: frames of 3110..11743 samples, R up to 3; 120 kHz: up to 7339 samples, R = 2; 260 kHz: up to 15901, R = 4)
+    for fsr, nsmp in ((192000, 70000), (120000, 40000), (260000, 50000)):
+        tt = np.arange(nsmp) / float(fsr)
+        xx = (0.3 * np.sin(2 * np.pi * 261.63 * tt) + 0.2 * np.sin(2 * np.pi * 392.0 * tt) + 0.1 * np.sin(2 * np.pi * 164.81 * tt)
+              + 1e-3 * rng.standard_normal(nsmp)).astype(np.float32)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            np.testing.assert_allclose(eng.prime_multif0(xx, fsr), o_prime.prime_compute(xx.astype(np.float64), fsr), rtol=RTOL, atol=1e-7)
     with pytest.raises(NotImplementedError):
-        eng.prime_multif0(np.zeros(100, dtype=np.float32), 192000)   # 8/f*fs > 6553 samples for the low candidates
+        eng.prime_multif0(np.zeros(100, dtype=np.float32), 384000)   # 8/f*fs > 16384 samples for the low candidates
     with pytest.raises(ValueError):
         eng.prime_multif0(np.zeros((2, 2), dtype=np.float32), FS)
 
