@@ -46,13 +46,17 @@ struct If0Chunk {
     int clip_left;         // samples of the clip from sig_start on (>= len unless the clip ends inside)
     int warm;              // run-in samples before sig_start (0 at the start of a clip)
     int pad;
-    long long yc_row0;     // the chunk's block of the output buffer starts at yc_row0 * channels; inside: [channel][len]
+    long long yc_row0;     // the chunk's block of the output buffer starts at yc_row0 * channels; inside: [frame][channel][frame_size]:
+                           // a frame's channels are one contiguous piece for the spectrum kernel, and a wave of 64 channels writes
+                           // inside a 64 x frame_size window (until round 3: [channel][len], rows a whole chunk apart)
 };
 
 struct If0Wfir {
     double a;
     double c[13];
 };
+
+constexpr int IF0_TW = 64;   // samples per channel the pipelined front end collects in LDS before it stores them
 
 struct If0TailGroup {   // chunks with the same (warm, len) whose leftover channels (channels % 64) share one wave
     int first, count;   // tail_list[first .. first + count)
@@ -67,8 +71,8 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                                                   const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
                                                   double* __restrict__ yc, const int* __restrict__ tail_list,
                                                   const If0TailGroup* __restrict__ tail_groups,
-                                                  double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
-                                                  int nch_u, const If0TailGroup g) {
+                                                  double (*tile)[IF0_TW + 1], long long* rowbase, long long ck_u, int ch0_u,
+                                                  int nch_u, const If0TailGroup g, int lg_nf) {
     // One wave per (chunk, group of 64 channels), one lane per channel; the channels % 64 left over (6 of the default
     // 70) would fill a wave to 9 %, so the leftovers of up to 64 / (channels % 64) chunks of equal length and run-in
     // share one: lane -> (chunk, channel).  All lanes of a wave share the loop bounds, and the outputs go
@@ -93,8 +97,9 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
     const int c_warm = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
     const int c_len = TAIL ? __builtin_amdgcn_readfirstlane(c.len) : c.len;
     const If0ChanCoef k = coefs[ch];
-    if (TAIL) rowbase[lane] = active ? c.yc_row0 * channels + (long long)ch * c_len : -1;
-    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + (size_t)ch0 * c_len;  // !TAIL: [channel - ch0][len]
+    // the chunk's block of the output buffer: [frame of the chunk][channel][frame_size] (see If0Chunk)
+    if (TAIL) rowbase[lane] = active ? c.yc_row0 * channels + ((long long)ch << lg_nf) : -1;
+    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + ((size_t)ch0 << lg_nf);  // !TAIL: frame 0, channel ch0
     // The chain is 17 filter stages deep (4 resonators, 12 all-passes, rectifier + low-pass).  Evaluated
     // sample by sample it is ONE dependent chain of ~20 fp64 operations per step, and a lone wave pays the
     // full FMA latency on each.  Software pipelining across samples removes that: in iteration tau stage j
@@ -137,6 +142,8 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
     const int c_end = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
     fetch(-c_warm);
     for (int tb = -c_warm; tb < c_end + DEPTH; tb += PF) {
+        const int t0 = tb - DEPTH;                             // this block produces the outputs t0 .. t0 + 15
+        const int tcol = t0 >= 0 ? (t0 & (IF0_TW - 1)) : 0;   // their columns in the tile (the run-in's outputs are dropped)
         float xs[PF];
 #pragma unroll
         for (int q = 0; q < PF; ++q) xs[q] = nx[q];
@@ -150,7 +157,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                 const double lp = k.lpb0 * r + l1;
                 l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
                 l2 = k.lpb2 * r - k.lpa2 * lp;
-                tile[lane][q] = (r + lp) / 2.0;   // output sample tau - DEPTH = tb - 16 + q
+                tile[lane][tcol + q] = (r + lp) / 2.0;   // output sample tau - DEPTH = tb - 16 + q
             }
             // ---- all-pass stages 11..0 (samples tau-15 .. tau-4), dsp/wfir.py:25-43
             {
@@ -194,26 +201,34 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                 qy = y;
             }
         }
-        const int t0 = tb - DEPTH;
-        if (t0 >= 0 && t0 < c_end) {   // uniform: warm-up and length are multiples of 16
+        // The tile collects IF0_TW = 64 samples per channel before it goes out: a store instruction then writes 512 contiguous
+        // bytes of ONE channel row (64 lanes x 8 B) where 16-sample tiles wrote four 128-byte pieces of four rows -- a thousand
+        // waves x 64 rows of scattered 128-byte lines held the whole launch at ~2 TB/s of HBM writes (the front end of the 1 h
+        // stream took the same 2.05 TB/s with 64 and with 70 channels).
+        if (t0 >= 0 && t0 < c_end && (tcol == IF0_TW - PF || t0 + PF >= c_end)) {   // uniform: a full tile, or the chunk's last block
+            const int tg = t0 - tcol, ncols = tcol + PF;   // first sample and width of what the tile holds
+            // where sample tg of channel 0 of this frame sits relative to frame 0, channel 0 (a tile never straddles a frame)
+            const size_t foff = (((size_t)(tg >> lg_nf) * channels) << lg_nf) + (size_t)(tg & ((1 << lg_nf) - 1));
             wave_lds_fence();
-            // (the tile is read unconditionally, all sixteen rows at once, and only the stores are predicated: with the read
-            //  inside the condition every element was a branch and two waits for the LDS)
-            double tv[PF];
-            long long rbv[PF];
 #pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int e = q * 64 + lane, r = e >> 4, cc = e & 15;
-                tv[q] = tile[r][cc];
-                if (TAIL) rbv[q] = rowbase[r];
-            }
+            for (int h = 0; h < 64 / 16; ++h) {
+                double tv[16];
+                long long rbv[16];
 #pragma unroll
-            for (int q = 0; q < PF; ++q) {
-                const int e = q * 64 + lane, r = e >> 4, cc = e & 15;
-                if (TAIL) {
-                    if (rbv[q] >= 0) yc[rbv[q] + t0 + cc] = tv[q];
-                } else if (r < nch_u) {
-                    out[(size_t)r * c_len + t0 + cc] = tv[q];
+                for (int q = 0; q < 16; ++q) {
+                    tv[q] = tile[16 * h + q][lane];   // row 16 h + q, sample tg + lane
+                    if (TAIL) rbv[q] = rowbase[16 * h + q];
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int r = 16 * h + q;
+                    if (lane < ncols) {
+                        if (TAIL) {
+                            if (rbv[q] >= 0) yc[rbv[q] + foff + lane] = tv[q];
+                        } else if (r < nch_u) {
+                            out[((size_t)r << lg_nf) + foff + lane] = tv[q];
+                        }
+                    }
                 }
             }
             wave_lds_fence();
@@ -231,7 +246,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
                                                       int channels, const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
                                                       double* __restrict__ yc, const int* __restrict__ tail_list,
                                                       double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
-                                                      int nch_u, const If0TailGroup g) {
+                                                      int nch_u, const If0TailGroup g, int lg_nf) {
     const int lane = threadIdx.x;
     const int full = channels >> 6, nt = channels & 63;
     long long ck;
@@ -251,8 +266,8 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
     const int c_warm = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
     const int c_len = TAIL ? __builtin_amdgcn_readfirstlane(c.len) : c.len;
     const If0ChanCoef k = coefs[ch];
-    if (TAIL) rowbase[lane] = active ? c.yc_row0 * channels + (long long)ch * c_len : -1;
-    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + (size_t)ch0 * c_len;
+    if (TAIL) rowbase[lane] = active ? c.yc_row0 * channels + ((long long)ch << lg_nf) : -1;
+    double* __restrict__ out = yc + (size_t)c.yc_row0 * channels + ((size_t)ch0 << lg_nf);   // frame 0 of the chunk, channel ch0
     double a1 = 0, a2 = 0, b1 = 0, b2 = 0, c1 = 0, c2 = 0, d1 = 0, d2 = 0, l1 = 0, l2 = 0;
     double z[12];
 #pragma unroll
@@ -270,7 +285,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         }
     };
     const int c_end = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
-    const size_t lane_off = (size_t)(lane >> 4) * c_len + (lane & 15);
+    const size_t lane_off = ((size_t)(lane >> 4) << lg_nf) + (lane & 15);
     fetch(-c_warm);
 #pragma unroll 1
     for (int t = -c_warm; t < c_end; t += G) {
@@ -311,6 +326,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         }
         if (t >= 0 && col == PF - G) {   // uniform; a tile of 16 samples is complete
             const int tb = t - (PF - G);
+            const size_t foff = (((size_t)(tb >> lg_nf) * channels) << lg_nf) + (size_t)(tb & ((1 << lg_nf) - 1));   // as in the pipelined body
             wave_lds_fence();
 #pragma unroll
             for (int h = 0; h < 4; ++h) {   // four rows at a time: registers
@@ -326,10 +342,10 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
                 for (int q = 0; q < PF / 4; ++q) {
                     const int e = (h * (PF / 4) + q) * 64 + lane, r = e >> 4, cc = e & 15;
                     if (TAIL) {
-                        if (rbv[q] >= 0) yc[rbv[q] + tb + cc] = tv[q];
+                        if (rbv[q] >= 0) yc[rbv[q] + foff + cc] = tv[q];
                     } else if (r < nch_u) {
                         // rows e >> 4 = 4 (4 h + q) + (lane >> 4): a wave-uniform base per store, one per-lane offset for all
-                        (out + (size_t)(4 * (h * (PF / 4) + q)) * c_len + tb)[lane_off] = tv[q];
+                        (out + ((size_t)(4 * (h * (PF / 4) + q)) << lg_nf) + foff)[lane_off] = tv[q];
                     }
                 }
             }
@@ -341,30 +357,30 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void if0_frontend2_kernel(
     const float* __restrict__ sig, const If0Chunk* __restrict__ chunks, long long num_chunks, int channels,
     const If0ChanCoef* __restrict__ coefs, If0Wfir wf, double* __restrict__ yc, const int* __restrict__ tail_list,
-    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups) {
+    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf) {
     __shared__ double tile[64][17];
     __shared__ long long rowbase[64];
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
-        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g);
+        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g, lg_nf);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)
         if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 64 * full,
-                                     channels & 63, g);
+                                     channels & 63, g, lg_nf);
     else
-        if0_frontend_seq_body<true>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g);
+        if0_frontend_seq_body<true>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf);
 }
 
 __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                           long long num_chunks, int channels,
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc, const int* __restrict__ tail_list,
-                                                          const If0TailGroup* __restrict__ tail_groups, int num_tail_groups) {
-    __shared__ double tile[64][17];
+                                                          const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf) {
+    __shared__ double tile[64][IF0_TW + 1];
     __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
@@ -374,16 +390,16 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
         if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 b / full, (int)(b % full) * 64, 64, g);
+                                 b / full, (int)(b % full) * 64, 64, g, lg_nf);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
         if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 tail_list[g.first], 64 * full, channels & 63, g);
+                                 tail_list[g.first], 64 * full, channels & 63, g, lg_nf);
     else
         if0_frontend_body<true>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
-                                0, g);
+                                0, g, lg_nf);
 }
 
 // ------------------------------------------------------------------ spectrum
@@ -391,7 +407,7 @@ struct If0Frame {
     long long yc_base;  // index in yc of the frame's first sample of channel 0
     int valid;          // samples of the frame that exist (tail of a clip is zero padded)
     int clip;
-    int ch_stride;      // distance between channels (= the chunk's length)
+    int ch_stride;      // distance between channels (= the frame size: [frame][channel][frame_size])
     int pad;
 };
 
@@ -1265,8 +1281,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             chunks.push_back(ck);
             for (int64_t fo = 0; fo < ck.len; fo += NF) {
                 If0Frame fr;
-                fr.yc_base = ck.yc_row0 * p.channels + fo;
-                fr.ch_stride = ck.len;
+                fr.yc_base = ck.yc_row0 * p.channels + (fo / NF) * (long long)p.channels * NF;   // [frame of the chunk][channel][NF]
+                fr.ch_stride = NF;
                 fr.pad = 0;
                 const int64_t fl = len - (t0 + fo);
                 fr.valid = (int)(fl >= NF ? NF : (fl > 0 ? fl : 0));
@@ -1335,15 +1351,17 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     double* ut = (double*)ctx->d_ws1.p;
     double* ur = ut + (size_t)nframes * n2;
     double* ud = ur + (size_t)nframes * n2;
+    int lg_nf = 0;
+    while ((1 << lg_nf) < NF) ++lg_nf;
     prof_mark(ctx, st, "if0_frontend_kernel");
     if (!fe_sequential)
         hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
                            d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                           d_tail_groups, (int)tail_groups.size());
+                           d_tail_groups, (int)tail_groups.size(), lg_nf);
     else
         hipLaunchKernelGGL(if0_frontend2_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
                            d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                           d_tail_groups, (int)tail_groups.size());
+                           d_tail_groups, (int)tail_groups.size(), lg_nf);
     MPX_HIP(ctx, hipGetLastError());
     prof_mark(ctx, st, "if0_spectrum_kernel");
     if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
