@@ -11,7 +11,7 @@ from oracle import harmonic_energy as o_he, prime_multif0 as o_pr
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 eng = cd.get_engine(0)
-bad = 0
+bad = skipped = 0
 
 
 def signal(n, fs):
@@ -30,7 +30,7 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for case in range(cases):
         fs = int(rng.choice([16000, 22050, 44100, 48000]))
-        N = int(rng.choice([1024, 2048, 4096, 8192, 16384, 600, 1000, 1023, 2227, 3000, 4095]))
+        N = int(rng.choice([1024, 2048, 4096, 8192, 16384, 600, 1000, 1023, 2227, 3000, 4095, 5000, 6500, 8000, 12000, 20000, 32768]))
         hop = min(N, int(rng.choice([N, N // 2, N // 4, 1000])))
         n = int(rng.choice([N - 1, N, N + 1, 3 * N + 5, 20 * hop + N]))
         kw = dict(num_harmonic=int(rng.integers(1, 4)), num_octave=int(rng.integers(1, 4)), num_bins=int(rng.integers(0, 4)))
@@ -41,6 +41,9 @@ with warnings.catch_warnings():
             want = e
         try:
             tot, per = eng.harmonic_energy(x, fs, N, hop, return_frames=True, **kw)
+        except NotImplementedError:     # a shape the library says it does not cover (more than 64 decimated passes)
+            skipped += 1
+            continue
         except Exception as e:
             per = e
         if isinstance(want, Exception) or isinstance(per, Exception):
@@ -52,8 +55,8 @@ with warnings.catch_warnings():
             bad += 1
             print("HE MISMATCH", case, fs, N, hop, n, kw, float(np.max(np.abs(per - want) / np.maximum(np.abs(want), 1e-300))))
     for case in range(cases // 3):
-        fs = 22050
-        n = int(rng.choice([3000, 22050, 44100, 50001]))
+        fs = int(rng.choice([22050, 22050, 44100, 48000, 96000, 120000, 192000]))   # above ~107 kHz: decimated chirp-z passes
+        n = int(rng.choice([3000, 22050, 44100, 50001])) * (1 if fs <= 48000 else 2)
         kw = dict(num_harmonic=int(rng.integers(1, 3)), num_octave=int(rng.integers(1, 3)),
                   harmonic_multiples_elim=int(rng.integers(1, 7)), harmonic_elim_runs=int(rng.integers(1, 4)))
         x = signal(n, fs)
@@ -64,5 +67,5 @@ with warnings.catch_warnings():
         if not np.allclose(got, want, rtol=1e-7, atol=1e-6):
             bad += 1
             print("PRIME MISMATCH", case, n, kw, got, want)
-print("cases %d + %d, mismatches %d" % (cases, cases // 3, bad))
+print("cases %d + %d, mismatches %d, unsupported shapes skipped %d" % (cases, cases // 3, bad, skipped))
 sys.exit(1 if bad else 0)
