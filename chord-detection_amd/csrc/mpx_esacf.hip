@@ -684,6 +684,112 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     }
 }
 
+// Non-power-of-two frames of 2049 ... 2730 samples (the reference's default 46.4 ms frame at 48 kHz: 2227): a full chirp-z
+// needs 2N - 1 > 4096 points, i.e. the 8192-point Stockham path at one workgroup per CU (sacf_big_kernel, ~4x the time per
+// frame).  But the SACF only ever looks at HALF of every transform: the bands are real, so |X[k]| is needed for k <= N/2
+// only, and the lags are the real part of the forward DFT of the even sequence S, r[n] = Re sum_{k <= N/2} w_k S[k] W_N^(kn) / N
+// (w = 1 at k = 0 and N/2, else 2), for n < N/2.  A chirp-z evaluated at K = N/2 + 1 bins is a circular convolution of
+// N + K - 1 ~ 1.5 N points: 4096 do.  So a frame is THREE real chirp-z transforms -- x_lo, x_hi, w S -- on the in-place
+// engine, all three with the same chirp and the same filter spectrum; the |.|^0.67 needs no final chirp multiplication (it
+// drops the phase), and bin k of the first two and sample k of the third belong to the same thread: no exchange through LDS.
+template <int L>
+__global__ __launch_bounds__(L / 8, 2) void sacf_rz_kernel(SacfArgs a) {
+    constexpr int T = L / 8;
+    static_assert(L == 4096, "N <= 2730 < 6 T inputs and K <= 1366 < 3 T outputs per thread are written for L = 4096");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = a.N, Mh = a.Mh, K = N / 2 + 1;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                      // L complex, slot sigma<L>(position)
+    double* yv = reinterpret_cast<double*>(smem + sizeof(cx<double>) * L);      // Mh + 2 doubles
+    const int tid = threadIdx.x;
+    MPX_POW067_LDS(a, tid, T);
+    const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(a.tw, tid);
+    const long long f = blockIdx.x;
+    cx<double> regs[8];
+    double hi[6];
+    const cx<double>* xin = a.xb + band_index(f, 0, N);
+    // length-L circular convolution of regs (natural order in, natural order out) with the chirp filter
+    auto convolve = [&]() {
+        dif_fft_keep_last<L, double>(buf, twd, regs, tid);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) regs[e] = cmul(regs[e], a.bhat[e * T + tid]);
+        idit_fft_from_last<L, double>(buf, twd, regs, tid);
+    };
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = tid + r * T;
+        regs[r] = {0.0, 0.0};
+        if (r < 6) {
+            const bool in = n < N;
+            const cx<double> v = xin[in ? (size_t)(n >> 4) * (64 * BS_TILE) + (n & 15) : 0];
+            const cx<double> ch = a.chirp[in ? n : 0];
+            hi[r] = in ? v.y : 0.0;
+            const double lo = in ? v.x : 0.0;
+            regs[r] = {lo * ch.x, -lo * ch.y};   // x_lo[n] conj(chirp[n])
+        }
+    }
+    convolve();
+    double sv[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) sv[r] = tid + r * T < K ? mag067(regs[r].x, regs[r].y, pow_tab) : 0.0;
+    __syncthreads();   // every wave has left the transform before the next one writes buf
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int n = tid + r * T;
+        regs[r] = {0.0, 0.0};
+        if (r < 6) {
+            const cx<double> ch = a.chirp[n < N ? n : 0];
+            regs[r] = {hi[r] * ch.x, -hi[r] * ch.y};   // hi[r] is zero beyond the frame
+        }
+    }
+    convolve();
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+        if (tid + r * T < K) sv[r] += mag067(regs[r].x, regs[r].y, pow_tab);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = tid + r * T;
+        regs[r] = {0.0, 0.0};
+        if (r < 3 && k < K) {
+            const double s = (k == 0 || 2 * k == N) ? sv[r] : 2.0 * sv[r];
+            const cx<double> ch = a.chirp[k];
+            regs[r] = {s * ch.x, -s * ch.y};
+        }
+    }
+    convolve();
+    const double inv_n = 1.0 / (double)N;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int n = tid + r * T;
+        if (n < Mh) {
+            const cx<double> ch = a.chirp[n];
+            const double v = (regs[r].x * ch.x + regs[r].y * ch.y) * inv_n;   // Re(y[n] conj(chirp[n])) / N
+            yv[n] = v;
+            if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+        }
+    }
+    __syncthreads();  // buf is dead from here on; the peak-picking scratch aliases it
+    double* yrow = a.y_out + f * (long long)Mh;
+    if (a.defer_enhance) {
+        for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
+        return;
+    }
+    for (int n = tid; n < Mh; n += T) {   // enhancement without the vocoder (no-op mode, or fewer than two rates): see sacf_kernel
+        double v = yv[n];
+        for (int r = 2; r <= a.n_peaks_elim; ++r) {
+            int cut = 0;
+            if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+            v = v < 0.0 ? 0.0 : v;
+            if (n < cut) v = v - v;
+            v = v < 0.0 ? 0.0 : v;
+        }
+        yv[n] = v;
+        yrow[n] = v;
+    }
+    __syncthreads();
+    peak_pick<T>(a, f, yv, smem, tid);
+}
+
 // ------------------------------------------------------------------ kernel 2, prime-factor engine
 // The reference's own frame lengths are products of small coprimes: 1023 = 3 * 11 * 31 (46.4 ms at 22.05 kHz) and
 // 2046 = 2 * 3 * 11 * 31 (44.1 kHz).  Good-Thomas: with the input index written as n = sum_i n_i N/N_i (mod N) and the
@@ -2654,6 +2760,43 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if (rc) return rc;
     EsacfPlan plan;
     if ((rc = esacf_plan(ctx, split ? N / 2 : N, plan, split))) return rc;
+    // non-powers of two of 2049 ... 2730 samples: three half-length chirp-z transforms on the in-place 4096-point engine
+    const bool rz = !split && plan.blue && plan.L == 8192 && N + N / 2 <= 4096 && !dev_env_on("MPX_SACF_NO_RZ");
+    if (rz) {
+        const std::string key = "esacf_rz" + std::to_string(N);
+        auto it = ctx->misc_plans.find(key);
+        if (it == ctx->misc_plans.end()) {
+            constexpr int LR = 4096;
+            const int K = N / 2 + 1;
+            std::vector<cx<double>> tw(LR), chirp(N), filt(LR, cx<double>{0.0, 0.0}), fr(LR);
+            for (int j = 0; j < LR; ++j) {
+                const long double ang = -2.0L * M_PIl * j / (long double)LR;
+                tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+            for (long long n = 0; n < N; ++n) {
+                const long long q = (n * n) % (2LL * N);
+                const long double ang = M_PIl * (long double)q / (long double)N;
+                chirp[n] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+            for (int m = 0; m < K; ++m) filt[m] = chirp[m];            // chirp[k - n], k - n = 0 .. K-1
+            for (int m = 1; m < N; ++m) filt[LR - m] = chirp[m];       // k - n = -1 .. -(N-1): N + K - 1 <= LR points in all
+            host_fft(filt);
+            for (auto& v : filt) {
+                v.x /= LR;
+                v.y /= LR;
+            }
+            for (int t = 0; t < LR / 8; ++t)
+                for (int e = 0; e < 8; ++e) fr[(size_t)e * (LR / 8) + t] = filt[dif_reg_freq(LR, t, e)];
+            void* d0 = upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+            void* d1 = upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
+            void* d2 = upload(ctx, fr.data(), fr.size() * sizeof(cx<double>));
+            if (!d0 || !d1 || !d2) return MPX_ENOMEM;
+            it = ctx->misc_plans.emplace(key, std::vector<void*>{d0, d1, d2}).first;
+        }
+        plan.tw = (cx<double>*)it->second[0];
+        plan.chirp = (cx<double>*)it->second[1];
+        plan.bhat = (cx<double>*)it->second[2];
+    }
     const cx<double>* twn = nullptr;
     if (split) {
         const std::string key = "esacf_twn" + std::to_string(N);
@@ -2756,7 +2899,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             a.pow_tab = (const double*)pt->second[0];
         }
         a.ablate = dev_env_int("MPX_SACF_ABLATE", 0);
-        prof_mark(ctx, st, split ? "sacf_split_kernel" : (use_pfa ? "sacf_pfa_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel")));
+        prof_mark(ctx, st, split ? "sacf_split_kernel" : (use_pfa ? "sacf_pfa_kernel" : (rz ? "sacf_rz_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel"))));
         if (split) {
             const size_t lds = sizeof(cx<double>) * lds_slots(8192);
             if (peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2) > lds)
@@ -2781,6 +2924,15 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                 hipLaunchKernelGGL(sacf_pfa_kernel<2>, dim3((unsigned)g), dim3(PFA_T), lds, st, a);
             else
                 hipLaunchKernelGGL(sacf_pfa_kernel<1>, dim3((unsigned)g), dim3(PFA_T), lds, st, a);
+            MPX_HIP(ctx, hipGetLastError());
+        } else if (rz) {
+            const size_t lds = sizeof(cx<double>) * 4096 + sizeof(double) * (size_t)(Mh + 2);
+            if (peak_scratch_bytes(Mh) > sizeof(cx<double>) * 4096)
+                return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", N);
+            a.pair = 0;
+            auto kern = sacf_rz_kernel<4096>;
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(512), lds, st, a);
             MPX_HIP(ctx, hipGetLastError());
         } else if (plan.L == 8192) {
             const size_t lds = sizeof(cx<double>) * lds_slots(8192) + sizeof(double) * (size_t)(Mh + 2);

@@ -271,7 +271,7 @@ def test_parameters_and_44100_default_frame(eng):
 
 def test_48k_default_frame_8192_point_bluestein(eng):
     """The reference's default 46.4 ms frame at 48 kHz is 2227 samples: non-power-of-two above 2048, so the
-    chirp-z length is 8192 (sacf_big_kernel on the Stockham engine) and the SACF (1113 lags) is in the real
+    full chirp-z length would be 8192; sacf_rz_kernel runs it as three half-length transforms of 4096 points, and the SACF (1113 lags) is in the real
     phase-vocoder regime.  Also 3000 and 4095 samples (largest supported)."""
     from oracle import esacf as o_esacf
     rng = np.random.default_rng(48)
