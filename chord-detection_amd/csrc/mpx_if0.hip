@@ -285,7 +285,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         }
     };
     const int c_end = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
-    const size_t lane_off = ((size_t)(lane >> 4) << lg_nf) + (lane & 15);
+    const unsigned lane_off = ((unsigned)(lane >> 4) << lg_nf) + (unsigned)(lane & 15);   // < 4 frame sizes: 32 bits
     fetch(-c_warm);
 #pragma unroll 1
     for (int t = -c_warm; t < c_end; t += G) {
@@ -328,24 +328,25 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
             const int tb = t - (PF - G);
             const size_t foff = (((size_t)(tb >> lg_nf) * channels) << lg_nf) + (size_t)(tb & ((1 << lg_nf) - 1));   // as in the pipelined body
             wave_lds_fence();
+            constexpr int SG = TAIL ? 2 : 4;   // store instructions per group (their values and row bases are registers)
 #pragma unroll
-            for (int h = 0; h < 4; ++h) {   // four rows at a time: registers
-                double tv[PF / 4];
-                long long rbv[PF / 4];
+            for (int h = 0; h < PF / SG; ++h) {
+                double tv[SG];
+                long long rbv[SG];
 #pragma unroll
-                for (int q = 0; q < PF / 4; ++q) {
-                    const int e = (h * (PF / 4) + q) * 64 + lane, r = e >> 4, cc = e & 15;
+                for (int q = 0; q < SG; ++q) {
+                    const int e = (h * SG + q) * 64 + lane, r = e >> 4, cc = e & 15;
                     tv[q] = tile[r][cc];
                     if (TAIL) rbv[q] = rowbase[r];
                 }
 #pragma unroll
-                for (int q = 0; q < PF / 4; ++q) {
-                    const int e = (h * (PF / 4) + q) * 64 + lane, r = e >> 4, cc = e & 15;
+                for (int q = 0; q < SG; ++q) {
+                    const int e = (h * SG + q) * 64 + lane, r = e >> 4, cc = e & 15;
                     if (TAIL) {
                         if (rbv[q] >= 0) yc[rbv[q] + foff + cc] = tv[q];
                     } else if (r < nch_u) {
-                        // rows e >> 4 = 4 (4 h + q) + (lane >> 4): a wave-uniform base per store, one per-lane offset for all
-                        (out + ((size_t)(4 * (h * (PF / 4) + q)) << lg_nf) + foff)[lane_off] = tv[q];
+                        // rows e >> 4 = 4 (SG h + q) + (lane >> 4): a wave-uniform base per store, one per-lane offset for all
+                        (out + ((size_t)(4 * (h * SG + q)) << lg_nf) + foff)[lane_off] = tv[q];
                     }
                 }
             }
