@@ -105,11 +105,12 @@ def _second_engine(device):
     return _SECOND_ENGINE[device]
 
 
-def synth_block(n_clips, fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, synth_device=None):
-    """This rank's clips, synthesised up front: {first clip id of a chunk: (ids, clips)} for run_corpus(resident=...) --
-    a corpus that is already in HBM when the clock starts (bench.py; 4096 two-second clips are 0.7 GB)."""
+def synth_block(n_clips, fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, synth_device=None, group=4):
+    """This rank's clips, synthesised up front: {first clip id of a group of chunks: (ids, clips)} for run_corpus(resident=...)
+    -- a corpus that is already in HBM when the clock starts (bench.py; 4096 two-second clips are 0.7 GB)."""
     lo, hi = partition(n_clips, world, rank)
     out = {}
+    chunk = chunk * max(1, int(group))   # see run_corpus
     for c0 in range(lo, hi, chunk):
         ids = list(range(c0, min(c0 + chunk, hi)))
         out[c0] = (ids, synth_chunk(ids, fs, seconds, synth_device))
@@ -120,11 +121,21 @@ def synth_block(n_clips, fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, syn
 
 
 def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024, rank=0, world=1, device=0,
-               compute=None, synth_device=None, overlap=True, note_names="unicode", resident=None):
+               compute=None, synth_device=None, overlap=True, note_names="unicode", resident=None, group=None):
     """Process this rank's block.  Returns (lo, hi, chroma[hi-lo, len(methods), 12] float64, seconds per method).
     `compute(method, clips, fs, device) -> [n,12]` defaults to the HIP engine's batch entry points; tests
-    substitute a CPU function to exercise the sharding logic without a GPU.  `resident`: the chunks of synth_block()
-    (same n_clips / chunk / rank / world) -- nothing is synthesised inside the call then."""
+    substitute a CPU function to exercise the sharding logic without a GPU.  `resident`: the groups of synth_block()
+    (same n_clips / chunk / group / rank / world) -- nothing is synthesised inside the call then.
+    `chunk` clips are what Iterative-F0 takes per engine call (its front-end output is 27 MB per two-second clip); the other
+    methods take `group` chunks at once: ESACF ends every call on the latency of its last runaway gaussian fits (5 of the 13 ms
+    a 1024-clip call takes: four such calls cost 53 ms where one call over 4096 clips costs 22), and no method waits for
+    another at a chunk boundary any more.  `group` defaults to 4 for a resident corpus and to 1 when the clips are synthesised
+    on the fly (the synthesis of the next chunk then runs under the engines' work on the current one; with groups it would
+    have to run ahead of a whole group)."""
+    if group is None:
+        group = 4 if resident is not None else 1
+    if0_chunk = max(1, int(chunk))
+    chunk = if0_chunk * max(1, int(group))
     if compute is None:
         compute = _engine_compute
         engine_path = True
@@ -206,8 +217,12 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
             import threading
             mi3 = list(methods).index(3)
             eng2 = _second_engine(device)
-            side = threading.Thread(target=run, args=(mi3, 3, lambda: eng2.iterative_f0_batch(clips, fs,
-                                                                                             note_names=note_names)))
+
+            def if0_pieces():   # the group, `if0_chunk` clips per engine call (rows of the [clips, samples] array: views)
+                return np.concatenate([np.asarray(eng2.iterative_f0_batch(clips[a:a + if0_chunk], fs, note_names=note_names))
+                                       for a in range(0, len(ids), if0_chunk)], axis=0)
+
+            side = threading.Thread(target=run, args=(mi3, 3, if0_pieces))
             side.start()
         side4 = None
         if side is not None and 4 in methods and len(methods) > 2 and os.environ.get("MPX_CORPUS_CONTEXTS", "3") == "3":
@@ -286,7 +301,8 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     ap.add_argument("--methods", default="1,2,3,4")
     ap.add_argument("--fs", type=int, default=22050)
     ap.add_argument("--seconds", type=float, default=2.0)
-    ap.add_argument("--chunk", type=int, default=1024)
+    ap.add_argument("--chunk", type=int, default=1024, help="clips per Iterative-F0 engine call")
+    ap.add_argument("--group", type=int, default=None, help="chunks the other methods take per engine call (default: 1; 4 for a resident corpus)")
     ap.add_argument("--out", default=None, help="write per-clip chroma [clips, methods, 12] to this .npz")
     ap.add_argument("--no-overlap", action="store_true", help="run Iterative-F0 after the other methods instead of next to them")
     ap.add_argument("--note-names", choices=("unicode", "ascii"), default="unicode",
@@ -309,7 +325,7 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     t0 = time.perf_counter()
     lo, hi, block, spent = run_corpus(args.clips, methods, args.fs, args.seconds, args.chunk, rank, world, local,
                                       compute=compute, synth_device=dev if on_gpu else None, overlap=not args.no_overlap,
-                                      note_names=args.note_names)
+                                      note_names=args.note_names, group=args.group)
     chroma = gather_blocks(block, args.clips, world, rank, dev if (world > 1 and on_gpu) else None)
     wall = time.perf_counter() - t0
     if world > 1:

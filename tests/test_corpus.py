@@ -88,6 +88,23 @@ def test_two_ranks_shard_clips_and_gather(tmp_path):
     assert set(res["methods"]) == {"2", "4"} and len(res["methods"]["2"]["first_clip"]) == 12
 
 
+def test_groups_of_chunks_give_the_same_rows():
+    """A resident corpus is handed to the methods in groups of chunks (Iterative-F0 keeps its own chunk): whatever the
+    grouping, every clip gets the same row (the clips do not depend on the chunk they are synthesised in)."""
+    n = 7
+    _, _, base, _ = corpus.run_corpus(n, (2, 4), 22050, 0.5, chunk=2, compute=_oracle_compute)
+    for group in (1, 2, 4):
+        res = corpus.synth_block(n, 22050, 0.5, chunk=2, group=group)
+        assert sorted(res) == list(range(0, n, 2 * group))
+        lo, hi, got, spent = corpus.run_corpus(n, (2, 4), 22050, 0.5, chunk=2, compute=_oracle_compute, resident=res, group=group)
+        assert (lo, hi) == (0, n) and len(spent) == 2
+        np.testing.assert_array_equal(got, base)
+    # default: groups of four chunks for a resident corpus
+    res = corpus.synth_block(n, 22050, 0.5, chunk=1)
+    assert sorted(res) == [0, 4]
+    np.testing.assert_array_equal(corpus.run_corpus(n, (2, 4), 22050, 0.5, chunk=1, compute=_oracle_compute, resident=res)[2], base)
+
+
 @pytest.mark.gpu
 def test_corpus_driver_matches_oracle_on_gpu():
     from oracle import harmonic_energy as o_he, prime_multif0 as o_pr
