@@ -46,7 +46,7 @@ out = {"n_gpus": d["n_gpus"], "value": d["value"], "unit": d["unit"], "ms_per_st
        "ms_per_step_repeats": d.get("ms_per_step_repeats"), "value_one_in_flight": d.get("value_one_in_flight"),
        "per_gpu": d["value"] / d["n_gpus"], "scaling": d["scaling"], "steps": d["steps"],
        "gather": "one all_gather of the [steps, 12] sums inside the timed region (bench.py)",
-       "workloads": {k: {kk: v.get(kk) for kk in ("value", "unit", "ms_per_batch", "wall_s", "scaling")} for k, v in d.get("workloads", {}).items()}}
+       "workloads": {k: {kk: v.get(kk) for kk in ("value", "unit", "ms", "scaling")} for k, v in d.get("workloads", {}).items()}}
 if n == 1 and plain:
     out["plain_bench_value"] = float(plain)
     out["launcher_equals_plain_within_5pct"] = abs(float(plain) - d["value"]) <= 0.05 * d["value"]

@@ -11,14 +11,58 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_bench(*extra, cpu_budget="1"):
+COMPACT_LIMIT = 6000   # bytes: the driver keeps the last 8 KB of stdout; round 3's single 24 KB line could not be parsed
+
+
+def _run_bench(*extra, cpu_budget="1", both=False):
+    """bench.py's stdout holds ONE JSON line, the compact record (<= 6 KB); the full record goes to --full-json.
+    Returns the full record (and the compact one with both=True)."""
+    import tempfile
     env = dict(os.environ, MPX_BENCH_CPU_BUDGET=cpu_budget)   # seconds per CPU leg: the contract, not the figures
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "6", *extra],
-                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout          # ONE JSON line
-    return json.loads(lines[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        full = os.path.join(tmp, "bench_full.json")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "6",
+                              "--full-json", full, *extra], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout          # ONE JSON line
+        assert out.stdout.strip().splitlines()[-1] == lines[0]      # and it is the LAST line of stdout
+        assert len(lines[0]) <= COMPACT_LIMIT, len(lines[0])
+        compact = json.loads(lines[0])
+        with open(full) as fh:
+            d = json.load(fh)
+    return (d, compact) if both else d
+
+
+def _check_compact(c, d):
+    """what the driver parses: the contract's keys, roofline, cpu_baseline and every workload incl. the north star's Target"""
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in c, k
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert c[k] == d[k], k
+    assert c["value"] == pytest.approx(d["value"], rel=1e-5) and c["ms_per_step"] == pytest.approx(d["ms_per_step"], rel=1e-5)
+    assert "workload" in c["config"] and "model" not in c["config"]
+    r = c["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "compulsory_bytes",
+              "wasted_traffic_ratio"):
+        assert k in r, k
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert r["frac"] == pytest.approx(d["roofline"]["frac"], rel=1e-5)
+    if "cpu_baseline" in d:
+        cb = c["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == c["unit"] and cb["value"] > 0 and cb["sample"]
+    if "workloads" in d:
+        w = c["workloads"]
+        assert set(w) == set(d["workloads"])
+        for name, e in w.items():
+            assert e["value"] == pytest.approx(d["workloads"][name]["value"], rel=1e-5) and e["unit"] and e["ms"] > 0, name
+            assert e["kernel"] and e["kernel_ms"] > 0 and "frac" in e and "wasted_traffic_ratio" in e, name
+            if "cpu_baseline" in d["workloads"][name]:
+                assert e["cpu"]["value"] > 0, name
+        assert w["esacf_stft_8192"]["ms"] == pytest.approx(d["workloads"]["esacf_stft_8192"]["ms_per_batch"], rel=1e-5)   # the Target
+        assert w["if0_stream_1h"]["value_first_pass"] > 0 and w["corpus_4096_all_methods"]["value_definition"]
+    assert c["full_record"]
 
 
 def _check_roofline(r):
@@ -45,7 +89,8 @@ def _check_roofline(r):
 
 
 def test_bench_line_has_the_contract_fields():
-    d = _run_bench()
+    d, compact = _run_bench(both=True)
+    _check_compact(compact, d)
     assert d["metric"].startswith("frames/sec STFT->chromagram") and d["unit"] == "frames/s"
     assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 60, 6)
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -82,6 +127,8 @@ def test_bench_line_has_the_contract_fields():
     assert w["corpus_4096_all_methods"]["unit"] == "clips/s" and w["corpus_4096_all_methods"]["nonzero_rows"] > 0.9 * 4 * 4096
     assert w["if0_stream_1h"]["unit"] == "x real time" and w["if0_stream_1h"]["frames"] == 19380
     assert w["if0_stream_1h"]["value_first_pass"] > 0 and w["corpus_4096_all_methods"]["value_with_streaming_synthesis"] > 0
+    cw = w["corpus_4096_all_methods"]   # what `value` times is said in the record (it changed between rounds 2 and 3)
+    assert cw["value_definition"] and cw["value_without_synthesis"] == cw["value"] and cw["synthesis_seconds_rank0"] > 0
     fe = w["if0_stream_1h"]["rooflines"]["if0_frontend_kernel"]
     assert fe["bytes_per_unit"] == 4 and fe["intermediate_bytes_per_unit"] == 560     # compulsory: the samples once; 70 x 8 B handed on
     for name, rec in w.items():
@@ -94,9 +141,10 @@ def test_bench_line_has_the_contract_fields():
 
 
 def test_bench_without_cpu_leg_and_smoke():
-    d = _run_bench("--no-cpu-baseline", "--streams", "1", "--headline-only")
-    assert d["config"]["batches_in_flight"] == 1 and "workloads" not in d
-    assert "roofline" in d and "cpu_baseline" not in d
+    d, compact = _run_bench("--no-cpu-baseline", "--streams", "1", "--headline-only", both=True)
+    _check_compact(compact, d)
+    assert d["config"]["batches_in_flight"] == 1 and "workloads" not in d and "workloads" not in compact
+    assert "roofline" in d and "cpu_baseline" not in d and "cpu_baseline" not in compact
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke(); print('smoke ok')"],
                          cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]

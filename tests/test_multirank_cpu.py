@@ -35,8 +35,21 @@ def _torchrun(nproc, script_and_args, extra_env=None, timeout=600):
     return json.loads(lines[0])
 
 
+def _bench_full(compact):
+    """bench.py's stdout line is the compact record; it names the file that holds the full one"""
+    assert len(json.dumps(compact, separators=(",", ":"))) <= 6000
+    with open(os.path.join(ROOT, compact["full_record"])) as fh:
+        return json.load(fh)
+
+
 def test_bench_py_two_ranks():
-    d = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2"], {"MPX_BENCH_STUB": "tests.bench_stub"})
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=ROOT) as tmp:
+        c = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--full-json",
+                          os.path.join(tmp, "full.json")], {"MPX_BENCH_STUB": "tests.bench_stub"})
+        d = _bench_full(c)
+    assert c["n_gpus"] == 2 and c["scaling"] == "weak" and np.isclose(c["value"], d["value"], rtol=1e-5)
+    assert set(c["workloads"]) == set(d["workloads"]) and "cpu_baseline" not in c
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "weak"
     assert d["config"]["frames_per_gpu"] == 8                     # the stand-in's toy size
     # whole-job aggregate over both ranks, max-over-ranks time
@@ -54,10 +67,14 @@ def test_bench_py_two_ranks():
 
 def test_bench_py_one_rank_stub_matches_contract():
     env = dict(os.environ, PYTHONPATH=ROOT, MPX_BENCH_STUB="tests.bench_stub", MPX_BENCH_CPU_BUDGET="0.2")
-    out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--headline-only"], cwd=ROOT, env=env,
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=ROOT) as tmp:
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--headline-only", "--full-json",
+                              os.path.join(tmp, "full.json")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        c = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        d = _bench_full(c)
+    assert c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0
     assert d["n_gpus"] == 1 and "workloads" not in d
     c = d["cpu_baseline"]                                          # the CPU legs ran first, before anything else
     assert c["cores"] == 1 and c["value"] > 0 and c["host"]["workers"] >= 1 and c["host"]["model"]
