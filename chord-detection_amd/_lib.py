@@ -15,6 +15,9 @@ MPX_FLAG_F32 = 0x1
 MPX_FLAG_DETERMINISTIC = 0x2
 MPX_ENHANCE_LIBROSA010, MPX_ENHANCE_NOOP = 0, 1
 MPX_NOTES_UNICODE, MPX_NOTES_ASCII = 0, 1
+MPX_OPT_IF0_WORKSPACE_BYTES, MPX_OPT_HE_KERNEL = 1, 2
+MPX_HE_KERNEL_AUTO, MPX_HE_KERNEL_WORKGROUP = 0, 1
+OPTIONS = {"if0_workspace_bytes": MPX_OPT_IF0_WORKSPACE_BYTES, "he_kernel": MPX_OPT_HE_KERNEL}
 NOTE_NAMES = {"unicode": MPX_NOTES_UNICODE, "ascii": MPX_NOTES_ASCII}
 STAGES = {"wfir": 0, "x_lo": 1, "x_hi": 2, "sacf": 3, "esacf": 4}
 
@@ -55,6 +58,8 @@ SIGNATURES = {
     "mpx_last_error": (C.c_char_p, [_vp]),
     "mpx_synchronize": (C.c_int, [_vp]),
     "mpx_stream": (_vp, [_vp]),
+    "mpx_set_option": (C.c_int, [_vp, C.c_int, C.c_int64]),
+    "mpx_get_option": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_int64)]),
     "mpx_num_frames": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mpx_harmonic_energy": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _dp, _dp]),
     "mpx_harmonic_energy_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _dp]),
@@ -120,7 +125,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.mpx_abi_version() != 2:
+    if lib.mpx_abi_version() != 3:
         raise RuntimeError("libmpx_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -184,6 +184,31 @@ void mpx_destroy(mpx_ctx* ctx) {
     delete ctx;
 }
 
+int mpx_set_option(mpx_ctx* ctx, int option, int64_t value) {
+    if (!ctx) return MPX_EINVAL;
+    switch (option) {
+        case MPX_OPT_IF0_WORKSPACE_BYTES:
+            if (value < ((int64_t)64 << 20)) return set_error(ctx, MPX_EINVAL, "MPX_OPT_IF0_WORKSPACE_BYTES: %lld < 64 MiB", (long long)value);
+            ctx->if0_ws_cap = (size_t)value;
+            return MPX_OK;
+        case MPX_OPT_HE_KERNEL:
+            if (value != MPX_HE_KERNEL_AUTO && value != MPX_HE_KERNEL_WORKGROUP)
+                return set_error(ctx, MPX_EINVAL, "MPX_OPT_HE_KERNEL: unknown kernel %lld", (long long)value);
+            ctx->he_kernel = (int)value;
+            return MPX_OK;
+    }
+    return set_error(ctx, MPX_EINVAL, "unknown option %d", option);
+}
+
+int mpx_get_option(mpx_ctx* ctx, int option, int64_t* value) {
+    if (!ctx || !value) return MPX_EINVAL;
+    switch (option) {
+        case MPX_OPT_IF0_WORKSPACE_BYTES: *value = (int64_t)ctx->if0_ws_cap; return MPX_OK;
+        case MPX_OPT_HE_KERNEL: *value = ctx->he_kernel; return MPX_OK;
+    }
+    return set_error(ctx, MPX_EINVAL, "unknown option %d", option);
+}
+
 void* mpx_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {

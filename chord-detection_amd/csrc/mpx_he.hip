@@ -576,8 +576,8 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
 
 // The wave-per-frame kernel (mpx_he_wave.hpp) for the headline shape: 4096-sample frames, fp64, at most 256 window bins.
 constexpr int HEW_WAVES = 8, HEW_ROUNDS = 4;
-static bool he_wave_applies(const HePlan& plan) {
-    if (dev_env("MPX_HE_WG")) return false;   // A/B switch: the workgroup-per-frame kernel below
+static bool he_wave_applies(const mpx_ctx* ctx, const HePlan& plan) {
+    if (ctx->he_kernel == MPX_HE_KERNEL_WORKGROUP) return false;   // mpx_set_option: the workgroup-per-frame kernel below
     return plan.nb <= 64 * HEW_ROUNDS && plan.nwin <= 192;
 }
 static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n, const FrameDesc* d_desc,
@@ -638,12 +638,18 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
     // every frame whole, inside the signal and 8-byte aligned: the instantiation without the ragged loader (no scratch)
     const bool all_fast = !d_desc && (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0 &&
                           (num_frames - 1) * (long long)hop + 4096 <= n;
-    auto kern = all_fast ? he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true> : he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false>;
+    // rows of ZA / ZB the window bins (and their mirrors) live in: the 44.1 kHz instantiation when they fit its 22 rows
+    unsigned k2 = 0;
+    for (int k : plan.h_bins) k2 |= hw_k2_bits(k);
+    const bool k44 = (k2 & ~HW_K2_44K) == 0;
+    using kern_t = void (*)(HeWaveArgs, cx<double>*);
+    const kern_t kerns[4] = {he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false, HW_K2_ALL>,
+                             he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true, HW_K2_ALL>,
+                             he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false, HW_K2_44K>,
+                             he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true, HW_K2_44K>};
+    const kern_t kern = kerns[(k44 ? 2 : 0) + (all_fast ? 1 : 0)];
     if (!ctx->occupancy.count("he_wave_lds")) {
-        MPX_HIP(ctx, hipFuncSetAttribute((const void*)he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        MPX_HIP(ctx, hipFuncSetAttribute((const void*)he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (kern_t k : kerns) MPX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->occupancy["he_wave_lds"] = 1;
     }
     prof_mark(ctx, stream, "he_wave_kernel");
@@ -664,7 +670,7 @@ static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, in
                      const FrameDesc* d_desc, int64_t num_frames, int hop, double* d_out, double* d_sum,
                      hipStream_t stream) {
     if constexpr (N == 4096 && std::is_same<Real, double>::value) {
-        if (he_wave_applies(plan)) return he_wave_launch(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+        if (he_wave_applies(ctx, plan)) return he_wave_launch(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
     }
     HeArgs<Real> a;
     a.sig = d_signal;

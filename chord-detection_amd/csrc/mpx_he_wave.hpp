@@ -209,7 +209,24 @@ __host__ __device__ constexpr int hw_shared_bytes(int rounds, int nwin) {
 // even hop: the headline shape), so the kernel holds the branch-free loader alone.  The general instantiation carries the
 // ragged loader as well, and the register allocation of a kernel is that of its worst path: with both, 24 bytes per lane
 // of scratch are reserved (and set up per wave) that the fast path never touches.
-template <int WAVES, int ROUNDS, bool DEBUG, bool FASTONLY = false>
+// K2MASK, bit q: some window bin k (or its mirror 1024 - k) has (k mod 1024) >> 5 == q.  Only those rows of ZA / ZB go into
+// the bin-ordered LDS copy: a store costs the LDS 6 cycles, and the 64 of this copy were a third of the kernel's LDS time.
+// The reference's windows at 44.1 kHz (bins 45 ... 375 and their mirrors 649 ... 979) need 22 of the 32 rows: HW_K2_44K;
+// the host launches that instantiation when the plan's own mask is a subset, the all-rows one otherwise.  (A run-time
+// mask -- 64 scalar branches in the loop body -- cost 112 bytes per lane of scratch.)
+constexpr unsigned HW_K2_ALL = 0xffffffffu, HW_K2_44K = 0x7ff00ffeu;
+__host__ __device__ constexpr unsigned hw_k2_bits(int k) {
+    return (1u << ((k & 1023) >> 5)) | (1u << (((1024 - (k & 1023)) & 1023) >> 5));
+}
+template <unsigned K2MASK, int P>
+__device__ __forceinline__ void hw_store_rows(double* mine, const cx<double>* b, bool imag) {
+    if constexpr (P < 32) {
+        if constexpr ((K2MASK >> hw_br5(P)) & 1u) mine[64 * hw_br5(P)] = imag ? b[P].y : b[P].x;
+        hw_store_rows<K2MASK, P + 1>(mine, b, imag);
+    }
+}
+
+template <int WAVES, int ROUNDS, bool DEBUG, bool FASTONLY = false, unsigned K2MASK = HW_K2_ALL>
 __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx<double>* dbg) {
     constexpr int N = 4096, T = WAVES * 64, NBP = 64 * ROUNDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -418,8 +435,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 wlast = wk_lds[2 * wi + 1] - 1;
                 wweight = ww_lds[wi];
             }
-#pragma unroll
-            for (int p = 0; p < 32; ++p) mine[64 * hw_br5(p)] = b[p].x;
+            hw_store_rows<K2MASK, 0>(mine, b, false);   // only the rows a window bin or its mirror lives in
             wave_lds_fence();
             {
                 // the registers of the real parts are free: request the next frame.  Unconditionally -- a wave without a
@@ -439,8 +455,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 re[r][3] = xb[sl[r].y >> 16];
             }
             wave_lds_fence();
-#pragma unroll
-            for (int p = 0; p < 32; ++p) mine[64 * hw_br5(p)] = b[p].y;
+            hw_store_rows<K2MASK, 0>(mine, b, true);
             wave_lds_fence();
             hw_phase();
             HW_STAMP(6);

@@ -62,6 +62,19 @@ struct If0TailGroup {   // chunks with the same (warm, len) whose leftover chann
     int first, count;   // tail_list[first .. first + count)
 };
 
+// Time slices (MPX_OPT_IF0_WORKSPACE_BYTES): a launch produces the outputs [t0, t1) of every chunk -- t0, t1 multiples of the
+// frame size, counted from the chunk's start -- into a hand-off buffer that holds ONE slice of every chunk (a chunk's block
+// starts at yc_row0 = chunk index x slice length), and carries the filter state of every lane from launch to launch in
+// `state` ([wave][value][lane] doubles).  state == nullptr: the whole chunk in one launch (t0 = 0, t1 = INT_MAX), the
+// layout of If0Chunk.  A slice boundary is a tile boundary (the tile is empty there) and a block boundary of the pipelined
+// body; what a lane carries over is exactly what the unsliced loop would have held at that step: same operations on the same
+// operands, bit-identical outputs.
+struct If0Slice {
+    int t0, t1;
+    double* state;
+};
+constexpr int IF0_STATE_PIPE = 66, IF0_STATE_SEQ = 22;   // doubles per lane: pipelined / sequential body
+
 // TAIL = false: a wave of 64 channels of ONE chunk -- chunk, input pointer and output rows are wave-uniform (scalar
 // loads, plain pointer arithmetic).  TAIL = true: a wave of leftover channels of several chunks -- per-lane chunk,
 // input pointer and an LDS table of output rows.  (One body for both had cost the common case 16 % of its speed.)
@@ -72,7 +85,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                                                   double* __restrict__ yc, const int* __restrict__ tail_list,
                                                   const If0TailGroup* __restrict__ tail_groups,
                                                   double (*tile)[IF0_TW + 1], long long* rowbase, long long ck_u, int ch0_u,
-                                                  int nch_u, const If0TailGroup g, int lg_nf) {
+                                                  int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl) {
     // One wave per (chunk, group of 64 channels), one lane per channel; the channels % 64 left over (6 of the default
     // 70) would fill a wave to 9 %, so the leftovers of up to 64 / (channels % 64) chunks of equal length and run-in
     // share one: lane -> (chunk, channel).  All lanes of a wave share the loop bounds, and the outputs go
@@ -139,9 +152,27 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
     // stops at the last real sample (rounded up to a tile) instead of filtering the zero padding up to the whole frame:
     // 44 112 instead of 49 168 steps for a two-second clip at 22.05 kHz.  (A wave of leftover channels of several chunks
     // keeps the common bound.)
-    const int c_end = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
-    fetch(-c_warm);
-    for (int tb = -c_warm; tb < c_end + DEPTH; tb += PF) {
+    const int c_end_all = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
+    if (sl.t0 >= c_end_all) return;                                  // (uniform) this chunk ended in an earlier slice
+    const int c_end = sl.t1 < c_end_all ? sl.t1 : c_end_all;         // this launch produces the outputs [sl.t0, c_end)
+    // every state variable of the loop, in a fixed order: [wave][value][lane]
+    double* __restrict__ st_lane = sl.state ? sl.state + (size_t)blockIdx.x * IF0_STATE_PIPE * 64 + lane : nullptr;
+    auto carry = [&](auto&& io) {
+        int n = 0;
+        io(a1, n++); io(a2, n++); io(b1, n++); io(b2, n++); io(c1, n++); io(c2, n++); io(d1, n++); io(d2, n++);
+        io(l1, n++); io(l2, n++); io(qy, n++); io(qu, n++); io(qv, n++); io(fxh, n++);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { io(z[i], n++); io(pin[i], n++); io(pxh[i], n++); }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) io(sob[i], n++);
+    };
+    int tb_first = -c_warm;
+    if (sl.t0 > 0) {   // the previous launch ended behind block tb = sl.t0 (outputs up to sl.t0 - 1, inputs up to sl.t0 + 15)
+        carry([&](double& v, int n) { v = st_lane[n * 64]; });
+        tb_first = sl.t0 + PF;
+    }
+    fetch(tb_first);
+    for (int tb = tb_first; tb < c_end + DEPTH; tb += PF) {
         const int t0 = tb - DEPTH;                             // this block produces the outputs t0 .. t0 + 15
         const int tcol = t0 >= 0 ? (t0 & (IF0_TW - 1)) : 0;   // their columns in the tile (the run-in's outputs are dropped)
         float xs[PF];
@@ -207,8 +238,9 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         // stream took the same 2.05 TB/s with 64 and with 70 channels).
         if (t0 >= 0 && t0 < c_end && (tcol == IF0_TW - PF || t0 + PF >= c_end)) {   // uniform: a full tile, or the chunk's last block
             const int tg = t0 - tcol, ncols = tcol + PF;   // first sample and width of what the tile holds
+            const int ts = tg - sl.t0;                      // ... counted from the first output of this launch
             // where sample tg of channel 0 of this frame sits relative to frame 0, channel 0 (a tile never straddles a frame)
-            const size_t foff = (((size_t)(tg >> lg_nf) * channels) << lg_nf) + (size_t)(tg & ((1 << lg_nf) - 1));
+            const size_t foff = (((size_t)(ts >> lg_nf) * channels) << lg_nf) + (size_t)(ts & ((1 << lg_nf) - 1));
             wave_lds_fence();
 #pragma unroll
             for (int h = 0; h < 64 / 16; ++h) {
@@ -234,6 +266,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             wave_lds_fence();
         }
     }
+    if (st_lane && c_end < c_end_all) carry([&](double& v, int n) { st_lane[n * 64] = v; });   // more slices of this chunk follow
 }
 
 // The same chain in its SEQUENTIAL form -- every sample walks the 17 stages one after the other -- for TWO waves per SIMD
@@ -246,7 +279,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
                                                       int channels, const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
                                                       double* __restrict__ yc, const int* __restrict__ tail_list,
                                                       double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
-                                                      int nch_u, const If0TailGroup g, int lg_nf) {
+                                                      int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl) {
     const int lane = threadIdx.x;
     const int full = channels >> 6, nt = channels & 63;
     long long ck;
@@ -284,11 +317,26 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
             nx[q] = ok ? v : 0.f;
         }
     };
-    const int c_end = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
+    const int c_end_all = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
+    if (sl.t0 >= c_end_all) return;                                  // (uniform) this chunk ended in an earlier slice
+    const int c_end = sl.t1 < c_end_all ? sl.t1 : c_end_all;         // this launch produces the outputs [sl.t0, c_end)
+    double* __restrict__ st_lane = sl.state ? sl.state + (size_t)blockIdx.x * IF0_STATE_SEQ * 64 + lane : nullptr;
+    auto carry = [&](auto&& io) {
+        int n = 0;
+        io(a1, n++); io(a2, n++); io(b1, n++); io(b2, n++); io(c1, n++); io(c2, n++); io(d1, n++); io(d2, n++);
+        io(l1, n++); io(l2, n++);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) io(z[i], n++);
+    };
+    int t_first = -c_warm;
+    if (sl.t0 > 0) {
+        carry([&](double& v, int n) { v = st_lane[n * 64]; });
+        t_first = sl.t0;
+    }
     const unsigned lane_off = ((unsigned)(lane >> 4) << lg_nf) + (unsigned)(lane & 15);   // < 4 frame sizes: 32 bits
-    fetch(-c_warm);
+    fetch(t_first);
 #pragma unroll 1
-    for (int t = -c_warm; t < c_end; t += G) {
+    for (int t = t_first; t < c_end; t += G) {
         float xs[G];
 #pragma unroll
         for (int q = 0; q < G; ++q) xs[q] = nx[q];
@@ -325,7 +373,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
             tile[lane][col + q] = (r + lp) / 2.0;
         }
         if (t >= 0 && col == PF - G) {   // uniform; a tile of 16 samples is complete
-            const int tb = t - (PF - G);
+            const int tb = t - (PF - G) - sl.t0;   // counted from the first output of this launch
             const size_t foff = (((size_t)(tb >> lg_nf) * channels) << lg_nf) + (size_t)(tb & ((1 << lg_nf) - 1));   // as in the pipelined body
             wave_lds_fence();
             constexpr int SG = TAIL ? 2 : 4;   // store instructions per group (their values and row bases are registers)
@@ -353,34 +401,36 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
             wave_lds_fence();
         }
     }
+    if (st_lane && c_end < c_end_all) carry([&](double& v, int n) { st_lane[n * 64] = v; });
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void if0_frontend2_kernel(
     const float* __restrict__ sig, const If0Chunk* __restrict__ chunks, long long num_chunks, int channels,
     const If0ChanCoef* __restrict__ coefs, If0Wfir wf, double* __restrict__ yc, const int* __restrict__ tail_list,
-    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf) {
+    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf, If0Slice sl) {
     __shared__ double tile[64][17];
     __shared__ long long rowbase[64];
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
-        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g, lg_nf);
+        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g, lg_nf, sl);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)
         if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 64 * full,
-                                     channels & 63, g, lg_nf);
+                                     channels & 63, g, lg_nf, sl);
     else
-        if0_frontend_seq_body<true>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf);
+        if0_frontend_seq_body<true>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl);
 }
 
 __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                           long long num_chunks, int channels,
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc, const int* __restrict__ tail_list,
-                                                          const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf) {
+                                                          const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf,
+                                                          If0Slice sl) {
     __shared__ double tile[64][IF0_TW + 1];
     __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
     const int full = channels >> 6;
@@ -391,16 +441,16 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
         if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 b / full, (int)(b % full) * 64, 64, g, lg_nf);
+                                 b / full, (int)(b % full) * 64, 64, g, lg_nf, sl);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
         if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 tail_list[g.first], 64 * full, channels & 63, g, lg_nf);
+                                 tail_list[g.first], 64 * full, channels & 63, g, lg_nf, sl);
     else
         if0_frontend_body<true>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
-                                0, g, lg_nf);
+                                0, g, lg_nf, sl);
 }
 
 // ------------------------------------------------------------------ spectrum
@@ -481,6 +531,7 @@ struct If0PerArgs {
     int note_names;  // MPX_NOTES_*
     double tau_min, tau_max, tau_prec, epsilon1, epsilon2, gamma;
     double* chroma;     // [F, 12]
+    const int* out_row; // frame f of this launch is row out_row[f] of chroma (nullptr: row f)
 };
 
 constexpr int PER_T = 256;
@@ -737,7 +788,7 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
                 }
             }
         }
-        for (int i = 0; i < 12; ++i) a.chroma[f * 12 + i] = chroma[i];
+        for (int i = 0; i < 12; ++i) a.chroma[(a.out_row ? (long long)a.out_row[f] : f) * 12 + i] = chroma[i];
     }
 }
 
@@ -1162,7 +1213,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         return set_error(ctx, MPX_EINVAL, "iterative F0: harmonic %d of tau_min falls outside the %d-bin spectrum (the "
                          "reference raises ValueError on the empty slice)", p.M - 1, n2);
     // The front-end output is 8 * channels bytes per sample (560 B at 70 channels): keep the workspace of one pass
-    // below 32 GiB of the 288 GB (env MPX_IF0_WS_GIB) by halving the clip list.  A clip is one serial chain per
+    // below 32 GiB of the 288 GB (MPX_OPT_IF0_WORKSPACE_BYTES) by halving the clip list.  A clip is one serial chain per
     // channel, so a pass wants thousands of clips in flight: 4096 two-second clips take 0.38 s in passes of 256
     // (8 GiB), 0.29 s in passes of 1024.
     {
@@ -1175,7 +1226,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             rows += r;
             if (c < mid) rows_first += r;
         }
-        const size_t ws_cap = (size_t)dev_env_int("MPX_IF0_WS_GIB", 32) << 30;
+        const size_t ws_cap = ctx->if0_ws_cap;   // mpx_set_option(MPX_OPT_IF0_WORKSPACE_BYTES), default 32 GiB
         if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap) {
             std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
             for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
@@ -1321,57 +1372,95 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         else if (chroma_sums) std::memset(chroma_sums, 0, (size_t)num_clips * 12 * sizeof(double));
         return MPX_OK;
     }
-    // the [t][channel] buffer of the front end is the big one: 560 B per sample at 70 channels
-    const size_t yc_bytes = (size_t)yc_rows * p.channels * sizeof(double);
+    // The [t][channel] hand-off buffer of the front end is the big one: 560 B per sample at 70 channels (83 GiB for an hour of
+    // 44.1 kHz audio in one piece, and the first hipMalloc of that size is seconds on a device whose memory was used before).
+    // Above the context's cap (MPX_OPT_IF0_WORKSPACE_BYTES; a clip LIST was halved above) the call runs in TIME SLICES: every
+    // launch of the front end advances every chunk by `slice` samples (whole frames) from the filter state the launch before
+    // left behind (If0Slice), the summary spectra and the period search of those frames follow, and the hand-off buffer, the
+    // spectra and the search's scratch hold one slice.  The chunks -- and with them the waves in flight and the run-in work
+    // -- are what they would be in one piece; the results are the same bits (tests/test_gpu_iterative_f0.py).
+    long long maxlen = 0;
+    for (const If0Chunk& ck : chunks) maxlen = std::max<long long>(maxlen, ck.len);
+    long long slice = maxlen;
+    bool sliced = false;
+    if ((size_t)yc_rows * p.channels * sizeof(double) > ctx->if0_ws_cap) {
+        long long fit = (long long)(ctx->if0_ws_cap / ((size_t)nchunks * p.channels * sizeof(double))) / NF * NF;
+        if (fit < NF) fit = NF;
+        if (fit < maxlen) {
+            slice = fit;
+            sliced = true;
+        }
+    }
+    const long long nslices = (maxlen + slice - 1) / slice;
+    // per slice: its frames (chunk after chunk) and the row of the call's [F, 12] output each one is
+    std::vector<If0Frame> sl_frames;
+    std::vector<int> sl_rows;
+    std::vector<long long> sl_off(1, 0);
+    std::vector<long long> chunk_frame0;   // index of a chunk's first frame in `frames`
+    if (sliced) {
+        long long g = 0;
+        for (long long i = 0; i < nchunks; ++i) {
+            chunk_frame0.push_back(g);
+            chunks[(size_t)i].yc_row0 = i * slice;   // the buffer holds one slice of every chunk
+            g += chunks[(size_t)i].len / NF;
+        }
+        sl_frames.reserve(frames.size());
+        sl_rows.reserve(frames.size());
+        for (long long sidx = 0; sidx < nslices; ++sidx) {
+            for (long long i = 0; i < nchunks; ++i) {
+                const long long lo = sidx * slice, hi = std::min<long long>(lo + slice, chunks[(size_t)i].len);
+                for (long long fo = lo; fo < hi; fo += NF) {
+                    If0Frame fr = frames[(size_t)(chunk_frame0[(size_t)i] + fo / NF)];
+                    fr.yc_base = i * slice * p.channels + ((fo - lo) / NF) * (long long)p.channels * NF;
+                    sl_frames.push_back(fr);
+                    sl_rows.push_back((int)(chunk_frame0[(size_t)i] + fo / NF));
+                }
+            }
+            sl_off.push_back((long long)sl_frames.size());
+        }
+    } else {
+        sl_off.push_back(nframes);
+    }
+    long long max_slice_frames = 0;
+    for (size_t i = 0; i + 1 < sl_off.size(); ++i) max_slice_frames = std::max(max_slice_frames, sl_off[i + 1] - sl_off[i]);
+    const std::vector<If0Frame>& up_frames = sliced ? sl_frames : frames;
+    const size_t yc_bytes = (size_t)(sliced ? nchunks * slice : yc_rows) * p.channels * sizeof(double);
     if (yc_bytes > ((size_t)96 << 30))
         return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: %lld chunks need %zu GiB of workspace; split the call", nchunks,
                          yc_bytes >> 30);
+    const long long fe_blocks = nchunks * full_groups + (long long)tail_groups.size();
+    const size_t state_bytes = sliced ? (size_t)fe_blocks * 64 * sizeof(double) * (fe_sequential ? IF0_STATE_SEQ : IF0_STATE_PIPE) : 0;
     if (!dev_io && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
-    if ((rc = ensure(ctx, ctx->d_ws1, (size_t)nframes * n2 * sizeof(double) * 3))) return rc;   // ut | ur | ud
-    if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
-                                       tail_groups.size() * sizeof(If0TailGroup) + 128))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ws1, (size_t)max_slice_frames * n2 * sizeof(double) * 3))) return rc;   // ut | ur | ud
+    if (sliced && (rc = ensure(ctx, ctx->d_ws2, state_bytes))) return rc;
+    if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + up_frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
+                                       tail_groups.size() * sizeof(If0TailGroup) + sl_rows.size() * sizeof(int) + 256))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
     If0Chunk* d_chunks = (If0Chunk*)ctx->d_desc.p;
     If0Frame* d_frames = (If0Frame*)((char*)ctx->d_desc.p + ((chunks.size() * sizeof(If0Chunk) + 15) & ~(size_t)15));
-    If0TailGroup* d_tail_groups = (If0TailGroup*)((char*)d_frames + ((frames.size() * sizeof(If0Frame) + 15) & ~(size_t)15));
+    If0TailGroup* d_tail_groups = (If0TailGroup*)((char*)d_frames + ((up_frames.size() * sizeof(If0Frame) + 15) & ~(size_t)15));
     int* d_tail_list = (int*)((char*)d_tail_groups + ((tail_groups.size() * sizeof(If0TailGroup) + 15) & ~(size_t)15));
+    int* d_rows = (int*)((char*)d_tail_list + ((tail_list.size() * sizeof(int) + 15) & ~(size_t)15));
     if (!dev_io && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
     const float* d_in = dev_io ? signals : (const float*)ctx->d_signal.p;   // the front end reads inside the clips only
     MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
-    MPX_HIP(ctx, hipMemcpyAsync(d_frames, frames.data(), frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
+    MPX_HIP(ctx, hipMemcpyAsync(d_frames, up_frames.data(), up_frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
     if (nt) {
         MPX_HIP(ctx, hipMemcpyAsync(d_tail_groups, tail_groups.data(), tail_groups.size() * sizeof(If0TailGroup), hipMemcpyHostToDevice, st));
         MPX_HIP(ctx, hipMemcpyAsync(d_tail_list, tail_list.data(), tail_list.size() * sizeof(int), hipMemcpyHostToDevice, st));
     }
+    if (sliced) MPX_HIP(ctx, hipMemcpyAsync(d_rows, sl_rows.data(), sl_rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
-    if (dev_io) MPX_HIP(ctx, hipStreamSynchronize(st));   // the tables above are host vectors of this call
+    if (dev_io || sliced) MPX_HIP(ctx, hipStreamSynchronize(st));   // the tables above are host vectors of this call
     double* yc = (double*)ctx->d_ws0.p;
     double* ut = (double*)ctx->d_ws1.p;
-    double* ur = ut + (size_t)nframes * n2;
-    double* ud = ur + (size_t)nframes * n2;
+    double* ur = ut + (size_t)max_slice_frames * n2;
+    double* ud = ur + (size_t)max_slice_frames * n2;
     int lg_nf = 0;
     while ((1 << lg_nf) < NF) ++lg_nf;
-    prof_mark(ctx, st, "if0_frontend_kernel");
-    if (!fe_sequential)
-        hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
-                           d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                           d_tail_groups, (int)tail_groups.size(), lg_nf);
-    else
-        hipLaunchKernelGGL(if0_frontend2_kernel, dim3((unsigned)(nchunks * full_groups + (long long)tail_groups.size())), dim3(64), 0, st,
-                           d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                           d_tail_groups, (int)tail_groups.size(), lg_nf);
-    MPX_HIP(ctx, hipGetLastError());
-    prof_mark(ctx, st, "if0_spectrum_kernel");
-    if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
-    else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
-    else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
-    else rc = if0_spectrum_launch<8192, 512>(ctx, yc, d_frames, nframes, p.channels, p.power, plan, ut, st);
-    if (rc) return rc;
-    prof_mark(ctx, st, nullptr);
-    if (ut_out) MPX_HIP(ctx, hipMemcpyAsync(ut_out, ut, (size_t)nframes * n2 * sizeof(double), hipMemcpyDeviceToHost, st));
     If0PerArgs a;
     a.ut = ut;
     a.ur = ur;
@@ -1391,14 +1480,55 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     a.epsilon2 = p.epsilon2;
     a.gamma = p.gamma;
     a.chroma = (dev_io && chroma_frames) ? chroma_frames : (double*)ctx->d_frames_out.p;
-    // (Measured and rejected at the end of round 3: the period search of one group of 2048 frames on a second stream next to
-    //  the summary spectra of the next group -- it fits beside them on every CU, but the whole-hour call went from 126.5 to
-    //  135 ms: its re-reads of the spectrum rows (6.9 x their bytes, through L2) slow the LDS/L2-bound spectra down by more
-    //  than its own 25 ms.)
-    prof_mark(ctx, st, "if0_periodicity_kernel");
-    hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
-    prof_mark(ctx, st, nullptr);
-    MPX_HIP(ctx, hipGetLastError());
+    for (long long sidx = 0; sidx < nslices; ++sidx) {
+        If0Slice sl;
+        sl.t0 = (int)(sidx * slice);
+        sl.t1 = sliced ? (int)((sidx + 1) * slice) : 0x7fffffff;
+        sl.state = sliced ? (double*)ctx->d_ws2.p : nullptr;
+        const long long nf_s = sl_off[(size_t)sidx + 1] - sl_off[(size_t)sidx];
+        prof_mark(ctx, st, "if0_frontend_kernel");
+        if (!fe_sequential)
+            hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st,
+                               d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
+                               d_tail_groups, (int)tail_groups.size(), lg_nf, sl);
+        else
+            hipLaunchKernelGGL(if0_frontend2_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st,
+                               d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
+                               d_tail_groups, (int)tail_groups.size(), lg_nf, sl);
+        MPX_HIP(ctx, hipGetLastError());
+        if (nf_s == 0) continue;
+        const If0Frame* d_fr = d_frames + sl_off[(size_t)sidx];
+        prof_mark(ctx, st, "if0_spectrum_kernel");
+        if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
+        else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
+        else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
+        else rc = if0_spectrum_launch<8192, 512>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
+        if (rc) return rc;
+        prof_mark(ctx, st, nullptr);
+        if (ut_out) {
+            if (!sliced) {
+                MPX_HIP(ctx, hipMemcpyAsync(ut_out, ut, (size_t)nframes * n2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            } else {   // a run of local rows that belongs to one chunk is a run of the call's rows
+                long long j = sl_off[(size_t)sidx];
+                while (j < sl_off[(size_t)sidx + 1]) {
+                    long long e = j + 1;
+                    while (e < sl_off[(size_t)sidx + 1] && sl_rows[(size_t)e] == sl_rows[(size_t)e - 1] + 1) ++e;
+                    MPX_HIP(ctx, hipMemcpyAsync(ut_out + (size_t)sl_rows[(size_t)j] * n2, ut + (size_t)(j - sl_off[(size_t)sidx]) * n2,
+                                                (size_t)(e - j) * n2 * sizeof(double), hipMemcpyDeviceToHost, st));
+                    j = e;
+                }
+            }
+        }
+        a.out_row = sliced ? d_rows + sl_off[(size_t)sidx] : nullptr;
+        // (Measured and rejected at the end of round 3: the period search of one group of 2048 frames on a second stream next to
+        //  the summary spectra of the next group -- it fits beside them on every CU, but the whole-hour call went from 126.5 to
+        //  135 ms: its re-reads of the spectrum rows (6.9 x their bytes, through L2) slow the LDS/L2-bound spectra down by more
+        //  than its own 25 ms.)
+        prof_mark(ctx, st, "if0_periodicity_kernel");
+        hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nf_s), dim3(PER_T), 0, st, a);
+        prof_mark(ctx, st, nullptr);
+        MPX_HIP(ctx, hipGetLastError());
+    }
     if (dev_io) {
         if (chroma_sums) return segment_sum(ctx, a.chroma, (const long long*)ctx->d_offsets.p, num_clips, nframes, chroma_sums, st);
         return MPX_OK;

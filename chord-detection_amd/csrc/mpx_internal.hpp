@@ -60,6 +60,8 @@ struct mpx_ctx {
     hipEvent_t copy_ev[8] = {};
     bool copy_ready = false;                  // copy_stream and all of copy_ev exist
     int copy_pieces = 4;                      // pieces of a large host batch (1: no overlap); fixed at mpx_create
+    size_t if0_ws_cap = (size_t)32 << 30;     // MPX_OPT_IF0_WORKSPACE_BYTES
+    int he_kernel = 0;                        // MPX_OPT_HE_KERNEL
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
     std::map<std::tuple<int, int, int, int, int>, mpx::HePlan> he_plans;

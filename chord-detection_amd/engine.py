@@ -112,6 +112,16 @@ class Engine:
     def stream(self):
         return self.lib.mpx_stream(self.ctx)
 
+    def set_option(self, name, value):
+        """mpx_set_option: "if0_workspace_bytes" (cap of one Iterative-F0 pass' hand-off buffer) or "he_kernel"
+        (0 auto, 1 workgroup-per-frame kernel for every shape).  Results do not depend on either."""
+        self._check(self.lib.mpx_set_option(self.ctx, _lib.OPTIONS[name], int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._check(self.lib.mpx_get_option(self.ctx, _lib.OPTIONS[name], C.byref(v)))
+        return int(v.value)
+
     # ------------------------------------------------------------- method 2
     def harmonic_energy(self, x, fs, frame=8192, hop=None, num_harmonic=2, num_octave=2, num_bins=2,
                         return_frames=False):

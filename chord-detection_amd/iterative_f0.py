@@ -45,16 +45,9 @@ class MultipitchIterativeF0(Multipitch):
         return 3
 
     def compute_pitches(self, display_plot_frame=-1):
-        from . import stream
-        if (stream.WARMUP % int(self.frame_size) == 0
-                and self.x.shape[0] * int(self.num_channels) * 8 > stream.PIECE_BYTES):
-            # hours of audio: the front-end output of one call would be tens of GB (the library refuses beyond
-            # 96 GiB): time shards with a halo, two in flight (stream.py), summed like the reference sums its frames
-            x, n = self.x, self.x.shape[0]
-            _, _, frames = stream.run_stream_rank(lambda a, b: x[a:b], n, self.fs, 0, 1, self.frame_size, self.device,
-                                                  sub=2, channels=self.num_channels, power=self.power,
-                                                  zeta0=self.zeta0, zeta1=self.zeta1, note_names=self.note_names)
-            return stream.chroma_of(frames)
+        # hours of audio go through the same call: above the context's workspace cap (include/mpx.h
+        # MPX_OPT_IF0_WORKSPACE_BYTES, 32 GiB of front-end output = ~21 min at 44.1 kHz) the library advances its chunks in
+        # time slices and carries the filter state over, so nothing has to be cut here
         total = get_engine(self.device).iterative_f0(
             self.x, self.fs, frame_size=self.frame_size, power=self.power, channels=self.num_channels,
             zeta0=self.zeta0, zeta1=self.zeta1, note_names=self.note_names)

@@ -102,26 +102,59 @@ def _engine_frames_on(j):
     return compute
 
 
-PIECE_BYTES = 32 << 30   # front-end output of one piece (560 B per sample at 70 channels): bounds the contexts' workspaces
-ONE_CALL_BYTES = 90 << 30   # a rank's whole share goes through ONE engine call when its front-end output fits this (the
-                            # library refuses beyond 96 GiB): the front end then cuts ONE launch of ~1000 long chunks -- 923
-                            # x 172 032 samples for an hour of 44.1 kHz audio, a run-in per chunk of 24 % instead of 62 % --
-                            # and the whole-hour call takes 0.127 s where three 30 GB pieces in flight took 0.145 s
+PIECE_BYTES = 32 << 30   # front-end output of one piece of an explicit `sub` > 1 run (560 B per sample at 70 channels)
+STREAM_WORKSPACE_BYTES = 8 << 30   # hand-off buffer of ONE engine call over a rank's whole share (MPX_OPT_IF0_WORKSPACE_BYTES):
+                                   # the library advances every chunk in time slices of whole frames and carries the filter
+                                   # state over, so an hour of 44.1 kHz audio is still ONE front-end launch geometry of 923
+                                   # long chunks (a run-in of 24 % per chunk), but its workspaces are ~9 GB instead of the 90 GB
+                                   # of round 3 -- whose first hipMalloc cost 1-2 s on a device that had been used before
 
 
-def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=None, channels=70, **kw):
-    """This rank's frames.  sub=None: one engine call when the share fits ONE_CALL_BYTES of front-end output, else three
-    time shards IN FLIGHT on the same GPU (one context and one host thread each; ctypes releases the GIL): the front end of
-    one shard runs next to the spectra and the period search of the other.  Same halo logic as between ranks: the rank's
-    block of frames is partitioned once more.  Returns (f0, f1, frames[f1-f0, 12])."""
+def _workspace_cap(device, want):
+    """`want` bytes, but never more than a third of the device memory that is free right now (>= 256 MiB)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            free, _ = torch.cuda.mem_get_info(int(device))
+            want = min(int(want), int(free) // 3)
+    except Exception:
+        pass
+    return max(int(want), 256 << 20)
+
+
+def _engine_frames_capped(j, cap):
+    """compute function of context j with the Iterative-F0 workspace cap set for the call (and restored afterwards: the
+    process-wide engine also serves clip batches, which the cap would cut into more passes)."""
+    inner = _engine_frames_on(j)
+
+    def compute(x, fs, frame_size, device, **kw):
+        from .engine import get_engine
+        eng = _ENGINES.get((int(device), j)) or (get_engine(device) if j == 0 else None)
+        if eng is None:
+            return inner(x, fs, frame_size, device, **kw)
+        before = eng.get_option("if0_workspace_bytes")
+        eng.set_option("if0_workspace_bytes", _workspace_cap(device, cap))
+        try:
+            return inner(x, fs, frame_size, device, **kw)
+        finally:
+            eng.set_option("if0_workspace_bytes", before)
+    return compute
+
+
+def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub=None, channels=70,
+                    workspace_bytes=None, **kw):
+    """This rank's frames.  sub=None or 1: ONE engine call over the rank's whole share, whatever its length -- the library
+    bounds its own workspaces (time slices, include/mpx.h MPX_OPT_IF0_WORKSPACE_BYTES; `workspace_bytes`, default
+    STREAM_WORKSPACE_BYTES, at most a third of the free device memory).  sub > 1: that many time shards IN FLIGHT on the
+    same GPU (one context and one host thread each; ctypes releases the GIL), the rank's block of frames partitioned once
+    more with the same halo logic as between ranks.  Returns (f0, f1, frames[f1-f0, 12])."""
     import threading
     warmup = engine_warmup(fs, device, frame_size=frame_size, channels=channels, **kw)
     F0, F1 = partition(num_frames(n, frame_size), world, rank)
-    if sub is None:
-        sub = 1 if (F1 - F0) * int(frame_size) * int(channels) * 8 <= ONE_CALL_BYTES else 3
-    if sub == 1 and (F1 - F0) * int(frame_size) * int(channels) * 8 <= ONE_CALL_BYTES:
-        return run_stream_shard(read, n, fs, rank, world, frame_size, device, compute=_engine_frames_on(0), frames=(F0, F1),
-                                warmup=warmup, channels=channels, **kw)
+    if sub is None or sub == 1:
+        cap = STREAM_WORKSPACE_BYTES if workspace_bytes is None else workspace_bytes
+        return run_stream_shard(read, n, fs, rank, world, frame_size, device, compute=_engine_frames_capped(0, cap),
+                                frames=(F0, F1), warmup=warmup, channels=channels, **kw)
     # pieces: a multiple of `sub`, each small enough for PIECE_BYTES of front-end output (a two-hour stream would
     # otherwise ask one context for 180 GB, and the library refuses beyond 96 GiB per call)
     per_frame = int(frame_size) * int(channels) * 8

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPX_ABI_VERSION 2
+#define MPX_ABI_VERSION 3
 
 typedef enum mpx_status {
     MPX_OK = 0,
@@ -76,6 +76,25 @@ int mpx_synchronize(mpx_ctx* ctx);
 /* The context's hipStream_t (as void*), for callers that want to order their
  * own work after ours. */
 void* mpx_stream(mpx_ctx* ctx);
+
+/* ---- per-context options (ABI 3) ----------------------------------------------
+ * Settings of a context that are not kwargs of the reference's constructors: how much device memory one pass may take and
+ * which of two equivalent kernels runs.  None of them changes what is computed (tests/ compare every setting with the
+ * oracle); they replace what rounds 1-3 read from the environment in development builds only.
+ *   MPX_OPT_IF0_WORKSPACE_BYTES  upper bound, in bytes, of the Iterative-F0 front-end hand-off buffer of ONE pass
+ *                                (8 B x channels per sample).  A clip batch that needs more is cut in halves that run one
+ *                                after the other; a single clip / stream that needs more runs in time slices of whole
+ *                                frames whose filter state is carried over.  Default 32 GiB, minimum 64 MiB.
+ *   MPX_OPT_HE_KERNEL            MPX_HE_KERNEL_AUTO (default): 4096-sample fp64 frames with <= 256 window bins run on the
+ *                                wave-per-frame kernel (csrc/mpx_he_wave.hpp), everything else on the workgroup-per-frame
+ *                                kernel.  MPX_HE_KERNEL_WORKGROUP: the workgroup-per-frame kernel for every shape (A/B).
+ * mpx_set_option returns MPX_EINVAL for an unknown option or a value out of range. */
+#define MPX_OPT_IF0_WORKSPACE_BYTES 1
+#define MPX_OPT_HE_KERNEL 2
+#define MPX_HE_KERNEL_AUTO 0
+#define MPX_HE_KERNEL_WORKGROUP 1
+int mpx_set_option(mpx_ctx* ctx, int option, int64_t value);
+int mpx_get_option(mpx_ctx* ctx, int option, int64_t* value);
 
 /* ---- where the samples live -------------------------------------------------
  * `signal` / `signals` of the entry points below (all but the *_dev ones, which run in place) may point to

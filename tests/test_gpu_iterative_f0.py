@@ -98,28 +98,111 @@ def test_chunked_front_end_matches_sequential_filtering(eng):
     np.testing.assert_allclose(ut[30:], Ut[30:], rtol=1e-9, atol=1e-9 * np.abs(Ut).max())
 
 
-def test_large_batch_is_split_without_changing_results(eng, monkeypatch):
-    """More clips than fit one front-end workspace (27.5 MB per 2 s clip at 70 channels; the cap is 32 GiB by
-    default, 8 GiB here through the per-call knob): the clip list is halved internally; every clip must come out
-    exactly as on its own."""
-    monkeypatch.setenv("MPX_IF0_WS_GIB", "8")
+def _poly(rng, n, fs=FS, voices=3):
+    t = np.arange(n) / fs
+    x = np.zeros(n)
+    for _ in range(voices):
+        f0 = 440.0 * 2.0 ** ((int(rng.integers(40, 80)) - 69) / 12.0)
+        for h in range(1, 5):
+            x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+    return (0.2 * x).astype(np.float32)
+
+
+def test_large_batch_is_split_without_changing_results():
+    """More clips than fit one front-end workspace (8 B x 70 channels per sample; the cap is 32 GiB by default, 64 MiB
+    here through mpx_set_option(MPX_OPT_IF0_WORKSPACE_BYTES) -- the release library's own route, no environment knob): the
+    clip list is halved internally until a pass fits (one 20 000-sample clip needs 13.8 MB, so 23 clips need three levels
+    of halving); every clip must come out exactly as from the unsplit call, and as the oracle computes it."""
+    import chord_detection_amd as cd
+    from oracle import iterative_f0 as o_if0
     rng = np.random.default_rng(3)
-    t = np.arange(44100) / FS
-    base = []
-    for _ in range(6):
-        x = np.zeros(44100)
-        for _ in range(3):
-            f0 = 440.0 * 2.0 ** ((int(rng.integers(40, 80)) - 69) / 12.0)
-            for h in range(1, 5):
-                x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
-        base.append((0.2 * x).astype(np.float32))
-    batch = np.stack([base[i % 6] for i in range(340)])          # [340, 44100]: the packed fast path as well
-    got = eng.iterative_f0_batch(batch, FS)
-    assert got.shape == (340, 12)
-    singles = [eng.iterative_f0(b, FS) for b in base]
-    for i in (0, 1, 169, 170, 171, 338, 339):
-        np.testing.assert_allclose(got[i], singles[i % 6], rtol=1e-12, atol=0)
-    np.testing.assert_array_equal(got[:6], got[6:12])
+    base = [_poly(rng, 20000) for _ in range(6)]
+    batch = [base[i % 6][: 20000 - 7 * (i % 5)] for i in range(23)]          # ragged lengths: the split points move
+    whole = cd.Engine(0)
+    cut = cd.Engine(0)
+    try:
+        assert cut.get_option("if0_workspace_bytes") == 32 << 30
+        cut.set_option("if0_workspace_bytes", 64 << 20)
+        assert cut.get_option("if0_workspace_bytes") == 64 << 20
+        with pytest.raises(ValueError):
+            cut.set_option("if0_workspace_bytes", 1 << 20)
+        need = sum(-(-len(b) // 8192) * 8192 for b in batch) * 70 * 8
+        assert need > 4 * (64 << 20)                                          # at least two levels of halving
+        got_cut = cut.iterative_f0_batch(batch, FS)
+        got_whole = whole.iterative_f0_batch(batch, FS)
+        np.testing.assert_array_equal(got_cut, got_whole)                     # split == unsplit, bit for bit
+        packed = np.stack([b[:19972] for b in batch])                         # [23, 19972]: the packed fast path as well
+        np.testing.assert_array_equal(cut.iterative_f0_batch(packed, FS), whole.iterative_f0_batch(packed, FS))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i in (0, 11, 12, 22):                                         # either side of the first split point, and the ends
+                np.testing.assert_allclose(got_cut[i], o_if0.iterative_f0_compute(batch[i], FS), rtol=1e-5, atol=0)
+    finally:
+        cut.close()
+        whole.close()
+
+
+@pytest.mark.parametrize("frame_size,channels", [(8192, 70), (1024, 70), (2048, 33), (8192, 64)])
+def test_time_slices_carry_the_filter_state_exactly(frame_size, channels):
+    """One clip whose front-end output exceeds the workspace cap (64 MiB here, the smallest the ABI takes): every chunk
+    advances in time slices of whole frames, the filter state of every lane travels from launch to launch (If0Slice), the
+    hand-off buffer holds one slice.  Same operations on the same operands: summary spectra and chroma equal the one-piece
+    call BIT FOR BIT -- with 64 + 6 channels (a full wave and a wave of leftover channels per chunk), 33 (leftovers only) and
+    64 (none), frames of 8192 / 2048 / 1024 -- and the oracle's sequential filtering to 1e-9 / 1e-5."""
+    import chord_detection_amd as cd
+    from oracle import iterative_f0 as o_if0
+    rng = np.random.default_rng(77 + frame_size + channels)
+    n = 150000 + 1234
+    x = _poly(rng, n) + (1e-3 * rng.standard_normal(n)).astype(np.float32)
+    kw = dict(frame_size=frame_size, channels=channels)
+    whole, cut = cd.Engine(0), cd.Engine(0)
+    try:
+        cut.set_option("if0_workspace_bytes", 64 << 20)
+        assert n * channels * 8 > 64 << 20                      # more than one slice
+        ut_w = whole.iterative_f0_spectra(x, FS, **kw)
+        ut_c = cut.iterative_f0_spectra(x, FS, **kw)
+        np.testing.assert_array_equal(ut_c, ut_w)
+        tot_w, per_w = whole.iterative_f0(x, FS, return_frames=True, **kw)
+        tot_c, per_c = cut.iterative_f0(x, FS, return_frames=True, **kw)
+        np.testing.assert_array_equal(per_c, per_w)
+        np.testing.assert_array_equal(tot_c, tot_w)
+        # the batch entry point with one oversized clip among small ones: the list is halved down to the clip, which is sliced
+        batch = [x[:9000], x, x[:20000]]
+        np.testing.assert_array_equal(cut.iterative_f0_batch(batch, FS, **kw), whole.iterative_f0_batch(batch, FS, **kw))
+    finally:
+        cut.close()
+        whole.close()
+    if frame_size == 8192 and channels == 70:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wper, wut = o_if0.iterative_f0_frames(x[:60000], FS, **kw)
+        nfr = wper.shape[0] - 1                               # the oracle's last frame is the zero-padded tail of the cut
+        np.testing.assert_allclose(ut_c[:nfr], wut[:nfr], rtol=1e-9, atol=1e-9 * np.abs(wut).max())
+        np.testing.assert_allclose(per_c[:nfr], wper[:nfr], rtol=1e-5, atol=1e-300)
+
+
+@pytest.mark.parametrize("frame_size", [1024, 2048, 4096])
+@pytest.mark.parametrize("power", [0.5, 1.0, 2.0])
+@pytest.mark.parametrize("channels", [31, 70])
+def test_frame_sizes_powers_channels_vs_oracle(eng, frame_size, power, channels):
+    """iterative_f0.py:22-33 takes frame_size, power and channels; every instantiation of the summary-spectrum kernel a
+    caller can reach (frame 1024 / 2048 / 4096 next to the default 8192, |X|^power with and without the power == 1 short
+    cut, one and two front-end waves per chunk) against the oracle: summary spectra 1e-9, per-frame chroma 1e-5, on a
+    clip with a ragged last frame."""
+    from oracle import iterative_f0 as o_if0
+    rng = np.random.default_rng(1000 + frame_size + channels)
+    n = 2 * frame_size + frame_size // 3 + 5
+    x = _poly(rng, n) + (1e-3 * rng.standard_normal(n)).astype(np.float32)
+    kw = dict(frame_size=frame_size, power=power, channels=channels)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wper, wut = o_if0.iterative_f0_frames(x, FS, **kw)
+    ut = eng.iterative_f0_spectra(x, FS, **kw)
+    tot, per = eng.iterative_f0(x, FS, return_frames=True, **kw)
+    assert ut.shape == wut.shape == (3, 2 * frame_size)
+    np.testing.assert_allclose(ut, wut, rtol=1e-9, atol=1e-9 * np.abs(wut).max())
+    np.testing.assert_allclose(per, wper, rtol=1e-5, atol=1e-300)
+    np.testing.assert_allclose(tot, wper.sum(0), rtol=1e-5, atol=1e-300)
 
 
 @pytest.mark.parametrize("channels", [5, 33, 64, 70, 80])

@@ -22,7 +22,9 @@ def table():
 
 
 SCRATCH_FREE = [
-    "mpx::he_wave_kernel<8, 4, false, true>",          # headline: every frame whole and aligned
+    "mpx::he_wave_kernel<8, 4, false, true, 2146439166u>",    # headline: every frame whole and aligned, 22 of 32 rows (HW_K2_44K)
+    "mpx::he_wave_kernel<8, 4, false, true, 4294967295u>",    # the same loader, window shapes / sample rates that need every row
+    "mpx::he_wave_kernel<8, 4, false, false, 2146439166u>",   # ragged / unaligned frames at 44.1 kHz
     "mpx::he_kernel<4096, 256, double>",
     "mpx::sacf_pfa_kernel<1>", "mpx::sacf_pfa_kernel<2>",
     "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
@@ -36,11 +38,11 @@ SCRATCH_FREE = [
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
     "mpx::peakfit_kernel<false>": 40,                  # small batches: the round-2 arrangement
-    "mpx::he_wave_kernel<8, 4, false, false>": 24,     # ragged / unaligned frames: the loader with per-sample guards
+    "mpx::he_wave_kernel<8, 4, false, false, 4294967295u>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
 }
 # occupancy (waves per SIMD) the launch geometry of the host code counts on
 OCCUPANCY = {
-    "mpx::he_wave_kernel<8, 4, false, true>": 2,
+    "mpx::he_wave_kernel<8, 4, false, true, 2146439166u>": 2,
     "mpx::sacf_pfa_kernel<2>": 4,
     "mpx::if0_spectrum_split_kernel<8192, true, 1>": 4,
     "mpx::prime_pers_kernel<1024>": 2,

@@ -132,17 +132,27 @@ def test_time_shards_in_flight_on_one_gpu():
 
 
 @pytest.mark.gpu
-def test_drop_in_class_takes_the_sharded_route_for_long_audio(monkeypatch):
-    """MultipitchIterativeF0.compute_pitches on audio whose front-end output exceeds one piece (forced here by a small
-    piece size) goes through the time shards and returns what the single call returns."""
+def test_drop_in_class_on_long_audio_runs_in_time_slices():
+    """MultipitchIterativeF0.compute_pitches on audio whose front-end output exceeds the context's workspace cap (forced
+    here by a 64 MiB cap: 30 frames need 137 MB) runs in time slices inside the library and returns what the one-piece call
+    returns, bit for bit; run_stream_rank's one-call route (its own cap, set for the call and restored) does too."""
     import chord_detection_amd as cd
     n = 30 * FRAME + 77
     x = stream.synth_stream(0, n, FS, "cuda:0").cpu().numpy()
+    eng = cd.get_engine(0)
     want = cd.MultipitchIterativeF0((x, FS)).compute_pitches()
-    monkeypatch.setattr(stream, "PIECE_BYTES", 4 * FRAME * 70 * 8)      # 4 frames per piece
-    got = cd.MultipitchIterativeF0((x, FS)).compute_pitches()
-    np.testing.assert_allclose(got.as_array(), want.as_array(), rtol=1e-9)
+    _, want_rows = eng.iterative_f0(x, FS, return_frames=True)
+    before = eng.get_option("if0_workspace_bytes")
+    try:
+        eng.set_option("if0_workspace_bytes", 64 << 20)
+        got = cd.MultipitchIterativeF0((x, FS)).compute_pitches()
+    finally:
+        eng.set_option("if0_workspace_bytes", before)
+    np.testing.assert_array_equal(got.as_array(), want.as_array())
     assert repr(got) == repr(want)
+    f0, f1, rows = stream.run_stream_rank(lambda a, b: x[a:b], n, FS, 0, 1, FRAME, 0, workspace_bytes=256 << 20)
+    assert (f0, f1) == (0, 31) and eng.get_option("if0_workspace_bytes") == before
+    np.testing.assert_array_equal(rows, want_rows)
 
 
 @pytest.mark.gpu

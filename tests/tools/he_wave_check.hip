@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
 #endif
     constexpr int N = 4096, M = 2048, HOP = 1024, WAVES = HWC_WAVES;
     const long long F = argc > 1 ? atoll(argv[1]) : 8192;
-    const int fs = 22050;
+    const int fs = getenv("HWC_FS") ? atoi(getenv("HWC_FS")) : 44100;
     unsigned* d_probe; CK(hipMalloc(&d_probe, 128 * 4));
     hipLaunchKernelGGL(swap_probe, dim3(1), dim3(64), 0, 0, d_probe);
 
@@ -110,6 +110,13 @@ int main(int argc, char** argv) {
     a.whalf = (const double*)up(whalf.data(), M * 8); a.tw = (const cx<double>*)up(tw.data(), M * 16);
     a.wk0 = (const int*)up(c0.data(), nwin * 4); a.wk1 = (const int*)up(c1.data(), nwin * 4); a.ww = (const double*)up(ww.data(), nwin * 8);
     a.slots = (const unsigned*)up(slots.data(), nb * 8); a.twnb = (const cx<double>*)up(twnb.data(), nb * 16);
+    unsigned k2 = 0;
+    for (int k : bins) k2 |= hw_k2_bits(k);
+#ifndef HWC_K2
+#define HWC_K2 HW_K2_44K
+#endif
+    printf("k2mask of the plan %08x (%d of 32 rows), kernel instantiated for %08x\n", k2, __builtin_popcount(k2), (unsigned)HWC_K2);
+    if (k2 & ~(unsigned)HWC_K2) { printf("plan needs rows outside the instantiated mask\n"); return 1; }
     a.nb = nb; a.nwin = nwin; a.wins_per_note = 4; a.num_harmonic = 2; a.quad_tail = getenv("HWC_GENERIC_TAIL") ? 0 : 1;
     double* d_out; CK(hipMalloc(&d_out, F * 12 * 8)); a.out = d_out; a.partial = nullptr;
     const long long G = std::min<long long>(256, (F + WAVES - 1) / WAVES) * (getenv("HWC_GMUL") ? atoi(getenv("HWC_GMUL")) : 1);
@@ -117,7 +124,7 @@ int main(int argc, char** argv) {
     printf("grid %lld x %d, LDS %zu B\n", G, WAVES * 64, lds);
     const long long FD = std::min<long long>(F, 24);
     cx<double>* d_dbg; CK(hipMalloc(&d_dbg, (size_t)F * M * 16));
-    auto kd = he_wave_kernel<WAVES, 4, true, true>; auto kr = he_wave_kernel<WAVES, 4, false, true>;
+    auto kd = he_wave_kernel<WAVES, 4, true, true, HWC_K2>; auto kr = he_wave_kernel<WAVES, 4, false, true, HWC_K2>;
     CK(hipFuncSetAttribute((const void*)kd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CK(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kd, dim3((unsigned)G), dim3(WAVES * 64), lds, 0, a, d_dbg);
