@@ -126,6 +126,73 @@ __device__ __forceinline__ void hw_fft32(cx<double>* r) {
     hw_stage_g<1, 0>(r);
 }
 
+// The same transform in its Cooley-Tukey form (natural order in, r[p] = X[br5(p)] out, like hw_fft32): the twiddle of a
+// butterfly multiplies its SECOND INPUT, so it fuses into the additions -- u = a + W b in four FMAs, a - W b = 2a - u in two:
+// six instructions where the Gentleman-Sande butterfly above takes eight ((a - b) first, then the product).  All butterflies
+// of a group share one twiddle, exponent br(group) x span: 46 of the 80 are trivial (four instructions), 34 take six:
+// 388 instructions against 456.
+template <int E>
+__device__ __forceinline__ void hw_bfly_ct(cx<double>& ra, cx<double>& rb) {
+    const cx<double> a = ra, b = rb;
+    if constexpr (E == 0) {
+        ra = cadd(a, b);
+        rb = csub(a, b);
+    } else if constexpr (E == 8) {   // W = -i
+        ra = {a.x + b.y, a.y - b.x};
+        rb = {a.x - b.y, a.y + b.x};
+    } else if constexpr (E == 4) {   // W = c (1 - i)
+        const double s1 = b.x + b.y, s2 = b.y - b.x;
+        ra = {fma(HW_C[4], s1, a.x), fma(HW_C[4], s2, a.y)};
+        rb = {fma(-HW_C[4], s1, a.x), fma(-HW_C[4], s2, a.y)};
+    } else if constexpr (E == 12) {  // W = -c (1 + i)
+        const double s1 = b.y - b.x, s2 = b.x + b.y;
+        ra = {fma(HW_C[4], s1, a.x), fma(-HW_C[4], s2, a.y)};
+        rb = {fma(-HW_C[4], s1, a.x), fma(HW_C[4], s2, a.y)};
+    } else {
+        constexpr double c = HW_C[E], sn = HW_S[E];   // W = c - i sn
+        cx<double> u;
+        u.x = fma(c, b.x, fma(sn, b.y, a.x));
+        u.y = fma(c, b.y, fma(-sn, b.x, a.y));
+        ra = u;
+        rb = {fma(2.0, a.x, -u.x), fma(2.0, a.y, -u.y)};
+    }
+}
+__host__ __device__ constexpr int hw_brn(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+template <int S, int G, int J>
+__device__ __forceinline__ void hw_ct_j(cx<double>* r) {
+    if constexpr (J < S) {
+        // group index G / (2 S), 16 / S groups in the stage: exponent = bit-reversed group index x span
+        constexpr int LG = S == 16 ? 0 : (S == 8 ? 1 : (S == 4 ? 2 : (S == 2 ? 3 : 4)));
+        hw_bfly_ct<hw_brn(G / (2 * S), LG) * S>(r[G + J], r[G + J + S]);
+        hw_ct_j<S, G, J + 1>(r);
+    }
+}
+template <int S, int G>
+__device__ __forceinline__ void hw_ct_g(cx<double>* r) {
+    if constexpr (G < 32) {
+        hw_ct_j<S, G, 0>(r);
+        hw_ct_g<S, G + 2 * S>(r);
+    }
+}
+// (the first level -- span 16, twiddle 1 -- is taken together with the window multiplication in the frame loop)
+__device__ __forceinline__ void hw_fft32_ct_after_first_level(cx<double>* r) {
+    hw_ct_g<8, 0>(r);
+    hw_ct_g<4, 0>(r);
+    hw_ct_g<2, 0>(r);
+    hw_ct_g<1, 0>(r);
+}
+__device__ __forceinline__ void hw_fft32_ct(cx<double>* r) {
+    hw_ct_g<16, 0>(r);
+    hw_ct_g<8, 0>(r);
+    hw_ct_g<4, 0>(r);
+    hw_ct_g<2, 0>(r);
+    hw_ct_g<1, 0>(r);
+}
+
 // The same transform of the MODULATED sequence x[c] * theta^c (theta per lane): in decimation in frequency the factor
 // theta^c of a pair (c, c + S) splits into theta^c -- which stays with the half-length subsequence -- and theta^S on the
 // second element, so every stage multiplies its second inputs by ONE per-lane constant th[s] = theta^S, fused into the
@@ -340,6 +407,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             // this wave's next frame: asked for now, read once the window reads below have drained the LDS queue anyway
             unsigned grabbed = 0;
             if (hw_opaque(lane) == 0) grabbed = take();
+#if defined(HW_FFT_A_GS) || defined(HW_WINDOW_SEPARATE)
             {
                 // window pairs through LDS, eight at a time and one group ahead of their use (the scheduler, left alone,
                 // requests each pair right before the multiplication and eats the LDS latency 32 times).  Pair index
@@ -372,10 +440,62 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                     for (int j = 0; j < 8; ++j) wv[j] = nx[j];
                 }
             }
+#else
+            {
+                // Window and the FIRST butterfly level of transform A in one step.  That level pairs the points n1 = e and
+                // e + 16 with twiddle 1: u = a wa + b wb, v = a wa - b wb -- one product and two FMAs per component where
+                // window, then butterfly, took two products, a sum and a difference (32 instructions fewer per frame, and
+                // b wb is not rounded on its own).  Window pairs through LDS, four points (e, e + 16) at a time and one group
+                // ahead of their use (the scheduler, left alone, requests each pair right before its product and eats the LDS
+                // latency 32 times): pair index m = lane + 64 n1 below 1024, the mirrored pair 2047 - m (values swapped) above.
+                const int ol = hw_opaque(lane);
+                const char* wlo = reinterpret_cast<const char*>(whalf) + 16 * ol;
+                const char* whi = reinterpret_cast<const char*>(whalf) + 16 * (63 - ol);
+                auto wload = [&](int e) -> double2 {
+                    return e < 16 ? *reinterpret_cast<const double2*>(wlo + 1024 * e)
+                                  : *reinterpret_cast<const double2*>(whi + 1024 * (31 - e));
+                };
+                double2 wv[8], nx[8];   // [2 j]: point e = 4 g + j, [2 j + 1]: point e + 16
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wv[2 * j] = wload(j);
+                    wv[2 * j + 1] = wload(j + 16);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (g < 3) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            nx[2 * j] = wload(4 * (g + 1) + j);
+                            nx[2 * j + 1] = wload(4 * (g + 1) + j + 16);
+                        }
+                    }
+                    hw_phase();
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g + j;
+                        const double pax = (double)raw[e].x * wv[2 * j].x, pay = (double)raw[e].y * wv[2 * j].y;
+                        const double bx = (double)raw[e + 16].x, by = (double)raw[e + 16].y;
+                        const double wbx = wv[2 * j + 1].y, wby = wv[2 * j + 1].x;   // upper half: the mirrored pair, swapped
+                        z[e] = {fma(bx, wbx, pax), fma(by, wby, pay)};
+                        z[e + 16] = {fma(-bx, wbx, pax), fma(-by, wby, pay)};
+                    }
+                    hw_phase();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) wv[j] = nx[j];
+                }
+            }
+#endif
             long long fn = g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed);
             HW_STAMP(1);
             // A: DFT over n1 in registers; z[p] = A[k1 = br5(p)]
+#if defined(HW_FFT_A_GS)
             hw_fft32(z);
+#elif defined(HW_WINDOW_SEPARATE)
+            hw_fft32_ct(z);
+#else
+            hw_fft32_ct_after_first_level(z);
+#endif
             hw_phase();
             if (pend_f >= 0) finish_tail();
             hw_phase();

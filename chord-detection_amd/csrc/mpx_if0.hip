@@ -78,7 +78,7 @@ constexpr int IF0_STATE_PIPE = 66, IF0_STATE_SEQ = 22;   // doubles per lane: pi
 // TAIL = false: a wave of 64 channels of ONE chunk -- chunk, input pointer and output rows are wave-uniform (scalar
 // loads, plain pointer arithmetic).  TAIL = true: a wave of leftover channels of several chunks -- per-lane chunk,
 // input pointer and an LDS table of output rows.  (One body for both had cost the common case 16 % of its speed.)
-template <bool TAIL>
+template <bool TAIL, bool SLICED>
 __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                   long long num_chunks, int channels,
                                                   const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
@@ -86,6 +86,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                                                   const If0TailGroup* __restrict__ tail_groups,
                                                   double (*tile)[IF0_TW + 1], long long* rowbase, long long ck_u, int ch0_u,
                                                   int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl) {
+#pragma clang fp contract(off)
     // One wave per (chunk, group of 64 channels), one lane per channel; the channels % 64 left over (6 of the default
     // 70) would fill a wave to 9 %, so the leftovers of up to 64 / (channels % 64) chunks of equal length and run-in
     // share one: lane -> (chunk, channel).  All lanes of a wave share the loop bounds, and the outputs go
@@ -153,10 +154,11 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
     // 44 112 instead of 49 168 steps for a two-second clip at 22.05 kHz.  (A wave of leftover channels of several chunks
     // keeps the common bound.)
     const int c_end_all = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
-    if (sl.t0 >= c_end_all) return;                                  // (uniform) this chunk ended in an earlier slice
-    const int c_end = sl.t1 < c_end_all ? sl.t1 : c_end_all;         // this launch produces the outputs [sl.t0, c_end)
+    const int sl_t0 = SLICED ? sl.t0 : 0;
+    if (SLICED && sl_t0 >= c_end_all) return;                        // (uniform) this chunk ended in an earlier slice
+    const int c_end = SLICED && sl.t1 < c_end_all ? sl.t1 : c_end_all;   // this launch produces the outputs [sl_t0, c_end)
     // every state variable of the loop, in a fixed order: [wave][value][lane]
-    double* __restrict__ st_lane = sl.state ? sl.state + (size_t)blockIdx.x * IF0_STATE_PIPE * 64 + lane : nullptr;
+    double* __restrict__ st_lane = SLICED ? sl.state + (size_t)blockIdx.x * IF0_STATE_PIPE * 64 + lane : nullptr;
     auto carry = [&](auto&& io) {
         int n = 0;
         io(a1, n++); io(a2, n++); io(b1, n++); io(b2, n++); io(c1, n++); io(c2, n++); io(d1, n++); io(d2, n++);
@@ -167,9 +169,9 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         for (int i = 0; i < 16; ++i) io(sob[i], n++);
     };
     int tb_first = -c_warm;
-    if (sl.t0 > 0) {   // the previous launch ended behind block tb = sl.t0 (outputs up to sl.t0 - 1, inputs up to sl.t0 + 15)
+    if (SLICED && sl_t0 > 0) {   // the previous launch ended behind block tb = sl_t0 (outputs up to sl_t0 - 1, inputs up to sl_t0 + 15)
         carry([&](double& v, int n) { v = st_lane[n * 64]; });
-        tb_first = sl.t0 + PF;
+        tb_first = sl_t0 + PF;
     }
     fetch(tb_first);
     for (int tb = tb_first; tb < c_end + DEPTH; tb += PF) {
@@ -182,53 +184,56 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             // ---- final stage (sample tau-16): residual, full-wave rectifier, low-pass, average
+            // (every multiply-add below is an EXPLICIT fma and contraction is off in this function: the pipelined, the
+            //  sequential and the time-sliced instantiations must round identically, and the compiler's own contraction
+            //  differed between them -- 11 of 800 per 16 samples -- once the loop bounds came from a slice)
             {
                 double r = sob[(q + 3) & 15] - fxh;   // written 13 steps ago
                 r = r < 0.0 ? -r : r;
-                const double lp = k.lpb0 * r + l1;
-                l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
-                l2 = k.lpb2 * r - k.lpa2 * lp;
+                const double lp = fma(k.lpb0, r, l1);
+                l1 = fma(-k.lpa1, lp, fma(k.lpb1, r, l2));
+                l2 = fma(-k.lpa2, lp, k.lpb2 * r);
                 tile[lane][tcol + q] = (r + lp) / 2.0;   // output sample tau - DEPTH = tb - 16 + q
             }
             // ---- all-pass stages 11..0 (samples tau-15 .. tau-4), dsp/wfir.py:25-43
             {
-                const double o = -wf.a * pin[11] + z[11];
-                z[11] = pin[11] + wf.a * o;
-                fxh = pxh[11] + wf.c[12] * o;
+                const double o = fma(-wf.a, pin[11], z[11]);
+                z[11] = fma(wf.a, o, pin[11]);
+                fxh = fma(wf.c[12], o, pxh[11]);
             }
 #pragma unroll
             for (int i = 10; i >= 0; --i) {
-                const double o = -wf.a * pin[i] + z[i];
-                z[i] = pin[i] + wf.a * o;
+                const double o = fma(-wf.a, pin[i], z[i]);
+                z[i] = fma(wf.a, o, pin[i]);
                 pin[i + 1] = o;
-                pxh[i + 1] = pxh[i] + wf.c[i + 1] * o;
+                pxh[i + 1] = fma(wf.c[i + 1], o, pxh[i]);
             }
             // ---- resonator 2 twice, resonator 1 twice (samples tau-3 .. tau), DF2T like scipy.signal.lfilter
             {
-                const double sres = k.r2b0 * qv + d1;
-                d1 = d2 - k.r2a1 * sres;
+                const double sres = fma(k.r2b0, qv, d1);
+                d1 = fma(-k.r2a1, sres, d2);
                 d2 = -k.r2a2 * sres;
                 pin[0] = sres;
                 sob[q] = sres;
                 pxh[0] = wf.c[0] * sres;
             }
             {
-                const double v = k.r2b0 * qu + c1;
-                c1 = c2 - k.r2a1 * v;
+                const double v = fma(k.r2b0, qu, c1);
+                c1 = fma(-k.r2a1, v, c2);
                 c2 = -k.r2a2 * v;
                 qv = v;
             }
             {
-                const double u = k.r1b0 * qy + b1;
-                b1 = b2 - k.r1a1 * u;
-                b2 = k.r1b2 * qy - k.r1a2 * u;
+                const double u = fma(k.r1b0, qy, b1);
+                b1 = fma(-k.r1a1, u, b2);
+                b2 = fma(-k.r1a2, u, k.r1b2 * qy);
                 qu = u;
             }
             {
                 const double xt = (double)xs[q];
-                const double y = k.r1b0 * xt + a1;
-                a1 = a2 - k.r1a1 * y;
-                a2 = k.r1b2 * xt - k.r1a2 * y;
+                const double y = fma(k.r1b0, xt, a1);
+                a1 = fma(-k.r1a1, y, a2);
+                a2 = fma(-k.r1a2, y, k.r1b2 * xt);
                 qy = y;
             }
         }
@@ -238,7 +243,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         // stream took the same 2.05 TB/s with 64 and with 70 channels).
         if (t0 >= 0 && t0 < c_end && (tcol == IF0_TW - PF || t0 + PF >= c_end)) {   // uniform: a full tile, or the chunk's last block
             const int tg = t0 - tcol, ncols = tcol + PF;   // first sample and width of what the tile holds
-            const int ts = tg - sl.t0;                      // ... counted from the first output of this launch
+            const int ts = tg - sl_t0;                      // ... counted from the first output of this launch
             // where sample tg of channel 0 of this frame sits relative to frame 0, channel 0 (a tile never straddles a frame)
             const size_t foff = (((size_t)(ts >> lg_nf) * channels) << lg_nf) + (size_t)(ts & ((1 << lg_nf) - 1));
             wave_lds_fence();
@@ -266,7 +271,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             wave_lds_fence();
         }
     }
-    if (st_lane && c_end < c_end_all) carry([&](double& v, int n) { st_lane[n * 64] = v; });   // more slices of this chunk follow
+    if (SLICED && c_end < c_end_all) carry([&](double& v, int n) { st_lane[n * 64] = v; });   // more slices of this chunk follow
 }
 
 // The same chain in its SEQUENTIAL form -- every sample walks the 17 stages one after the other -- for TWO waves per SIMD
@@ -274,12 +279,13 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
 // fewer than the pipelined body above.  The dependent chain of a sample is ~21 operations deep against 59 fp64 operations
 // to issue, the state updates fill its latency, and the second wave fills what is left; the 16 samples of a tile are unrolled,
 // so the compiler may still overlap neighbouring samples where registers allow.  Same operations on the same operands.
-template <bool TAIL>
+template <bool TAIL, bool SLICED>
 __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                       int channels, const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
                                                       double* __restrict__ yc, const int* __restrict__ tail_list,
                                                       double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
                                                       int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl) {
+#pragma clang fp contract(off)
     const int lane = threadIdx.x;
     const int full = channels >> 6, nt = channels & 63;
     long long ck;
@@ -318,9 +324,10 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         }
     };
     const int c_end_all = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
-    if (sl.t0 >= c_end_all) return;                                  // (uniform) this chunk ended in an earlier slice
-    const int c_end = sl.t1 < c_end_all ? sl.t1 : c_end_all;         // this launch produces the outputs [sl.t0, c_end)
-    double* __restrict__ st_lane = sl.state ? sl.state + (size_t)blockIdx.x * IF0_STATE_SEQ * 64 + lane : nullptr;
+    const int sl_t0 = SLICED ? sl.t0 : 0;
+    if (SLICED && sl_t0 >= c_end_all) return;                        // (uniform) this chunk ended in an earlier slice
+    const int c_end = SLICED && sl.t1 < c_end_all ? sl.t1 : c_end_all;   // this launch produces the outputs [sl_t0, c_end)
+    double* __restrict__ st_lane = SLICED ? sl.state + (size_t)blockIdx.x * IF0_STATE_SEQ * 64 + lane : nullptr;
     auto carry = [&](auto&& io) {
         int n = 0;
         io(a1, n++); io(a2, n++); io(b1, n++); io(b2, n++); io(c1, n++); io(c2, n++); io(d1, n++); io(d2, n++);
@@ -329,9 +336,9 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         for (int i = 0; i < 12; ++i) io(z[i], n++);
     };
     int t_first = -c_warm;
-    if (sl.t0 > 0) {
+    if (SLICED && sl_t0 > 0) {
         carry([&](double& v, int n) { v = st_lane[n * 64]; });
-        t_first = sl.t0;
+        t_first = sl_t0;
     }
     const unsigned lane_off = ((unsigned)(lane >> 4) << lg_nf) + (unsigned)(lane & 15);   // < 4 frame sizes: 32 bits
     fetch(t_first);
@@ -344,36 +351,36 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         const int col = t & (PF - 1);   // the run-in and the chunk start are multiples of 16
 #pragma unroll
         for (int q = 0; q < G; ++q) {
-            const double xt = (double)xs[q];
-            const double y = k.r1b0 * xt + a1;
-            a1 = a2 - k.r1a1 * y;
-            a2 = k.r1b2 * xt - k.r1a2 * y;
-            const double u = k.r1b0 * y + b1;
-            b1 = b2 - k.r1a1 * u;
-            b2 = k.r1b2 * y - k.r1a2 * u;
-            const double v = k.r2b0 * u + c1;
-            c1 = c2 - k.r2a1 * v;
+            const double xt = (double)xs[q];   // (explicit fmas, contraction off: see the pipelined body)
+            const double y = fma(k.r1b0, xt, a1);
+            a1 = fma(-k.r1a1, y, a2);
+            a2 = fma(-k.r1a2, y, k.r1b2 * xt);
+            const double u = fma(k.r1b0, y, b1);
+            b1 = fma(-k.r1a1, u, b2);
+            b2 = fma(-k.r1a2, u, k.r1b2 * y);
+            const double v = fma(k.r2b0, u, c1);
+            c1 = fma(-k.r2a1, v, c2);
             c2 = -k.r2a2 * v;
-            const double sres = k.r2b0 * v + d1;
-            d1 = d2 - k.r2a1 * sres;
+            const double sres = fma(k.r2b0, v, d1);
+            d1 = fma(-k.r2a1, sres, d2);
             d2 = -k.r2a2 * sres;
             double in = sres, xh = wf.c[0] * sres;
 #pragma unroll
             for (int i = 0; i < 12; ++i) {
-                const double o = -wf.a * in + z[i];
-                z[i] = in + wf.a * o;
-                xh = xh + wf.c[i + 1] * o;
+                const double o = fma(-wf.a, in, z[i]);
+                z[i] = fma(wf.a, o, in);
+                xh = fma(wf.c[i + 1], o, xh);
                 in = o;
             }
             double r = sres - xh;
             r = r < 0.0 ? -r : r;
-            const double lp = k.lpb0 * r + l1;
-            l1 = (l2 + k.lpb1 * r) - k.lpa1 * lp;
-            l2 = k.lpb2 * r - k.lpa2 * lp;
+            const double lp = fma(k.lpb0, r, l1);
+            l1 = fma(-k.lpa1, lp, fma(k.lpb1, r, l2));
+            l2 = fma(-k.lpa2, lp, k.lpb2 * r);
             tile[lane][col + q] = (r + lp) / 2.0;
         }
         if (t >= 0 && col == PF - G) {   // uniform; a tile of 16 samples is complete
-            const int tb = t - (PF - G) - sl.t0;   // counted from the first output of this launch
+            const int tb = t - (PF - G) - sl_t0;   // counted from the first output of this launch
             const size_t foff = (((size_t)(tb >> lg_nf) * channels) << lg_nf) + (size_t)(tb & ((1 << lg_nf) - 1));   // as in the pipelined body
             wave_lds_fence();
             constexpr int SG = TAIL ? 2 : 4;   // store instructions per group (their values and row bases are registers)
@@ -401,9 +408,10 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
             wave_lds_fence();
         }
     }
-    if (st_lane && c_end < c_end_all) carry([&](double& v, int n) { st_lane[n * 64] = v; });
+    if (SLICED && c_end < c_end_all) carry([&](double& v, int n) { st_lane[n * 64] = v; });
 }
 
+template <bool SLICED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void if0_frontend2_kernel(
     const float* __restrict__ sig, const If0Chunk* __restrict__ chunks, long long num_chunks, int channels,
     const If0ChanCoef* __restrict__ coefs, If0Wfir wf, double* __restrict__ yc, const int* __restrict__ tail_list,
@@ -414,17 +422,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
     If0TailGroup g = {0, 0};
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
-        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g, lg_nf, sl);
+        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g, lg_nf, sl);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)
-        if0_frontend_seq_body<false>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 64 * full,
+        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 64 * full,
                                      channels & 63, g, lg_nf, sl);
     else
-        if0_frontend_seq_body<true>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl);
+        if0_frontend_seq_body<true, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl);
 }
 
+template <bool SLICED>
 __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                           long long num_chunks, int channels,
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
@@ -440,16 +449,16 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     // end on the fast kind.
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
-        if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
+        if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
                                  b / full, (int)(b % full) * 64, 64, g, lg_nf, sl);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
-        if0_frontend_body<false>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
+        if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
                                  tail_list[g.first], 64 * full, channels & 63, g, lg_nf, sl);
     else
-        if0_frontend_body<true>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
+        if0_frontend_body<true, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
                                 0, g, lg_nf, sl);
 }
 
@@ -1387,7 +1396,26 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         long long fit = (long long)(ctx->if0_ws_cap / ((size_t)nchunks * p.channels * sizeof(double))) / NF * NF;
         if (fit < NF) fit = NF;
         if (fit < maxlen) {
-            slice = fit;
+            // Among the slice lengths that fit, the one whose launches waste the least: the summary-spectrum kernel runs two
+            // equally long workgroups per frame in lock-step rounds of (CUs x 16384 / frame size) -- 923 chunks x 2 frames
+            // are 7.2 rounds (the eighth a fifth full: +10 %, measured 67.7 against 60.8 ms per hour of audio), x 3 frames
+            // 10.8 -- and every slice costs three launch ramps (counted as a twentieth of a round).
+            const long long slots = std::max<long long>(1, (long long)ctx->num_cus * 16384 / NF);
+            double best = -1.0;
+            for (long long cand = fit; cand >= NF; cand -= NF) {
+                double cost = 0.0;
+                long long nsl = 0;
+                for (long long lo = 0; lo < maxlen; lo += cand, ++nsl) {
+                    long long fr = 0;
+                    for (const If0Chunk& ck : chunks) fr += std::max<long long>(0, std::min<long long>(lo + cand, ck.len) - lo) / NF;
+                    cost += (double)((2 * fr + slots - 1) / slots);
+                }
+                cost += 0.05 * (double)nsl;
+                if (best < 0.0 || cost < best * (1.0 - 1e-9)) {   // (the longest slice on a tie)
+                    best = cost;
+                    slice = cand;
+                }
+            }
             sliced = true;
         }
     }
@@ -1487,14 +1515,10 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         sl.state = sliced ? (double*)ctx->d_ws2.p : nullptr;
         const long long nf_s = sl_off[(size_t)sidx + 1] - sl_off[(size_t)sidx];
         prof_mark(ctx, st, "if0_frontend_kernel");
-        if (!fe_sequential)
-            hipLaunchKernelGGL(if0_frontend_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st,
-                               d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                               d_tail_groups, (int)tail_groups.size(), lg_nf, sl);
-        else
-            hipLaunchKernelGGL(if0_frontend2_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st,
-                               d_in, d_chunks, nchunks, p.channels, plan.d_coefs, plan.wf, yc, d_tail_list,
-                               d_tail_groups, (int)tail_groups.size(), lg_nf, sl);
+        auto fe_kernel = !fe_sequential ? (sliced ? if0_frontend_kernel<true> : if0_frontend_kernel<false>)
+                                        : (sliced ? if0_frontend2_kernel<true> : if0_frontend2_kernel<false>);
+        hipLaunchKernelGGL(fe_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st, d_in, d_chunks, nchunks, p.channels,
+                           plan.d_coefs, plan.wf, yc, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl);
         MPX_HIP(ctx, hipGetLastError());
         if (nf_s == 0) continue;
         const If0Frame* d_fr = d_frames + sl_off[(size_t)sidx];

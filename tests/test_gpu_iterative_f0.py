@@ -152,7 +152,7 @@ def test_time_slices_carry_the_filter_state_exactly(frame_size, channels):
     import chord_detection_amd as cd
     from oracle import iterative_f0 as o_if0
     rng = np.random.default_rng(77 + frame_size + channels)
-    n = 150000 + 1234
+    n = 300000 + 1234
     x = _poly(rng, n) + (1e-3 * rng.standard_normal(n)).astype(np.float32)
     kw = dict(frame_size=frame_size, channels=channels)
     whole, cut = cd.Engine(0), cd.Engine(0)

@@ -33,7 +33,8 @@ SCRATCH_FREE = [
     "mpx::peakfit_kernel<true>",                      # large batches: samples in LDS, fvec recomputed
     "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
-    "mpx::if0_frontend_kernel", "mpx::if0_frontend2_kernel", "mpx::if0_periodicity_kernel",
+    "mpx::if0_frontend_kernel<false>", "mpx::if0_frontend2_kernel<false>", "mpx::if0_periodicity_kernel",
+    "mpx::if0_frontend_kernel<true>", "mpx::if0_frontend2_kernel<true>",     # time slices (MPX_OPT_IF0_WORKSPACE_BYTES)
 ]
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
