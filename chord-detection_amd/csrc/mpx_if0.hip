@@ -471,6 +471,7 @@ struct If0Frame {
     int pad;
 };
 
+#ifdef MPX_DEV_KNOBS
 template <int NF, int T>   // NF = frame size = complex FFT length (2*NF real points, upper half zero)
 __global__ __launch_bounds__(T) void if0_spectrum_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
                                                          int channels, double power, const double* __restrict__ window,
@@ -527,6 +528,8 @@ __global__ __launch_bounds__(T) void if0_spectrum_kernel(const double* __restric
         }
     }
 }
+
+#endif  // MPX_DEV_KNOBS
 
 // ------------------------------------------------------------------ periodicity
 struct If0PerArgs {
@@ -853,6 +856,26 @@ static long long if0_warmup(int fs, const mpx_if0_params& p, double* rho_out) {
 
 int remez_taps_for(mpx_ctx* ctx, int fs, double* c13);  // mpx_esacf.hip
 
+static void if0_host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, forward; plan tables only
+    const size_t n = a.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) std::swap(a[i], a[j]);
+    }
+    for (size_t len = 2; len <= n; len <<= 1)
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const long double ang = -2.0L * M_PIl * (long double)k / (long double)len;
+                const long double wx = cosl(ang), wy = sinl(ang);
+                const cx<double> u = a[i + k], t = a[i + k + len / 2];
+                const cx<double> v = {(double)(t.x * wx - t.y * wy), (double)(t.x * wy + t.y * wx)};
+                a[i + k] = {u.x + v.x, u.y + v.y};
+                a[i + k + len / 2] = {u.x - v.x, u.y - v.y};
+            }
+}
+
 static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan) {
     char keyb[256];
     snprintf(keyb, sizeof keyb, "if0r3_%d_%d_%d_%.17g_%.17g", fs, p.frame_size, p.channels, p.zeta0, p.zeta1);
@@ -917,13 +940,45 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
     plan.d_window = (double*)upload(ctx, win.data(), win.size() * sizeof(double));
     plan.d_tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
     plan.d_twn = (cx<double>*)upload(ctx, twn.data(), twn.size() * sizeof(cx<double>));
-    {
+    if (NF == 1024 || NF == 2048 || NF == 4096 || NF == 8192) {
         const int H = NF / 2, T = H / 8;
         std::vector<cx<double>> tr((size_t)2 * H);
         for (int P = 0; P < 2; ++P)
             for (int e = 0; e < 8; ++e)
                 for (int t = 0; t < T; ++t) tr[((size_t)P * 8 + e) * T + t] = twn[2 * if0_reg_freq(H, t, e) + P];
         plan.d_twn_r = (cx<double>*)upload(ctx, tr.data(), tr.size() * sizeof(cx<double>));
+    } else {
+        // Any other frame size (iterative_f0.py:25 takes any integer): the 2 NF-point spectrum by chirp-z on the padded
+        // Stockham engine, X[k] = conj(c[k]) sum_n (x[n] conj(c[n])) c[k - n], c[m] = exp(i pi m^2 / 2NF), n < NF, k <= NF:
+        // a cyclic convolution of L >= 2 NF points.  d_tw: W_L, d_twn: c[0 .. NF], d_twn_r: FFT_L(c on -(NF-1) .. NF) / L.
+        int L = 4096;
+        while (L < 2 * NF) L <<= 1;
+        tw.assign((size_t)L, cx<double>{0.0, 0.0});
+        for (int j = 0; j < L; ++j) {
+            const long double ang = -2.0L * M_PIl * j / (long double)L;
+            tw[(size_t)j] = {(double)cosl(ang), (double)sinl(ang)};
+        }
+        const long long n2 = 2LL * NF;
+        for (long long m = 0; m <= NF; ++m) {
+            const long long q = (m * m) % (2 * n2);   // exact phase reduction: pi m^2 / n2 = pi q / n2 (mod 2 pi)
+            const long double ang = M_PIl * (long double)q / (long double)n2;
+            twn[(size_t)m] = {(double)cosl(ang), (double)sinl(ang)};
+        }
+        std::vector<cx<double>> filt((size_t)L, cx<double>{0.0, 0.0});
+        for (int m = 0; m <= NF; ++m) filt[(size_t)m] = twn[(size_t)m];
+        for (int m = 1; m < NF; ++m) filt[(size_t)(L - m)] = twn[(size_t)m];
+        if0_host_fft(filt);
+        for (auto& v : filt) {
+            v.x /= L;
+            v.y /= L;
+        }
+        hipFree(plan.d_tw);    // (the NF-point tables uploaded above are of no use to this path)
+        hipFree(plan.d_twn);
+        for (void* dead : {(void*)plan.d_tw, (void*)plan.d_twn})
+            ctx->owned.erase(std::remove(ctx->owned.begin(), ctx->owned.end(), dead), ctx->owned.end());
+        plan.d_tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+        plan.d_twn = (cx<double>*)upload(ctx, twn.data(), twn.size() * sizeof(cx<double>));
+        plan.d_twn_r = (cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
     }
     if (!plan.d_coefs || !plan.d_window || !plan.d_tw || !plan.d_twn || !plan.d_twn_r) return MPX_ENOMEM;
     ctx->misc_plans[key] = {plan.d_coefs, plan.d_window, plan.d_tw, plan.d_twn, plan.d_twn_r};
@@ -987,6 +1042,7 @@ __device__ __forceinline__ void if0_half_spectrum(cx<double>* buf, const DifTwid
     __syncthreads();  // the mirror reads are done before the next transform writes buf
 }
 
+#ifdef MPX_DEV_KNOBS
 template <int NF>
 __global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_dif_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
                                                                      int channels, double power, const double* __restrict__ window,
@@ -1023,6 +1079,8 @@ __global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_dif_kernel(const doub
         if (j == 0) row[NF] = acc_nyq;
     }
 }
+
+#endif  // MPX_DEV_KNOBS
 
 // Round 3: the same transform pair, ONE parity per workgroup.  A workgroup that computes both parities carries 17
 // accumulators across the channel loop next to two transforms' worth of temporaries: under the 128 registers that two
@@ -1134,8 +1192,14 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
     }
 }
 
+// Waves per SIMD the register allocator is held to: four at the default frame size with power 1 (121-124 registers, no
+// scratch) and at 1024; the other shapes a caller can reach -- frames of 2048 / 4096, |X|^power through pow() -- spilled
+// 96-324 bytes per lane under that limit (round 3) and are scratch-free at two or three waves (tests/test_kernel_resources.py).
+__host__ __device__ constexpr int if0_split_waves(int NF, bool POW1) {
+    return POW1 ? ((NF == 8192 || NF == 1024) ? 4 : 2) : (NF == 8192 ? 3 : 2);
+}
 template <int NF, bool POW1, int PF>
-__global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_split_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
+__global__ __launch_bounds__(NF / 16, if0_split_waves(NF, POW1)) void if0_spectrum_split_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
                                                                        long long nframes, int channels, double power,
                                                                        const double* __restrict__ window,
                                                                        const cx<double>* __restrict__ twNF,  // W_NF^j, j < NF
@@ -1167,9 +1231,93 @@ __global__ __launch_bounds__(NF / 16, 4) void if0_spectrum_split_kernel(const do
     }
 }
 
+// Frame sizes that are not 1024 / 2048 / 4096 / 8192: one workgroup per frame, per channel a chirp-z transform of the
+// Hamming-windowed frame on the padded Stockham engine (two L-point transforms: L = 4096 up to 2048 samples, 8192 up to
+// 4095), |X[k]| = |y[k]| (the final chirp has modulus one), k <= NF, mirrored into the 2 NF-bin row like the other kernels.
+// Correct and complete, not tuned: the reference's default and the powers of two around it run on the split kernel above.
+template <int L, int T>
+__global__ __launch_bounds__(T) void if0_spectrum_blue_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
+                                                              int NF, int channels, double power,
+                                                              const double* __restrict__ window, const cx<double>* __restrict__ tw,
+                                                              const cx<double>* __restrict__ chirp, const cx<double>* __restrict__ bhat,
+                                                              double* __restrict__ ut) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    const int tid = threadIdx.x;
+    const If0Frame fr = frames[blockIdx.x];
+    constexpr int KPT = L / 2 / T + 1;   // bins k = tid + j T <= NF <= L / 2
+    double acc[KPT];
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) acc[j] = 0.0;
+    cx<double> regs[L / T];
+    const double* src = yc + fr.yc_base;
+    for (int ch = 0; ch < channels; ++ch) {
+        const double* x = src + (size_t)ch * fr.ch_stride;
+        for (int n = tid; n < L; n += T) {
+            cx<double> v = {0.0, 0.0};
+            if (n < NF) {
+                const double xv = n < fr.valid ? x[n] : 0.0;   // the reference pads the FILTERED signal with zeros
+                const double xw = xv * window[n];
+                const cx<double> c = chirp[n];
+                v = {xw * c.x, -(xw * c.y)};
+            }
+            buf[lds_slot(n)] = v;
+        }
+        __syncthreads();
+        fft_lds<L, T, false, double>(buf, tw, regs, tid);
+        for (int k = tid; k < L; k += T) {   // swapped: the forward transform of (im, re) is the swapped inverse transform
+            const cx<double> v = cmul(buf[lds_slot(k)], bhat[k]);
+            buf[lds_slot(k)] = {v.y, v.x};
+        }
+        __syncthreads();
+        fft_lds<L, T, false, double>(buf, tw, regs, tid);
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+            const int k = tid + j * T;
+            if (k <= NF) {
+                const cx<double> y = buf[lds_slot(k)];
+                const double mag = hypot(y.x, y.y);
+                acc[j] += power == 1.0 ? mag : pow(mag, power);
+            }
+        }
+        __syncthreads();   // buf is rewritten by the next channel
+    }
+    double* row = ut + (size_t)blockIdx.x * 2 * NF;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int k = tid + j * T;
+        if (k <= NF) {
+            row[k] = acc[j];
+            if (k > 0 && k < NF) row[2 * NF - k] = acc[j];   // |X[N-k]| = |X[k]| for a real frame
+        }
+    }
+}
+
+static int if0_spectrum_blue_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int NF, int channels,
+                                    double power, const If0Plan& plan, double* ut, hipStream_t st) {
+    if (2 * NF <= 4096) {
+        constexpr int L = 4096, T = 256;
+        const size_t lds = sizeof(cx<double>) * lds_slots(L);
+        auto kern = if0_spectrum_blue_kernel<L, T>;
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, NF, channels, power, plan.d_window, plan.d_tw,
+                           plan.d_twn, plan.d_twn_r, ut);
+    } else {
+        constexpr int L = 8192, T = 512;
+        const size_t lds = sizeof(cx<double>) * lds_slots(L);
+        auto kern = if0_spectrum_blue_kernel<L, T>;
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, NF, channels, power, plan.d_window, plan.d_tw,
+                           plan.d_twn, plan.d_twn_r, ut);
+    }
+    MPX_HIP(ctx, hipGetLastError());
+    return MPX_OK;
+}
+
 template <int NF, int T>
 static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int channels,
                                double power, const If0Plan& plan, double* ut, hipStream_t st) {
+#ifdef MPX_DEV_KNOBS   // the two earlier spectrum kernels exist in development builds only (A/B through the environment)
     if (dev_env("MPX_IF0_STOCKHAM")) {  // profiling knob: the padded NF-point Stockham transform
         const size_t lds = sizeof(cx<double>) * lds_slots(NF);
         auto kern = if0_spectrum_kernel<NF, T>;
@@ -1184,11 +1332,17 @@ static int if0_spectrum_launch(mpx_ctx* ctx, const double* yc, const If0Frame* f
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(NF / 16), lds, st, yc, frames, channels, power, plan.d_window,
                            plan.d_tw, plan.d_twn, ut);
-    } else {
+    } else
+#endif
+    {
         const size_t lds = sizeof(cx<double>) * (NF / 2);
+#ifdef MPX_DEV_KNOBS
         const int pf = dev_env_int("MPX_IF0_PF", 1);
         auto kern = power == 1.0 ? (pf == 2 ? if0_spectrum_split_kernel<NF, true, 2> : (pf == 1 ? if0_spectrum_split_kernel<NF, true, 1> : if0_spectrum_split_kernel<NF, true, 0>))
                                  : if0_spectrum_split_kernel<NF, false, 0>;
+#else
+        auto kern = power == 1.0 ? if0_spectrum_split_kernel<NF, true, 1> : if0_spectrum_split_kernel<NF, false, 0>;
+#endif
         if (lds > 48 * 1024)
             MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const long long groups = ((nf + 7) / 8) * 16;
@@ -1209,8 +1363,10 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                  hipStream_t stream) {
     mpx_if0_params p = params ? *params
                               : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
-    if (p.frame_size != 1024 && p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192)
-        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: 1024, 2048, 4096, 8192)", p.frame_size);
+    // 1024 / 2048 / 4096 / 8192: the tuned kernels; any other size up to 4095 samples: chirp-z (if0_spectrum_blue_kernel)
+    const bool blue = p.frame_size != 1024 && p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192;
+    if (p.frame_size < 16 || (blue && p.frame_size > 4095))
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 4096, and 8192)", p.frame_size);
     if (p.channels < 1 || p.channels > IF0_MAXCH || p.max_voices < 1 || p.max_voices > 8 || p.Q < 2 || p.Q > 32 || p.M < 2 ||
         p.M > 64 || !(p.tau_min > 0) || !(p.tau_max > p.tau_min) || fs <= 0)
         return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
@@ -1225,21 +1381,42 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     // below 32 GiB of the 288 GB (MPX_OPT_IF0_WORKSPACE_BYTES) by halving the clip list.  A clip is one serial chain per
     // channel, so a pass wants thousands of clips in flight: 4096 two-second clips take 0.38 s in passes of 256
     // (8 GiB), 0.29 s in passes of 1024.
+    // Chirp-z frame sizes: a chunk is a whole number of frames AND of 64-sample tiles -- a multiple of lcm(NF, 64), the
+    // smallest one of at least 65536 samples (IF0_CHUNK at most: 64 x 4095 = 262080 fits) -- and the front end writes it as ONE
+    // "frame" of 2^lgp >= chunk samples per channel: [chunk][channel][2^lgp], a frame of the chunk is a piece of every row.
+    long long blue_chunk = 0;
+    int blue_lgp = 0;
+    if (blue) {
+        long long g = NF, h = 64;
+        while (h) {
+            const long long t = g % h;
+            g = h;
+            h = t;
+        }
+        const long long base = (long long)NF / g * 64;
+        blue_chunk = base * std::max<long long>(1, (65536 + base - 1) / base);
+        if (blue_chunk > IF0_CHUNK) blue_chunk = base;
+        while ((1LL << blue_lgp) < blue_chunk) ++blue_lgp;
+    }
     {
-        size_t rows = 0, rows_first = 0;
+        size_t rows = 0;
         const int mid = num_clips / 2;
         for (int c = 0; c < num_clips; ++c) {
             const int64_t len = offsets[c + 1] - offsets[c];
             if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
-            const size_t r = len <= 0 ? 0 : (size_t)((len + NF - 1) / NF) * NF;
+            size_t r = len <= 0 ? 0 : (size_t)((len + NF - 1) / NF) * NF;
+            if (blue && r) r = (size_t)((r + blue_chunk - 1) / blue_chunk) << blue_lgp;
             rows += r;
-            if (c < mid) rows_first += r;
         }
         const size_t ws_cap = ctx->if0_ws_cap;   // mpx_set_option(MPX_OPT_IF0_WORKSPACE_BYTES), default 32 GiB
         if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap) {
             std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
             for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
-            const size_t frames_first = rows_first / NF;
+            size_t frames_first = 0;
+            for (int c = 0; c < mid; ++c) {
+                const int64_t len = offsets[c + 1] - offsets[c];
+                if (len > 0) frames_first += (size_t)((len + NF - 1) / NF);
+            }
             int rc1 = if0_run_host(ctx, signals, offsets, mid, fs, &p, chroma_frames, chroma_sums, ut_out, dev_io, stream);
             if (rc1) return rc1;
             return if0_run_host(ctx, signals + (offsets[mid] - offsets[0]), off2.data(), num_clips - mid, fs, &p,
@@ -1263,9 +1440,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     std::vector<long long> seg(1, 0);
     long long yc_rows = 0;
     // Chunk length: a chunk is a serial chain per channel, so a long stream cut into few chunks leaves the GPU empty
-    // (600 s in 262144-sample chunks: 51 chunks = 102 waves on 1024 SIMDs).  Halve the chunk -- at the price of one
-    // 65536-sample run-in per chunk -- while the machine is not full AND the longest lane gets shorter by it (a clip
-    // below 65536 samples gains nothing: its later chunks would re-run it from the start).
+    // (600 s in 262144-sample chunks: 51 chunks = 102 waves on 1024 SIMDs).  Shorter chunks fill it -- at the price of one
+    // run-in of if0_warmup() samples (40960 for the default chain) per chunk; a clip shorter than that gains nothing: its
+    // later chunks would re-run it from the start.
     int64_t longest = 0;
     for (int c = 0; c < num_clips; ++c) longest = std::max<int64_t>(longest, offsets[c + 1] - offsets[c]);
     auto lane_steps = [&](long long chunk) {  // samples the busiest lane of the longest clip walks through
@@ -1321,8 +1498,17 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     };
     long long chunk_p = IF0_CHUNK, chunk_s = IF0_CHUNK;
     const long long cost_p = plan_chunk(false, chunk_p), cost_s = plan_chunk(true, chunk_s);
-    const bool fe_sequential = fe_force == 1 ? false : (fe_force == 3 ? true : cost_s < cost_p);
-    const long long chunk = fe_sequential ? chunk_s : chunk_p;
+    bool fe_sequential = fe_force == 1 ? false : (fe_force == 3 ? true : cost_s < cost_p);
+    long long chunk = fe_sequential ? chunk_s : chunk_p;
+    if (blue) {   // one chunk length (above); the sequential kernel when the waves outnumber the SIMDs
+        chunk = blue_chunk;
+        long long chunks_total = 0;
+        for (int c = 0; c < num_clips; ++c) {
+            const int64_t len = offsets[c + 1] - offsets[c];
+            if (len > 0) chunks_total += (len + chunk - 1) / chunk;
+        }
+        fe_sequential = fe_force == 1 ? false : (fe_force == 3 ? true : waves_for(chunks_total) > simds);
+    }
     for (int c = 0; c < num_clips; ++c) {
         const int64_t len = offsets[c + 1] - offsets[c];
         if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
@@ -1338,12 +1524,16 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             ck.warm = (int)(t0 < warmup ? t0 : warmup);
             ck.pad = 0;
             ck.yc_row0 = yc_rows;
-            yc_rows += ck.len;
+            yc_rows += blue ? (1LL << blue_lgp) : ck.len;
             chunks.push_back(ck);
             for (int64_t fo = 0; fo < ck.len; fo += NF) {
                 If0Frame fr;
                 fr.yc_base = ck.yc_row0 * p.channels + (fo / NF) * (long long)p.channels * NF;   // [frame of the chunk][channel][NF]
                 fr.ch_stride = NF;
+                if (blue) {   // [chunk][channel][2^lgp]
+                    fr.yc_base = ck.yc_row0 * p.channels + fo;
+                    fr.ch_stride = 1 << blue_lgp;
+                }
                 fr.pad = 0;
                 const int64_t fl = len - (t0 + fo);
                 fr.valid = (int)(fl >= NF ? NF : (fl > 0 ? fl : 0));
@@ -1392,7 +1582,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     for (const If0Chunk& ck : chunks) maxlen = std::max<long long>(maxlen, ck.len);
     long long slice = maxlen;
     bool sliced = false;
-    if ((size_t)yc_rows * p.channels * sizeof(double) > ctx->if0_ws_cap) {
+    if (!blue && (size_t)yc_rows * p.channels * sizeof(double) > ctx->if0_ws_cap) {   // (chirp-z frame sizes: one piece)
         long long fit = (long long)(ctx->if0_ws_cap / ((size_t)nchunks * p.channels * sizeof(double))) / NF * NF;
         if (fit < NF) fit = NF;
         if (fit < maxlen) {
@@ -1489,6 +1679,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     double* ud = ur + (size_t)max_slice_frames * n2;
     int lg_nf = 0;
     while ((1 << lg_nf) < NF) ++lg_nf;
+    if (blue) lg_nf = blue_lgp;   // the front end's "frame" is the chunk
     If0PerArgs a;
     a.ut = ut;
     a.ur = ur;
@@ -1523,7 +1714,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         if (nf_s == 0) continue;
         const If0Frame* d_fr = d_frames + sl_off[(size_t)sidx];
         prof_mark(ctx, st, "if0_spectrum_kernel");
-        if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
+        if (blue) rc = if0_spectrum_blue_launch(ctx, yc, d_fr, nf_s, NF, p.channels, p.power, plan, ut, st);
+        else if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
         else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
         else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
         else rc = if0_spectrum_launch<8192, 512>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);

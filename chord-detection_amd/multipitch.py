@@ -8,6 +8,11 @@ Differences from the reference, all additive:
   * `note_names=` ("unicode" default | "ascii") says how the librosa the reference runs with spells sharps in
     `hz_to_note` -- with unicode names the reference's `chromagram[note] += v` loses C#, D#, F#, G#, A#
     (chromagram.py:19-29; include/mpx.h MPX_NOTES_*).  Methods 1, 3, 4; method 2 never calls hz_to_note.
+
+Interface mirror of sevagh/chord-detection's chord_detection/multipitch.py (MIT License, Copyright (c) Sevag
+Hanssian): the plug-in API -- the `METHODS` registry filled by `__init_subclass__`, the registration error and the four
+abstract hooks (`display_name`, `method_number`, `compute_pitches`, `__init__`) -- is the reference's on purpose, so that
+a method class written for the reference registers here unchanged; the constructor body is new.
 """
 from abc import ABCMeta, abstractmethod
 from collections import OrderedDict

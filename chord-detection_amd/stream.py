@@ -103,11 +103,14 @@ def _engine_frames_on(j):
 
 
 PIECE_BYTES = 32 << 30   # front-end output of one piece of an explicit `sub` > 1 run (560 B per sample at 70 channels)
-STREAM_WORKSPACE_BYTES = 8 << 30   # hand-off buffer of ONE engine call over a rank's whole share (MPX_OPT_IF0_WORKSPACE_BYTES):
+STREAM_WORKSPACE_BYTES = 12 << 30  # hand-off buffer of ONE engine call over a rank's whole share (MPX_OPT_IF0_WORKSPACE_BYTES):
                                    # the library advances every chunk in time slices of whole frames and carries the filter
                                    # state over, so an hour of 44.1 kHz audio is still ONE front-end launch geometry of 923
-                                   # long chunks (a run-in of 24 % per chunk), but its workspaces are ~9 GB instead of the 90 GB
-                                   # of round 3 -- whose first hipMalloc cost 1-2 s on a device that had been used before
+                                   # long chunks (a run-in of 24 % per chunk) in 7 slices of 3 frames per chunk, and its
+                                   # workspaces are 13 GB instead of round 3's 90 GB, whose first hipMalloc cost 2-4 s on a
+                                   # device that had been used before.  Measured (scripts/dev/if0_hour_caps.py, MI355X):
+                                   # 12 GiB 0.131 s warm, 8 GiB 0.135 s (11 slices of 2 frames: the summary-spectrum kernel's
+                                   # eighth round a fifth full), 4.5 GiB 0.139 s, one 83 GiB piece 0.123 s
 
 
 def _workspace_cap(device, want):

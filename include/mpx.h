@@ -217,8 +217,11 @@ int mpx_prime_multif0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs
 /* ---- Iterative F0 (method 3): iterative_f0.py:21-33, periodicity.py:15-28 kwargs ----
  * replaces iterative_f0.py:54-96 + periodicity.py:48-163: 70-channel resonator filterbank over the
  * WHOLE signal (quirk A.1 kept), warped-FIR compression, full-wave rectifier, (y + LP(y, fc))/2,
- * frames of `frame_size` (1024/2048/4096/8192) x Hamming zero-padded to 2*frame_size, sum over channels of
- * |FFT|^power, then the iterative period search / harmonic cancellation per frame.
+ * frames of `frame_size` x Hamming zero-padded to 2*frame_size, sum over channels of |FFT|^power, then the iterative
+ * period search / harmonic cancellation per frame.  frame_size (iterative_f0.py:25 takes any integer): 1024, 2048, 4096 and
+ * the default 8192 run on the tuned power-of-two kernels; any other size in 16 ... 4095 by chirp-z (correct, untuned: such
+ * a call runs in one piece, without the time slices of MPX_OPT_IF0_WORKSPACE_BYTES); MPX_EUNSUPPORTED for non-powers of two
+ * above 4095 samples.
  * Long signals are filtered in chunks of up to 262144 samples, each with a zero-state run-in of
  * mpx_iterative_f0_warmup samples (40960 for the defaults: the chain has decayed to fp64 rounding by then), so
  * chunks run in parallel and shard across GPUs. */
@@ -258,6 +261,9 @@ int mpx_iterative_f0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs,
  * pole_radius != NULL; 0.99893 and 40960 for the defaults at any sample rate; until round 3 the bound was the absolute
  * rho^W W^3 <= 1e-15: 65536).  The library uses it for its own
  * chunks; a caller that shards one stream over GPUs starts each shard this many samples early (stream.py).
+ * The bound is RELATIVE to the chain's whole response: what a chunk or shard boundary leaves behind is <= 1e-13 of the
+ * level of the ~0.9 s of signal in front of it, so a quiet frame right after a passage 100 dB louder sees that passage's
+ * tail at 1e-13 x its level rather than at fp64 rounding of its own (the sequential reference has no such boundary).
  * MPX_EINVAL when the chain is unstable or would need more than 4 M samples: mpx_iterative_f0* then refuse too. */
 int mpx_iterative_f0_warmup(mpx_ctx* ctx, int fs, const mpx_if0_params* params, int64_t* samples, double* pole_radius);
 

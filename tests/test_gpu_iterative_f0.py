@@ -76,7 +76,9 @@ def test_spectra_and_batch_vs_oracle(eng, clips):
         np.testing.assert_allclose(got[3], o_if0.iterative_f0_compute(batch[3], FS), rtol=1e-5, atol=0)
     assert np.array_equal(got, eng.iterative_f0_batch(batch, FS))      # deterministic
     with pytest.raises(NotImplementedError):
-        eng.iterative_f0(x, FS, frame_size=1000)
+        eng.iterative_f0(x, FS, frame_size=5000)       # non-powers of two above 4095 samples have no kernel
+    with pytest.raises(NotImplementedError):
+        eng.iterative_f0(x, FS, frame_size=8)
     with pytest.raises(ValueError):
         eng.iterative_f0(np.zeros((2, 2), dtype=np.float32), FS)
 
@@ -179,6 +181,38 @@ def test_time_slices_carry_the_filter_state_exactly(frame_size, channels):
         nfr = wper.shape[0] - 1                               # the oracle's last frame is the zero-padded tail of the cut
         np.testing.assert_allclose(ut_c[:nfr], wut[:nfr], rtol=1e-9, atol=1e-9 * np.abs(wut).max())
         np.testing.assert_allclose(per_c[:nfr], wper[:nfr], rtol=1e-5, atol=1e-300)
+
+
+@pytest.mark.parametrize("frame_size,power,channels", [(1000, 1.0, 70), (1500, 0.5, 70), (2047, 1.0, 33), (3000, 1.0, 70),
+                                                       (4095, 2.0, 64), (512, 1.0, 70), (777, 1.0, 70)])
+def test_any_frame_size_by_chirp_z_vs_oracle(eng, frame_size, power, channels):
+    """iterative_f0.py:25 takes any integer frame_size.  Sizes other than 1024 / 2048 / 4096 / 8192 -- up to 4095 samples --
+    run the 2 x frame_size-point spectrum as a chirp-z transform (if0_spectrum_blue_kernel: 4096 points up to 2048 samples,
+    8192 above) on front-end chunks of lcm(frame_size, 64) x k samples: odd, even and prime-ish sizes, a power of two below
+    1024, both transform lengths, a clip of several chunks, against the oracle (spectra 1e-9, per-frame chroma 1e-5)."""
+    from oracle import iterative_f0 as o_if0
+    rng = np.random.default_rng(5000 + frame_size)
+    kw = dict(frame_size=frame_size, power=power, channels=channels)
+    for n in (2 * frame_size + frame_size // 3 + 5, 150000 if frame_size in (1000, 3000) else 0):
+        if not n:
+            continue
+        x = _poly(rng, n) + (1e-3 * rng.standard_normal(n)).astype(np.float32)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wper, wut = o_if0.iterative_f0_frames(x, FS, **kw)
+        ut = eng.iterative_f0_spectra(x, FS, **kw)
+        tot, per = eng.iterative_f0(x, FS, return_frames=True, **kw)
+        assert ut.shape == wut.shape == (-(-n // frame_size), 2 * frame_size)
+        np.testing.assert_allclose(ut, wut, rtol=1e-9, atol=1e-9 * np.abs(wut).max())
+        np.testing.assert_allclose(per, wper, rtol=1e-5, atol=1e-300)
+        np.testing.assert_allclose(tot, wper.sum(0), rtol=1e-5, atol=1e-300)
+    batch = [x[:9000], np.zeros(0, dtype=np.float32), x[:frame_size - 1]]
+    got = eng.iterative_f0_batch(batch, FS, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(got[0], o_if0.iterative_f0_compute(batch[0], FS, **kw), rtol=1e-5, atol=1e-300)
+        np.testing.assert_allclose(got[2], o_if0.iterative_f0_compute(batch[2], FS, **kw), rtol=1e-5, atol=1e-300)
+    assert np.all(got[1] == 0)
 
 
 @pytest.mark.parametrize("frame_size", [1024, 2048, 4096])

@@ -33,6 +33,12 @@ SCRATCH_FREE = [
     "mpx::peakfit_kernel<true>",                      # large batches: samples in LDS, fvec recomputed
     "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
+    # ... and every other instantiation a caller can reach through frame_size / power (iterative_f0.py:22-33); round 3 shipped
+    # these with 96-324 bytes per lane of scratch under a four-waves-per-SIMD limit (if0_split_waves)
+    "mpx::if0_spectrum_split_kernel<8192, false, 0>",
+    "mpx::if0_spectrum_split_kernel<4096, true, 1>", "mpx::if0_spectrum_split_kernel<4096, false, 0>",
+    "mpx::if0_spectrum_split_kernel<2048, true, 1>", "mpx::if0_spectrum_split_kernel<2048, false, 0>",
+    "mpx::if0_spectrum_split_kernel<1024, true, 1>", "mpx::if0_spectrum_split_kernel<1024, false, 0>",
     "mpx::if0_frontend_kernel<false>", "mpx::if0_frontend2_kernel<false>", "mpx::if0_periodicity_kernel",
     "mpx::if0_frontend_kernel<true>", "mpx::if0_frontend2_kernel<true>",     # time slices (MPX_OPT_IF0_WORKSPACE_BYTES)
 ]
@@ -61,6 +67,14 @@ def test_hot_kernels_stay_scratch_free(table):
 def test_known_spills_do_not_grow(table):
     for k, cap in SCRATCH_CEILING.items():
         assert table[k]["scratch"] <= cap, (k, table[k])
+
+
+def test_release_build_has_no_development_only_kernels(table):
+    """if0_spectrum_kernel / if0_spectrum_dif_kernel and the prefetch variants of the split kernel are reachable only through
+    dev_env knobs, which are constants in the release build: they are compiled under MPX_DEV_KNOBS only."""
+    dead = [k for k in table if "if0_spectrum_kernel<" in k or "if0_spectrum_dif_kernel<" in k
+            or ("if0_spectrum_split_kernel<" in k and not (k.endswith("true, 1>") or k.endswith("false, 0>")))]
+    assert not dead, dead
 
 
 def test_occupancy_assumptions(table):
