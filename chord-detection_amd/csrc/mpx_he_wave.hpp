@@ -359,10 +359,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
     __syncthreads();   // the counter
 
 #ifdef HW_TRACE   // timing experiments only: shader-clock stamps of workgroup 0 at the phase boundaries, [wave][frame][16]
+// (scheduling barriers on BOTH sides and a volatile s_memtime: without the first one the compiler let the read float up
+//  over the phase's arithmetic and the per-phase figures were meaningless; frame totals were right)
 #define HW_STAMP(pt)                                                                                                \
     do {                                                                                                            \
-        if (dbg && blockIdx.x == 0 && lane == 0 && nframe < 32)                                                     \
-            reinterpret_cast<long long*>(dbg)[(wave * 32 + nframe) * 16 + (pt)] = (long long)__builtin_amdgcn_s_memtime(); \
+        hw_phase();                                                                                                 \
+        if (dbg && blockIdx.x == 0 && nframe < 32) {                                                                \
+            unsigned long long t_;                                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : : "memory");                           \
+            if (lane == 0) reinterpret_cast<long long*>(dbg)[(wave * 32 + nframe) * 16 + (pt)] = (long long)t_;     \
+        }                                                                                                           \
         hw_phase();                                                                                                 \
     } while (0)
 #else
@@ -512,6 +518,30 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 const char* rd = xbuf + HW_PAIR * (ol >> 1) + 8 * (ol & 1);
 #pragma unroll
                 for (int st = 0; st < 5; ++st) th[st] = theta_lds[32 * st + (ol >> 1)];
+#if defined(HW_ABL_NO_TRANSPOSE)   // ablation (results are garbage): where does a frame's time go?  tests/tools/he_wave_check.hip
+#pragma unroll
+                for (int c = 0; c < 32; ++c) b[c] = z[c];
+                (void)wr;
+                (void)rd;
+#elif defined(HW_ABL_NO_TRANSPOSE_WRITES)
+#pragma unroll
+                for (int c = 0; c < 32; ++c) b[c].x = *reinterpret_cast<const double*>(rd + 16 * c) + z[c].x;
+                wave_lds_fence();
+#pragma unroll
+                for (int c = 0; c < 32; ++c) b[c].y = *reinterpret_cast<const double*>(rd + 16 * c) + z[c].y;
+                wave_lds_fence();
+                (void)wr;
+#elif defined(HW_ABL_NO_TRANSPOSE_READS)
+#pragma unroll
+                for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].x;
+                wave_lds_fence();
+#pragma unroll
+                for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].y;
+                wave_lds_fence();
+#pragma unroll
+                for (int c = 0; c < 32; ++c) b[c] = z[c];
+                (void)rd;
+#else
 #pragma unroll
                 for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].x;
                 wave_lds_fence();
@@ -524,6 +554,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
 #pragma unroll
                 for (int c = 0; c < 32; ++c) b[c].y = *reinterpret_cast<const double*>(rd + 16 * c);
                 wave_lds_fence();
+#endif
             }
             hw_phase();
             HW_STAMP(4);
@@ -555,7 +586,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 wlast = wk_lds[2 * wi + 1] - 1;
                 wweight = ww_lds[wi];
             }
+#ifndef HW_ABL_NO_BINCOPY
             hw_store_rows<K2MASK, 0>(mine, b, false);   // only the rows a window bin or its mirror lives in
+#else
+            mine[0] = b[0].x + b[7].x + b[13].y + b[31].x;
+#endif
             wave_lds_fence();
             {
                 // the registers of the real parts are free: request the next frame.  Unconditionally -- a wave without a
@@ -575,7 +610,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 re[r][3] = xb[sl[r].y >> 16];
             }
             wave_lds_fence();
+#ifndef HW_ABL_NO_BINCOPY
             hw_store_rows<K2MASK, 0>(mine, b, true);
+#else
+            mine[64] = b[1].y + b[9].x + b[21].y + b[30].y;
+#endif
             wave_lds_fence();
             hw_phase();
             HW_STAMP(6);

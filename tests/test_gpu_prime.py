@@ -187,3 +187,33 @@ def test_device_resident_entry_equals_host_entry(eng, clips):
     assert not d_sum.cpu().numpy().any()
     with pytest.raises(Exception):
         eng.prime_multif0_dev(xd.data_ptr(), 100, FS, None)
+
+
+@pytest.mark.parametrize("drop_db", [80, 120, 200])
+def test_paired_frames_with_a_large_level_difference(eng, drop_db):
+    """prime_pers_kernel transforms two consecutive frames of a candidate as a + i b and separates their spectra by
+    conjugate symmetry: the quiet one of a pair carries its loud partner's rounding noise, ~1e-16 of the LOUD frame's
+    magnitudes.  A clip whose second half is 80 / 120 / 200 dB below its first (a decay tail, a fade-out): the quiet frames'
+    arg-max may differ from numpy's per-frame FFT once that noise reaches their own level, but what they add to the clip's
+    chroma is bounded by that noise -- the sums agree with the oracle to 1e-5 relative plus 1e-13 of the largest bin (the
+    bound include/mpx.h states), with both note spellings."""
+    from oracle import prime_multif0 as o_prime
+    rng = np.random.default_rng(drop_db)
+    n = 2 * FS
+    t = np.arange(n) / FS
+    x = np.zeros(n)
+    for f0 in (196.0, 246.94, 329.63):
+        for h in range(1, 6):
+            x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+    x = 0.25 * x + 0.01 * rng.standard_normal(n)
+    env = np.ones(n)
+    env[n // 2:] = 10.0 ** (-drop_db / 20.0)                       # an abrupt drop: pairs straddle it for every candidate
+    env[n // 4:n // 2] = np.linspace(1.0, 10.0 ** (-drop_db / 40.0), n // 2 - n // 4)   # and a ramp: every ratio in between
+    x = (x * env).astype(np.float32)
+    for mode in ("unicode", "ascii"):
+        got = eng.prime_multif0(x, FS, note_names=mode)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = o_prime.prime_compute(x, FS, note_names=mode)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-13 * np.abs(want).max())
+        assert np.abs(want).max() > 0

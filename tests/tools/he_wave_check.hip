@@ -223,11 +223,14 @@ int main(int argc, char** argv) {
             for (int fr = 0; fr + 1 < nf; ++fr) printf(" %lld", tl[(wv * 32 + fr + 1) * 16] - tl[(wv * 32 + fr) * 16]);
             printf(" | last frame ends %lld\n", nf ? tl[(wv * 32 + nf - 1) * 16 + 9] - t0 : 0);
         }
+        // phase durations (clocks) of frames 1 .. 3 of waves 0, 4: 0 window+level-1 | 1 transform A | 2 deferred tail |
+        // 3 (nothing) | 4 transpose | 5 transform B | 6 bin copy + gathers + prefetch issue | 7 split | 9 magnitudes + window maxima
         for (int wv = 0; wv < WAVES; wv += 4)
-            for (int fr = 4; fr < 6; ++fr) {
-                printf("TRACE wave %d frame %d:", wv, fr);
-                for (int pt = 0; pt < 10; ++pt) printf(" %lld", tl[(wv * 32 + fr) * 16 + pt] - t0);
-                printf("\n");
+            for (int fr = 1; fr < 4; ++fr) {
+                const long long* q = &tl[(wv * 32 + fr) * 16];
+                if (!q[0]) continue;
+                printf("PHASES wave %d frame %d: window %lld | fftA %lld | tail %lld | transpose %lld | fftB %lld | bincopy %lld | split %lld | maxima %lld | total %lld\n",
+                       wv, fr, q[1] - q[0], q[2] - q[1], q[3] - q[2], q[4] - q[3], q[5] - q[4], q[6] - q[5], q[7] - q[6], q[9] - q[7], q[9] - q[0]);
             }
     }
 #endif
