@@ -534,8 +534,8 @@ __global__ __launch_bounds__(T) void if0_spectrum_kernel(const double* __restric
 // ------------------------------------------------------------------ periodicity
 struct If0PerArgs {
     const double* ut;   // [F, n]
-    double* ur;         // [F, n] residual spectrum (scratch)
-    double* ud;         // [F, n] detected spectrum (scratch)
+    double* ur;         // [num_slots, n] residual spectrum (scratch of a workgroup)
+    double* ud;         // [num_slots, n] detected spectrum (scratch of a workgroup)
     int n;              // 2*frame_size
     double fs, K;       // K = window_size / fs
     double wsize;       // window_size (frame_size) as a double
@@ -544,6 +544,9 @@ struct If0PerArgs {
     double tau_min, tau_max, tau_prec, epsilon1, epsilon2, gamma;
     double* chroma;     // [F, 12]
     const int* out_row; // frame f of this launch is row out_row[f] of chroma (nullptr: row f)
+    long long num_frames;
+    unsigned* slot_busy;   // [num_slots] 0 = free (all free between launches)
+    int num_slots;
 };
 
 constexpr int PER_T = 256;
@@ -586,11 +589,29 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     __shared__ double bmax[256];  // maxima of the 64-bin blocks of ur (n <= 16384)
     __shared__ int qbest_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long f = blockIdx.x;
     const int n = a.n;
+    // One workgroup per frame, as before -- but the pair of scratch rows (residual and detected spectrum, 2 x 128 KB at the
+    // default frame size) belongs to a SLOT the workgroup takes at its start and gives back at its end, not to the frame:
+    // 2 x (resident workgroups) slots, 0.5 GB, where every frame had its own pair (5 GB per hour of audio: with the
+    // hand-off buffer bounded by time slices this was the next largest workspace, and it went through HBM once per frame).
+    // (A persistent grid with one pair per workgroup measured SLOWER -- 23.8-24.8 against 19.8 ms per hour of audio, with
+    //  static shares and with an atomic frame counter alike -- so the frames stay the hardware's to schedule.)
+    __shared__ int slot_sh;
+    const long long f = blockIdx.x;
+    if (tid == 0) {
+        unsigned s0 = (unsigned)(blockIdx.x * 2654435761u) % (unsigned)a.num_slots;
+        for (;;) {   // a free slot always exists: there are twice as many as workgroups can be resident
+            if (atomicCAS(&a.slot_busy[s0], 0u, 1u) == 0u) break;
+            s0 = s0 + 1 == (unsigned)a.num_slots ? 0u : s0 + 1;
+        }
+        slot_sh = (int)s0;
+    }
+    __syncthreads();
+    const int slot = slot_sh;
+    double* __restrict__ ur = a.ur + (long long)slot * n;
+    double* __restrict__ ud = a.ud + (long long)slot * n;
+    {
     const double* __restrict__ uk = a.ut + f * (long long)n;
-    double* __restrict__ ur = a.ur + f * (long long)n;
-    double* __restrict__ ud = a.ud + f * (long long)n;
     auto build_bmax = [&]() {  // after ur has been (re)written and made visible
         for (int b = wave; b < (n >> 6); b += PER_T / 64) {
             double m = ur[b * 64 + lane];
@@ -801,6 +822,12 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
             }
         }
         for (int i = 0; i < 12; ++i) a.chroma[(a.out_row ? (long long)a.out_row[f] : f) * 12 + i] = chroma[i];
+    }
+    }
+    __syncthreads();   // everybody's last access to the slot's rows
+    if (tid == 0) {
+        __threadfence();
+        atomicExch(&a.slot_busy[slot], 0u);
     }
 }
 
@@ -1650,7 +1677,15 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     const size_t state_bytes = sliced ? (size_t)fe_blocks * 64 * sizeof(double) * (fe_sequential ? IF0_STATE_SEQ : IF0_STATE_PIPE) : 0;
     if (!dev_io && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
-    if ((rc = ensure(ctx, ctx->d_ws1, (size_t)max_slice_frames * n2 * sizeof(double) * 3))) return rc;   // ut | ur | ud
+    // the period search runs ONCE, behind the last slice, on persistent workgroups with a scratch pair each
+    if (!ctx->occupancy.count("if0_periodicity")) {
+        int occ = 0;
+        MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel, PER_T, 0));
+        ctx->occupancy["if0_periodicity"] = occ > 0 ? occ : 1;
+    }
+    const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy["if0_periodicity"]);   // scratch slots
+    (void)max_slice_frames;
+    if ((rc = ensure(ctx, ctx->d_ws1, ((size_t)nframes + 2 * (size_t)per_grid) * n2 * sizeof(double)))) return rc;   // ut | ur | ud
     if (sliced && (rc = ensure(ctx, ctx->d_ws2, state_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + up_frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
                                        tail_groups.size() * sizeof(If0TailGroup) + sl_rows.size() * sizeof(int) + 256))) return rc;
@@ -1674,14 +1709,14 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     if (dev_io || sliced) MPX_HIP(ctx, hipStreamSynchronize(st));   // the tables above are host vectors of this call
     double* yc = (double*)ctx->d_ws0.p;
-    double* ut = (double*)ctx->d_ws1.p;
-    double* ur = ut + (size_t)max_slice_frames * n2;
-    double* ud = ur + (size_t)max_slice_frames * n2;
+    double* ut_all = (double*)ctx->d_ws1.p;              // [F, n2], slice after slice
+    double* ur = ut_all + (size_t)nframes * n2;          // [per_grid, n2]
+    double* ud = ur + (size_t)per_grid * n2;
     int lg_nf = 0;
     while ((1 << lg_nf) < NF) ++lg_nf;
     if (blue) lg_nf = blue_lgp;   // the front end's "frame" is the chunk
     If0PerArgs a;
-    a.ut = ut;
+    a.ut = ut_all;
     a.ur = ur;
     a.ud = ud;
     a.n = n2;
@@ -1713,6 +1748,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         MPX_HIP(ctx, hipGetLastError());
         if (nf_s == 0) continue;
         const If0Frame* d_fr = d_frames + sl_off[(size_t)sidx];
+        double* ut = ut_all + (size_t)sl_off[(size_t)sidx] * n2;
         prof_mark(ctx, st, "if0_spectrum_kernel");
         if (blue) rc = if0_spectrum_blue_launch(ctx, yc, d_fr, nf_s, NF, p.channels, p.power, plan, ut, st);
         else if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
@@ -1735,16 +1771,23 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                 }
             }
         }
-        a.out_row = sliced ? d_rows + sl_off[(size_t)sidx] : nullptr;
-        // (Measured and rejected at the end of round 3: the period search of one group of 2048 frames on a second stream next to
-        //  the summary spectra of the next group -- it fits beside them on every CU, but the whole-hour call went from 126.5 to
-        //  135 ms: its re-reads of the spectrum rows (6.9 x their bytes, through L2) slow the LDS/L2-bound spectra down by more
-        //  than its own 25 ms.)
-        prof_mark(ctx, st, "if0_periodicity_kernel");
-        hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nf_s), dim3(PER_T), 0, st, a);
-        prof_mark(ctx, st, nullptr);
-        MPX_HIP(ctx, hipGetLastError());
     }
+    a.out_row = sliced ? d_rows : nullptr;
+    a.num_frames = nframes;
+    if (ctx->d_queue.bytes < (size_t)per_grid * sizeof(unsigned)) {
+        if ((rc = ensure(ctx, ctx->d_queue, (size_t)per_grid * sizeof(unsigned) + 4096))) return rc;
+        MPX_HIP(ctx, hipMemsetAsync(ctx->d_queue.p, 0, ctx->d_queue.bytes, st));   // every launch leaves its slots free
+    }
+    a.slot_busy = (unsigned*)ctx->d_queue.p;
+    a.num_slots = (int)per_grid;
+    // (Measured and rejected at the end of round 3: the period search of one group of 2048 frames on a second stream next to
+    //  the summary spectra of the next group -- it fits beside them on every CU, but the whole-hour call went from 126.5 to
+    //  135 ms: its re-reads of the spectrum rows (6.9 x their bytes, through L2) slow the LDS/L2-bound spectra down by more
+    //  than its own 25 ms.)
+    prof_mark(ctx, st, "if0_periodicity_kernel");
+    hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    prof_mark(ctx, st, nullptr);
+    MPX_HIP(ctx, hipGetLastError());
     if (dev_io) {
         if (chroma_sums) return segment_sum(ctx, a.chroma, (const long long*)ctx->d_offsets.p, num_clips, nframes, chroma_sums, st);
         return MPX_OK;
