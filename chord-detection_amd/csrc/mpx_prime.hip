@@ -228,11 +228,11 @@ __device__ __forceinline__ double prime_wave_max(double v) {
     return fmax(fmax(prime_readlane(v, 0), prime_readlane(v, 16)), fmax(prime_readlane(v, 32), prime_readlane(v, 48)));
 }
 
-template <int L, bool CLIPS>
+template <int L>
 __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restrict__ sig, const PrimeItem* __restrict__ items,
                                                            const PrimeWork* __restrict__ work, const PrimeCand* __restrict__ cands,
                                                            int runs, int elim, int note_names, int* out_pc, double* out_val,
-                                                           int uniform_clips, long long clip_len, long long clip_slots, int clip_cands) {
+                                                           int uniform_clips, long long clip_len, long long clip_slots) {
     constexpr int T = L / 8, NW = T / 64;
     static_assert(T % 64 == 0, "whole waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -242,26 +242,11 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
     __shared__ int red_i[2][2][NW];
     __shared__ int nonzero[2][2];        // [parity][frame]: some sample of the frame is not zero
     const int tid = threadIdx.x;
-    if (tid < 4) nonzero[tid >> 1][tid & 1] = 0;
-    // CLIP MODE (clip_cands > 0; batches of equal-length clips that fill the machine several times over): a workgroup takes
-    // whole clips -- blockIdx.x, blockIdx.x + gridDim.x, ... -- and walks ALL candidates of its chirp-z class over each one,
-    // reloading the candidate's tables at every switch (a few dozen loads per thread, L2 hits, against 16-60 frame pairs
-    // of work).  A clip is then read from HBM by ONE workgroup and re-read from that CU's caches by the other candidates:
-    // until round 4 every candidate's workgroups swept all clips on their own, and the twelve sweeps of a class met in
-    // eight different L2s (FETCH_SIZE 4.3-4.7 x the clips per launch: profiles/r3/pmc_after.json).  The shares are equal by
-    // construction (every workgroup does the same work per clip) where the per-candidate shares were rounded to whole
-    // workgroups.  Otherwise (clip_cands == 0): one candidate per workgroup and a strided walk over its items, as before.
-    const int nseg = CLIPS ? clip_cands : 1;   // (CLIPS: compile-time, the strided instantiation keeps round 3's register allocation)
-    const long long clip_first = CLIPS ? (long long)blockIdx.x : 0, clip_end = CLIPS ? (long long)uniform_clips : 1,
-                    clip_step = CLIPS ? (long long)gridDim.x : 1;
-    const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(cands[work[CLIPS ? 0 : blockIdx.x].cand].tw, tid);   // W_L: the class's
-    int par = 0, fpar = 0;   // parity of the argmax slots (per round) and of the zero-frame flags (per item)
-    for (long long clip = clip_first; clip < clip_end; clip += clip_step)
-    for (int seg_i = 0; seg_i < nseg; ++seg_i) {
-    const PrimeWork wk = work[CLIPS ? seg_i : (int)blockIdx.x];
+    const PrimeWork wk = work[blockIdx.x];
     const PrimeCand c = cands[wk.cand];
     const int N = c.N, half = c.half;
-    // what depends on the candidate only, once per workgroup (clip mode: once per clip and candidate)
+    if (tid < 4) nonzero[tid >> 1][tid & 1] = 0;
+    // what depends on the candidate only, once per workgroup
     cx<double> wc[8], bh[8], oc[2];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -283,17 +268,17 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
             oc[r] = {ch.x, -ch.y};
         }
     }
-    const long long total = CLIPS ? (clip + 1) * wk.count : (uniform_clips ? (long long)wk.count * uniform_clips : wk.count);
-    const long long istep = CLIPS ? 1 : wk.workers;
+    const DifTwiddles<L, double> twd = dif_load_twiddles<L, double>(c.tw, tid);
+    const long long total = uniform_clips ? (long long)wk.count * uniform_clips : wk.count;
     __syncthreads();
 
     auto item_at = [&](long long i) -> PrimeItem {
         PrimeItem it;
         if (uniform_clips) {
-            const long long cl = i / wk.count;
-            it = items[wk.item0 + (int)(i - cl * wk.count)];
-            it.start += cl * clip_len;
-            it.slot += cl * clip_slots;
+            const long long clip = i / wk.count;
+            it = items[wk.item0 + (int)(i - clip * wk.count)];
+            it.start += clip * clip_len;
+            it.slot += clip * clip_slots;
         } else {
             it = items[wk.item0 + i];
         }
@@ -310,12 +295,13 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
         }
     };
 
-    long long i = CLIPS ? clip * wk.count : wk.worker;
-    if (i >= total) continue;   // (uniform over the workgroup)
+    long long i = wk.worker;
+    if (i >= total) return;
     PrimeItem it = item_at(i);
     float xa[8], xb[8];
     fetch(it, xa, xb);
-    for (; i < total; i += istep) {
+    int par = 0, fpar = 0;   // parity of the argmax slots (per round) and of the zero-frame flags (per item)
+    for (; i < total; i += wk.workers) {
         int t = tid;
         asm volatile("" : "+v"(t));   // addresses are rebuilt per item: hoisted, they cost more registers than they save
         // TWO real frames per transform: u = (a + i b) x window x conj(chirp); their spectra are separated afterwards by
@@ -334,7 +320,7 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
         if (nza) nonzero[fpar][0] = 1;
         if (nzb) nonzero[fpar][1] = 1;
         // the next item's samples travel under this item's transforms
-        const long long inext = i + istep;
+        const long long inext = i + wk.workers;
         const PrimeItem itn = item_at(inext < total ? inext : i);
         fetch(itn, xa, xb);
         dif_fft_keep_last<L, double>(buf, twd, regs, t);     // (one workgroup barrier inside: the flags are visible after it)
@@ -432,8 +418,6 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
         }
         it = itn;
     }
-    __syncthreads();   // clip mode: the last item's reads of the reduction slots before the next candidate's first round
-    }   // candidates of the class (clip mode) / the workgroup's one candidate
 }
 
 // one workgroup per clip: chroma[clip] = sum over its item slots, in slot order per pitch class
@@ -658,18 +642,13 @@ static void prime_launch(const float* d_sig, const PrimeItem* d_items, size_t co
 template <int L>
 static int prime_pers_launch(mpx_ctx* ctx, const float* d_sig, const PrimeItem* d_items, const PrimeWork* d_work, size_t groups,
                              const PrimeCand* d_cands, int runs, int elim, int note_names, int* d_pc, double* d_val, hipStream_t st,
-                             int uniform_clips, long long clip_len, long long clip_slots, int clip_cands) {
+                             int uniform_clips, long long clip_len, long long clip_slots) {
     if (!groups) return MPX_OK;
     const size_t lds = sizeof(cx<double>) * L;
-    auto kern = prime_pers_kernel<L, false>;
-    if constexpr (L <= 2048) {   // (the 4096-point class in clip mode needs 28 bytes per lane of scratch: it keeps the strided walk)
-        if (clip_cands) kern = prime_pers_kernel<L, true>;
-    } else if (clip_cands) {
-        return set_error(ctx, MPX_EINVAL, "prime-multiF0: clip mode is not built for %d-point transforms", L);
-    }
+    auto kern = prime_pers_kernel<L>;
     if (lds > 48 * 1024) MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(L / 8), lds, st, d_sig, d_items, d_work, d_cands, runs, elim, note_names,
-                       d_pc, d_val, uniform_clips, clip_len, clip_slots, clip_cands);
+                       d_pc, d_val, uniform_clips, clip_len, clip_slots);
     return MPX_OK;
 }
 // resident workgroups of prime_pers_kernel<L> on the whole device (cached per context)
@@ -679,7 +658,7 @@ static int prime_pers_slots(mpx_ctx* ctx) {
     auto it = ctx->occupancy.find(key);
     if (it != ctx->occupancy.end()) return it->second;
     const size_t lds = sizeof(cx<double>) * L;
-    auto kern = prime_pers_kernel<L, false>;
+    auto kern = prime_pers_kernel<L>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, L / 8, lds) != hipSuccess || occ < 1) occ = 1;
@@ -779,23 +758,10 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     // proportion to their items (equal cost inside a class), so that every workgroup walks about the same number of frames
     std::vector<PrimeWork> work[3];
     const int slots_of[3] = {prime_pers_slots<1024>(ctx), prime_pers_slots<2048>(ctx), prime_pers_slots<4096>(ctx)};
-    // clip mode (prime_pers_kernel): equal-length clips, at least one per resident workgroup of the class; the grid is the
-    // largest one that gives every workgroup the same number of clips (4096 clips on 1024 slots: 4 each; 5000: 1000 x 5)
-    int clip_cands[3] = {0, 0, 0};
-    size_t clip_grid[3] = {0, 0, 0};
     for (int cls = 0; cls < 3; ++cls) {
         const long long mult = uniform ? num_clips : 1;
         const long long class_items = (long long)items[cls].size() * mult;
         if (!class_items) continue;
-        if (uniform && cls < 2 && num_clips >= slots_of[cls]) {
-            for (size_t k = 0; k < plan->cands.size(); ++k)
-                if (class_of(plan->cands[k].L) == cls && !by_cand[k].empty())
-                    work[cls].push_back(PrimeWork{(int)k, 0, 1, cand_item0[k], (int)by_cand[k].size()});
-            clip_cands[cls] = (int)work[cls].size();
-            const long long per = (num_clips + slots_of[cls] - 1) / slots_of[cls];
-            clip_grid[cls] = (size_t)((num_clips + per - 1) / per);
-            continue;
-        }
         for (size_t k = 0; k < plan->cands.size(); ++k) {
             if (class_of(plan->cands[k].L) != cls || by_cand[k].empty()) continue;
             const long long mine = (long long)by_cand[k].size() * mult;
@@ -825,12 +791,12 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         const int uclips = uniform ? num_clips : 0;
         if (cls < 3) {
             const PrimeWork* dw = (const PrimeWork*)((char*)ctx->d_ws1.p + woff);
-            const size_t groups = clip_cands[cls] ? clip_grid[cls] : work[cls].size();
-            if (cls == 0) rc = prime_pers_launch<1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots, clip_cands[cls]);
-            if (cls == 1) rc = prime_pers_launch<2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots, clip_cands[cls]);
-            if (cls == 2) rc = prime_pers_launch<4096>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots, clip_cands[cls]);
+            const size_t groups = work[cls].size();
+            if (cls == 0) rc = prime_pers_launch<1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 1) rc = prime_pers_launch<2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 2) rc = prime_pers_launch<4096>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
             if (rc) return rc;
-            woff += work[cls].size() * sizeof(PrimeWork);
+            woff += groups * sizeof(PrimeWork);
         } else {   // chirp-z on 8192 points (frames above 3277 samples: input rates above 53 kHz): a workgroup per item, Stockham engine
             const int per_clip = uniform ? (int)items[cls].size() : 0;
             const size_t count = uniform ? items[cls].size() * (size_t)num_clips : items[cls].size();

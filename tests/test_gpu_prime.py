@@ -217,34 +217,3 @@ def test_paired_frames_with_a_large_level_difference(eng, drop_db):
             want = o_prime.prime_compute(x, FS, note_names=mode)
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-13 * np.abs(want).max())
         assert np.abs(want).max() > 0
-
-
-def test_clip_mode_equals_the_strided_walk(eng):
-    """A batch of equal-length clips with at least one clip per resident workgroup runs in CLIP MODE (a workgroup takes
-    whole clips and walks every candidate of its chirp-z class over each: prime_pers_kernel<L, true>); the same clips with
-    one clip of another length appended are a ragged batch and take the strided per-candidate walk.  Same arithmetic per
-    frame pair: bit-identical rows; and the oracle on three of them."""
-    from oracle import prime_multif0 as o_prime
-    rng = np.random.default_rng(12)
-    n, clips = 6000, 1100                                           # 1100 > the 1024 resident workgroups of the 1024-point class
-    t = np.arange(n) / FS
-    base = []
-    for _ in range(9):
-        x = np.zeros(n)
-        for _ in range(3):
-            f0 = 440.0 * 2.0 ** ((int(rng.integers(40, 80)) - 69) / 12.0)
-            for h in range(1, 5):
-                x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
-        base.append((0.2 * x + 0.01 * rng.standard_normal(n)).astype(np.float32))
-    batch = np.stack([base[i % 9] for i in range(clips)])
-    eng.profile_begin()
-    got = eng.prime_multif0_batch(batch, FS)
-    assert "prime_kernel" in eng.profile_end()
-    ragged = [batch[i] for i in range(clips)] + [base[0][:5000]]
-    want = eng.prime_multif0_batch(ragged, FS)
-    np.testing.assert_array_equal(got, want[:clips])
-    np.testing.assert_array_equal(got[:9], got[9:18])
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        for i in (0, 4, 8):
-            np.testing.assert_allclose(got[i], o_prime.prime_compute(base[i], FS), rtol=RTOL, atol=1e-9)

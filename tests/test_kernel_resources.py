@@ -31,8 +31,7 @@ SCRATCH_FREE = [
     "mpx::bandsplit_kernel<false>", "mpx::bandsplit_kernel<true>",
     "mpx::coopfit_kernel", "mpx::pv_enhance_kernel<true, 2>", "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
     "mpx::peakfit_kernel<true>",                      # large batches: samples in LDS, fvec recomputed
-    "mpx::prime_pers_kernel<1024, false>", "mpx::prime_pers_kernel<2048, false>", "mpx::prime_pers_kernel<4096, false>",
-    "mpx::prime_pers_kernel<1024, true>", "mpx::prime_pers_kernel<2048, true>",   # clip mode (a workgroup walks all candidates over its clips)
+    "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
     # ... and every other instantiation a caller can reach through frame_size / power (iterative_f0.py:22-33); round 3 shipped
     # these with 96-324 bytes per lane of scratch under a four-waves-per-SIMD limit (if0_split_waves)
@@ -53,8 +52,7 @@ OCCUPANCY = {
     "mpx::he_wave_kernel<8, 4, false, true, 2146439166u>": 2,
     "mpx::sacf_pfa_kernel<2>": 4,
     "mpx::if0_spectrum_split_kernel<8192, true, 1>": 4,
-    "mpx::prime_pers_kernel<1024, false>": 2,
-    "mpx::prime_pers_kernel<1024, true>": 2,
+    "mpx::prime_pers_kernel<1024>": 2,
     "mpx::peakfit_kernel<true>": 2,
 }
 
