@@ -588,6 +588,7 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     __shared__ double wts[128];   // [interval * 64 + harmonic]: m fs / tau_up + epsilon2
     __shared__ double bmax[256];  // maxima of the 64-bin blocks of ur (n <= 16384)
     __shared__ int qbest_sh;
+    __shared__ unsigned char dirty[256];   // 64-bin blocks of the residual a cancellation step has changed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n;
     // One workgroup per frame, as before -- but the pair of scratch rows (residual and detected spectrum, 2 x 128 KB at the
@@ -612,25 +613,28 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     double* __restrict__ ud = a.ud + (long long)slot * n;
     {
     const double* __restrict__ uk = a.ut + f * (long long)n;
-    auto build_bmax = [&]() {  // after ur has been (re)written and made visible
-        for (int b = wave; b < (n >> 6); b += PER_T / 64) {
-            double m = ur[b * 64 + lane];
+    // residual = spectrum, detected = 0, and the block maxima of the residual in the same pass (a wave copies whole 64-bin
+    // blocks, so it holds each block's maximum: until round 4 build_bmax read the row back)
+    for (int i0 = wave * 64; i0 < n; i0 += PER_T) {
+        const int i = i0 + lane;
+        const bool ok = i < n;
+        double m = ok ? uk[i] : -INFINITY;
+        if (ok) {
+            ur[i] = m;
+            ud[i] = 0.0;
+        }
+        if (i0 + 64 <= n) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const double o = __shfl_xor(m, off);
                 m = o > m ? o : m;
             }
-            if (lane == 0) bmax[b] = m;
+            if (lane == 0) bmax[i0 >> 6] = m;
         }
-        __syncthreads();
-    };
-    for (int i = tid; i < n; i += PER_T) {
-        ur[i] = uk[i];
-        ud[i] = 0.0;
     }
+    if (tid < 256) dirty[tid] = 0;
     __syncthreads();
     __threadfence_block();
-    build_bmax();
 
     // periodicity.py:144-163, the range maxima of TWO intervals (a halving step of min_search evaluates the new interval
     // and the best one so far): one wave per harmonic m and both intervals per pass; the loads -- the ragged ends from ur,
@@ -779,30 +783,65 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
         const int topm = (int)(tau * (a.fs / a.wsize) * n);  // periodicity.py:78
         const double srovertau = a.fs / tau;
         const double weight = srovertau + a.epsilon1;
-        for (int m = 1 + tid; m < topm; m += PER_T) {
-            const double partialK = m * a.K / tau + 0.5;
-            if (partialK <= n) {
-                const int ip = (int)partialK;
-                if (ip < n) {  // the reference would raise IndexError at exactly n; unreachable with the defaults
-                    double urw = ur[ip];
-                    urw *= weight / (m * srovertau + a.epsilon2);
-                    int lowk = (int)(partialK - 4);
-                    if (lowk < 0) lowk = 0;
-                    int highk = (int)(partialK + 4);
-                    if (highk > n) highk = n;
-                    for (int j = lowk; j <= highk && j < n; ++j) ud[j] += IF0_HAMMING9[(int)(j - partialK + 4)] * urw;
+        // The 9-bin windows of neighbouring partials are m K / tau bins apart: below nine bins (f0 under ~48 Hz at the default
+        // frame size) they overlap, and two threads adding into one bin would race.  Wave 0 then takes all partials alone:
+        // its lanes' read-modify-writes of one bin fall into different iterations of the window loop, which a wave issues
+        // in order.  (Until round 4 all four waves scattered in every case: a lost update at m = 64 k was possible.)
+        const bool overlap = a.K / tau < 9.0;   // uniform
+        const int mstep = overlap ? 64 : PER_T;
+        if (!overlap || wave == 0) {
+            for (int m = 1 + (overlap ? lane : tid); m < topm; m += mstep) {
+                const double partialK = m * a.K / tau + 0.5;
+                if (partialK <= n) {
+                    const int ip = (int)partialK;
+                    if (ip < n) {  // the reference would raise IndexError at exactly n; unreachable with the defaults
+                        double urw = ur[ip];
+                        urw *= weight / (m * srovertau + a.epsilon2);
+                        int lowk = (int)(partialK - 4);
+                        if (lowk < 0) lowk = 0;
+                        int highk = (int)(partialK + 4);
+                        if (highk > n) highk = n;
+                        for (int j = lowk; j <= highk && j < n; ++j) ud[j] += IF0_HAMMING9[(int)(j - partialK + 4)] * urw;
+                    }
                 }
             }
         }
         __syncthreads();
         __threadfence_block();
-        for (int i = tid; i < n; i += PER_T) {
-            const double d = uk[i] - 1.0 * ud[i];  // cancellation_weight = 1.0
-            ur[i] = d > 0.0 ? d : 0.0;
+        // residual = max(spectrum - detected, 0) changes only where `detected` just did: the same windows again (a bin two
+        // windows share is written twice with one value), and the block maxima of the blocks they touch.  Until round 4 this
+        // was a pass over the whole row (read two rows, write one) and a second one for the maxima -- per voice; the rows
+        // live behind the L2 (a CU's four workgroups hold 1.5 MB of them), and the kernel waited 76 % of its cycles.
+        for (int m = 1 + tid; m < topm; m += PER_T) {
+            const double partialK = m * a.K / tau + 0.5;
+            if (partialK <= n && (int)partialK < n) {
+                int lowk = (int)(partialK - 4);
+                if (lowk < 0) lowk = 0;
+                int highk = (int)(partialK + 4);
+                if (highk > n) highk = n;
+                for (int j = lowk; j <= highk && j < n; ++j) {
+                    const double d = uk[j] - 1.0 * ud[j];  // cancellation_weight = 1.0
+                    ur[j] = d > 0.0 ? d : 0.0;
+                    dirty[j >> 6] = 1;   // (bins past the last whole block: no block maximum to refresh; index <= 255 for n <= 16384)
+                }
+            }
         }
         __syncthreads();
         __threadfence_block();
-        build_bmax();
+        for (int b = wave; b < (n >> 6); b += PER_T / 64) {
+            if (!dirty[b]) continue;   // uniform over the wave
+            double m = ur[b * 64 + lane];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double o = __shfl_xor(m, off);
+                m = o > m ? o : m;
+            }
+            if (lane == 0) {
+                bmax[b] = m;
+                dirty[b] = 0;
+            }
+        }
+        __syncthreads();
     }
     if (tid == 0) {
         double chroma[12];
