@@ -11,7 +11,7 @@ from oracle import iterative_f0 as o
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 eng = cd.get_engine(0)
-bad = 0
+bad = skipped = 0
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for case in range(cases):
@@ -28,13 +28,18 @@ with warnings.catch_warnings():
                 x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28))
         x = (0.3 * x / max(np.abs(x).max(), 1e-9) + 1e-3 * rng.standard_normal(n)).astype(np.float32)
         kw = dict(frame_size=NF, power=power, channels=ch)
+        try:
+            wper, wut = o.iterative_f0_frames(x, fs, **kw)
+        except (IndexError, ValueError) as exc:   # the reference itself raises for this input (tiny frames: a partial's window
+            skipped += 1                           # reaches bin n, periodicity.py:93-96): nothing to compare with
+            print("skipped (the reference raises %s): frame %d channels %d n %d" % (type(exc).__name__, NF, ch, n))
+            continue
         ut = eng.iterative_f0_spectra(x, fs, **kw)
         tot, per = eng.iterative_f0(x, fs, return_frames=True, **kw)
-        wper, wut = o.iterative_f0_frames(x, fs, **kw)
         ok1 = np.allclose(ut, wut, rtol=1e-9, atol=1e-9 * np.abs(wut).max())
         ok2 = np.allclose(per, wper, rtol=1e-5, atol=1e-300)
         if not (ok1 and ok2):
             bad += 1
             print("MISMATCH", case, NF, ch, power, n, "spectra", ok1, "chroma", ok2)
-print("cases %d, mismatches %d" % (cases, bad))
+print("cases %d, mismatches %d, skipped because the reference raises %d" % (cases, bad, skipped))
 sys.exit(1 if bad else 0)
