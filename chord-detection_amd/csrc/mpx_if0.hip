@@ -85,7 +85,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                                                   double* __restrict__ yc, const int* __restrict__ tail_list,
                                                   const If0TailGroup* __restrict__ tail_groups,
                                                   double (*tile)[IF0_TW + 1], long long* rowbase, long long ck_u, int ch0_u,
-                                                  int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl) {
+                                                  int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl, const int warm_cap) {
 #pragma clang fp contract(off)
     // One wave per (chunk, group of 64 channels), one lane per channel; the channels % 64 left over (6 of the default
     // 70) would fill a wave to 9 %, so the leftovers of up to 64 / (channels % 64) chunks of equal length and run-in
@@ -93,7 +93,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
     // through an LDS tile [lane][16 samples] so that the buffer can be [chunk][channel][t] -- every channel's
     // samples contiguous for the spectrum kernel -- with 128-byte row segments per store instead of 8-byte ones
     const int lane = threadIdx.x;
-    const int full = channels >> 6, nt = channels & 63;
+    const int nt = channels & 63;
     long long ck;
     int ch, ch0 = 0;
     bool active = true;
@@ -105,10 +105,11 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         const int sub = lane / nt;
         active = sub < g.count;
         ck = tail_list[g.first + (active ? sub : 0)];   // idle lanes shadow the first chunk (results discarded)
-        ch = 64 * full + lane % nt;
+        ch = lane % nt;                                  // the leftover channels are the FIRST channels % 64 (if0_run_host)
     }
     const If0Chunk c = chunks[ck];
-    const int c_warm = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
+    const int c_warm_all = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
+    const int c_warm = c_warm_all < warm_cap ? c_warm_all : warm_cap;   // the leftover channels' own (shorter) run-in
     const int c_len = TAIL ? __builtin_amdgcn_readfirstlane(c.len) : c.len;
     const If0ChanCoef k = coefs[ch];
     // the chunk's block of the output buffer: [frame of the chunk][channel][frame_size] (see If0Chunk)
@@ -284,10 +285,10 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
                                                       int channels, const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
                                                       double* __restrict__ yc, const int* __restrict__ tail_list,
                                                       double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
-                                                      int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl) {
+                                                      int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl, const int warm_cap) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x;
-    const int full = channels >> 6, nt = channels & 63;
+    const int nt = channels & 63;
     long long ck;
     int ch, ch0 = 0;
     bool active = true;
@@ -299,10 +300,11 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         const int sub = lane / nt;
         active = sub < g.count;
         ck = tail_list[g.first + (active ? sub : 0)];
-        ch = 64 * full + lane % nt;
+        ch = lane % nt;
     }
     const If0Chunk c = chunks[ck];
-    const int c_warm = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
+    const int c_warm_all = TAIL ? __builtin_amdgcn_readfirstlane(c.warm) : c.warm;
+    const int c_warm = c_warm_all < warm_cap ? c_warm_all : warm_cap;
     const int c_len = TAIL ? __builtin_amdgcn_readfirstlane(c.len) : c.len;
     const If0ChanCoef k = coefs[ch];
     if (TAIL) rowbase[lane] = active ? c.yc_row0 * channels + ((long long)ch << lg_nf) : -1;
@@ -415,22 +417,22 @@ template <bool SLICED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void if0_frontend2_kernel(
     const float* __restrict__ sig, const If0Chunk* __restrict__ chunks, long long num_chunks, int channels,
     const If0ChanCoef* __restrict__ coefs, If0Wfir wf, double* __restrict__ yc, const int* __restrict__ tail_list,
-    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf, If0Slice sl) {
+    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf, If0Slice sl, int warm_tail) {
     __shared__ double tile[64][17];
     __shared__ long long rowbase[64];
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
-        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (int)(b % full) * 64, 64, g, lg_nf, sl);
+        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (channels & 63) + (int)(b % full) * 64, 64, g, lg_nf, sl, 0x7fffffff);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)
-        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 64 * full,
-                                     channels & 63, g, lg_nf, sl);
+        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 0,
+                                     channels & 63, g, lg_nf, sl, warm_tail);
     else
-        if0_frontend_seq_body<true, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl);
+        if0_frontend_seq_body<true, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl, warm_tail);
 }
 
 template <bool SLICED>
@@ -439,27 +441,30 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc, const int* __restrict__ tail_list,
                                                           const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf,
-                                                          If0Slice sl) {
+                                                          If0Slice sl, int warm_tail) {
     __shared__ double tile[64][IF0_TW + 1];
     __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
     // The waves of leftover channels come FIRST in the grid: they are the slower ones per step (per-lane streams), and a
     // launch that needs more than one round of waves (1024 two-second clips: 1127 waves on 1024 one-wave SIMDs) should
-    // end on the fast kind.
+    // end on the fast kind.  Round 4: the leftover channels are the FIRST channels % 64 of the bank, not the last: quirk A.1
+    // makes the resonators' pole radius grow with the channel frequency, so the low channels forget their start within
+    // 8192 samples (their low-pass is the slowest pole there) where the top channels need 40 960 -- the leftover waves, 13 %
+    // slower per step, no longer carry the longest run-in as well and stopped being the ones a launch waits for.
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
         if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 b / full, (int)(b % full) * 64, 64, g, lg_nf, sl);
+                                 b / full, (channels & 63) + (int)(b % full) * 64, 64, g, lg_nf, sl, 0x7fffffff);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
         if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 tail_list[g.first], 64 * full, channels & 63, g, lg_nf, sl);
+                                 tail_list[g.first], 0, channels & 63, g, lg_nf, sl, warm_tail);
     else
         if0_frontend_body<true, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
-                                0, g, lg_nf, sl);
+                                0, g, lg_nf, sl, warm_tail);
 }
 
 // ------------------------------------------------------------------ spectrum
@@ -902,9 +907,15 @@ static int if0_reg_freq(int H, int t, int e) {
 // through the rectifier).  (Rounds 1-2 bounded the ABSOLUTE envelope, rho^W W^3 <= 1e-15, which ignores the 1e-12 gain
 // of the four sections and asked for 65536 samples: a third more front-end work per chunk.)
 // 0 when the chain is too slow for IF0_WARMUP_MAX (or unstable).
+// (c0, c1, min_w: the same for the channels [c0, c1) alone -- the wave of leftover channels has its own run-in, see
+//  if0_run_host -- with a floor of min_w samples instead of IF0_WARMUP)
+static long long if0_warmup_range(int fs, const mpx_if0_params& p, double* rho_out, int c0, int c1, long long min_w);
 static long long if0_warmup(int fs, const mpx_if0_params& p, double* rho_out) {
+    return if0_warmup_range(fs, p, rho_out, 0, p.channels, IF0_WARMUP);
+}
+static long long if0_warmup_range(int fs, const mpx_if0_params& p, double* rho_out, int c0, int c1, long long min_w) {
     double rho = std::fabs(1.0674 * std::sqrt((2.0 / M_PI) * std::atan(0.06583 * fs / 1000.0)) - 0.1916);
-    for (int c = 0; c < p.channels; ++c) {
+    for (int c = c0; c < c1; ++c) {
         const double fc = 229 * (std::pow(10.0, (p.zeta1 * c + p.zeta0) / 21.4) - 1);
         const double A = std::exp(-(3.0 / 4) * M_PI / (fc * std::sqrt(std::pow(2.0, 1.0 / 4) - 1)));   // quirk A.1: "fs" is fc
         const double kk = std::tan(M_PI * fc / fs);
@@ -913,7 +924,7 @@ static long long if0_warmup(int fs, const mpx_if0_params& p, double* rho_out) {
     }
     if (rho_out) *rho_out = rho;
     if (!(rho < 1.0)) return 0;
-    for (long long w = IF0_WARMUP; w <= IF0_WARMUP_MAX; w += 8192) {
+    for (long long w = min_w; w <= IF0_WARMUP_MAX; w += 8192) {
         const double u = (double)w * (1.0 - rho);
         if (-u + std::log((u * u * u + 3.0 * u * u + 6.0 * u + 6.0) / 6.0) <= std::log(1e-13)) return w;
     }
@@ -1496,6 +1507,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if (rc) return rc;
     double rho = 0.0;
     const long long warmup = if0_warmup(fs, p, &rho);
+    // run-in of the waves of leftover channels (channels 0 .. channels % 64 - 1): their own slowest pole, floor 8192 samples
+    long long warm_tail = (p.channels & 63) ? if0_warmup_range(fs, p, nullptr, 0, p.channels & 63, 8192) : warmup;
+    if (!warm_tail || warm_tail > warmup) warm_tail = warmup;
     if (!warmup)
         return set_error(ctx, MPX_EINVAL, "iterative F0: the slowest pole of the filter chain has radius %.9f; chunks and time "
                          "shards start from zero state and would need more than %lld samples of run-in", rho, IF0_WARMUP_MAX);
@@ -1624,7 +1638,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         for (long long i = 0; i < nchunks; ++i) {
             if (tail_groups.empty() || tail_groups.back().count == per_wave ||
                 chunks[(size_t)tail_list[(size_t)tail_groups.back().first]].len != chunks[(size_t)i].len ||
-                chunks[(size_t)tail_list[(size_t)tail_groups.back().first]].warm != chunks[(size_t)i].warm)
+                std::min<long long>(chunks[(size_t)tail_list[(size_t)tail_groups.back().first]].warm, warm_tail) !=
+                    std::min<long long>(chunks[(size_t)i].warm, warm_tail))
                 tail_groups.push_back({(int)tail_list.size(), 0});
             tail_list.push_back((int)i);
             ++tail_groups.back().count;
@@ -1783,7 +1798,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         auto fe_kernel = !fe_sequential ? (sliced ? if0_frontend_kernel<true> : if0_frontend_kernel<false>)
                                         : (sliced ? if0_frontend2_kernel<true> : if0_frontend2_kernel<false>);
         hipLaunchKernelGGL(fe_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st, d_in, d_chunks, nchunks, p.channels,
-                           plan.d_coefs, plan.wf, yc, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl);
+                           plan.d_coefs, plan.wf, yc, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl, (int)warm_tail);
         MPX_HIP(ctx, hipGetLastError());
         if (nf_s == 0) continue;
         const If0Frame* d_fr = d_frames + sl_off[(size_t)sidx];
