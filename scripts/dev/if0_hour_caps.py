@@ -6,6 +6,7 @@ import numpy as np, torch
 import chord_detection_amd as cd
 from chord_detection_amd import stream
 fs, secs = 44100, 3600
+CH = int(os.environ.get("IF0_CHANNELS", "70"))   # e.g. 64: no waves of leftover channels
 x = stream.synth_stream(0, secs * fs, fs, "cuda:0")
 torch.cuda.synchronize(); torch.cuda.empty_cache()
 ref = None
@@ -19,7 +20,7 @@ for gib in [float(a) for a in (sys.argv[1:] or ["4", "8", "16", "32", "90"])]:
         if rep == 3:
             eng.profile_begin()
         t0 = time.perf_counter()
-        eng.iterative_f0_dev(x.data_ptr(), x.numel(), fs, d_frames.data_ptr(), None, frame_size=8192)
+        eng.iterative_f0_dev(x.data_ptr(), x.numel(), fs, d_frames.data_ptr(), None, frame_size=8192, channels=CH)
         eng.synchronize()
         walls.append(time.perf_counter() - t0)
     prof = eng.profile_end()

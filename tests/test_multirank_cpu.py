@@ -108,3 +108,30 @@ def test_run_stream_script_two_ranks():
     assert one.returncode == 0, one.stderr[-3000:]
     s = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
     assert s["n_gpus"] == 1 and s["chroma"] == d["chroma"] and s["key"] == d["key"]   # sharded == unsharded
+
+
+def test_compact_record_of_a_full_gpu_record_fits_the_driver():
+    """bench.compact_record on a REAL full record (profiles/r4/bench_plain_full.json: every workload, every roofline, every
+    CPU leg -- 24 KB) gives the line the driver parses: under 6000 bytes, with the contract's keys, the headline roofline,
+    cpu_baseline and the north star's Target.  (Round 3's bench printed the full record as its one line: the driver kept
+    the last 8 KB and could not parse it.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r4", "bench_plain_full.json")) as fh:
+        full = json.load(fh)
+    assert len(json.dumps(full)) > 15000
+    c = bench.compact_record(full, "bench_full.json")
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line) <= bench.COMPACT_LIMIT == 6000
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "workloads", "full_record"):
+        assert k in c, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "compulsory_bytes", "wasted_traffic_ratio"):
+        assert k in c["roofline"], k
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] == 1
+    t = c["workloads"]["esacf_stft_8192"]
+    assert t["unit"] == "frames/s" and t["ms"] > 0 and t["kernel"] and t["cpu"]["value"] > 0
+    assert c["workloads"]["if0_stream_1h"]["value_warm"] >= c["workloads"]["if0_stream_1h"]["value"] * 0.5
+    assert np.isclose(c["value"], full["value"], rtol=1e-5)
