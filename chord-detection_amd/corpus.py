@@ -218,9 +218,11 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
             mi3 = list(methods).index(3)
             eng2 = _second_engine(device)
 
-            def if0_pieces():   # the group, `if0_chunk` clips per engine call (rows of the [clips, samples] array: views)
-                return np.concatenate([np.asarray(eng2.iterative_f0_batch(clips[a:a + if0_chunk], fs, note_names=note_names))
-                                       for a in range(0, len(ids), if0_chunk)], axis=0)
+            def if0_pieces():
+                # the whole group in ONE engine call since round 4: above its workspace cap the library runs a clip list
+                # in time slices with every clip in flight (include/mpx.h MPX_OPT_IF0_WORKSPACE_BYTES) -- until then
+                # `if0_chunk` clips per call, each call a front-end launch of its own with one leftover-channel wave per clip
+                return np.asarray(eng2.iterative_f0_batch(clips, fs, note_names=note_names))
 
             side = threading.Thread(target=run, args=(mi3, 3, if0_pieces))
             side.start()

@@ -1486,7 +1486,18 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             rows += r;
         }
         const size_t ws_cap = ctx->if0_ws_cap;   // mpx_set_option(MPX_OPT_IF0_WORKSPACE_BYTES), default 32 GiB
-        if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap) {
+        // A clip list above the cap is NOT cut while one frame of every chunk fits: it runs in time slices like a long
+        // stream (below), every clip in flight -- 4096 two-second clips are 4506 waves with the leftover channels of ten
+        // clips packed into one, where four passes of 1024 clips were 4 x 2048 waves with a 6-lane leftover wave per clip
+        // (front end 59.6 -> see DESIGN 5.2c, ms per 4096 clips).  The list is halved for chirp-z frame sizes (no slices there)
+        // and when even one frame per chunk would not fit.
+        size_t est_chunks = 0;
+        for (int c = 0; c < num_clips; ++c) {
+            const int64_t len = offsets[c + 1] - offsets[c];
+            if (len > 0) est_chunks += (size_t)((len + IF0_CHUNK - 1) / IF0_CHUNK);   // (the planner may cut finer: the cap is soft)
+        }
+        const bool slices_fit = !blue && est_chunks * (size_t)NF * p.channels * sizeof(double) <= ws_cap;
+        if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap && !slices_fit) {
             std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
             for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
             size_t frames_first = 0;

@@ -110,11 +110,38 @@ def _poly(rng, n, fs=FS, voices=3):
     return (0.2 * x).astype(np.float32)
 
 
+def test_clip_list_above_the_cap_runs_in_time_slices_with_every_clip_in_flight():
+    """A clip list whose front-end output exceeds the cap while ONE frame of every clip fits is not halved: it runs in time
+    slices with every clip in flight (the corpus driver hands Iterative-F0 a whole 4096-clip group this way).  300 ragged
+    clips of ~20 000 samples under a 1 GiB cap (3.4 GB of hand-off: three frames per clip, so one or two frames per slice):
+    rows equal to the uncapped call bit for bit, and to the oracle."""
+    import chord_detection_amd as cd
+    from oracle import iterative_f0 as o_if0
+    rng = np.random.default_rng(31)
+    base = [_poly(rng, 20000) for _ in range(7)]
+    batch = [base[i % 7][: 20000 - 11 * (i % 13)] for i in range(300)]
+    whole, cut = cd.Engine(0), cd.Engine(0)
+    try:
+        cut.set_option("if0_workspace_bytes", 1 << 30)
+        assert sum(-(-len(b) // 8192) * 8192 for b in batch) * 70 * 8 > 3 * (1 << 30)
+        got_cut = cut.iterative_f0_batch(batch, FS)
+        got_whole = whole.iterative_f0_batch(batch, FS)
+        np.testing.assert_array_equal(got_cut, got_whole)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i in (0, 149, 299):
+                np.testing.assert_allclose(got_cut[i], o_if0.iterative_f0_compute(batch[i], FS), rtol=1e-5, atol=0)
+    finally:
+        cut.close()
+        whole.close()
+
+
 def test_large_batch_is_split_without_changing_results():
     """More clips than fit one front-end workspace (8 B x 70 channels per sample; the cap is 32 GiB by default, 64 MiB
-    here through mpx_set_option(MPX_OPT_IF0_WORKSPACE_BYTES) -- the release library's own route, no environment knob): the
-    clip list is halved internally until a pass fits (one 20 000-sample clip needs 13.8 MB, so 23 clips need three levels
-    of halving); every clip must come out exactly as from the unsplit call, and as the oracle computes it."""
+    here through mpx_set_option(MPX_OPT_IF0_WORKSPACE_BYTES) -- the release library's own route, no environment knob).  One
+    frame of each of the 23 clips is 105 MB: the list is halved (one frame per clip must fit for time slices), and each half
+    -- 12 / 11 clips, 55 / 50 MB per frame, 165 MB in all -- then runs in time slices.  Every clip must come out exactly as
+    from the uncapped call, and as the oracle computes it."""
     import chord_detection_amd as cd
     from oracle import iterative_f0 as o_if0
     rng = np.random.default_rng(3)
@@ -129,7 +156,7 @@ def test_large_batch_is_split_without_changing_results():
         with pytest.raises(ValueError):
             cut.set_option("if0_workspace_bytes", 1 << 20)
         need = sum(-(-len(b) // 8192) * 8192 for b in batch) * 70 * 8
-        assert need > 4 * (64 << 20)                                          # at least two levels of halving
+        assert need > 4 * (64 << 20)
         got_cut = cut.iterative_f0_batch(batch, FS)
         got_whole = whole.iterative_f0_batch(batch, FS)
         np.testing.assert_array_equal(got_cut, got_whole)                     # split == unsplit, bit for bit
