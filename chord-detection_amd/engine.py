@@ -242,6 +242,18 @@ class Engine:
         p = self._if0_params(**kw)
         self._ensure_remez(fs)
         nf = max(self.num_frames(x.shape[0], p.frame_size, p.frame_size), 0)
+        if isinstance(x, _DevFlat) and nf:
+            # a signal that lives in HBM is read IN PLACE (mpx_iterative_f0_dev): the host entry point would copy it into a
+            # workspace of its own first -- 635 MB for an hour of audio, allocated inside the first call of a process
+            import torch
+            t = x._t
+            d_frames = torch.empty((nf, 12), dtype=torch.float64, device=t.device)
+            d_sum = torch.empty(12, dtype=torch.float64, device=t.device)
+            self._check(self.lib.mpx_iterative_f0_dev(self.ctx, t.data_ptr(), t.numel(), int(fs), C.byref(p),
+                                                      d_frames.data_ptr(), d_sum.data_ptr(), None))
+            self.synchronize()
+            total = d_sum.cpu().numpy()
+            return (total, d_frames.cpu().numpy()) if return_frames else total
         total = np.zeros(12, dtype=np.float64)
         frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
         self._check(self.lib.mpx_iterative_f0(
