@@ -171,7 +171,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void* p : ctx->owned) hipFree(p);
     for (DevBuf* b : {&ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
-                      &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3, &ctx->d_counter, &ctx->d_queue})
+                      &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3, &ctx->d_ws4, &ctx->d_counter, &ctx->d_queue})
         if (b->p) hipFree(b->p);
     for (auto& m : ctx->prof_marks) hipEventDestroy(m.ev);
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);

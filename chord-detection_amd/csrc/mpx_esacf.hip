@@ -322,12 +322,42 @@ __device__ __forceinline__ void block_minmax(double* sh, double& mx, double& mn)
 // index, decides "higher" -- the visiting order of peakutils), so a candidate can decide as soon as
 // all its higher neighbours have; every round decides at least the highest undecided one.
 // flag words per set: >= (Mh + T) / 64 for T <= 512; at most 64, one per lane of the wave that ranks them (Mh <= 4095)
-__host__ __device__ inline int peak_words(int Mh) { return Mh <= 2047 ? 40 : 64; }
+// (above 4095 lags -- sacf_huge_kernel's rows -- up to 128 words, two per lane of the ranking wave: peak_pick<T, true>)
+__host__ __device__ inline int peak_words(int Mh) { return Mh <= 2047 ? 40 : (Mh <= 4095 ? 64 : 128); }
 __host__ __device__ inline size_t peak_scratch_bytes(int Mh) {
     return ((size_t)peak_words(Mh) * 32 + (size_t)(Mh / 2 + 2) * 8 + 15) & ~(size_t)15;
 }
 
-template <int T>
+// exclusive prefix sums over up to 64 (WIDE: 128) per-word counts held as c0 = count(word lane), c1 = count(word lane + 64);
+// word_base() reads the sum in front of word w (wave-uniform w)
+template <bool WIDE>
+struct WordScan {
+    int e0, e1, total;
+    __device__ __forceinline__ WordScan(int c0, int c1, int lane) {
+        int incl = c0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        e0 = incl - c0;
+        total = __shfl(incl, 63);
+        e1 = 0;
+        if (WIDE) {
+            int incl1 = c1;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl1, off);
+                if (lane >= off) incl1 += o;
+            }
+            e1 = total + incl1 - c1;
+            total += __shfl(incl1, 63);
+        }
+    }
+    __device__ __forceinline__ int word_base(int w) const { return (WIDE && w >= 64) ? __shfl(e1, w - 64) : __shfl(e0, w); }
+};
+
+template <int T, bool WIDE = false>
 __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double* yv, char* scratch, int tid) {
     typedef unsigned long long u64;
     constexpr int NW = T / 64;
@@ -360,7 +390,8 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
         if (lane == 0) nzw[e * NW + wave] = b;
     }
     __syncthreads();
-    if (D <= 0 || !__any(lane < nwords && nzw[lane < nwords ? lane : 0] != 0)) {
+    if (D <= 0 || !__any((lane < nwords && nzw[lane < nwords ? lane : 0] != 0) ||
+                         (WIDE && lane + 64 < nwords && nzw[lane + 64 < nwords ? lane + 64 : 0] != 0))) {
         if (tid == 0) a.peak_count[f] = 0;  // totally flat signal: no peaks (peakutils returns [])
         return;
     }
@@ -395,15 +426,11 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     int ncand;
     {
         const int cnt = lane < nwords ? __popcll(candw[lane < nwords ? lane : 0]) : 0;
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
-        ncand = __shfl(incl, 63);
+        const int cnt_hi = WIDE && lane + 64 < nwords ? __popcll(candw[lane + 64 < nwords ? lane + 64 : 0]) : 0;
+        const WordScan<WIDE> scan(cnt, cnt_hi, lane);
+        ncand = scan.total;
         for (int e = 0; e < E; ++e) {
-            const int base = __shfl(incl - cnt, e * NW + wave);
+            const int base = scan.word_base(e * NW + wave);
             const u64 b = candw[e * NW + wave];
             if ((b >> lane) & 1ull) {
                 const int rank = base + __popcll(b & lt_mask);
@@ -485,13 +512,11 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     }
     __syncthreads();
     const int cnt2 = lane < cwords ? __popcll(keptw[lane < cwords ? lane : 0]) | (__popcll(longw[lane < cwords ? lane : 0]) << 16) : 0;
-    int incl2 = cnt2;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(incl2, off);
-        if (lane >= off) incl2 += o;
-    }
-    const int tot = __shfl(incl2, 63);
+    const int cnt2_hi = WIDE && lane + 64 < cwords
+                            ? __popcll(keptw[lane + 64 < cwords ? lane + 64 : 0]) | (__popcll(longw[lane + 64 < cwords ? lane + 64 : 0]) << 16)
+                            : 0;
+    const WordScan<WIDE> scan2(cnt2, cnt2_hi, lane);
+    const int tot = scan2.total;
     int n_kept = tot & 0xffff;
     const int n_long = tot >> 16;
     int* out = a.peak_idx + f * (long long)a.maxp;
@@ -513,7 +538,7 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     }
     __syncthreads();
     for (int q = 0; q < Q; ++q) {
-        const int base = __shfl(incl2 - cnt2, q * NW + wave);
+        const int base = scan2.word_base(q * NW + wave);
         const u64 bk = keptw[q * NW + wave], bl = longw[q * NW + wave];
         if ((bk >> lane) & 1ull) {
             const int p = (base & 0xffff) + __popcll(bk & lt_mask);
@@ -1365,6 +1390,93 @@ __global__ __launch_bounds__(T) void sacf_split_kernel(SacfArgs a) {
     peak_pick<T>(a, f, yv, smem, tid);
 }
 
+// Frame lengths no LDS engine holds: odd above 4096 samples, anything above 8192 (esacf.py:27 takes int(fs * 46.4 / 1000)
+// whatever fs is: 192 kHz -> 8908 samples).  The N-point transforms are chirp-z convolutions of L = 8192 R points, R = 2 or 4
+// (2N - 1 <= L), and an L-point transform is R transforms of 8192 points on the padded Stockham engine around one radix-R
+// step that never leaves the workgroup:
+//   forward, decimation in frequency:  A[R k + r] = FFT_8192(u_r)[k],  u_r[m] = W_L^{m r} sum_j a[m + 8192 j] W_R^{j r}
+//            (a = z conj(chirp), zero from N on: j < R / 2 only)
+//   times the filter spectrum, stored as [r][k]
+//   inverse, decimation in time:       y[n] = sum_r conj(W_L^{n r}) IFFT_8192(Y_r)[n mod 8192]
+// so each residue r is transformed, filtered and transformed back while it is in LDS, and only the wanted outputs (N bins,
+// then (N - 1) / 2 lags) are accumulated, in a per-workgroup scratch row in HBM (24 N bytes, L2 / MALL resident: the grid is
+// one persistent workgroup per CU).  4 R transforms of 8192 points per frame.  Correct and complete, not tuned.
+struct HugeArgs {
+    const cx<double>* twL;     // [L] W_L^j
+    const cx<double>* bhat_r;  // [R][8192] FFT_L(chirp filter) / L at bins R k + r
+    cx<double>* scratch;       // [grid][2 N]: N accumulators, then N doubles of |X|^0.67 sums
+    int R, L;
+};
+
+template <int T, typename Src>
+__device__ __forceinline__ void chirpz_huge(cx<double>* buf, const SacfArgs& a, const HugeArgs& h, int nout, Src src,
+                                            cx<double>* acc, cx<double>* regs, int tid) {
+    constexpr int M = 8192;
+    const int N = a.N, R = h.R, Lm = h.L - 1;
+    for (int rp = 0; rp < R; ++rp) {
+        for (int m = tid; m < M; m += T) {
+            cx<double> u = {0.0, 0.0};
+            if (m < N) u = cmulc(src(m), a.chirp[m]);
+            if (R == 4 && m + M < N) {
+                cx<double> v = cmulc(src(m + M), a.chirp[m + M]);   // times W_4^rp = (-i)^rp
+                if (rp == 1) v = {v.y, -v.x};
+                else if (rp == 2) v = {-v.x, -v.y};
+                else if (rp == 3) v = {-v.y, v.x};
+                u = cadd(u, v);
+            }
+            buf[lds_slot(m)] = cmul(u, h.twL[(m * rp) & Lm]);
+        }
+        __syncthreads();
+        fft_lds<M, T, false, double>(buf, a.tw, regs, tid);
+        const cx<double>* bh = h.bhat_r + (size_t)rp * M;
+        // swapped: the next forward transform is then the inverse one
+        for (int k = tid; k < M; k += T) buf[lds_slot(k)] = cswap(cmul(buf[lds_slot(k)], bh[k]));
+        __syncthreads();
+        fft_lds<M, T, false, double>(buf, a.tw, regs, tid);
+        for (int n = tid; n < nout; n += T) {   // a thread owns its outputs across the residues: no barrier for acc
+            const cx<double> t = cmulc(cswap(buf[lds_slot(n & (M - 1))]), h.twL[(n * rp) & Lm]);
+            acc[n] = rp == 0 ? t : cadd(acc[n], t);
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < nout; n += T) acc[n] = cmulc(acc[n], a.chirp[n]);
+    __syncthreads();
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void sacf_huge_kernel(SacfArgs a, HugeArgs h) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 8192;
+    const int N = a.N, Mh = a.Mh;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);   // 8192 complex, padded
+    const int tid = threadIdx.x;
+    MPX_POW067_LDS(a, tid, T);
+    cx<double> regs[M / T];
+    cx<double>* acc = h.scratch + (size_t)blockIdx.x * 2 * N;
+    double* sreal = reinterpret_cast<double*>(acc + N);
+    const double inv_n = 1.0 / (double)N;
+    for (long long f = blockIdx.x; f < a.num_frames; f += gridDim.x) {
+        const cx<double>* xin = a.xb + band_index(f, 0, N);
+        chirpz_huge<T>(buf, a, h, N, [&](int n) { return xin[(size_t)(n >> 4) * (64 * BS_TILE) + (n & 15)]; }, acc, regs, tid);
+        for (int k = tid; k < N; k += T) {
+            const cx<double> A = acc[k];
+            const cx<double> B = cconj(acc[k == 0 ? 0 : N - k]);
+            const double lr = 0.5 * (A.x + B.x), li = 0.5 * (A.y + B.y);
+            const double hr = 0.5 * (A.y - B.y), hm = -0.5 * (A.x - B.x);
+            sreal[k] = mag067(lr, li, pow_tab) + mag067(hr, hm, pow_tab);
+        }
+        __syncthreads();
+        // S is real and symmetric: its inverse transform is its forward transform (over N)
+        chirpz_huge<T>(buf, a, h, Mh, [&](int n) { return cx<double>{sreal[n], 0.0}; }, acc, regs, tid);
+        for (int n = tid; n < Mh; n += T) {
+            const double v = acc[n].x * inv_n;
+            a.y_out[f * (long long)Mh + n] = v;
+            if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = v;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ kernel 2b / 2c
 // Enhancement when librosa.effects.time_stretch is a REAL phase vocoder, i.e. when the STFT of the
 // Mh-lag SACF has more than two frames (Mh >= 1024: ESACF frames above 2048 samples).  Per rate r
@@ -1587,6 +1699,166 @@ __global__ __launch_bounds__(PV_T, MAXS > 2 ? 1 : 2) void pv_enhance_kernel(PvAr
         __syncthreads();   // the transform buffer is dead: it is the picker's scratch
         peak_pick<PV_T>(sa, f, x, reinterpret_cast<char*>(buf), tid);
     }
+}
+
+// The same enhancement for rows of 4096 ... 8191 lags (sacf_huge_kernel's): up to MAXS = 8 output frames per rate, carried
+// as in pv_enhance_kernel<., 4> (unit vectors instead of angles), the synthesis spectra of all output frames in registers
+// (one workgroup per CU, a wave per SIMD: 512 registers), the row in LDS (64 KB), peak picking on 128 flag words.
+template <int MAXS>
+__global__ __launch_bounds__(PV_T, 1) void pv_enhance_big_kernel(PvArgs a, SacfArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, Mh = a.Mh;
+    size_t front = sizeof(cx<double>) * lds_slots(PV_NFFT);
+    if (peak_scratch_bytes(Mh) > front) front = peak_scratch_bytes(Mh);
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);      // 2048 complex (padded); later the picker's scratch
+    double* x = reinterpret_cast<double*>(smem + front);        // [Mh] working copy of the SACF
+    const long long f = blockIdx.x;
+    double* row = a.y + f * (long long)Mh;
+    cx<double> regs[PV_NFFT / PV_T];
+    constexpr int NB = (PV_BINS + PV_T - 1) / PV_T;  // 5
+    constexpr int NQ = MAXS * PV_HOP / PV_T;         // len_out <= MAXS * 512 samples, a thread's share
+    cx<double> d[MAXS][NB], dir[NB];
+    for (int n = tid; n < Mh; n += PV_T) x[n] = row[n];
+    __syncthreads();
+    const int n_frames = 1 + Mh / PV_HOP;
+    for (int r = 2; r <= a.n_peaks_elim; ++r) {
+        for (int n = tid; n < Mh; n += PV_T) x[n] = x[n] < 0.0 ? 0.0 : x[n];
+        __syncthreads();
+        const int len_out = (int)nearbyint((double)Mh / (double)r);
+        const int nsteps = (n_frames + r - 1) / r;
+        if (nsteps < 2) {   // one output frame: time_stretch returns x[:len_out] (see pv_enhance_kernel)
+            for (int i = tid; i < len_out && i < Mh; i += PV_T) x[i] = 0.0;
+            __syncthreads();
+            continue;
+        }
+#pragma unroll
+        for (int t = 0; t < MAXS; ++t) {
+            if (t >= nsteps) break;
+            const int c0 = t * r, c1 = c0 + 1;
+            for (int n = tid; n < PV_NFFT; n += PV_T) {
+                const int i0 = c0 * PV_HOP + n - PV_NFFT / 2, i1 = c1 * PV_HOP + n - PV_NFFT / 2;
+                const double w = pv_hann(a.tw, n);
+                const double v0 = (i0 >= 0 && i0 < Mh) ? x[i0] * w : 0.0;
+                const double v1 = (c1 < n_frames && i1 >= 0 && i1 < Mh) ? x[i1] * w : 0.0;
+                buf[lds_slot(n)] = {v0, v1};
+            }
+            __syncthreads();
+            fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int k = tid + j * PV_T;
+                if (k < PV_BINS) {
+                    const cx<double> Z = buf[lds_slot(k & (PV_NFFT - 1))];
+                    const cx<double> Zc = cconj(buf[lds_slot((PV_NFFT - k) & (PV_NFFT - 1))]);
+                    const cx<double> A = {0.5 * (Z.x + Zc.x), 0.5 * (Z.y + Zc.y)};   // rfft of column c0
+                    const cx<double> B = {0.5 * (Z.y - Zc.y), -0.5 * (Z.x - Zc.x)};  // rfft of column c1
+                    const double nb = sqrt(B.x * B.x + B.y * B.y);
+                    const double inb = nb > 0.0 ? 1.0 / nb : 0.0;
+                    const cx<double> ub = nb > 0.0 ? cx<double>{B.x * inb, B.y * inb} : cx<double>{1.0, 0.0};
+                    if (t == 0) {
+                        d[0][j] = A;        // |A| e^{i angle(A)}
+                        dir[j] = ub;        // e^{i phase_acc} of frame 1: angle(A) + (angle(B) - angle(A))
+                    } else {
+                        const double mag = sqrt(A.x * A.x + A.y * A.y);
+                        d[t][j] = {mag * dir[j].x, mag * dir[j].y};
+                        if (t + 1 < nsteps) {
+                            const double ia = mag > 0.0 ? 1.0 / mag : 0.0;
+                            const cx<double> ua = mag > 0.0 ? cx<double>{A.x * ia, A.y * ia} : cx<double>{1.0, 0.0};
+                            dir[j] = cmul(dir[j], cmulc(ub, ua));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const double inv = 1.0 / (double)PV_NFFT;
+        double acc[NQ];   // overlap-add of a thread's samples i = tid + 256 q, frames in ascending order
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+#pragma unroll
+        for (int pr = 0; pr < MAXS / 2; ++pr) {
+            if (2 * pr >= nsteps) break;
+            const bool second = 2 * pr + 1 < nsteps;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int k = tid + j * PV_T;
+                if (k < PV_BINS) {
+                    cx<double> e0 = d[2 * pr][j], e1 = d[2 * pr + 1][j];
+                    if (!second) e1 = {0.0, 0.0};
+                    if (k == 0 || k == PV_NFFT / 2) e0.y = e1.y = 0.0;
+                    buf[lds_slot(k & (PV_NFFT - 1))] = cswap(cx<double>{e0.x - e1.y, e0.y + e1.x});
+                    if (k != 0 && k != PV_NFFT / 2)
+                        buf[lds_slot(PV_NFFT - k)] = cswap(cx<double>{e0.x + e1.y, -e0.y + e1.x});
+                }
+            }
+            __syncthreads();
+            fft_lds<PV_NFFT, PV_T, false, double>(buf, a.tw, regs, tid);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int i = tid + q * PV_T;
+                if (i < len_out) {
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int m = i + PV_NFFT / 2 - (2 * pr + hh) * PV_HOP;   // sample of output frame 2 pr + hh
+                        if ((hh == 0 || second) && m >= 0 && m < PV_NFFT) {
+                            const double w = pv_hann(a.tw, m);
+                            const cx<double> z = cswap(buf[lds_slot(m)]);
+                            acc[q] += w * ((hh == 0 ? z.x : z.y) * inv);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = tid + q * PV_T;
+            if (i < len_out && i < Mh) {
+                double t = acc[q], wss = 0.0;   // window sum-square over the frames that cover sample i, same order
+                for (int fr = 0; fr < nsteps; ++fr) {
+                    const int m = i + PV_NFFT / 2 - fr * PV_HOP;
+                    if (m >= 0 && m < PV_NFFT) {
+                        const double w = pv_hann(a.tw, m);
+                        wss += w * w;
+                    }
+                }
+                if (wss > 2.2250738585072014e-308) t /= wss;
+                const double v = x[i] - t;
+                x[i] = v < 0.0 ? 0.0 : v;
+            }
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < Mh; n += PV_T) row[n] = x[n];
+    __syncthreads();
+    peak_pick<PV_T, true>(sa, f, x, smem, tid);
+}
+
+// Rows above 4095 lags without the phase vocoder (`noop` enhancement, or fewer than two rates): esacf.py:117-127's
+// clip / subtract / clip on the raw row, then the 128-word peak picking.
+template <int T>
+__global__ __launch_bounds__(T) void enhance_pick_big_kernel(SacfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Mh = a.Mh, tid = threadIdx.x;
+    const long long f = blockIdx.x;
+    double* yv = reinterpret_cast<double*>(smem + peak_scratch_bytes(Mh));
+    double* row = a.y_out + f * (long long)Mh;
+    for (int n = tid; n < Mh; n += T) yv[n] = row[n];
+    __syncthreads();
+    for (int r = 2; r <= a.n_peaks_elim; ++r) {
+        int cut = 0;
+        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
+        for (int n = tid; n < Mh; n += T) {
+            double v = yv[n];
+            v = v < 0.0 ? 0.0 : v;
+            if (n < cut) v = v - v;
+            v = v < 0.0 ? 0.0 : v;
+            yv[n] = v;
+        }
+        __syncthreads();
+    }
+    for (int n = tid; n < Mh; n += T) row[n] = yv[n];
+    peak_pick<T, true>(a, f, yv, smem, tid);
 }
 
 // Peak picking on rows that are already enhanced (phase-vocoder regime).
@@ -2741,9 +3013,11 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     const bool deterministic = (ctx->flags & MPX_FLAG_DETERMINISTIC) != 0;
     const int N = frame, Mh = (N - 1) / 2;
     // above 4096 samples: one radix-2 split around chirp-z transforms of N/2 points (sacf_split_kernel), even N only
-    const bool split = N > 4096;
-    if (N < 64 || N > 8192 || (split && (N & 1)))
-        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: frame length %d (supported: 64 ... 4096, and even lengths up to 8192)", N);
+    // odd lengths above 4096 and everything above 8192: chirp-z of 16384 / 32768 points around a radix-2 / 4 step (sacf_huge_kernel)
+    const bool huge = N > 8192 || (N > 4096 && (N & 1));
+    const bool split = N > 4096 && !huge;
+    if (N < 64 || N > 16384)
+        return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: frame length %d (supported: 64 ... 16384)", N);
     if (p.enhance_mode != MPX_ENHANCE_LIBROSA010 && p.enhance_mode != MPX_ENHANCE_NOOP)
         return set_error(ctx, MPX_EINVAL, "ESACF: unknown enhance_mode %d", p.enhance_mode);
     if (p.peak_min_dist < 0 || p.n_peaks_elim < 0 || p.n_peaks_elim > 64)
@@ -2759,9 +3033,51 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     int rc = band_coefs(ctx, fs, coef);
     if (rc) return rc;
     EsacfPlan plan;
-    if ((rc = esacf_plan(ctx, split ? N / 2 : N, plan, split))) return rc;
+    HugeArgs hg{};
+    if (huge) {
+        constexpr int M = 8192;
+        const int R = 2 * N - 1 <= 2 * M ? 2 : 4, L = R * M;
+        const std::string key = "esacf_huge" + std::to_string(N);
+        auto it = ctx->misc_plans.find(key);
+        if (it == ctx->misc_plans.end()) {
+            std::vector<cx<double>> tw(M), twL(L), chirp(N), filt(L, cx<double>{0.0, 0.0}), fr(L);
+            for (int j = 0; j < M; ++j) {
+                const long double ang = -2.0L * M_PIl * j / (long double)M;
+                tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+            for (int j = 0; j < L; ++j) {
+                const long double ang = -2.0L * M_PIl * j / (long double)L;
+                twL[j] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+            for (long long n = 0; n < N; ++n) {
+                const long long q = (n * n) % (2LL * N);  // exact phase reduction
+                const long double ang = M_PIl * (long double)q / (long double)N;
+                chirp[n] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+            filt[0] = chirp[0];
+            for (int m = 1; m < N; ++m) filt[m] = filt[L - m] = chirp[m];
+            host_fft(filt);
+            for (int r = 0; r < R; ++r)
+                for (int k = 0; k < M; ++k) fr[(size_t)r * M + k] = {filt[(size_t)R * k + r].x / L, filt[(size_t)R * k + r].y / L};
+            void* d0 = upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+            void* d1 = upload(ctx, chirp.data(), chirp.size() * sizeof(cx<double>));
+            void* d2 = upload(ctx, fr.data(), fr.size() * sizeof(cx<double>));
+            void* d3 = upload(ctx, twL.data(), twL.size() * sizeof(cx<double>));
+            if (!d0 || !d1 || !d2 || !d3) return MPX_ENOMEM;
+            it = ctx->misc_plans.emplace(key, std::vector<void*>{d0, d1, d2, d3}).first;
+        }
+        plan.tw = (cx<double>*)it->second[0];
+        plan.chirp = (cx<double>*)it->second[1];
+        plan.bhat = nullptr;
+        plan.L = M;
+        plan.blue = true;
+        hg.bhat_r = (const cx<double>*)it->second[2];
+        hg.twL = (const cx<double>*)it->second[3];
+        hg.R = R;
+        hg.L = L;
+    } else if ((rc = esacf_plan(ctx, split ? N / 2 : N, plan, split))) return rc;
     // non-powers of two of 2049 ... 2730 samples: three half-length chirp-z transforms on the in-place 4096-point engine
-    const bool rz = !split && plan.blue && plan.L == 8192 && N + N / 2 <= 4096 && !dev_env_on("MPX_SACF_NO_RZ");
+    const bool rz = !split && !huge && plan.blue && plan.L == 8192 && N + N / 2 <= 4096 && !dev_env_on("MPX_SACF_NO_RZ");
     if (rz) {
         const std::string key = "esacf_rz" + std::to_string(N);
         auto it = ctx->misc_plans.find(key);
@@ -2814,12 +3130,13 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         twn = (const cx<double>*)it->second[0];
     }
     // the reference's own frame lengths (1023, 2046) run on the prime-factor engine; MPX_SACF_BLUESTEIN=1 forces the chirp-z
-    const bool use_pfa = !split && pfa_supported(N) && !dev_env_on("MPX_SACF_BLUESTEIN");
+    const bool use_pfa = !split && !huge && pfa_supported(N) && !dev_env_on("MPX_SACF_BLUESTEIN");
     PfaPlan pfa;
     if (use_pfa && (rc = pfa_plan(ctx, N, pfa))) return rc;
     if (plan.L > 8192)
         return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: non power-of-two frame %d needs a %d-point FFT (> 8192)", N, plan.L);
-    const int maxp = p.peak_min_dist > 1 ? Mh / (p.peak_min_dist + 1) + 2 : Mh / 2 + 2;
+    int maxp = p.peak_min_dist > 1 ? Mh / (p.peak_min_dist + 1) + 2 : Mh / 2 + 2;
+    if (maxp > 4095 && (Mh - 1) / 2 <= 4095) maxp = 4095;   // peaks sit at 1 .. Mh - 2 and are never adjacent: (Mh - 1) / 2 at most
     if (maxp > 4095) return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: too many peak slots");
 
     // frames are processed in batches that fit a fixed workspace budget
@@ -2899,8 +3216,50 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             a.pow_tab = (const double*)pt->second[0];
         }
         a.ablate = dev_env_int("MPX_SACF_ABLATE", 0);
-        prof_mark(ctx, st, split ? "sacf_split_kernel" : (use_pfa ? "sacf_pfa_kernel" : (rz ? "sacf_rz_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel"))));
-        if (split) {
+        prof_mark(ctx, st, huge ? "sacf_huge_kernel" : split ? "sacf_split_kernel" : (use_pfa ? "sacf_pfa_kernel" : (rz ? "sacf_rz_kernel" : (plan.L == 8192 ? "sacf_big_kernel" : "sacf_kernel"))));
+        if (huge) {
+            const size_t lds = sizeof(cx<double>) * lds_slots(8192);
+            const long long grid = nf < ctx->num_cus ? nf : ctx->num_cus;   // persistent: one workgroup per CU (139 KB of LDS)
+            if ((rc = ensure(ctx, ctx->d_ws4, (size_t)grid * 2 * N * sizeof(cx<double>)))) return rc;
+            hg.scratch = (cx<double>*)ctx->d_ws4.p;
+            a.pair = 0;
+            auto kern = sacf_huge_kernel<512>;
+            MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a, hg);
+            MPX_HIP(ctx, hipGetLastError());
+            const size_t row_lds = sizeof(double) * (size_t)(Mh + 2);
+            if (pv) {
+                auto pit = ctx->misc_plans.find("pv_tw2048");
+                if (pit == ctx->misc_plans.end()) {
+                    std::vector<cx<double>> tw(PV_NFFT);
+                    for (int j = 0; j < PV_NFFT; ++j) {
+                        const long double ang = -2.0L * M_PIl * j / (long double)PV_NFFT;
+                        tw[j] = {(double)cosl(ang), (double)sinl(ang)};
+                    }
+                    void* d = upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
+                    if (!d) return MPX_ENOMEM;
+                    pit = ctx->misc_plans.emplace("pv_tw2048", std::vector<void*>{d}).first;
+                }
+                PvArgs pa;
+                pa.y = y;
+                pa.Mh = Mh;
+                pa.n_peaks_elim = p.n_peaks_elim;
+                pa.tw = (const cx<double>*)pit->second[0];
+                size_t front = sizeof(cx<double>) * lds_slots(PV_NFFT);
+                if (peak_scratch_bytes(Mh) > front) front = peak_scratch_bytes(Mh);
+                auto pvk = pv_enhance_big_kernel<8>;
+                MPX_HIP(ctx, hipFuncSetAttribute((const void*)pvk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(front + row_lds)));
+                prof_mark(ctx, st, "pv_enhance_big_kernel");
+                hipLaunchKernelGGL(pvk, dim3((unsigned)nf), dim3(PV_T), front + row_lds, st, pa, a);
+            } else {
+                auto ek = enhance_pick_big_kernel<512>;
+                const size_t e_lds = peak_scratch_bytes(Mh) + row_lds;
+                MPX_HIP(ctx, hipFuncSetAttribute((const void*)ek, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e_lds));
+                prof_mark(ctx, st, "enhance_pick_big_kernel");
+                hipLaunchKernelGGL(ek, dim3((unsigned)nf), dim3(512), e_lds, st, a);
+            }
+            MPX_HIP(ctx, hipGetLastError());
+        } else if (split) {
             const size_t lds = sizeof(cx<double>) * lds_slots(8192);
             if (peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2) > lds)
                 return set_error(ctx, MPX_EUNSUPPORTED, "ESACF: peak-picking scratch does not fit (N=%d)", N);
@@ -2952,7 +3311,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             else rc = sacf_launch<4096, false>(ctx, a, nf, st);
         }
         if (rc) return rc;
-        if (pv) {
+        if (pv && !huge) {
             auto pit = ctx->misc_plans.find("pv_tw2048");
             if (pit == ctx->misc_plans.end()) {
                 std::vector<cx<double>> tw(PV_NFFT);
@@ -2985,7 +3344,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             }
             MPX_HIP(ctx, hipGetLastError());
         }
-        if (!pv && (a.ablate & 16)) {
+        if (!pv && !huge && (a.ablate & 16)) {
             const size_t pk_lds = peak_scratch_bytes(Mh) + sizeof(double) * (size_t)(Mh + 2);
             hipLaunchKernelGGL(peakpick_kernel<64>, dim3((unsigned)nf), dim3(64), pk_lds, st, a);
         }

@@ -67,7 +67,7 @@ struct mpx_ctx {
     std::map<std::tuple<int, int, int, int, int>, mpx::HePlan> he_plans;
     std::map<std::string, std::vector<void*>> misc_plans;
     // grow-only device workspaces
-    mpx::DevBuf d_signal, d_frames_out, d_partials, d_sum, d_desc, d_offsets, d_ws0, d_ws1, d_ws2, d_ws3, d_counter, d_queue;   // (d_counter: he_kernel's tickets, left at zero; d_queue: scratch-slot flags, all free between launches)
+    mpx::DevBuf d_signal, d_frames_out, d_partials, d_sum, d_desc, d_offsets, d_ws0, d_ws1, d_ws2, d_ws3, d_ws4, d_counter, d_queue;   // (d_ws4: sacf_huge_kernel accumulators; d_counter: he_kernel's tickets, left at zero; d_queue: scratch-slot flags, all free between launches)
     std::map<std::string, std::vector<unsigned char>> host_blobs;  // host copies of plan records, per context
     std::map<std::string, int> occupancy;      // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answers
     std::map<int, std::vector<double>> remez;  // user-registered warped-FIR taps per sample rate

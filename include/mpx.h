@@ -171,9 +171,10 @@ typedef struct mpx_esacf_params {
 } mpx_esacf_params;
 
 /* One signal, host buffers.  replaces esacf.py:41-91.  frame = ham_samples
- * (any length in [64, 4096] and even lengths up to 8192; the reference default
- * int(fs*46.4/1000) is 1023 at 22050 Hz, 2046 at 44100 Hz, 4454 at 96 kHz and 8184 at
- * 176.4 kHz; MPX_EUNSUPPORTED for odd lengths above 4096 and anything above 8192),
+ * (any length in [64, 16384]; the reference default int(fs*46.4/1000) is 1023 at
+ * 22050 Hz, 2046 at 44100 Hz, 4454 at 96 kHz, 8184 at 176.4 kHz, 8908 at 192 kHz and
+ * 16369 at 352.8 kHz; odd lengths above 4096 and everything above 8192 run an untuned
+ * kernel; MPX_EUNSUPPORTED above 16384),
  * hop in [1, frame]. */
 int mpx_esacf(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
               const mpx_esacf_params* params, int frame, int hop,

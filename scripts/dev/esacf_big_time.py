@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""ESACF at frame lengths above 4096 samples (sacf_split_kernel, pv_enhance_kernel<.., 4>): per-kernel times of 4096 frames."""
+"""ESACF at frame lengths above 4096 samples (sacf_split_kernel, pv_enhance_kernel<.., 4>; sacf_huge_kernel, pv_enhance_big_kernel<8>): per-kernel times of 4096 frames."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import chord_detection_amd as cd
 eng = cd.Engine(0)
 dev = torch.device("cuda", 0)
-for fs, N in ((96000, 4454), (176400, 8184), (44100, 4096), (48000, 2227)):
+for fs, N in ((96000, 4454), (176400, 8184), (192000, 8908), (352800, 16369), (88300, 4097), (44100, 4096), (48000, 2227)):
     F = 4096
     n = F * N
     rng = np.random.default_rng(fs)

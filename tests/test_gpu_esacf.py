@@ -349,8 +349,49 @@ def test_frames_above_4096_samples_radix2_split(eng):
         if N == 4454:
             _check_clip(eng, x, fs, N, hop=N // 2, key="96000/4454/hop2227/elim3", n_peaks_elim=3)
             _check_clip(eng, x, fs, N, key="96000/4454/noop", enhance_mode="noop", peak_min_dist=1)
-    # what stays refused says so: odd lengths above 4096 (no radix-2 split) and anything above 8192
-    for bad in (4455, 8194, 8908):
+
+
+def _harmonic_clip(fs, n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / float(fs)
+    x = np.zeros(n)
+    for f0 in (146.83, 220.0, 277.18, 369.99):
+        for h in range(1, 7):
+            x += 0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+    return (0.25 * x + 0.004 * rng.standard_normal(n)).astype(np.float32)
+
+
+@pytest.mark.parametrize("fs,N,nfr", [(192000, 8908, 3), (88300, 4097, 2), (96000, 8191, 2), (96000, 8193, 2),
+                                      (352800, 16369, 2), (96000, 16384, 1), (96000, 5003, 2), (96000, 12001, 1)])
+def test_frames_of_any_length_up_to_16384(eng, fs, N, nfr):
+    """esacf.py:27: int(fs * 46.4 / 1000) is 8908 samples at 192 kHz and 16369 at 352.8 kHz, odd at other rates.  Odd lengths
+    above 4096 and everything above 8192 run sacf_huge_kernel (16384 / 32768-point chirp-z around a radix-2 / 4 step); their
+    4096 ... 8191-lag rows give the phase vocoder up to 16 STFT columns / 8 output frames (pv_enhance_big_kernel<8>) and the
+    peak picker 128 flag words.  SACF and ESACF rows against the oracle's, then the clip frame by frame."""
+    from oracle import esacf as o_esacf
+    from oracle import dsp as o_dsp
+    if N in (8908, 4097, 16369):
+        assert o_esacf.ham_samples(fs) == N
+    x = _harmonic_clip(fs, nfr * N - 300, N)
+    frames = o_dsp.frame_matrix(x, N, N)
+    _, lo, hi = o_esacf.band_split(frames, fs)
+    s = o_esacf.sacf(lo, hi)
+    got = eng.esacf_stage("sacf", x, fs, N)
+    assert got.shape == s.shape == (nfr, (N - 1) // 2)
+    np.testing.assert_allclose(got, s, rtol=0, atol=1e-10 * np.abs(s).max())
+    got = eng.esacf_stage("esacf", x, fs, N)
+    want = np.array([o_esacf.esacf_enhance(r, 6, "librosa010") for r in s])
+    assert not np.allclose(want, np.clip(s, 0, None))
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * np.abs(s).max())
+    _check_clip(eng, x, fs, N, key="%d/%d" % (fs, N))
+    if N == 8908:
+        _check_clip(eng, x, fs, N, hop=N // 2, key="192000/8908/hop4454/elim3", n_peaks_elim=3)
+        _check_clip(eng, x, fs, N, key="192000/8908/noop", enhance_mode="noop", peak_min_dist=2)
+        _check_clip(eng, x, fs, N, key="192000/8908/elim1", n_peaks_elim=1)
+
+
+def test_frame_lengths_refused(eng):
+    for bad in (16385, 20000, 63):
         with pytest.raises(Exception, match="frame length %d" % bad):
             eng.esacf(np.zeros(2 * bad, np.float32), 96000, bad)
 
@@ -366,7 +407,7 @@ def test_edge_cases_and_batch(eng, clips):
     with pytest.raises(ValueError):
         eng.esacf(np.zeros(10, dtype=np.float32), FS, 1023, enhance_mode="bogus")
     with pytest.raises(NotImplementedError):
-        eng.esacf(np.zeros(10, dtype=np.float32), FS, 5001)   # odd and above 4096
+        eng.esacf(np.zeros(10, dtype=np.float32), FS, 16385)   # above 16384
     batch = [clips["tone_E4"], clips["short_ragged"], np.zeros(0, dtype=np.float32), clips["poly_seed1"][:1023]]
     got = eng.esacf_batch(batch, FS, 1023)
     for i, x in enumerate(batch):

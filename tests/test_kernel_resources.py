@@ -30,6 +30,7 @@ SCRATCH_FREE = [
     "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
     "mpx::bandsplit_kernel<false>", "mpx::bandsplit_kernel<true>",
     "mpx::coopfit_kernel", "mpx::pv_enhance_kernel<true, 2>", "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
+    "mpx::sacf_huge_kernel<512>", "mpx::pv_enhance_big_kernel<8>", "mpx::enhance_pick_big_kernel<512>",   # frames of odd length above 4096 / above 8192 samples
     "mpx::peakfit_kernel<true>",                      # large batches: samples in LDS, fvec recomputed
     "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1

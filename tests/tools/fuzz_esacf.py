@@ -21,7 +21,7 @@ with warnings.catch_warnings():
     for case in range(cases):
         fs = int(rng.choice([8000, 16000, 22050, 32000, 44100, 48000]))
         sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else \
-            [64, 100, 255, 256, 511, 512, 742, 1000, 1023, 1024, 1500, 2046, 2047, 2048, 2049, 2227, 2500, 2730, 2731, 3000, 4095, 4096, 4098, 4454, 6000, 8184, 8192]
+            [64, 100, 255, 256, 511, 512, 742, 1000, 1023, 1024, 1500, 2046, 2047, 2048, 2049, 2227, 2500, 2730, 2731, 3000, 4095, 4096, 4097, 4098, 4454, 5003, 6000, 8184, 8191, 8192, 8193, 8908, 12001, 16369, 16384]
         N = int(rng.choice(sizes))   # FUZZ_SIZES=1023,2046: the prime-factor SACF engine only
         nfr = int(rng.integers(1, 5))
         n = nfr * N - int(rng.integers(0, N // 2))
