@@ -1028,11 +1028,14 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
         // Any other frame size (iterative_f0.py:25 takes any integer): the 2 NF-point spectrum by chirp-z on the padded
         // Stockham engine, X[k] = conj(c[k]) sum_n (x[n] conj(c[n])) c[k - n], c[m] = exp(i pi m^2 / 2NF), n < NF, k <= NF:
         // a cyclic convolution of L >= 2 NF points.  d_tw: W_L, d_twn: c[0 .. NF], d_twn_r: FFT_L(c on -(NF-1) .. NF) / L.
+        // Above 4096 samples L = 16384 is two residues of 8192 points around one radix-2 step (if0_spectrum_blue2_kernel):
+        // d_tw: W_8192, d_twn_r: the filter spectrum as [residue r][k] = bin 2 k + r, then W_16384^m for m < 8192.
         int L = 4096;
         while (L < 2 * NF) L <<= 1;
-        tw.assign((size_t)L, cx<double>{0.0, 0.0});
-        for (int j = 0; j < L; ++j) {
-            const long double ang = -2.0L * M_PIl * j / (long double)L;
+        const int LE = L > 8192 ? 8192 : L;   // points of the LDS engine
+        tw.assign((size_t)LE, cx<double>{0.0, 0.0});
+        for (int j = 0; j < LE; ++j) {
+            const long double ang = -2.0L * M_PIl * j / (long double)LE;
             tw[(size_t)j] = {(double)cosl(ang), (double)sinl(ang)};
         }
         const long long n2 = 2LL * NF;
@@ -1048,6 +1051,16 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
         for (auto& v : filt) {
             v.x /= L;
             v.y /= L;
+        }
+        if (L > 8192) {
+            std::vector<cx<double>> fr((size_t)3 * LE);
+            for (int r = 0; r < 2; ++r)
+                for (int k = 0; k < LE; ++k) fr[(size_t)r * LE + k] = filt[(size_t)2 * k + r];
+            for (int m = 0; m < LE; ++m) {
+                const long double ang = -2.0L * M_PIl * m / (long double)L;
+                fr[(size_t)2 * LE + m] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+            filt.swap(fr);
         }
         hipFree(plan.d_tw);    // (the NF-point tables uploaded above are of no use to this path)
         hipFree(plan.d_twn);
@@ -1370,6 +1383,73 @@ __global__ __launch_bounds__(T) void if0_spectrum_blue_kernel(const double* __re
     }
 }
 
+// 4097 ... 8191 samples: the convolution has 16384 points -- two residues of 8192 around one radix-2 step that stays in the
+// workgroup (as sacf_huge_kernel, mpx_esacf.hip): forward by decimation in frequency (the input is zero from 8192 on, so
+// u_r[m] = a[m] W_16384^{m r}), the filter spectrum per residue, inverse by decimation in time: y[k] = v_0[k] + conj(W_16384^k)
+// v_1[k] for k <= NF < 8192; v_0 waits in a per-workgroup row in HBM while residue 1 is transformed (in registers it spilled:
+// 456 bytes per lane; the grid is one persistent workgroup per CU, the rows stay in L2).  Four 8192-point transforms per channel.
+template <int T>
+__global__ __launch_bounds__(T) void if0_spectrum_blue2_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
+                                                               int NF, int channels, double power,
+                                                               const double* __restrict__ window, const cx<double>* __restrict__ tw,
+                                                               const cx<double>* __restrict__ chirp, const cx<double>* __restrict__ bhat_r,
+                                                               double* __restrict__ ut, long long nframes, cx<double>* v0_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 8192;   // bins k <= NF < M
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    const cx<double>* __restrict__ twL = bhat_r + 2 * M;
+    const int tid = threadIdx.x;
+    cx<double>* v0 = v0_rows + (size_t)blockIdx.x * M;   // element k: written and read by the same thread
+  for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
+    const If0Frame fr = frames[f];
+    double* row = ut + (size_t)f * 2 * NF;   // the sums over the channels accumulate in the row itself (a bin belongs to one thread)
+    for (int k = tid; k <= NF; k += T) row[k] = 0.0;
+    cx<double> regs[M / T];
+    const double* src = yc + fr.yc_base;
+    for (int ch = 0; ch < channels; ++ch) {
+        const double* x = src + (size_t)ch * fr.ch_stride;
+#pragma nounroll   // (unrolled, four inlined transforms' hoisted twiddle loads spill 500 bytes per lane)
+        for (int r = 0; r < 2; ++r) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // nothing below is hoisted out of the loops (twiddle and table addresses: registers)
+            for (int n = tid; n < M; n += T) {
+                cx<double> v = {0.0, 0.0};
+                if (n < NF) {
+                    const double xv = n < fr.valid ? x[n] : 0.0;
+                    const double xw = xv * window[n];
+                    const cx<double> c = chirp[n];
+                    v = {xw * c.x, -(xw * c.y)};
+                    if (r) v = cmul(v, twL[n]);
+                }
+                buf[lds_slot(n)] = v;
+            }
+            __syncthreads();
+            fft_lds<M, T, false, double>(buf, tw, regs, tid);
+            for (int k = tid; k < M; k += T) {   // swapped: the forward transform of (im, re) is the swapped inverse transform
+                const cx<double> v = cmul(buf[lds_slot(k)], bhat_r[r * M + k]);
+                buf[lds_slot(k)] = {v.y, v.x};
+            }
+            __syncthreads();
+            fft_lds<M, T, false, double>(buf, tw, regs, tid);
+            for (int k = tid; k <= NF; k += T) {
+                const cx<double> s = buf[lds_slot(k)];
+                const cx<double> v = {s.y, s.x};
+                if (r == 0) {
+                    v0[k] = v;
+                } else {
+                    const cx<double> w = twL[k], u = v0[k];   // v conj(w)
+                    const double yr = u.x + (v.x * w.x + v.y * w.y), yi = u.y + (v.y * w.x - v.x * w.y);
+                    const double mag = hypot(yr, yi);
+                    row[k] += power == 1.0 ? mag : pow(mag, power);
+                }
+            }
+            __syncthreads();   // buf is rewritten by the next residue / channel
+        }
+    }
+    for (int k = tid + 1; k < NF; k += T) row[2 * NF - k] = row[k];   // |X[N-k]| = |X[k]| for a real frame
+  }
+}
+
 static int if0_spectrum_blue_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int NF, int channels,
                                     double power, const If0Plan& plan, double* ut, hipStream_t st) {
     if (2 * NF <= 4096) {
@@ -1379,6 +1459,16 @@ static int if0_spectrum_blue_launch(mpx_ctx* ctx, const double* yc, const If0Fra
         MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, NF, channels, power, plan.d_window, plan.d_tw,
                            plan.d_twn, plan.d_twn_r, ut);
+    } else if (2 * NF > 8192) {
+        constexpr int T = 512;
+        const size_t lds = sizeof(cx<double>) * lds_slots(8192);
+        const long long grid = nf < ctx->num_cus ? nf : ctx->num_cus;   // persistent: one workgroup per CU (139 KB of LDS)
+        int rc = ensure(ctx, ctx->d_ws4, (size_t)grid * 8192 * sizeof(cx<double>));
+        if (rc) return rc;
+        auto kern = if0_spectrum_blue2_kernel<T>;
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T), lds, st, yc, frames, NF, channels, power, plan.d_window, plan.d_tw,
+                           plan.d_twn, plan.d_twn_r, ut, nf, (cx<double>*)ctx->d_ws4.p);
     } else {
         constexpr int L = 8192, T = 512;
         const size_t lds = sizeof(cx<double>) * lds_slots(L);
@@ -1440,10 +1530,11 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                  hipStream_t stream) {
     mpx_if0_params p = params ? *params
                               : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
-    // 1024 / 2048 / 4096 / 8192: the tuned kernels; any other size up to 4095 samples: chirp-z (if0_spectrum_blue_kernel)
+    // 1024 / 2048 / 4096 / 8192: the tuned kernels; any other size up to 8191 samples: chirp-z (if0_spectrum_blue_kernel up to
+    // 4095, if0_spectrum_blue2_kernel above)
     const bool blue = p.frame_size != 1024 && p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192;
-    if (p.frame_size < 16 || (blue && p.frame_size > 4095))
-        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 4096, and 8192)", p.frame_size);
+    if (p.frame_size < 16 || p.frame_size > 8192)
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 8192)", p.frame_size);
     if (p.channels < 1 || p.channels > IF0_MAXCH || p.max_voices < 1 || p.max_voices > 8 || p.Q < 2 || p.Q > 32 || p.M < 2 ||
         p.M > 64 || !(p.tau_min > 0) || !(p.tau_max > p.tau_min) || fs <= 0)
         return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
@@ -1472,7 +1563,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         }
         const long long base = (long long)NF / g * 64;
         blue_chunk = base * std::max<long long>(1, (65536 + base - 1) / base);
-        if (blue_chunk > IF0_CHUNK) blue_chunk = base;
+        if (blue_chunk > IF0_CHUNK) blue_chunk = base;   // (64 x 8191 = 524 224 samples at most: the one case above IF0_CHUNK)
         while ((1LL << blue_lgp) < blue_chunk) ++blue_lgp;
     }
     {

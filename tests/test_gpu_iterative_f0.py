@@ -76,7 +76,7 @@ def test_spectra_and_batch_vs_oracle(eng, clips):
         np.testing.assert_allclose(got[3], o_if0.iterative_f0_compute(batch[3], FS), rtol=1e-5, atol=0)
     assert np.array_equal(got, eng.iterative_f0_batch(batch, FS))      # deterministic
     with pytest.raises(NotImplementedError):
-        eng.iterative_f0(x, FS, frame_size=5000)       # non-powers of two above 4095 samples have no kernel
+        eng.iterative_f0(x, FS, frame_size=8193)       # above 8192 samples there is no kernel
     with pytest.raises(NotImplementedError):
         eng.iterative_f0(x, FS, frame_size=8)
     with pytest.raises(ValueError):
@@ -211,16 +211,18 @@ def test_time_slices_carry_the_filter_state_exactly(frame_size, channels):
 
 
 @pytest.mark.parametrize("frame_size,power,channels", [(1000, 1.0, 70), (1500, 0.5, 70), (2047, 1.0, 33), (3000, 1.0, 70),
-                                                       (4095, 2.0, 64), (512, 1.0, 70), (777, 1.0, 70)])
+                                                       (4095, 2.0, 64), (512, 1.0, 70), (777, 1.0, 70),
+                                                       (4097, 1.0, 70), (5000, 0.5, 70), (6000, 1.0, 33), (8191, 1.0, 70), (8190, 2.0, 64)])
 def test_any_frame_size_by_chirp_z_vs_oracle(eng, frame_size, power, channels):
-    """iterative_f0.py:25 takes any integer frame_size.  Sizes other than 1024 / 2048 / 4096 / 8192 -- up to 4095 samples --
+    """iterative_f0.py:25 takes any integer frame_size.  Sizes other than 1024 / 2048 / 4096 / 8192 -- up to 8191 samples --
     run the 2 x frame_size-point spectrum as a chirp-z transform (if0_spectrum_blue_kernel: 4096 points up to 2048 samples,
-    8192 above) on front-end chunks of lcm(frame_size, 64) x k samples: odd, even and prime-ish sizes, a power of two below
-    1024, both transform lengths, a clip of several chunks, against the oracle (spectra 1e-9, per-frame chroma 1e-5)."""
+    8192 up to 4095; if0_spectrum_blue2_kernel: 16384 points as two residues of 8192 above) on front-end chunks of
+    lcm(frame_size, 64) x k samples: odd, even and prime-ish sizes, a power of two below 1024, all three transform lengths,
+    a clip of several chunks, against the oracle (spectra 1e-9, per-frame chroma 1e-5)."""
     from oracle import iterative_f0 as o_if0
     rng = np.random.default_rng(5000 + frame_size)
     kw = dict(frame_size=frame_size, power=power, channels=channels)
-    for n in (2 * frame_size + frame_size // 3 + 5, 150000 if frame_size in (1000, 3000) else 0):
+    for n in (2 * frame_size + frame_size // 3 + 5, 150000 if frame_size in (1000, 3000, 6000) else 0):
         if not n:
             continue
         x = _poly(rng, n) + (1e-3 * rng.standard_normal(n)).astype(np.float32)

@@ -42,6 +42,7 @@ SCRATCH_FREE = [
     "mpx::if0_spectrum_split_kernel<1024, true, 1>", "mpx::if0_spectrum_split_kernel<1024, false, 0>",
     "mpx::if0_frontend_kernel<false>", "mpx::if0_frontend2_kernel<false>", "mpx::if0_periodicity_kernel",
     "mpx::if0_frontend_kernel<true>", "mpx::if0_frontend2_kernel<true>",     # time slices (MPX_OPT_IF0_WORKSPACE_BYTES)
+    "mpx::if0_spectrum_blue_kernel<4096, 256>", "mpx::if0_spectrum_blue_kernel<8192, 512>", "mpx::if0_spectrum_blue2_kernel<512>",   # chirp-z frame sizes
 ]
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
