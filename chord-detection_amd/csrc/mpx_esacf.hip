@@ -3372,9 +3372,12 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),
                                dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP));
             if (park) prof_mark(ctx, st, "coopfit_kernel");
-            if (park)  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
-                hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * 12)), dim3(64), 0, st, parked, total + 3,
+            if (park) {  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
+                const int per_cu = dev_env_int("MPX_COOP_PER_CU", 12), pad_kb = dev_env_int("MPX_COOP_PAD_KB", 0);
+                if (pad_kb) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad_kb * 1024));
+                hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * per_cu)), dim3(64), (size_t)pad_kb * 1024, st, parked, total + 3,
                                    total + 4, y, center, okf, maxfev);
+            }
         }
         prof_mark(ctx, st, nullptr);
         if (dev_env("MPX_DEBUG_FITS")) {  // profiling aid: work-list counters of this batch
