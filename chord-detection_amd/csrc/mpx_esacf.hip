@@ -2014,6 +2014,7 @@ struct ParkedFit {
 constexpr int PARK_NFEV_SMALL = 100;   // batches below 2048 frames (one clip: 2.57 instead of 2.80 ms): nothing to wait for, the cooperative trips are the faster ones
 constexpr int PARK_NFEV = 160;   // (swept 60 ... 550 on three workloads: 130-180 is the flat optimum)
 constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinished fits ...
+constexpr int COOP_PASS1_TRIPS = 24;   // coopfit_kernel, first pass: trips after which a fit still open is parked again
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
 // Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
@@ -2075,9 +2076,16 @@ __device__ __forceinline__ void count_evals(int* counter, unsigned mine) {
     }
 }
 
+// Two passes (round 4).  The 8192-frame batch parks several thousand fits, most of which need a few more trips and a few
+// hundred of which burn MINPACK's whole budget (160 more trips): while the rows of a wave hold fits in different states the
+// wave executes the union of their paths, and two busy waves share a SIMD's fp64 issue -- 15 us per trip where an uncrowded
+// fit takes 10.5.  Pass 1 (`repark` set) stops every fit that is still open after `max_trips` trips at the top of lmdif's outer
+// loop and parks it again (the same 128-byte state); pass 2 (`spread` set) gives the survivors a wave each as far as the
+// grid reaches -- fit i to row i / waves of wave i % waves -- before the rows fetch on.  Same arithmetic, same bits.
 __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
                                                      int* next_parked, const double* __restrict__ y, double* center,
-                                                     int* ok, int maxfev) {
+                                                     int* ok, int maxfev, ParkedFit* repark, int* repark_count, int max_trips,
+                                                     int spread, int* evals) {
     using namespace lm;
     __shared__ double exp_tab[64];
     exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
@@ -2087,10 +2095,16 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
     unsigned my_evals = 0;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const double eps = sqrt(EPSMCH);
+    bool first = spread != 0;
     for (;;) {
         int idx = 0;
-        if (l == 0) idx = atomicAdd(next_parked, 1);
-        idx = __shfl(idx, 0, 16);
+        if (first) {
+            idx = (int)(threadIdx.x >> 4) * (int)gridDim.x + (int)blockIdx.x;
+            first = false;
+        } else {
+            if (l == 0) idx = atomicAdd(next_parked, 1);
+            idx = __shfl(idx, 0, 16) + (spread ? 4 * (int)gridDim.x : 0);
+        }
         if (idx >= total) break;
         const ParkedFit pf = parked[idx];
         const bool ona = l < pf.m, onb = l + 16 < pf.m;
@@ -2105,7 +2119,14 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
             return {ona ? ra : 0.0, onb ? rb : 0.0};
         };
         D2 f = resid(x);
+        int trips = 0;
+        bool again = false;
         for (;;) {
+            if (repark != nullptr && trips >= max_trips) {   // (uniform in the row)
+                again = true;
+                break;
+            }
+            ++trips;
             // forward-difference jacobian: this lane's two rows
             D2 J0, J1, J2;
             {
@@ -2308,12 +2329,33 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
             if (info != 0) break;
         }
         if (l == 0) {
-            ok[pf.out] = (info >= 1 && info <= 4) ? 1 : 0;
-            center[pf.out] = x[1];
+            if (again) {
+                ParkedFit* q = repark + atomicAdd(repark_count, 1);   // (field by field: a local copy of the record cost a stack slot)
+                q->out = pf.out;
+                q->row_off = pf.row_off;
+                q->x0 = pf.x0;
+                q->x[0] = x[0];
+                q->x[1] = x[1];
+                q->x[2] = x[2];
+                q->diag[0] = diag[0];
+                q->diag[1] = diag[1];
+                q->diag[2] = diag[2];
+                q->par = par;
+                q->delta = delta;
+                q->xnorm = xnorm;
+                q->fnorm = fnorm;
+                q->m = pf.m;
+                q->it = it;
+                q->nfev = nfev;
+                q->pad = 0;
+            } else {
+                ok[pf.out] = (info >= 1 && info <= 4) ? 1 : 0;
+                center[pf.out] = x[1];
+            }
             my_evals += (unsigned)(nfev - pf.nfev);
         }
     }
-    count_evals(next_parked + 2, my_evals);   // total[6..7]: function evaluations of the batch (statistics only)
+    count_evals(evals, my_evals);   // total[6..7]: function evaluations of the batch (statistics only)
 }
 
 // SAMPLES_IN_LDS = true (batches with enough fits to fill the machine several times over): the lane's 21 samples live in
@@ -3149,7 +3191,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if ((rc = ensure(ctx, ctx->d_ws0, (size_t)((batch + 63) / 64) * ((N + BS_TILE - 1) / BS_TILE) * 64 * BS_TILE * 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)batch * Mh * 8 + 64))) return rc;              // y
     const long long fit_resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));  // blocks
-    const size_t park_bytes = (size_t)fit_resident * FIT_THREADS * sizeof(ParkedFit);  // at most one parked fit per lane
+    const size_t park_bytes = 2 * (size_t)fit_resident * FIT_THREADS * sizeof(ParkedFit);  // at most one parked fit per lane; a second list for coopfit_kernel's second pass
     if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 256 + park_bytes))) return rc;
     cx<double>* xb = (cx<double>*)ctx->d_ws0.p;
     double* y = (double*)ctx->d_ws1.p;
@@ -3159,8 +3201,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     int* okf = peak_idx + (size_t)batch * maxp;
     int* worklist = okf + (size_t)batch * maxp;
     int* peak_count = worklist + (size_t)batch * maxp;
-    int* total = peak_count + batch;  // 5 counters, see SacfArgs::total_peaks; [3] parked fits, [4] next parked fit
-    ParkedFit* parked = reinterpret_cast<ParkedFit*>(((uintptr_t)(total + 8) + 63) & ~(uintptr_t)63);
+    int* total = peak_count + batch;  // counters, see SacfArgs::total_peaks; [3] parked fits, [4] next parked fit, [8] fits parked again, [9] next of those
+    ParkedFit* parked = reinterpret_cast<ParkedFit*>(((uintptr_t)(total + 16) + 63) & ~(uintptr_t)63);
+    ParkedFit* parked2 = parked + (size_t)fit_resident * FIT_THREADS;
 
     for (long long f0 = 0; f0 < num_frames; f0 += batch) {
         const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
@@ -3178,7 +3221,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                d_stage_out + (size_t)f0 * N);
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
         prof_mark(ctx, st, nullptr);
-        MPX_HIP(ctx, hipMemsetAsync(total, 0, 8 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts; [6..7] evaluations
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, 12 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts; [6..7] evaluations
         SacfArgs a;
         a.xb = xb;
         a.N = N;
@@ -3375,16 +3418,23 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             if (park) {  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
                 const int per_cu = dev_env_int("MPX_COOP_PER_CU", 12), pad_kb = dev_env_int("MPX_COOP_PAD_KB", 0);
                 if (pad_kb) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad_kb * 1024));
+                // pass 1: every parked fit, at most COOP_PASS1_TRIPS trips each; pass 2: the fits still open, a wave each first
+                const int pass1 = dev_env_int("MPX_COOP_PASS1_TRIPS", COOP_PASS1_TRIPS);
                 hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * per_cu)), dim3(64), (size_t)pad_kb * 1024, st, parked, total + 3,
-                                   total + 4, y, center, okf, maxfev);
+                                   total + 4, y, center, okf, maxfev, pass1 > 0 ? parked2 : (ParkedFit*)nullptr, total + 8, pass1, 0, total + 6);
+                if (pass1 > 0)
+                    hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * dev_env_int("MPX_COOP_PASS2_PER_CU", 8))), dim3(64),
+                                       (size_t)dev_env_int("MPX_COOP_PASS2_PAD_KB", 0) * 1024, st, parked2, total + 8, total + 9, y, center, okf,
+                                       maxfev, (ParkedFit*)nullptr, total + 8, 0, 1, total + 6);
             }
         }
         prof_mark(ctx, st, nullptr);
         if (dev_env("MPX_DEBUG_FITS")) {  // profiling aid: work-list counters of this batch
-            int h[5];
+            int h[9];
             MPX_HIP(ctx, hipMemcpyAsync(h, total, sizeof(h), hipMemcpyDeviceToHost, st));
             MPX_HIP(ctx, hipStreamSynchronize(st));
-            fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d\n", nf, h[0] + h[2], h[0], h[3]);
+            fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d, open after the first cooperative pass %d\n", nf,
+                    h[0] + h[2], h[0], h[3], h[8]);
         }
         if (ctx->prof_on) {  // fit statistics of the profiled call (mpx_esacf_fit_stats): one small synchronous copy per batch
             unsigned h[8];

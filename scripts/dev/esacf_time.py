@@ -12,6 +12,8 @@ eng = cd.Engine(0); dev = torch.device("cuda", 0)
 for label, fs, mode in (("clips 44.1 kHz", 44100, "frame"), ("clips 22.05 kHz", 22050, "frame"), ("stft 4096/1024", 44100, "stft")):
     if mode == "stft":
         x = bench.synth_signal_device(20260101, dev); frame, hop = 4096, 1024
+        if os.environ.get("ESACF_TIME_FRAMES"):   # a shorter signal: that many frames
+            x = x[:(int(os.environ["ESACF_TIME_FRAMES"]) - 1) * hop + frame].contiguous()
     else:
         uniq = torch.from_numpy(B.synth_clips(fs=fs)).to(dev)
         x = uniq.repeat(4096 // 64, 1).reshape(-1).contiguous(); frame = hop = int(fs * 46.4 / 1000)

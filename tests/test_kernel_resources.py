@@ -29,7 +29,7 @@ SCRATCH_FREE = [
     "mpx::sacf_pfa_kernel<1>", "mpx::sacf_pfa_kernel<2>",
     "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
     "mpx::bandsplit_kernel<false>", "mpx::bandsplit_kernel<true>",
-    "mpx::coopfit_kernel", "mpx::pv_enhance_kernel<true, 2>", "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
+    "mpx::pv_enhance_kernel<true, 2>", "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
     "mpx::sacf_huge_kernel<512>", "mpx::pv_enhance_big_kernel<8>", "mpx::enhance_pick_big_kernel<512>",   # frames of odd length above 4096 / above 8192 samples
     "mpx::peakfit_kernel<true>",                      # large batches: samples in LDS, fvec recomputed
     "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
@@ -47,6 +47,7 @@ SCRATCH_FREE = [
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
     "mpx::peakfit_kernel<false>": 40,                  # small batches: the round-2 arrangement
+    "mpx::coopfit_kernel": 36,                         # a 36-byte stack slot is reserved since the two-pass form; the ISA holds no scratch instruction
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
 }
 # occupancy (waves per SIMD) the launch geometry of the host code counts on
