@@ -2076,12 +2076,13 @@ __device__ __forceinline__ void count_evals(int* counter, unsigned mine) {
     }
 }
 
-// Two passes (round 4).  The 8192-frame batch parks several thousand fits, most of which need a few more trips and a few
-// hundred of which burn MINPACK's whole budget (160 more trips): while the rows of a wave hold fits in different states the
-// wave executes the union of their paths, and two busy waves share a SIMD's fp64 issue -- 15 us per trip where an uncrowded
-// fit takes 10.5.  Pass 1 (`repark` set) stops every fit that is still open after `max_trips` trips at the top of lmdif's outer
-// loop and parks it again (the same 128-byte state); pass 2 (`spread` set) gives the survivors a wave each as far as the
-// grid reaches -- fit i to row i / waves of wave i % waves -- before the rows fetch on.  Same arithmetic, same bits.
+// Two passes (round 4).  A batch parks thousands of fits; many need a few more trips, the rest burn MINPACK's whole budget
+// (160 more trips).  Pass 1 (`repark` set) stops every fit still open after `max_trips` trips at the top of lmdif's outer loop and
+// parks it again (the same 128-byte state); pass 2 takes the survivors, again four to a wave: the short fits are gone, the long
+// ones sit densely packed in fewer waves, and fewer waves share a SIMD's fp64 issue (clip batches: 1.9 -> 1.65 and 3.2 -> 2.55
+// ms; a batch whose parked fits all survive pays the second launch, 0.05 ms).  Same arithmetic, same bits.  `spread` (measured,
+// not used: development knob) gives the survivors a wave each first -- fit i to row i / waves of wave i % waves: SLOWER, 1.06 ->
+// 1.70 ms for 512 fits; a wave of one live row costs what a wave of four does, and four times as many waves are busy.
 __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
                                                      int* next_parked, const double* __restrict__ y, double* center,
                                                      int* ok, int maxfev, ParkedFit* repark, int* repark_count, int max_trips,
@@ -3418,14 +3419,14 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             if (park) {  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
                 const int per_cu = dev_env_int("MPX_COOP_PER_CU", 12), pad_kb = dev_env_int("MPX_COOP_PAD_KB", 0);
                 if (pad_kb) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad_kb * 1024));
-                // pass 1: every parked fit, at most COOP_PASS1_TRIPS trips each; pass 2: the fits still open, a wave each first
+                // pass 1: every parked fit, at most COOP_PASS1_TRIPS trips each; pass 2: the fits still open, packed again
                 const int pass1 = dev_env_int("MPX_COOP_PASS1_TRIPS", COOP_PASS1_TRIPS);
                 hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * per_cu)), dim3(64), (size_t)pad_kb * 1024, st, parked, total + 3,
                                    total + 4, y, center, okf, maxfev, pass1 > 0 ? parked2 : (ParkedFit*)nullptr, total + 8, pass1, 0, total + 6);
                 if (pass1 > 0)
                     hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * dev_env_int("MPX_COOP_PASS2_PER_CU", 8))), dim3(64),
                                        (size_t)dev_env_int("MPX_COOP_PASS2_PAD_KB", 0) * 1024, st, parked2, total + 8, total + 9, y, center, okf,
-                                       maxfev, (ParkedFit*)nullptr, total + 8, 0, 1, total + 6);
+                                       maxfev, (ParkedFit*)nullptr, total + 8, 0, dev_env_int("MPX_COOP_PASS2_SPREAD", 0), total + 6);
             }
         }
         prof_mark(ctx, st, nullptr);
