@@ -2014,6 +2014,8 @@ struct ParkedFit {
 constexpr int PARK_NFEV_SMALL = 100;   // batches below 2048 frames (one clip: 2.57 instead of 2.80 ms): nothing to wait for, the cooperative trips are the faster ones
 constexpr int PARK_NFEV = 160;   // (swept 60 ... 550 on three workloads: 130-180 is the flat optimum)
 constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinished fits ...
+constexpr int COOP_THREADS = 256, COOP_PAD_KB = 100;   // the cooperative kernels: one workgroup of four waves per CU (a wave per SIMD), held apart by unused LDS
+constexpr int COOP_SPLIT = 4096;        // parked lists longer than this -- more than a wave per SIMD at four fits each -- run eight fits to a wave (coopfit8_kernel)
 constexpr int COOP_PASS1_TRIPS = 24;   // coopfit_kernel, first pass: trips after which a fit still open is parked again
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
@@ -2083,16 +2085,17 @@ __device__ __forceinline__ void count_evals(int* counter, unsigned mine) {
 // ms; a batch whose parked fits all survive pays the second launch, 0.05 ms).  Same arithmetic, same bits.  `spread` (measured,
 // not used: development knob) gives the survivors a wave each first -- fit i to row i / waves of wave i % waves: SLOWER, 1.06 ->
 // 1.70 ms for 512 fits; a wave of one live row costs what a wave of four does, and four times as many waves are busy.
-__global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
-                                                     int* next_parked, const double* __restrict__ y, double* center,
-                                                     int* ok, int maxfev, ParkedFit* repark, int* repark_count, int max_trips,
-                                                     int spread, int* evals) {
+__global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
+                                                      int* next_parked, const double* __restrict__ y, double* center,
+                                                      int* ok, int maxfev, ParkedFit* repark, int* repark_count, int max_trips,
+                                                      int spread, int* evals, int min_total, int max_total) {
     using namespace lm;
+    const int total = *parked_count;
+    if (total < min_total || total > max_total) return;   // the other form of the kernel takes this list (see esacf_run)
     __shared__ double exp_tab[64];
-    exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    if (threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
     __syncthreads();
     const int l = threadIdx.x & 15;
-    const int total = *parked_count;
     unsigned my_evals = 0;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const double eps = sqrt(EPSMCH);
@@ -2104,7 +2107,7 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
             first = false;
         } else {
             if (l == 0) idx = atomicAdd(next_parked, 1);
-            idx = __shfl(idx, 0, 16) + (spread ? 4 * (int)gridDim.x : 0);
+            idx = __shfl(idx, 0, 16) + (spread ? (int)(blockDim.x >> 4) * (int)gridDim.x : 0);
         }
         if (idx >= total) break;
         const ParkedFit pf = parked[idx];
@@ -2358,6 +2361,325 @@ __global__ __launch_bounds__(64) void coopfit_kernel(const ParkedFit* __restrict
     }
     count_evals(evals, my_evals);   // total[6..7]: function evaluations of the batch (statistics only)
 }
+
+// ---- the same fit on EIGHT lanes (round 4): coopfit8_kernel ---------------------------------------------------------------
+// The cooperative trips are bound by the SIMD's fp64 issue (a lone wave runs its 3.3 k instructions per trip at 4.8 clocks
+// each; two waves on a SIMD take twice as long per trip), and the 3x3 algebra of a trip is replicated in every lane whatever
+// the number of fits in the wave: eight fits per wave -- lane l of a fit's eight holds rows l, l + 8 and l + 16 -- are half
+// the busy waves for 1.3x the instructions.  The sums keep the order of dot_rows / coop_leaf bit for bit: slot A (+ C, fused)
+// is leaf l, slot B leaf l + 8 of the 16-leaf tree; quad_perm, quad_perm and row_half_mirror reduce the leaves 0..7 to
+// q0 + q1 and the leaves 8..15 to q2 + q3 in every lane of the eight, and their sum is (q0 + q1) + (q2 + q3).
+struct D3 {  // this lane's three samples: rows l, l + 8 and l + 16 of the m <= 21 rows
+    double a, b, c;
+};
+__device__ __forceinline__ double half_sum(double v) {
+    v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);   // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ double coop8_sum(int l, int from, D3 x, D3 y) {
+    const double p = row_leaf(l >= from, x.a, y.a);
+    const double f = fma_as_written(x.c, y.c, p);
+    const double leaf_lo = l + 16 < lm::MAXM ? f : p;   // leaf l: rows l and l + 16
+    const double leaf_hi = prod(x.b, y.b);              // leaf l + 8: row l + 8 (never above `from` <= 3)
+    return half_sum(leaf_lo) + half_sum(leaf_hi);
+}
+// value of lane J of the caller's eight: broadcast inside each quad, then the quads 1 and 3 of the DPP row take the
+// value of the quad to their left (row_shr:4 written to banks 1 and 3 only)
+template <int J>
+__device__ __forceinline__ double half_bcast_c(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, J * 0x55, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, J * 0x55, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x114, 0xf, 0xa, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x114, 0xf, 0xa, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double half_bcast(double v, int j) {  // j in 0..2, a constant after unrolling
+    return j == 0 ? half_bcast_c<0>(v) : (j == 1 ? half_bcast_c<1>(v) : half_bcast_c<2>(v));
+}
+
+__global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restrict__ parked, const int* __restrict__ parked_count,
+                                                     int* next_parked, const double* __restrict__ y, double* center,
+                                                     int* ok, int maxfev, ParkedFit* repark, int* repark_count, int max_trips,
+                                                     int spread, int* evals, int min_total, int max_total) {
+    using namespace lm;
+    const int total = *parked_count;
+    if (total < min_total || total > max_total) return;
+    __shared__ double exp_tab[64];
+    if (threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+    const int l = threadIdx.x & 7;
+    unsigned my_evals = 0;
+    const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
+    const double eps = sqrt(EPSMCH);
+    bool first = spread != 0;
+    for (;;) {
+        int idx = 0;
+        if (first) {
+            idx = (int)(threadIdx.x >> 3) * (int)gridDim.x + (int)blockIdx.x;   // (development knob, see coopfit_kernel)
+            first = false;
+        } else {
+            if (l == 0) idx = atomicAdd(next_parked, 1);
+            idx = __shfl(idx, 0, 8) + (spread ? (int)(blockDim.x >> 3) * (int)gridDim.x : 0);
+        }
+        if (idx >= total) break;
+        const ParkedFit pf = parked[idx];
+        const bool ona = l < pf.m, onb = l + 8 < pf.m, onc = l + 16 < pf.m;
+        const D3 px = {pf.x0 + (double)l, pf.x0 + (double)(l + 8), pf.x0 + (double)(l + 16)};
+        const D3 py = {ona ? y[pf.row_off + l] : 0.0, onb ? y[pf.row_off + l + 8] : 0.0, onc ? y[pf.row_off + l + 16] : 0.0};
+        double x[NP] = {pf.x[0], pf.x[1], pf.x[2]}, diag[NP] = {pf.diag[0], pf.diag[1], pf.diag[2]};
+        double par = pf.par, delta = pf.delta, xnorm = pf.xnorm, fnorm = pf.fnorm;
+        int it = pf.it, nfev = pf.nfev, info = 0;
+        auto resid = [&](const double* p) -> D3 {
+            const GaussEval g = gauss_prep(p, exp_tab);
+            const double ra = gauss_resid(g, px.a, py.a), rb = gauss_resid(g, px.b, py.b), rc = gauss_resid(g, px.c, py.c);
+            return {ona ? ra : 0.0, onb ? rb : 0.0, onc ? rc : 0.0};
+        };
+        D3 f = resid(x);
+        int trips = 0;
+        bool again = false;
+        for (;;) {
+            if (repark != nullptr && trips >= max_trips) {   // (uniform in the row)
+                again = true;
+                break;
+            }
+            ++trips;
+            // forward-difference jacobian: this lane's three rows
+            D3 J0, J1, J2;
+            {
+                if (x[0] != 0.0) {
+                    const double inv_a = 1.0 / x[0];
+                    J0 = {ona ? (f.a + py.a) * inv_a : 0.0, onb ? (f.b + py.b) * inv_a : 0.0, onc ? (f.c + py.c) * inv_a : 0.0};
+                } else {
+                    x[0] = eps;
+                    const D3 w = resid(x);
+                    J0 = {(w.a - f.a) * (1.0 / eps), (w.b - f.b) * (1.0 / eps), (w.c - f.c) * (1.0 / eps)};
+                    x[0] = 0.0;
+                }
+                D3 jj[NP];
+#pragma unroll
+                for (int j = 1; j < NP; ++j) {
+                    const double temp = x[j];
+                    double h = eps * fabs(temp);
+                    if (h == 0.0) h = eps;
+                    x[j] = temp + h;
+                    const D3 w = resid(x);
+                    x[j] = temp;
+                    const double inv_h = 1.0 / h;
+                    jj[j] = {(w.a - f.a) * inv_h, (w.b - f.b) * inv_h, (w.c - f.c) * inv_h};
+                }
+                J1 = jj[1];
+                J2 = jj[2];
+            }
+            nfev += NP;
+            int ipvt[NP] = {0, 1, 2};
+            double acnorm[NP], rdiag[NP], wa[NP];
+            acnorm[0] = sqrt(coop8_sum(l, 0, J0, J0));
+            acnorm[1] = sqrt(coop8_sum(l, 0, J1, J1));
+            acnorm[2] = sqrt(coop8_sum(l, 0, J2, J2));
+#pragma unroll
+            for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
+            double qtf[NP];
+            D3 w4 = f;  // becomes Q^T fvec
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                int kmax = j;
+                double rmax = rdiag[j];
+#pragma unroll
+                for (int k = j + 1; k < NP; ++k)
+                    if (rdiag[k] > rmax) {
+                        kmax = k;
+                        rmax = rdiag[k];
+                    }
+                if (kmax != j) {
+                    D3& cjs = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                    D3& cks = kmax == 1 ? J1 : J2;
+                    const D3 t0 = cjs;
+                    cjs = cks;
+                    cks = t0;
+                    put3(rdiag, kmax, rdiag[j]);
+                    put3(wa, kmax, wa[j]);
+                    const int t = ipvt[j];
+                    ipvt[j] = sel3(ipvt, kmax);
+                    put3(ipvt, kmax, t);
+                }
+                D3& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                const bool below = l >= j;  // rows j..7 of the first slot; the other two slots (rows 8.., 16..) are always below
+                double ajnorm = sqrt(coop8_sum(l, j, cj, cj));
+                if (ajnorm != 0.0) {
+                    if (half_bcast(cj.a, j) < 0.0) ajnorm = -ajnorm;
+                    const double inv_aj = 1.0 / ajnorm;
+                    if (below) cj.a *= inv_aj;
+                    cj.b *= inv_aj;
+                    cj.c *= inv_aj;
+                    if (l == j) cj.a += 1.0;
+                    const double inv_ajj = 1.0 / half_bcast(cj.a, j);
+#pragma unroll
+                    for (int k = j + 1; k < NP; ++k) {
+                        D3& ck = k == 1 ? J1 : J2;
+                        const double temp = coop8_sum(l, j, cj, ck) * inv_ajj;
+                        if (below) ck.a = fma_as_written(-temp, cj.a, ck.a);
+                        ck.b = fma_as_written(-temp, cj.b, ck.b);
+                        ck.c = fma_as_written(-temp, cj.c, ck.c);
+                        if (rdiag[k] != 0.0) {
+                            const double t = half_bcast(ck.a, j) / rdiag[k];
+                            const double u = fma(-t, t, 1.0);
+                            rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
+                            const double q = rdiag[k] / wa[k];
+                            if (0.05 * q * q <= EPSMCH) {
+                                rdiag[k] = sqrt(coop8_sum(l, j + 1, ck, ck));
+                                wa[k] = rdiag[k];
+                            }
+                        }
+                    }
+                    const double temp = -coop8_sum(l, j, cj, w4) * inv_ajj;
+                    if (below) w4.a = fma_as_written(cj.a, temp, w4.a);
+                    w4.b = fma_as_written(cj.b, temp, w4.b);
+                    w4.c = fma_as_written(cj.c, temp, w4.c);
+                }
+                rdiag[j] = -ajnorm;
+                qtf[j] = half_bcast(w4.a, j);
+            }
+            if (it == 1) {
+                double wa3[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    diag[j] = acnorm[j] != 0.0 ? acnorm[j] : 1.0;
+                    wa3[j] = diag[j] * x[j];
+                }
+                xnorm = enorm3(wa3);
+                delta = factor * xnorm;
+                if (delta == 0.0) delta = factor;
+            }
+            // replicate the 3x3 upper triangle R (row i lives in lane i of the fit's eight, first slot; its diagonal is rdiag)
+            double r[NP * NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                r[i * NP + 0] = i == 0 ? rdiag[0] : half_bcast(J0.a, i);
+                r[i * NP + 1] = i == 1 ? rdiag[1] : half_bcast(J1.a, i);
+                r[i * NP + 2] = i == 2 ? rdiag[2] : half_bcast(J2.a, i);
+            }
+            double gnorm = 0.0;
+            if (fnorm != 0.0) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double an = sel3(acnorm, ipvt[j]);
+                    if (an != 0.0) {
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], qtf[i] / fnorm, s2);
+                        const double g = fabs(s2 / an);
+                        gnorm = g > gnorm ? g : gnorm;
+                    }
+                }
+            }
+            if (gnorm <= gtol) {
+                info = 4;
+                break;
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
+            for (;;) {
+                double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
+#pragma unroll
+                for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
+                par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    p[j] = -p[j];
+                    xnew[j] = x[j] + p[j];
+                    wa3[j] = diag[j] * p[j];
+                }
+                const double pnorm = enorm3(wa3);
+                if (it == 1) delta = delta < pnorm ? delta : pnorm;
+                const D3 fn = resid(xnew);
+                ++nfev;
+                const double fnorm1 = sqrt(coop8_sum(l, 0, fn, fn));
+                double actred = -1.0;
+                if (0.1 * fnorm1 < fnorm) {
+                    const double q = fnorm1 / fnorm;
+                    actred = fma(-q, q, 1.0);
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double temp = sel3(p, ipvt[j]);
+#pragma unroll
+                    for (int i = 0; i <= j; ++i) wa3[i] = fma(r[i * NP + j], temp, wa3[i]);
+                }
+                const double temp1 = enorm3(wa3) / fnorm;
+                const double temp2 = (sqrt(par) * pnorm) / fnorm;
+                const double prered = fma(temp1, temp1, temp2 * temp2 / 0.5);
+                const double dirder = -fma(temp1, temp1, temp2 * temp2);
+                const double ratio = prered != 0.0 ? actred / prered : 0.0;
+                if (ratio <= 0.25) {
+                    double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+                    if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                    const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
+                    delta = temp * dm;
+                    par = par / temp;
+                } else if (par == 0.0 || ratio >= 0.75) {
+                    delta = pnorm / 0.5;
+                    par = 0.5 * par;
+                }
+                if (ratio >= 1e-4) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        x[j] = xnew[j];
+                        wa3[j] = diag[j] * x[j];
+                    }
+                    f = fn;
+                    xnorm = enorm3(wa3);
+                    fnorm = fnorm1;
+                    ++it;
+                }
+                const bool c1 = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+                if (c1) info = 1;
+                if (delta <= xtol * xnorm) info = 2;
+                if (c1 && info == 2) info = 3;
+                if (info != 0) break;
+                if (nfev >= maxfev) info = 5;
+                if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1.0) info = 6;
+                if (delta <= EPSMCH * xnorm) info = 7;
+                if (gnorm <= EPSMCH) info = 8;
+                if (info != 0) break;
+                if (ratio >= 1e-4) break;
+            }
+            if (info != 0) break;
+        }
+        if (l == 0) {
+            if (again) {
+                ParkedFit* q = repark + atomicAdd(repark_count, 1);   // (field by field: a local copy of the record cost a stack slot)
+                q->out = pf.out;
+                q->row_off = pf.row_off;
+                q->x0 = pf.x0;
+                q->x[0] = x[0];
+                q->x[1] = x[1];
+                q->x[2] = x[2];
+                q->diag[0] = diag[0];
+                q->diag[1] = diag[1];
+                q->diag[2] = diag[2];
+                q->par = par;
+                q->delta = delta;
+                q->xnorm = xnorm;
+                q->fnorm = fnorm;
+                q->m = pf.m;
+                q->it = it;
+                q->nfev = nfev;
+                q->pad = 0;
+            } else {
+                ok[pf.out] = (info >= 1 && info <= 4) ? 1 : 0;
+                center[pf.out] = x[1];
+            }
+            my_evals += (unsigned)(nfev - pf.nfev);
+        }
+    }
+    count_evals(evals, my_evals);   // total[6..7]: function evaluations of the batch (statistics only)
+}
+
 
 // SAMPLES_IN_LDS = true (batches with enough fits to fill the machine several times over): the lane's 21 samples live in
 // LDS and fvec is recomputed -- no global loads inside the trip loop (10 % faster per 2.1 M fits, 1/31 of the traffic).
@@ -3416,17 +3738,28 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),
                                dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP));
             if (park) prof_mark(ctx, st, "coopfit_kernel");
-            if (park) {  // the runaway fits still open when the list ran dry: 16 lanes each, all at once
-                const int per_cu = dev_env_int("MPX_COOP_PER_CU", 12), pad_kb = dev_env_int("MPX_COOP_PAD_KB", 0);
-                if (pad_kb) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad_kb * 1024));
-                // pass 1: every parked fit, at most COOP_PASS1_TRIPS trips each; pass 2: the fits still open, packed again
+            if (park) {  // the runaway fits still open when the list ran dry: eight lanes each (coopfit8_kernel), all at once
+                // Lists of up to COOP_SPLIT fits go to coopfit_kernel (16 lanes per fit: four to a wave), longer ones to
+                // coopfit8_kernel (eight to a wave).  The host does not know the count: both forms are launched and the one
+                // whose range the count is not in returns at once.  Workgroups of four waves, one per CU (LDS padding): a wave
+                // per SIMD.  Pass 1: every parked fit, at most COOP_PASS1_TRIPS trips each; pass 2: the fits still open, packed again.
+                const int split = dev_env_int("MPX_COOP_SPLIT", COOP_SPLIT);
+                const int t16 = dev_env_int("MPX_COOP16_THREADS", COOP_THREADS), c16 = dev_env_int("MPX_COOP16_PER_CU", 1), p16 = dev_env_int("MPX_COOP16_PAD_KB", COOP_PAD_KB);
+                const int t8 = dev_env_int("MPX_COOP_THREADS", COOP_THREADS), c8 = dev_env_int("MPX_COOP_PER_CU", 1), p8 = dev_env_int("MPX_COOP_PAD_KB", COOP_PAD_KB);
+                if (p16) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p16 * 1024));
+                if (p8) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, p8 * 1024));
                 const int pass1 = dev_env_int("MPX_COOP_PASS1_TRIPS", COOP_PASS1_TRIPS);
-                hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * per_cu)), dim3(64), (size_t)pad_kb * 1024, st, parked, total + 3,
-                                   total + 4, y, center, okf, maxfev, pass1 > 0 ? parked2 : (ParkedFit*)nullptr, total + 8, pass1, 0, total + 6);
-                if (pass1 > 0)
-                    hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * dev_env_int("MPX_COOP_PASS2_PER_CU", 8))), dim3(64),
-                                       (size_t)dev_env_int("MPX_COOP_PASS2_PAD_KB", 0) * 1024, st, parked2, total + 8, total + 9, y, center, okf,
-                                       maxfev, (ParkedFit*)nullptr, total + 8, 0, dev_env_int("MPX_COOP_PASS2_SPREAD", 0), total + 6);
+                const int spread2 = dev_env_int("MPX_COOP_PASS2_SPREAD", 0);
+                for (int pass = 0; pass < (pass1 > 0 ? 2 : 1); ++pass) {
+                    const ParkedFit* src = pass ? parked2 : parked;
+                    int* cnt = pass ? total + 8 : total + 3;
+                    int* nxt = pass ? total + 9 : total + 4;
+                    ParkedFit* again = pass == 0 && pass1 > 0 ? parked2 : (ParkedFit*)nullptr;
+                    hipLaunchKernelGGL(coopfit_kernel, dim3((unsigned)(ctx->num_cus * c16)), dim3(t16), (size_t)p16 * 1024, st, src, cnt, nxt, y,
+                                       center, okf, maxfev, again, total + 8, pass1, pass ? spread2 : 0, total + 6, 0, split);
+                    hipLaunchKernelGGL(coopfit8_kernel, dim3((unsigned)(ctx->num_cus * c8)), dim3(t8), (size_t)p8 * 1024, st, src, cnt, nxt, y,
+                                       center, okf, maxfev, again, total + 8, pass1, pass ? spread2 : 0, total + 6, split + 1, 0x7fffffff);
+                }
             }
         }
         prof_mark(ctx, st, nullptr);

@@ -48,6 +48,7 @@ SCRATCH_FREE = [
 SCRATCH_CEILING = {
     "mpx::peakfit_kernel<false>": 40,                  # small batches: the round-2 arrangement
     "mpx::coopfit_kernel": 36,                         # a 36-byte stack slot is reserved since the two-pass form; the ISA holds no scratch instruction
+    "mpx::coopfit8_kernel": 36,                        # the same kernel with eight lanes per fit
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
 }
 # occupancy (waves per SIMD) the launch geometry of the host code counts on
