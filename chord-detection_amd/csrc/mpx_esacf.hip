@@ -3728,10 +3728,16 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             const int maxfev = dev_env_int("MPX_FIT_MAXFEV", 200 * (lm::NP + 1));
             const bool park = !deterministic && !dev_env_on("MPX_FIT_NOPARK");
             prof_mark(ctx, st, "peakfit_kernel");
-            // samples in LDS when the fits fill the 131 072 resident lanes about four times over (12 .. 25 fits per frame): the
-            // kernel is then throughput-bound; below that its time is the trip count of its longest fits (bit-identical either way)
-            const bool in_lds = dev_env("MPX_FIT_SAMPLES") ? dev_env_on("MPX_FIT_SAMPLES") : nf >= 32768;
+            // Samples in LDS, fvec recomputed: the arrangement of every batch since the end of round 4.  (Round 3 kept the round-2
+            // arrangement -- fvec in LDS, the samples re-read from the row: 40 bytes of scratch, 9.7x the compulsory traffic -- for
+            // batches below 32 768 frames, where it was 0.1 ms faster; with the cooperative kernels of round 4 it no longer is:
+            // 8192 frames 5.54 against 5.51 ms, 2048 frames 3.75 against 3.95.  Development builds keep it behind MPX_FIT_SAMPLES=0.)
+#ifdef MPX_DEV_KNOBS
+            const bool in_lds = dev_env("MPX_FIT_SAMPLES") ? dev_env_on("MPX_FIT_SAMPLES") : true;
             auto fit_kernel = in_lds ? peakfit_kernel<true> : peakfit_kernel<false>;
+#else
+            auto fit_kernel = peakfit_kernel<true>;
+#endif
             hipLaunchKernelGGL(fit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, dev_env_int("MPX_FIT_PARK_NFEV", nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),

@@ -31,7 +31,7 @@ SCRATCH_FREE = [
     "mpx::bandsplit_kernel<false>", "mpx::bandsplit_kernel<true>",
     "mpx::pv_enhance_kernel<true, 2>", "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
     "mpx::sacf_huge_kernel<512>", "mpx::pv_enhance_big_kernel<8>", "mpx::enhance_pick_big_kernel<512>",   # frames of odd length above 4096 / above 8192 samples
-    "mpx::peakfit_kernel<true>",                      # large batches: samples in LDS, fvec recomputed
+    "mpx::peakfit_kernel<true>",                      # samples in LDS, fvec recomputed: every batch (the round-2 arrangement, 40 B of scratch, is a development-build option)
     "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
     # ... and every other instantiation a caller can reach through frame_size / power (iterative_f0.py:22-33); round 3 shipped
@@ -46,7 +46,6 @@ SCRATCH_FREE = [
 ]
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
-    "mpx::peakfit_kernel<false>": 40,                  # small batches: the round-2 arrangement
     "mpx::coopfit_kernel": 36,                         # a 36-byte stack slot is reserved since the two-pass form; the ISA holds no scratch instruction
     "mpx::coopfit8_kernel": 36,                        # the same kernel with eight lanes per fit
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
