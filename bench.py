@@ -331,7 +331,8 @@ def kernel_models(n, mh, channels=70, nf=8192):
 MARK_KERNELS = {"prime_kernel": ("prime_pers_kernel", "prime_kernel"),
                 "if0_frontend_kernel": ("if0_frontend_kernel", "if0_frontend2_kernel"),   # pipelined | sequential (mpx_if0.hip)
                 "if0_spectrum_kernel": ("if0_spectrum_split_kernel", "if0_spectrum_dif_kernel", "if0_spectrum_kernel"),
-                "he_kernel": ("he_wave_kernel", "he_kernel", "he_blue_kernel")}
+                "he_kernel": ("he_wave_kernel", "he_kernel", "he_blue_kernel"),
+                "coopfit_kernel": ("coopfit_kernel", "coopfit8_kernel")}   # four or eight fits to a wave, chosen on the device (mpx_esacf.hip)
 _TRAFFIC = None
 
 
