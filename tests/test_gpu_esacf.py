@@ -478,6 +478,21 @@ def test_cooperative_finish_is_bit_identical_to_lane_mode(eng, det_eng):
         np.testing.assert_array_equal(a, b)
 
 
+def test_long_parked_list_eight_lanes_per_fit_is_bit_identical_to_lane_mode(eng, det_eng):
+    """The north star's Target shape (one signal, 8192 frames of 4096 samples, hop 1024) parks about 6500 fits -- more than
+    the 4096 that coopfit_kernel takes at four fits to a wave, so the device picks coopfit8_kernel (eight lanes per fit, the same
+    summation tree) -- and 96 % of them survive the first cooperative pass: per-frame chroma of the default engine ==
+    MPX_FLAG_DETERMINISTIC (every fit finished on its own lane), bit for bit."""
+    import torch
+    import bench
+    x = bench.synth_signal_device(20260101, torch.device("cuda", 0)).cpu().numpy()
+    a, fa = det_eng.esacf(x, 44100, 4096, 1024, return_frames=True, note_names="ascii")
+    b, fb = eng.esacf(x, 44100, 4096, 1024, return_frames=True, note_names="ascii")
+    assert fa.shape == (8192, 12) and (fa.sum(axis=1) > 0).all()
+    np.testing.assert_array_equal(fa, fb)
+    np.testing.assert_array_equal(a, b)
+
+
 def test_full_size_batch_is_periodic_in_the_clips(eng, det_eng):
     """BASELINE configs[2] at full size: 4096 clips x 2 s @44.1 kHz (176 573 frames, ~2 M gaussian fits) made of
     64 distinct clips repeated 64 times.  Size-independent property: a clip's chroma does not depend on where it
