@@ -2014,7 +2014,7 @@ struct ParkedFit {
 constexpr int PARK_NFEV_SMALL = 100;   // batches below 2048 frames (one clip: 2.57 instead of 2.80 ms): nothing to wait for, the cooperative trips are the faster ones
 constexpr int PARK_NFEV = 160;   // (swept 60 ... 550 on three workloads: 130-180 is the flat optimum)
 constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinished fits ...
-constexpr int COOP_THREADS = 256, COOP_PAD_KB = 100;   // the cooperative kernels: one workgroup of four waves per CU (a wave per SIMD), held apart by unused LDS
+constexpr int COOP_THREADS = 256, COOP_PAD_KB = 84;   // the cooperative kernels: one workgroup of four waves per CU (a wave per SIMD), held apart by unused LDS (more than half of the 160 KB; what is left takes a 64 KB workgroup of another context)
 constexpr int COOP_SPLIT = 4096;        // parked lists longer than this -- more than a wave per SIMD at four fits each -- run eight fits to a wave (coopfit8_kernel)
 constexpr int COOP_PASS1_TRIPS = 24;   // coopfit_kernel, first pass: trips after which a fit still open is parked again
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
