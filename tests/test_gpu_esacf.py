@@ -388,6 +388,11 @@ def test_frames_of_any_length_up_to_16384(eng, fs, N, nfr):
         _check_clip(eng, x, fs, N, hop=N // 2, key="192000/8908/hop4454/elim3", n_peaks_elim=3)
         _check_clip(eng, x, fs, N, key="192000/8908/noop", enhance_mode="noop", peak_min_dist=2)
         _check_clip(eng, x, fs, N, key="192000/8908/elim1", n_peaks_elim=1)
+        batch = [x, x[:N + 5], np.zeros(0, dtype=np.float32), x[N // 2:2 * N]]   # the batch entry point on the same kernels
+        got = eng.esacf_batch(batch, fs, N)
+        for i, clip in enumerate(batch):
+            want = eng.esacf(clip, fs, N) if len(clip) else np.zeros(12)
+            np.testing.assert_allclose(got[i], want, rtol=1e-12, atol=0)
 
 
 def test_frame_lengths_refused(eng):
