@@ -85,7 +85,8 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                                                   double* __restrict__ yc, const int* __restrict__ tail_list,
                                                   const If0TailGroup* __restrict__ tail_groups,
                                                   double (*tile)[IF0_TW + 1], long long* rowbase, long long ck_u, int ch0_u,
-                                                  int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl, const int warm_cap) {
+                                                  int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl, const int warm_cap,
+                                                  const double* __restrict__ hwin, const int wmask) {
 #pragma clang fp contract(off)
     // One wave per (chunk, group of 64 channels), one lane per channel; the channels % 64 left over (6 of the default
     // 70) would fill a wave to 9 %, so the leftovers of up to 64 / (channels % 64) chunks of equal length and run-in
@@ -175,6 +176,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         tb_first = sl_t0 + PF;
     }
     fetch(tb_first);
+    double wv_next = hwin[lane & wmask];   // window of the first tile of this launch (a slice starts on a frame)
     for (int tb = tb_first; tb < c_end + DEPTH; tb += PF) {
         const int t0 = tb - DEPTH;                             // this block produces the outputs t0 .. t0 + 15
         const int tcol = t0 >= 0 ? (t0 & (IF0_TW - 1)) : 0;   // their columns in the tile (the run-in's outputs are dropped)
@@ -247,6 +249,16 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             const int ts = tg - sl_t0;                      // ... counted from the first output of this launch
             // where sample tg of channel 0 of this frame sits relative to frame 0, channel 0 (a tile never straddles a frame)
             const size_t foff = (((size_t)(ts >> lg_nf) * channels) << lg_nf) + (size_t)(ts & ((1 << lg_nf) - 1));
+            // The frame's Hamming window (iterative_f0.py:80) goes onto the samples HERE (round 4): in the flush a lane is a
+            // time step, so the 64 rows of the tile share one window value per lane -- one coalesced load per 64 samples and one
+            // multiply per store, the same product the spectrum kernel formed (x * w, x = (r + lp) / 2 already rounded) -- and the
+            // spectrum kernel no longer loads 64 KB of window per channel.  (As the scale of the tile store in the loop above, the
+            // wave-uniform window value became a scalar load per step on the counter the LDS traffic waits on: front end 42 -> 51 ms.)
+            // Chirp-z frame sizes keep their window in the spectrum kernel: hwin is a single 1.0 there (wmask = 0).
+            // (fetched one tile ahead: under a launch that writes 2 TB/s a load issued here returned after microseconds, and the
+            //  first store of the flush waited for it -- 44 -> 55 ms per hour of audio)
+            const double wv = wv_next;
+            wv_next = hwin[((int)((ts + IF0_TW) & ((1 << lg_nf) - 1)) + lane) & wmask];
             wave_lds_fence();
 #pragma unroll
             for (int h = 0; h < 64 / 16; ++h) {
@@ -262,9 +274,9 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
                     const int r = 16 * h + q;
                     if (lane < ncols) {
                         if (TAIL) {
-                            if (rbv[q] >= 0) yc[rbv[q] + foff + lane] = tv[q];
+                            if (rbv[q] >= 0) yc[rbv[q] + foff + lane] = tv[q] * wv;
                         } else if (r < nch_u) {
-                            out[((size_t)r << lg_nf) + foff + lane] = tv[q];
+                            out[((size_t)r << lg_nf) + foff + lane] = tv[q] * wv;
                         }
                     }
                 }
@@ -285,7 +297,8 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
                                                       int channels, const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
                                                       double* __restrict__ yc, const int* __restrict__ tail_list,
                                                       double (*tile)[17], long long* rowbase, long long ck_u, int ch0_u,
-                                                      int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl, const int warm_cap) {
+                                                      int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl, const int warm_cap,
+                                                      const double* __restrict__ hwin, const int wmask) {
 #pragma clang fp contract(off)
     const int lane = threadIdx.x;
     const int nt = channels & 63;
@@ -344,6 +357,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
     }
     const unsigned lane_off = ((unsigned)(lane >> 4) << lg_nf) + (unsigned)(lane & 15);   // < 4 frame sizes: 32 bits
     fetch(t_first);
+    double wv_next = hwin[(lane & 15) & wmask];
 #pragma unroll 1
     for (int t = t_first; t < c_end; t += G) {
         float xs[G];
@@ -384,6 +398,8 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
         if (t >= 0 && col == PF - G) {   // uniform; a tile of 16 samples is complete
             const int tb = t - (PF - G) - sl_t0;   // counted from the first output of this launch
             const size_t foff = (((size_t)(tb >> lg_nf) * channels) << lg_nf) + (size_t)(tb & ((1 << lg_nf) - 1));   // as in the pipelined body
+            const double wv = wv_next;   // this lane's column of the tile: one window value for its 16 stores, fetched a tile ahead (see the pipelined body)
+            wv_next = hwin[((int)((tb + PF) & ((1 << lg_nf) - 1)) + (lane & 15)) & wmask];
             wave_lds_fence();
             constexpr int SG = TAIL ? 2 : 4;   // store instructions per group (their values and row bases are registers)
 #pragma unroll
@@ -400,10 +416,10 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
                 for (int q = 0; q < SG; ++q) {
                     const int e = (h * SG + q) * 64 + lane, r = e >> 4, cc = e & 15;
                     if (TAIL) {
-                        if (rbv[q] >= 0) yc[rbv[q] + foff + cc] = tv[q];
+                        if (rbv[q] >= 0) yc[rbv[q] + foff + cc] = tv[q] * wv;
                     } else if (r < nch_u) {
                         // rows e >> 4 = 4 (SG h + q) + (lane >> 4): a wave-uniform base per store, one per-lane offset for all
-                        (out + ((size_t)(4 * (h * SG + q)) << lg_nf) + foff)[lane_off] = tv[q];
+                        (out + ((size_t)(4 * (h * SG + q)) << lg_nf) + foff)[lane_off] = tv[q] * wv;
                     }
                 }
             }
@@ -417,22 +433,23 @@ template <bool SLICED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void if0_frontend2_kernel(
     const float* __restrict__ sig, const If0Chunk* __restrict__ chunks, long long num_chunks, int channels,
     const If0ChanCoef* __restrict__ coefs, If0Wfir wf, double* __restrict__ yc, const int* __restrict__ tail_list,
-    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf, If0Slice sl, int warm_tail) {
+    const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf, If0Slice sl, int warm_tail,
+    const double* __restrict__ hwin, int wmask) {
     __shared__ double tile[64][17];
     __shared__ long long rowbase[64];
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
-        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (channels & 63) + (int)(b % full) * 64, 64, g, lg_nf, sl, 0x7fffffff);
+        if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, b / full, (channels & 63) + (int)(b % full) * 64, 64, g, lg_nf, sl, 0x7fffffff, hwin, wmask);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)
         if0_frontend_seq_body<false, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, tail_list[g.first], 0,
-                                     channels & 63, g, lg_nf, sl, warm_tail);
+                                     channels & 63, g, lg_nf, sl, warm_tail, hwin, wmask);
     else
-        if0_frontend_seq_body<true, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl, warm_tail);
+        if0_frontend_seq_body<true, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl, warm_tail, hwin, wmask);
 }
 
 template <bool SLICED>
@@ -441,7 +458,7 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc, const int* __restrict__ tail_list,
                                                           const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf,
-                                                          If0Slice sl, int warm_tail) {
+                                                          If0Slice sl, int warm_tail, const double* __restrict__ hwin, int wmask) {
     __shared__ double tile[64][IF0_TW + 1];
     __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
     const int full = channels >> 6;
@@ -455,16 +472,16 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
         if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 b / full, (channels & 63) + (int)(b % full) * 64, 64, g, lg_nf, sl, 0x7fffffff);
+                                 b / full, (channels & 63) + (int)(b % full) * 64, 64, g, lg_nf, sl, 0x7fffffff, hwin, wmask);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
         if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
-                                 tail_list[g.first], 0, channels & 63, g, lg_nf, sl, warm_tail);
+                                 tail_list[g.first], 0, channels & 63, g, lg_nf, sl, warm_tail, hwin, wmask);
     else
         if0_frontend_body<true, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
-                                0, g, lg_nf, sl, warm_tail);
+                                0, g, lg_nf, sl, warm_tail, hwin, wmask);
 }
 
 // ------------------------------------------------------------------ spectrum
@@ -501,8 +518,8 @@ __global__ __launch_bounds__(T) void if0_spectrum_kernel(const double* __restric
             const int s = 2 * p;
             double x0 = 0.0, x1 = 0.0;
             if (s < NF) {  // the second half of the 2*NF-point frame is the zero padding
-                if (s < fr.valid) x0 = yc[fr.yc_base + (size_t)ch * fr.ch_stride + s] * window[s];
-                if (s + 1 < fr.valid) x1 = yc[fr.yc_base + (size_t)ch * fr.ch_stride + s + 1] * window[s + 1];
+                if (s < fr.valid) x0 = yc[fr.yc_base + (size_t)ch * fr.ch_stride + s];       // (windowed by the front end)
+                if (s + 1 < fr.valid) x1 = yc[fr.yc_base + (size_t)ch * fr.ch_stride + s + 1];
             }
             regs[e] = {x0, x1};
         }
@@ -879,6 +896,7 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
 struct If0Plan {
     If0ChanCoef* d_coefs = nullptr;
     double* d_window = nullptr;
+    double* d_one = nullptr;         // a single 1.0: the front end's "window" for the chirp-z frame sizes (they window in the spectrum kernel)
     cx<double>* d_tw = nullptr;
     cx<double>* d_twn = nullptr;
     cx<double>* d_twn_r = nullptr;   // [2][8][H/8], H = frame/2: W_{2NF}^(2j+P) in the register order of the DIF engine (if0_split_body)
@@ -955,7 +973,7 @@ static void if0_host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, for
 
 static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan) {
     char keyb[256];
-    snprintf(keyb, sizeof keyb, "if0r3_%d_%d_%d_%.17g_%.17g", fs, p.frame_size, p.channels, p.zeta0, p.zeta1);
+    snprintf(keyb, sizeof keyb, "if0r4_%d_%d_%d_%.17g_%.17g", fs, p.frame_size, p.channels, p.zeta0, p.zeta1);
     const std::string key = keyb;
     int rc = remez_taps_for(ctx, fs, plan.wf.c);
     if (rc) return rc;
@@ -967,6 +985,7 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
         plan.d_tw = (cx<double>*)it->second[2];
         plan.d_twn = (cx<double>*)it->second[3];
         plan.d_twn_r = (cx<double>*)it->second[4];
+        plan.d_one = (double*)it->second[5];
         return MPX_OK;
     }
     std::vector<If0ChanCoef> coefs(p.channels);
@@ -1070,8 +1089,10 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
         plan.d_twn = (cx<double>*)upload(ctx, twn.data(), twn.size() * sizeof(cx<double>));
         plan.d_twn_r = (cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
     }
-    if (!plan.d_coefs || !plan.d_window || !plan.d_tw || !plan.d_twn || !plan.d_twn_r) return MPX_ENOMEM;
-    ctx->misc_plans[key] = {plan.d_coefs, plan.d_window, plan.d_tw, plan.d_twn, plan.d_twn_r};
+    const double one = 1.0;
+    plan.d_one = (double*)upload(ctx, &one, sizeof one);
+    if (!plan.d_coefs || !plan.d_window || !plan.d_tw || !plan.d_twn || !plan.d_twn_r || !plan.d_one) return MPX_ENOMEM;
+    ctx->misc_plans[key] = {plan.d_coefs, plan.d_window, plan.d_tw, plan.d_twn, plan.d_twn_r, plan.d_one};
     return MPX_OK;
 }
 
@@ -1097,12 +1118,11 @@ __device__ __forceinline__ void if0_half_spectrum(cx<double>* buf, const DifTwid
         const int m = tid + r * T, s0 = 2 * m;
         double x0 = 0.0, x1 = 0.0;
         if (s0 + 1 < valid) {
-            const cx<double> v = *reinterpret_cast<const cx<double>*>(src + s0);
-            const cx<double> w = *reinterpret_cast<const cx<double>*>(window + s0);
-            x0 = v.x * w.x;
-            x1 = v.y * w.y;
+            const cx<double> v = *reinterpret_cast<const cx<double>*>(src + s0);   // (windowed by the front end)
+            x0 = v.x;
+            x1 = v.y;
         } else if (s0 < valid) {
-            x0 = src[s0] * window[s0];
+            x0 = src[s0];
         }
         regs[r] = {x0, x1};
         if (P) regs[r] = cmul(regs[r], twNF[m]);
@@ -1221,9 +1241,15 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
     // replaced by zeros (selects, no branches).
     const double* src = yc + fr.yc_base;
     cx<double> xn[8];
+    // (the samples arrive Hamming-windowed: the front end's tile flush multiplies them, see if0_frontend_body)
     auto fetch = [&](const double* __restrict__ p, int tid) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) xn[r] = *reinterpret_cast<const cx<double>*>(p + 2 * (tid + r * T));
+        for (int r = 0; r < 8; ++r) {
+            const int m = tid + r * T;
+            const cx<double> v = *reinterpret_cast<const cx<double>*>(p + 2 * m);
+            if (FULL) xn[r] = v;
+            else xn[r] = {2 * m < fr.valid ? v.x : 0.0, 2 * m + 1 < fr.valid ? v.y : 0.0};
+        }
     };
     fetch(src, tid0);
     for (int ch = 0; ch < channels; ++ch) {
@@ -1233,11 +1259,7 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int m = tid + r * T;
-            const cx<double> w = *reinterpret_cast<const cx<double>*>(window + 2 * m);
-            // (the select sits on the sample, not on the product: otherwise the compiler makes the WINDOW load conditional,
-            //  a branch and a full wait per point)
-            if (FULL) regs[r] = {xn[r].x * w.x, xn[r].y * w.y};
-            else regs[r] = {(2 * m < fr.valid ? xn[r].x : 0.0) * w.x, (2 * m + 1 < fr.valid ? xn[r].y : 0.0) * w.y};
+            regs[r] = xn[r];
             if (P) regs[r] = cmul(regs[r], twNF[m]);
         }
         if (IF0_PF == 2)
@@ -1900,7 +1922,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         auto fe_kernel = !fe_sequential ? (sliced ? if0_frontend_kernel<true> : if0_frontend_kernel<false>)
                                         : (sliced ? if0_frontend2_kernel<true> : if0_frontend2_kernel<false>);
         hipLaunchKernelGGL(fe_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st, d_in, d_chunks, nchunks, p.channels,
-                           plan.d_coefs, plan.wf, yc, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl, (int)warm_tail);
+                           plan.d_coefs, plan.wf, yc, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl, (int)warm_tail,
+                           blue ? plan.d_one : plan.d_window, blue ? 0 : NF - 1);   // the window goes on in the front end's tile flush
         MPX_HIP(ctx, hipGetLastError());
         if (nf_s == 0) continue;
         const If0Frame* d_fr = d_frames + sl_off[(size_t)sidx];
