@@ -1215,6 +1215,31 @@ __device__ __forceinline__ double sqrt_sumsq(double x) {
     return x == 0.0 ? 0.0 : g;
 }
 
+// d * W_16^E, E a compile-time exponent < 8 (W = exp(-2 pi i / 16))
+template <int E>
+__device__ __forceinline__ cx<double> if0_mul_w16(cx<double> d) {
+    constexpr double H2 = 0.70710678118654752440, C1 = 0.92387953251128675613, S1 = 0.38268343236508977173;
+    if constexpr (E == 0) return d;
+    else if constexpr (E == 4) return {d.y, -d.x};
+    else if constexpr (E == 2) return {H2 * (d.x + d.y), H2 * (d.y - d.x)};
+    else if constexpr (E == 6) return {H2 * (d.y - d.x), -H2 * (d.x + d.y)};
+    else {
+        constexpr double c = E == 1 ? C1 : (E == 3 ? S1 : (E == 5 ? -S1 : -C1)), sn = (E == 1 || E == 7) ? S1 : C1;   // W = c - i sn
+        return {d.x * c + d.y * sn, d.y * c - d.x * sn};
+    }
+}
+__device__ __forceinline__ cx<double> if0_mul_w16_e(cx<double> d, int e) {   // e is a constant after unrolling
+    switch (e) {
+        case 0: return if0_mul_w16<0>(d);
+        case 1: return if0_mul_w16<1>(d);
+        case 2: return if0_mul_w16<2>(d);
+        case 3: return if0_mul_w16<3>(d);
+        case 4: return if0_mul_w16<4>(d);
+        case 5: return if0_mul_w16<5>(d);
+        case 6: return if0_mul_w16<6>(d);
+        default: return if0_mul_w16<7>(d);
+    }
+}
 template <int NF, int P, bool POW1, int IF0_PF, bool FULL>   // FULL: every sample of the frame exists (no zero padding to select)
 __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __restrict__ yc, const If0Frame fr, int channels,
                                                double power, const double* __restrict__ window, const cx<double>* __restrict__ twNF,
@@ -1227,6 +1252,11 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
     DifTwiddles<H, double> twd;
 #pragma unroll
     for (int i = 0; i < PL::n - 1; ++i) twd.w[i] = twNF[2 * ((tid0 & (PL::stride(i) - 1)) * (H / PL::block(i)))];  // W_H = W_NF^2
+    // NF = 8192 (16 T): the modulation W_NF^m of the odd parity, m = tid + r T, is W_NF^tid x W_16^r, and the split twiddle of
+    // register e, W_2NF^(2 (j0 + e H/8) + P), is W_2NF^(2 j0 + P) x W_16^e -- one table value per thread and eight constants
+    // where every channel read sixteen table values per thread (as much as its samples).  (The two values are re-read per
+    // channel: held across the loop they cost the eight registers this kernel does not have under four waves per SIMD.)
+    constexpr bool TW16 = NF == 8192;
     double acc[8];
     // the Nyquist bin belongs to the one thread that holds bin 0: its sum lives in LDS (touched by that thread alone) instead
     // of in two registers of every thread
@@ -1260,7 +1290,12 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
         for (int r = 0; r < 8; ++r) {
             const int m = tid + r * T;
             regs[r] = xn[r];
-            if (P) regs[r] = cmul(regs[r], twNF[m]);
+            if (P && !TW16) regs[r] = cmul(regs[r], twNF[m]);
+        }
+        if (P && TW16) {
+            const cx<double> wmod = twNF[tid];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) regs[r] = if0_mul_w16_e(cmul(regs[r], wmod), r);
         }
         if (IF0_PF == 2)
         // the next channel's samples travel under this channel's transform (the last channel re-reads itself)
@@ -1270,6 +1305,7 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
         for (int e = 0; e < 8; ++e) buf[sigma<H>(dif_last_pos<H>(tid, e / RL, e % RL))] = regs[e];
         if (IF0_PF == 1)
         fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
+        const cx<double> wsplit = TW16 ? twn[2 * dif_freq<H>(dif_last_pos<H>(tid, 0, 0)) + P] : cx<double>{1.0, 0.0};
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -1281,7 +1317,7 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
             const cx<double> E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
             const cx<double> D = {0.5 * (A.x - B.x), 0.5 * (A.y - B.y)};
             // split twiddle W_{2NF}^(2j+P) from the table in register order (by bin it was a 16-byte gather per lane)
-            const cx<double> X = cadd(E, mul_mi(cmul(twn_r[(P * 8 + e) * T + tid], D)));
+            const cx<double> X = cadd(E, mul_mi(TW16 ? if0_mul_w16_e(cmul(wsplit, D), e) : cmul(twn_r[(P * 8 + e) * T + tid], D)));
             const double mag = sqrt_sumsq(X.x * X.x + X.y * X.y);  // |X| of audio-range data: no need for hypot's scaling
             acc[e] += POW1 ? mag : pow(mag, power);
             if (!P && j == 0) {  // bin NF pairs Z[0] with itself
