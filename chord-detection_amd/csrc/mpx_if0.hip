@@ -1256,7 +1256,7 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
     // register e, W_2NF^(2 (j0 + e H/8) + P), is W_2NF^(2 j0 + P) x W_16^e -- one table value per thread and eight constants
     // where every channel read sixteen table values per thread (as much as its samples).  (The two values are re-read per
     // channel: held across the loop they cost the eight registers this kernel does not have under four waves per SIMD.)
-    constexpr bool TW16 = NF == 8192;
+    constexpr bool TW16 = NF == 8192 || NF == 1024;   // (the sizes whose last DIF pass is a radix-8 one)
     double acc[8];
     // the Nyquist bin belongs to the one thread that holds bin 0: its sum lives in LDS (touched by that thread alone) instead
     // of in two registers of every thread
