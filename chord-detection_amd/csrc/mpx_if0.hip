@@ -143,6 +143,14 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
     float nx[PF];
     const int x_lim = c.clip_left < c_len ? c.clip_left : c_len;   // samples from x on that exist and are wanted
     auto fetch = [&](int tb) {
+        // A lone wave issues one instruction every four clocks whatever its kind, and the clamped address of a sample is eight
+        // scalar instructions + two selects: a block that lies inside the clip (all but the last of a chunk) is fetched as 16
+        // consecutive floats -- one scalar load on the uniform path -- and only the block across the end takes the per-sample form.
+        if (!TAIL && tb + PF <= x_lim) {   // (uniform)
+#pragma unroll
+            for (int q = 0; q < PF; ++q) nx[q] = x[tb + q];
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < PF; ++q) {
             const bool ok = tb + q < x_lim;
