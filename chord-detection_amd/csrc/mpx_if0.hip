@@ -200,7 +200,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             //  differed between them -- 11 of 800 per 16 samples -- once the loop bounds came from a slice)
             {
                 double r = sob[(q + 3) & 15] - fxh;   // written 13 steps ago
-                r = r < 0.0 ? -r : r;
+                r = fabs(r);   // (np.abs; as `r < 0 ? -r : r` it was a compare, a sign flip and a select per sample, fabs is an operand modifier of the next instruction)
                 const double lp = fma(k.lpb0, r, l1);
                 l1 = fma(-k.lpa1, lp, fma(k.lpb1, r, l2));
                 l2 = fma(-k.lpa2, lp, k.lpb2 * r);
@@ -397,7 +397,7 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
                 in = o;
             }
             double r = sres - xh;
-            r = r < 0.0 ? -r : r;
+            r = fabs(r);
             const double lp = fma(k.lpb0, r, l1);
             l1 = fma(-k.lpa1, lp, fma(k.lpb1, r, l2));
             l2 = fma(-k.lpa2, lp, k.lpb2 * r);
