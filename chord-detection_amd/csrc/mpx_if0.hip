@@ -1265,6 +1265,7 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
     // where every channel read sixteen table values per thread (as much as its samples).  (The two values are re-read per
     // channel: held across the loop they cost the eight registers this kernel does not have under four waves per SIMD.)
     constexpr bool TW16 = NF == 8192 || NF == 1024;   // (the sizes whose last DIF pass is a radix-8 one)
+    constexpr bool PAIR = TW16 && POW1;   // one thread splits a bin AND its mirror bin (below); with pow() inlined twice per pair the kernel spilled
     double acc[8];
     // the Nyquist bin belongs to the one thread that holds bin 0: its sum lives in LDS (touched by that thread alone) instead
     // of in two registers of every thread
@@ -1310,11 +1311,43 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
         fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
         dif_fft_keep_last<H, double>(buf, twd, regs, tid);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) buf[sigma<H>(dif_last_pos<H>(tid, e / RL, e % RL))] = regs[e];
+        for (int e = PAIR ? 4 : 0; e < 8; ++e) buf[sigma<H>(dif_last_pos<H>(tid, e / RL, e % RL))] = regs[e];
         if (IF0_PF == 1)
         fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
         const cx<double> wsplit = TW16 ? twn[2 * dif_freq<H>(dif_last_pos<H>(tid, 0, 0)) + P] : cx<double>{1.0, 0.0};
         __syncthreads();
+        if constexpr (PAIR) {
+            // A bin and its mirror bin come from the same pair (Z[j], Z[jm]): with t = W^k D they are E - i t and E + i t.  A thread's
+            // bins are j0 + e H/8, their mirrors (H - 1 - j0) + (7 - e) H/8 (odd parity) or (H/8 - j0) + (7 - e) H/8 (even parity,
+            // j0 > 0): register 7 - e of ONE partner thread.  So a thread splits its registers 0..3 against the partner's 7..4 and
+            // takes BOTH bins of each pair -- four LDS writes and four reads per thread where every thread wrote and read eight,
+            // one twiddle product per pair.  Even parity, j0 = 0 (one thread): Z[0] pairs with itself, its "mirror" bin is NF
+            // (Nyquist), and Z[H/2] -- register 4 -- is its own mirror: that bin is the thread's extra one (nyq_sh).
+            const int j0 = dif_freq<H>(dif_last_pos<H>(tid, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = j0 + e * (H / 8);
+                const int jm = P ? H - 1 - j : (H - j) & (H - 1);
+                const cx<double> A = regs[e];
+                cx<double> B = buf[sigma<H>(dif_pos<H>(jm))];
+                if (!P && j == 0) B = A;   // (what was read there is stale: register 0 is not exchanged)
+                B.y = -B.y;
+                const cx<double> E = {0.5 * (A.x + B.x), 0.5 * (A.y + B.y)};
+                const cx<double> D = {0.5 * (A.x - B.x), 0.5 * (A.y - B.y)};
+                const cx<double> t = if0_mul_w16_e(cmul(wsplit, D), e);
+                const double x0 = E.x + t.y, y0 = E.y - t.x, x1 = E.x - t.y, y1 = E.y + t.x;
+                const double m0 = sqrt_sumsq(x0 * x0 + y0 * y0), m1 = sqrt_sumsq(x1 * x1 + y1 * y1);
+                acc[e] += POW1 ? m0 : pow(m0, power);
+                acc[4 + e] += POW1 ? m1 : pow(m1, power);
+            }
+            if (!P && j0 == 0) {
+                const cx<double> A = regs[4];   // Z[H/2] and its own conjugate: E = (A.x, 0), D = (0, A.y)
+                const cx<double> t = if0_mul_w16_e(cmul(wsplit, cx<double>{0.0, A.y}), 4);
+                const double x0 = A.x + t.y, y0 = -t.x;
+                const double m0 = sqrt_sumsq(x0 * x0 + y0 * y0);
+                nyq_sh += POW1 ? m0 : pow(m0, power);
+            }
+        } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int j = dif_freq<H>(dif_last_pos<H>(tid, e / RL, e % RL));
@@ -1334,9 +1367,26 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
                 nyq_sh += POW1 ? mn : pow(mn, power);
             }
         }
+        }
         if (IF0_PF == 0)
         fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
         __syncthreads();  // the mirror reads are done before the next transform writes buf
+    }
+    if constexpr (PAIR) {
+        const int j0 = dif_freq<H>(dif_last_pos<H>(tid0, 0, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = 2 * (j0 + e * (H / 8)) + P, km = NF - k;   // the bin and its mirror bin
+            row[k] = acc[e];
+            if (k > 0) row[2 * NF - k] = acc[e];  // |X[N-k]| = |X[k]| for a real frame
+            row[km] = acc[4 + e];
+            if (km < NF) row[2 * NF - km] = acc[4 + e];
+        }
+        if (!P && j0 == 0) {   // the bin that is its own mirror
+            row[NF / 2] = nyq_sh;
+            row[2 * NF - NF / 2] = nyq_sh;
+        }
+        return;
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
