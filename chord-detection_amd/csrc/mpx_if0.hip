@@ -639,21 +639,29 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
     }
     __syncthreads();
     const int slot = slot_sh;
+    // What the search ever READS of the residual are the bins up to (M - 1) K / tau_min (the upper end of harmonic M - 1's range
+    // in the interval that starts at tau_min: 7411 of the 16 384 at the defaults), but the cancellation walked the partials of a
+    // voice up to the top of the spectrum, and the rows were initialised over all of it.  A window changes bins within four of
+    // its centre and takes its amplitude from its centre bin, so what happens above a bound can reach down by four bins per
+    // voice (<= 8 voices): rows are initialised, partials cancelled and block maxima kept below nl = that bin + 128 only --
+    // everything a decision reads is computed exactly as before, 45 % of the row traffic and of the partials at the defaults.
+    const int hi_read = (int)((a.M - 1) * a.K / a.tau_min + 0.5);
+    const int nl = hi_read + 128 + 63 < n ? ((hi_read + 128 + 63) & ~63) : n;
     double* __restrict__ ur = a.ur + (long long)slot * n;
     double* __restrict__ ud = a.ud + (long long)slot * n;
     {
     const double* __restrict__ uk = a.ut + f * (long long)n;
     // residual = spectrum, detected = 0, and the block maxima of the residual in the same pass (a wave copies whole 64-bin
-    // blocks, so it holds each block's maximum: until round 4 build_bmax read the row back)
-    for (int i0 = wave * 64; i0 < n; i0 += PER_T) {
+    // blocks, so it holds each block's maximum: until round 4 build_bmax read the row back) -- for the bins below nl only
+    for (int i0 = wave * 64; i0 < nl; i0 += PER_T) {
         const int i = i0 + lane;
-        const bool ok = i < n;
+        const bool ok = i < nl;
         double m = ok ? uk[i] : -INFINITY;
         if (ok) {
             ur[i] = m;
             ud[i] = 0.0;
         }
-        if (i0 + 64 <= n) {
+        if (i0 + 64 <= nl) {
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const double o = __shfl_xor(m, off);
@@ -818,11 +826,14 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
         // its lanes' read-modify-writes of one bin fall into different iterations of the window loop, which a wave issues
         // in order.  (Until round 4 all four waves scattered in every case: a lost update at m = 64 k was possible.)
         const bool overlap = a.K / tau < 9.0;   // uniform
+        // partials whose window lies below nl: m K / tau + 0.5 < nl - 4 (checked exactly per partial below)
+        const int mlim = (int)((nl - 4.5) * tau / a.K) + 2;
+        const int mend = nl < n && mlim < topm ? mlim : topm;
         const int mstep = overlap ? 64 : PER_T;
         if (!overlap || wave == 0) {
-            for (int m = 1 + (overlap ? lane : tid); m < topm; m += mstep) {
+            for (int m = 1 + (overlap ? lane : tid); m < mend; m += mstep) {
                 const double partialK = m * a.K / tau + 0.5;
-                if (partialK <= n) {
+                if (partialK <= n && partialK < nl - 4) {
                     const int ip = (int)partialK;
                     if (ip < n) {  // the reference would raise IndexError at exactly n; unreachable with the defaults
                         double urw = ur[ip];
@@ -842,9 +853,9 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
         // windows share is written twice with one value), and the block maxima of the blocks they touch.  Until round 4 this
         // was a pass over the whole row (read two rows, write one) and a second one for the maxima -- per voice; the rows
         // live behind the L2 (a CU's four workgroups hold 1.5 MB of them), and the kernel waited 76 % of its cycles.
-        for (int m = 1 + tid; m < topm; m += PER_T) {
+        for (int m = 1 + tid; m < mend; m += PER_T) {
             const double partialK = m * a.K / tau + 0.5;
-            if (partialK <= n && (int)partialK < n) {
+            if (partialK <= n && (int)partialK < n && partialK < nl - 4) {
                 int lowk = (int)(partialK - 4);
                 if (lowk < 0) lowk = 0;
                 int highk = (int)(partialK + 4);
@@ -858,7 +869,7 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
         }
         __syncthreads();
         __threadfence_block();
-        for (int b = wave; b < (n >> 6); b += PER_T / 64) {
+        for (int b = wave; b < (nl >> 6); b += PER_T / 64) {
             if (!dirty[b]) continue;   // uniform over the wave
             double m = ur[b * 64 + lane];
 #pragma unroll
