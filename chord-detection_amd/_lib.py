@@ -64,6 +64,8 @@ SIGNATURES = {
     "mpx_harmonic_energy": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _dp, _dp]),
     "mpx_harmonic_energy_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _dp]),
     "mpx_harmonic_energy_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _vp, _vp, _vp]),
+    "mpx_harmonic_energy_argmax": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int,
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mpx_esacf": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp, _dp]),
     "mpx_esacf_batch": (C.c_int, [_vp, _fp, _ip, C.c_int, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_esacf_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _vp, _vp, _vp]),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "mpx_prime_multif0_dev": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.POINTER(PrimeParams), _vp, _vp]),
     "mpx_iterative_f0_warmup": (C.c_int, [_vp, C.c_int, C.POINTER(If0Params), C.POINTER(C.c_int64), _dp]),
     "mpx_iterative_f0_spectra": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(If0Params), _dp]),
+    "mpx_iterative_f0_periodicity": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, C.c_int, C.POINTER(If0Params), _dp]),
     "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_set_remez_taps": (C.c_int, [_vp, C.c_int, _dp]),
     "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),
@@ -89,6 +92,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 4   # include/mpx.h MPX_ABI_VERSION
 
 
 def _share_torch_hip_runtime():
@@ -121,13 +125,19 @@ def load():
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
     _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
+    # The library must be the ABI this binding was written for.  A library named by MPX_LIB_PATH (development A/B builds)
+    # is held to the same check; only with MPX_ALLOW_OLD_ABI=1 is an earlier ABI (>= 2) accepted, and then the symbols it
+    # lacks are simply not bound (calling one raises AttributeError naming it).
+    abi = lib.mpx_abi_version() if hasattr(lib, "mpx_abi_version") else -1
+    old_ok = bool(os.environ.get("MPX_LIB_PATH")) and os.environ.get("MPX_ALLOW_OLD_ABI") == "1" and 2 <= abi < ABI_VERSION
+    if abi != ABI_VERSION and not old_ok:
+        raise RuntimeError("%s: ABI version %d, this binding needs %d (rebuild: make -C chord-detection_amd/csrc; an older "
+                           "A/B library loads only with MPX_LIB_PATH and MPX_ALLOW_OLD_ABI=1)" % (LIB_PATH, abi, ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
-        if os.environ.get("MPX_LIB_PATH") and not hasattr(lib, name):
-            continue   # an A/B build of an earlier ABI (development tools only; the default library must export everything)
+        if old_ok and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
-    if lib.mpx_abi_version() != 3 and not os.environ.get("MPX_LIB_PATH"):
-        raise RuntimeError("libmpx_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -254,9 +254,11 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
     return lo, hi, out, spent
 
 
-def gather_blocks(block, n_clips, world, rank, device=None):
-    """The job's one collective: all_gather of the (padded) per-rank blocks -> [n_clips, M, 12] on every rank."""
-    if world == 1:
+def gather_blocks(block, n_clips, world, rank, device=None, force=False):
+    """The job's one collective: all_gather of the (padded) per-rank blocks -> [n_clips, M, 12] on every rank.  With one
+    rank there is nothing to gather and the block is returned as it is, unless `force` (launch.wants_collective: a
+    one-rank process group exists and the collective is to run over it all the same)."""
+    if world == 1 and not force:
         return block
     import torch
     import torch.distributed as dist
@@ -309,40 +311,38 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     ap.add_argument("--no-overlap", action="store_true", help="run Iterative-F0 after the other methods instead of next to them")
     ap.add_argument("--note-names", choices=("unicode", "ascii"), default="unicode",
                     help="spelling of sharps by the librosa the reference runs with (include/mpx.h MPX_NOTES_*)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="create the process group and run the closing all_gather even with ONE rank (RCCL on a one-GPU box)")
     args = ap.parse_args(argv)
     methods = [int(m) for m in args.methods.split(",")]
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from . import launch
+    rank, world, local = launch.rank_world_local()
     import torch
     on_gpu = device == "cuda"
     dev = torch.device("cuda", local) if on_gpu else torch.device(device)
-    if world > 1:
-        import torch.distributed as dist
+    use_dist = launch.wants_collective(world, args.force_collective)
+    if use_dist:   # before anything else touches the GPU: the communicator is bound to the device here
+        dist = launch.init_group(backend, dev if on_gpu else None)
         if on_gpu:
             torch.cuda.set_device(dev)
-            dist.init_process_group(backend, device_id=dev)
-        else:
-            dist.init_process_group(backend)
     t0 = time.perf_counter()
     lo, hi, block, spent = run_corpus(args.clips, methods, args.fs, args.seconds, args.chunk, rank, world, local,
                                       compute=compute, synth_device=dev if on_gpu else None, overlap=not args.no_overlap,
                                       note_names=args.note_names, group=args.group)
-    chroma = gather_blocks(block, args.clips, world, rank, dev if (world > 1 and on_gpu) else None)
+    chroma = gather_blocks(block, args.clips, world, rank, dev if (use_dist and on_gpu) else None, force=use_dist)
     wall = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
+    if use_dist:
         tt = torch.tensor([wall] + spent, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, spent = float(tt[0]), [float(v) for v in tt[1:]]
     if rank == 0:
         res = summarise(chroma, methods, spent, args.clips, wall)
         res["n_gpus"] = world
+        res["collective"] = ("%s all_gather over %d rank(s)" % (backend, world)) if use_dist else None
         res["synthesis_seconds_rank0"] = LAST_SYNTH_SECONDS
         if args.out:
             np.savez_compressed(args.out, chroma=chroma, methods=np.array(methods))
         print(json.dumps(res))
-    if world > 1:
-        import torch.distributed as dist
+    if use_dist:
         dist.destroy_process_group()
     return 0

@@ -396,7 +396,17 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if (build_descs(offsets, num_clips, frame, hop, descs, seg))
         return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
     const int64_t nf = (int64_t)descs.size();
-    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
+    // where the samples live (include/mpx.h): clips already in HBM are read IN PLACE, no copy into the context's buffer
+    bool on_device = false;
+    {
+        hipPointerAttribute_t attr;
+        if (total && hipPointerGetAttributes(&attr, signals) == hipSuccess)
+            on_device = attr.type == hipMemoryTypeDevice;
+        else
+            (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
+    }
+    if (!on_device && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
+    const float* d_in = on_device ? signals : (const float*)ctx->d_signal.p;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_desc, (size_t)(nf ? nf : 1) * sizeof(FrameDesc)))) return rc;
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
@@ -409,15 +419,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     // the copy of piece k+1 (ESACF, 4096 clips: the 1.4 GB copy and the 27 ms of kernels take about as long as each
     // other).  Device-resident batches and small ones: one copy, one pass.
     int pieces = 1;
-    {
-        hipPointerAttribute_t attr;
-        bool on_device = false;
-        if (hipPointerGetAttributes(&attr, signals) == hipSuccess)
-            on_device = attr.type == hipMemoryTypeDevice;
-        else
-            (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
-        if (!on_device && (size_t)total * sizeof(float) >= (size_t(64) << 20) && num_clips >= 8) pieces = ctx->copy_pieces;
-    }
+    if (!on_device && (size_t)total * sizeof(float) >= (size_t(64) << 20) && num_clips >= 8) pieces = ctx->copy_pieces;
     if (pieces > 1 && !ctx->copy_ready) {
         // the copy stream and its eight events exist together or not at all: a partial failure is undone, and the batch
         // (and the next one: it tries again) goes in one piece
@@ -438,8 +440,8 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
         }
     }
     if (pieces == 1) {
-        if (total && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
-        if (nf && (rc = run(ctx, (const float*)ctx->d_signal.p, total, (const FrameDesc*)ctx->d_desc.p, nf, fs, params,
+        if (total && !on_device && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
+        if (nf && (rc = run(ctx, d_in, total, (const FrameDesc*)ctx->d_desc.p, nf, fs, params,
                             frame, hop, (double*)ctx->d_frames_out.p, nullptr, &did_sum, st)))
             return rc;
     } else {
@@ -493,6 +495,26 @@ int mpx_harmonic_energy_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int 
     return method_dev(ctx, run_he, d_signal, n, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, stream);
 }
 
+int mpx_harmonic_energy_argmax(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_he_params* params, int frame,
+                               int hop, int32_t* best_ind, int32_t* bounds) {
+    int rc = check_common(ctx, signal, n, frame, hop);
+    if (rc) return rc;
+    const int64_t nf = num_frames_of(n, frame, hop);
+    if (nf && !best_ind) return set_error(ctx, MPX_EINVAL, "best_ind must not be NULL");
+    const mpx_he_params p = params ? *params : mpx_he_params{2, 2, 2};
+    if (nf == 0) return he_argmax_run(ctx, nullptr, 0, 0, fs, &p, frame, hop, nullptr, bounds, ctx->stream);
+    if (p.num_harmonic < 1 || p.num_octave < 1 || p.num_harmonic * p.num_octave > 64)
+        return set_error(ctx, MPX_EINVAL, "bad harmonic-energy params (%d,%d,%d)", p.num_harmonic, p.num_octave, p.num_bins);
+    const size_t nwin = (size_t)12 * p.num_octave * p.num_harmonic;
+    if ((rc = ensure(ctx, ctx->d_signal, (size_t)n * sizeof(float)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_ws0, (size_t)nf * nwin * sizeof(int32_t)))) return rc;
+    if ((rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) return rc;
+    if ((rc = he_argmax_run(ctx, (const float*)ctx->d_signal.p, n, nf, fs, &p, frame, hop, (int*)ctx->d_ws0.p, bounds, ctx->stream))) return rc;
+    MPX_HIP(ctx, hipMemcpyAsync(best_ind, ctx->d_ws0.p, (size_t)nf * nwin * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MPX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return MPX_OK;
+}
+
 // ------------------------------------------------------------------ method 1
 int mpx_esacf(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_esacf_params* params, int frame,
               int hop, double* chroma_frames, double* chroma_sum) {
@@ -537,6 +559,14 @@ int mpx_iterative_f0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const
     int rc = if0_common(ctx, signal, offsets, 1);
     if (rc) return rc;
     return if0_run_host(ctx, signal, offsets, 1, fs, params, chroma_frames, chroma_sum, nullptr);
+}
+
+int mpx_iterative_f0_periodicity(mpx_ctx* ctx, const double* spectra, int64_t num_frames, int bins, int fs,
+                                 const mpx_if0_params* params, double* chroma_frames) {
+    if (!ctx) return MPX_EINVAL;
+    ctx->err.clear();
+    MPX_HIP(ctx, hipSetDevice(ctx->device));
+    return if0_periodicity_host(ctx, spectra, num_frames, bins, fs, params, chroma_frames);
 }
 
 int mpx_iterative_f0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_if0_params* params,

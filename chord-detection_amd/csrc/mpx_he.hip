@@ -493,14 +493,26 @@ int segment_sum(mpx_ctx* ctx, const double* d_frames, const long long* d_seg, in
 // ------------------------------------------------------------------ plan build
 static double he_round_half_even(double v) { return std::nearbyint(v); }
 
-template <typename Real>
-static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, HePlan& plan) {
-    const int M = N / 2;
+// The windows of harmonic_energy.py:44-62 on an nbins-bin spectrum: bin numbers [k0, k1) per (note, octave, harmonic), the
+// weights 1/h, and the COMPACT BIN LIST the kernels evaluate -- every window is a run [c0, c1) of it.  The list is the
+// ascending union of the windows' bins; a window that starts below bin 0 is indexed by the reference with negative k, which
+// Python wraps to the top of the spectrum (x_dft[k], k < 0 -> x_dft[nbins + k]): such a window gets a run of its own after
+// the ascending part (bins nbins + k0 .. nbins - 1, then 0 .. k1 - 1: the reference's order).  A window that reaches past
+// the last bin, or below -nbins, raises IndexError in the reference: MPX_EINVAL here.
+struct HeWindows {
+    std::vector<int> k0, k1;     // bin numbers as the reference computes them (k0 may be negative)
+    std::vector<int> c0, c1;     // the window's run of `bins`
+    std::vector<double> w;       // 1 / harmonic
+    std::vector<int> bins;       // compact bin list (never empty)
+    int kmin = 0, kmax = 0;      // [kmin, kmax) covers every listed bin
+    bool wrapped = false;
+    int sorted_bins = 0;         // length of the ascending part
+};
+static int he_windows(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, HeWindows& W) {
+    const int nbins = N / 2 + 1;
     // note table: librosa.cqt_frequencies(12, fmin=note_to_hz('C3')) harmonic_energy.py:33
     const double c3 = 440.0 * std::pow(2.0, (48.0 - 69.0) / 12.0);
     const double divisor_ratio = (fs / 4.0) / N;  // harmonic_energy.py:35 (quirk A.2)
-    std::vector<int> k0, k1;
-    std::vector<Real> ww;
     int kmin = 1 << 30, kmax = -(1 << 30);
     for (int n = 0; n < 12; ++n) {
         const double note = c3 * std::pow(2.0, n / 12.0);
@@ -508,20 +520,59 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
             for (int h = 1; h <= p.num_harmonic; ++h) {
                 const double kp = he_round_half_even((note * oct * h) / divisor_ratio);
                 const int a = (int)(kp - p.num_bins * h), b = (int)(kp + p.num_bins * h);
-                k0.push_back(a);
-                k1.push_back(b);
-                ww.push_back((Real)(1.0 / h));
+                W.k0.push_back(a);
+                W.k1.push_back(b);
+                W.w.push_back(1.0 / h);
                 if (b > a) {
+                    if (a < -nbins || b > nbins)
+                        return set_error(ctx, MPX_EINVAL, "harmonic-energy window [%d,%d) outside the %d-bin spectrum (the "
+                                         "reference raises IndexError here)", a, b, nbins);
+                    if (a < 0) W.wrapped = true;
                     kmin = a < kmin ? a : kmin;
                     kmax = b > kmax ? b : kmax;
                 }
             }
     }
     if (kmin > kmax) kmin = kmax = 0;
-    if (kmin < 0 || kmax > M + 1)
-        return set_error(ctx, MPX_EINVAL,
-                         "harmonic-energy window [%d,%d) outside the %d-bin spectrum (the reference "
-                         "raises IndexError / wraps here)", kmin, kmax, M + 1);
+    if (W.wrapped) {   // bins at both ends of the spectrum are looked at
+        kmin = 0;
+        kmax = nbins;
+    }
+    W.kmin = kmin;
+    W.kmax = kmax;
+    for (size_t w = 0; w < W.k0.size(); ++w)
+        if (W.k0[w] >= 0)
+            for (int k = W.k0[w]; k < W.k1[w]; ++k) W.bins.push_back(k);
+    std::sort(W.bins.begin(), W.bins.end());
+    W.bins.erase(std::unique(W.bins.begin(), W.bins.end()), W.bins.end());
+    W.sorted_bins = (int)W.bins.size();
+    W.c0.resize(W.k0.size());
+    W.c1.resize(W.k0.size());
+    for (size_t w = 0; w < W.k0.size(); ++w) {
+        const int len = W.k1[w] > W.k0[w] ? W.k1[w] - W.k0[w] : 0;
+        int c0;
+        if (len && W.k0[w] < 0) {
+            c0 = (int)W.bins.size();
+            for (int k = W.k0[w]; k < W.k1[w]; ++k) W.bins.push_back(k < 0 ? k + nbins : k);
+        } else {
+            c0 = (int)(std::lower_bound(W.bins.begin(), W.bins.begin() + W.sorted_bins, W.k0[w]) - W.bins.begin());
+        }
+        W.c0[w] = c0;
+        W.c1[w] = c0 + len;
+    }
+    if (W.bins.empty()) W.bins.push_back(0);
+    return MPX_OK;
+}
+
+template <typename Real>
+static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, HePlan& plan) {
+    const int M = N / 2;
+    HeWindows W;
+    if (int rc = he_windows(ctx, fs, N, p, W)) return rc;
+    std::vector<int> k0 = W.k0, k1 = W.k1;
+    std::vector<Real> ww(W.w.begin(), W.w.end());
+    const int kmin = W.kmin, kmax = W.kmax;
+    plan.wrapped = W.wrapped;
     plan.nwin = (int)k0.size();
     plan.h_k0 = k0;   // (bin numbers; the device arrays below index the compact bin list)
     plan.h_k1 = k1;
@@ -548,19 +599,10 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
     plan.window = upload(ctx, wang.data(), wang.size() * sizeof(cx<Real>));
     plan.tw = upload(ctx, tw.data(), tw.size() * sizeof(cx<Real>));
     plan.twn = upload(ctx, twn.data(), twn.size() * sizeof(cx<Real>));
-    // the bins some window touches, ascending; a window is a run of consecutive bins, hence a run of this list
-    std::vector<int> bins;
-    for (size_t w = 0; w < k0.size(); ++w)
-        for (int k = k0[w]; k < k1[w]; ++k) bins.push_back(k);
-    std::sort(bins.begin(), bins.end());
-    bins.erase(std::unique(bins.begin(), bins.end()), bins.end());
-    for (size_t w = 0; w < k0.size(); ++w) {
-        const int len = k1[w] > k0[w] ? k1[w] - k0[w] : 0;
-        const int c0 = (int)(std::lower_bound(bins.begin(), bins.end(), k0[w]) - bins.begin());
-        k0[w] = c0;
-        k1[w] = c0 + len;
-    }
-    if (bins.empty()) bins.push_back(0);
+    // the compact bin list (he_windows): ascending bins, a window is a run of it
+    std::vector<int> bins = W.bins;
+    k0 = W.c0;
+    k1 = W.c1;
     plan.nb = (int)bins.size();
     plan.h_bins = bins;
     std::vector<cx<Real>> twnb(bins.size());
@@ -578,6 +620,7 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
 constexpr int HEW_WAVES = 8, HEW_ROUNDS = 4;
 static bool he_wave_applies(const mpx_ctx* ctx, const HePlan& plan) {
     if (ctx->he_kernel == MPX_HE_KERNEL_WORKGROUP) return false;   // mpx_set_option: the workgroup-per-frame kernel below
+    if (plan.wrapped) return false;   // windows that wrap to the top of the spectrum: rows the pruned bin copy does not hold
     return plan.nb <= 64 * HEW_ROUNDS && plan.nwin <= 192;
 }
 static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n, const FrameDesc* d_desc,
@@ -810,6 +853,8 @@ struct HeBlueArgs {
     const double* ww;
     int nb, nwin, wins_per_note, num_harmonic;
     double* out;             // [F, 12]
+    int* argmax;             // debug tap (mpx_harmonic_energy_argmax), else NULL: [F, nwin] bin of each window's FIRST maximum,
+    const int* wbase;        //   counted like the reference does (wbase[w] = k0, negative in a wrapped window); INT_MIN: empty
 };
 
 template <int L, int T>
@@ -859,8 +904,14 @@ __global__ __launch_bounds__(T) void he_blue_kernel(HeBlueArgs a) {
     __syncthreads();
     for (int wi = tid; wi < a.nwin; wi += T) {
         double m = -INFINITY;
-        for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) m = mag[k] > m ? mag[k] : m;
+        int best = -1;
+        for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k)
+            if (mag[k] > m) {   // strict: the first maximum wins (harmonic_energy.py:60-62)
+                m = mag[k];
+                best = k;
+            }
         winmax[wi] = m;
+        if (a.argmax) a.argmax[f * a.nwin + wi] = best < 0 ? INT_MIN : a.wbase[wi] + (best - a.wk0[wi]);
     }
     __syncthreads();
     if (tid < 12) {
@@ -949,8 +1000,14 @@ __global__ __launch_bounds__(T) void he_blue_split_kernel(HeBlueSplitArgs sa) {
     __syncthreads();
     for (int wi = tid; wi < a.nwin; wi += T) {
         double m = -INFINITY;
-        for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k) m = mag[k] > m ? mag[k] : m;
+        int best = -1;
+        for (int k = a.wk0[wi]; k < a.wk1[wi]; ++k)
+            if (mag[k] > m) {   // strict: the first maximum wins (harmonic_energy.py:60-62)
+                m = mag[k];
+                best = k;
+            }
         winmax[wi] = m;
+        if (a.argmax) a.argmax[f * a.nwin + wi] = best < 0 ? INT_MIN : a.wbase[wi] + (best - a.wk0[wi]);
     }
     __syncthreads();
     if (tid < 12) {
@@ -987,44 +1044,21 @@ static void he_host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, forw
 }
 
 static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames, int fs,
-                       const mpx_he_params& p, int N, int hop, double* d_rows, double* d_sum, hipStream_t stream) {
+                       const mpx_he_params& p, int N, int hop, double* d_rows, double* d_sum, hipStream_t stream,
+                       int* d_argmax = nullptr) {
     char keyb[128];
     snprintf(keyb, sizeof keyb, "he_blue_%d_%d_%d_%d_%d", fs, N, p.num_harmonic, p.num_octave, p.num_bins);
     const std::string key = keyb;
     auto it = ctx->misc_plans.find(key);
     if (it == ctx->misc_plans.end()) {
-        const double c3 = 440.0 * std::pow(2.0, (48.0 - 69.0) / 12.0);
-        const double divisor_ratio = (fs / 4.0) / N;  // harmonic_energy.py:35 (quirk A.2)
-        std::vector<int> k0, k1, bins;
-        std::vector<double> ww;
-        for (int nn = 0; nn < 12; ++nn) {
-            const double note = c3 * std::pow(2.0, nn / 12.0);
-            for (int oct = 1; oct <= p.num_octave; ++oct)
-                for (int h = 1; h <= p.num_harmonic; ++h) {
-                    const double kp = he_round_half_even((note * oct * h) / divisor_ratio);
-                    const int a0 = (int)(kp - p.num_bins * h), b0 = (int)(kp + p.num_bins * h);
-                    if (b0 > a0 && (a0 < 0 || b0 > N / 2 + 1))
-                        return set_error(ctx, MPX_EINVAL, "harmonic-energy window [%d,%d) outside the %d-bin spectrum (the "
-                                         "reference raises IndexError / wraps here)", a0, b0, N / 2 + 1);
-                    k0.push_back(a0);
-                    k1.push_back(b0);
-                    ww.push_back(1.0 / h);
-                    for (int k = a0; k < b0; ++k) bins.push_back(k);
-                }
-        }
-        std::sort(bins.begin(), bins.end());
-        bins.erase(std::unique(bins.begin(), bins.end()), bins.end());
-        for (size_t w = 0; w < k0.size(); ++w) {
-            const int len = k1[w] > k0[w] ? k1[w] - k0[w] : 0;
-            const int c0 = (int)(std::lower_bound(bins.begin(), bins.end(), k0[w]) - bins.begin());
-            k0[w] = c0;
-            k1[w] = c0 + len;
-        }
-        if (bins.empty()) bins.push_back(0);
+        HeWindows W;
+        if (int rc = he_windows(ctx, fs, N, p, W)) return rc;
+        std::vector<int> k0 = W.c0, k1 = W.c1, bins = W.bins;
+        std::vector<double> ww = W.w;
         // Only the bins below the highest window are looked at: the chirp-z convolution spans chirp[-(N-1) .. K-1],
         // K = that bin + 1, so a circular length of N + K - 1 does (not 2N - 1): sizes up to ~6900 samples fit the
         // 8192-point engine with the default windows, and 2049..3500 take the 4096-point one.
-        const int K = bins.back() + 1;
+        const int K = *std::max_element(bins.begin(), bins.end()) + 1;   // (a wrapped window reaches bin N / 2)
         int L = 1024;
         while (L < N + K - 1 && L < 8192) L <<= 1;
         // beyond 8192 points: decimate the input by R (he_blue_split_kernel), R passes of ceil(N / R) + K - 1 <= 8192 points
@@ -1076,7 +1110,8 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
                                 upload(ctx, k0.data(), k0.size() * sizeof(int)),
                                 upload(ctx, k1.data(), k1.size() * sizeof(int)),
                                 upload(ctx, ww.data(), ww.size() * sizeof(double)),
-                                upload(ctx, coef.data(), coef.size() * sizeof(cx<double>))};
+                                upload(ctx, coef.data(), coef.size() * sizeof(cx<double>)),
+                                upload(ctx, W.k0.data(), W.k0.size() * sizeof(int))};
         for (void* q : d)
             if (!q) return MPX_ENOMEM;
         std::vector<unsigned char> blob(meta.size() * sizeof(int));
@@ -1112,6 +1147,8 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
     a.num_harmonic = meta[3];
     const int L = meta[4];
     a.out = rows;
+    a.argmax = d_argmax;
+    a.wbase = (const int*)it->second[9];
     const size_t extra = sizeof(double) * (size_t)(a.nb + a.nwin + 2);
     auto launch = [&](auto kern, int T, size_t lds) -> int {
         if (lds > 160 * 1024) return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame %d needs %zu B of LDS", N, lds);
@@ -1172,6 +1209,27 @@ int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_de
     }
     return f32 ? he_dispatch<float>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, d_chroma_sum, stream)
                : he_dispatch<double>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, d_chroma_sum, stream);
+}
+
+// Debug tap: the bin of every window's first maximum, [F, nwin] (MultipitchHarmonicEnergy.dft_maxes, harmonic_energy.py:57-65).
+// Any frame size runs the chirp-z kernels here (one workgroup per frame): a plot-only attribute, not a tuned path.
+int he_argmax_run(mpx_ctx* ctx, const float* d_signal, int64_t n, int64_t num_frames, int fs, const mpx_he_params* params,
+                  int frame, int hop, int* d_argmax, int* h_bounds, hipStream_t stream) {
+    mpx_he_params p = params ? *params : mpx_he_params{2, 2, 2};
+    if (p.num_harmonic < 1 || p.num_octave < 1 || p.num_bins < 0 || p.num_harmonic * p.num_octave > 64)
+        return set_error(ctx, MPX_EINVAL, "bad harmonic-energy params (%d,%d,%d)", p.num_harmonic, p.num_octave, p.num_bins);
+    if (fs <= 0) return set_error(ctx, MPX_EINVAL, "fs must be positive");
+    if (frame < 2 || frame > (1 << 18)) return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d", frame);
+    if (h_bounds) {   // [nwin][2]: k0, k1 as the reference computes them (harmonic_energy.py:50-55)
+        HeWindows W;
+        if (int rc = he_windows(ctx, fs, frame, p, W)) return rc;
+        for (size_t w = 0; w < W.k0.size(); ++w) {
+            h_bounds[2 * w] = W.k0[w];
+            h_bounds[2 * w + 1] = W.k1[w];
+        }
+    }
+    if (num_frames == 0) return MPX_OK;
+    return he_blue_run(ctx, d_signal, n, nullptr, num_frames, fs, p, frame, hop, nullptr, nullptr, stream, d_argmax);
 }
 
 }  // namespace mpx

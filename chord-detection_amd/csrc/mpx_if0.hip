@@ -346,7 +346,11 @@ __device__ __forceinline__ void if0_frontend_seq_body(const float* __restrict__ 
             nx[q] = ok ? v : 0.f;
         }
     };
-    const int c_end_all = TAIL ? c_len : ((x_lim + PF - 1) / PF * PF < c_len ? (x_lim + PF - 1) / PF * PF : c_len);
+    // Only whole 16-sample tiles reach the buffer, so the end is rounded UP to a tile: at a chirp-z frame size a clip's last
+    // chunk is nfr * NF - t0 samples, which need not be a multiple of 16 (its row is 2^lgp >= the 64-multiple full chunk
+    // long, so the rounded tail stays inside the row; at the power-of-two frame sizes c_len is a multiple of 1024).
+    const int c_len16 = (c_len + PF - 1) / PF * PF;
+    const int c_end_all = TAIL ? c_len16 : ((x_lim + PF - 1) / PF * PF < c_len16 ? (x_lim + PF - 1) / PF * PF : c_len16);
     const int sl_t0 = SLICED ? sl.t0 : 0;
     if (SLICED && sl_t0 >= c_end_all) return;                        // (uniform) this chunk ended in an earlier slice
     const int c_end = SLICED && sl.t1 < c_end_all ? sl.t1 : c_end_all;   // this launch produces the outputs [sl_t0, c_end)
@@ -2084,6 +2088,73 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             return rc;
         MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
+    MPX_HIP(ctx, hipStreamSynchronize(st));
+    return MPX_OK;
+}
+
+// Debug tap / drop-in for IterativeF0PeriodicityAnalysis.compute (periodicity.py:48-163): the period search alone on summary
+// spectra the CALLER hands in (host memory, [F, n2] doubles, n2 = 2 x window size), per-frame chroma out.
+int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes, int n2, int fs, const mpx_if0_params* params,
+                         double* chroma_frames) {
+    mpx_if0_params p = params ? *params
+                              : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
+    if (fs <= 0 || nframes < 0 || n2 < 32 || (n2 & 1) || n2 != 2 * p.frame_size || !chroma_frames || (nframes && !spectra))
+        return set_error(ctx, MPX_EINVAL, "iterative F0 periodicity: need [F, 2 x frame_size] spectra (got n2 = %d, frame_size = %d)", n2, p.frame_size);
+    // (the same bounds as the whole method, if0_run_host)
+    if (p.max_voices < 1 || p.max_voices > 8 || p.Q < 2 || p.Q > 32 || p.M < 2 || p.M > 64 || !(p.tau_min > 0) || !(p.tau_max > p.tau_min))
+        return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
+    if (p.note_names != MPX_NOTES_UNICODE && p.note_names != MPX_NOTES_ASCII)
+        return set_error(ctx, MPX_EINVAL, "iterative F0: unknown note_names %d", p.note_names);
+    if (p.frame_size < 16 || p.frame_size > 8192)
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 8192)", p.frame_size);
+    if ((p.M - 1) * ((double)p.frame_size / fs) / p.tau_min + 1.5 >= n2)
+        return set_error(ctx, MPX_EINVAL, "iterative F0: harmonic %d of tau_min falls outside the %d-bin spectrum (the "
+                         "reference raises ValueError on the empty slice)", p.M - 1, n2);
+    if (nframes == 0) return MPX_OK;
+    hipStream_t st = ctx->stream;
+    int rc;
+    if (!ctx->occupancy.count("if0_periodicity")) {
+        int occ = 0;
+        MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel, PER_T, 0));
+        ctx->occupancy["if0_periodicity"] = occ > 0 ? occ : 1;
+    }
+    const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy["if0_periodicity"]);
+    if ((rc = ensure(ctx, ctx->d_ws1, ((size_t)nframes + 2 * (size_t)per_grid) * n2 * sizeof(double)))) return rc;   // ut | ur | ud
+    if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * 12 * sizeof(double)))) return rc;
+    double* ut_all = (double*)ctx->d_ws1.p;
+    MPX_HIP(ctx, hipMemcpyAsync(ut_all, spectra, (size_t)nframes * n2 * sizeof(double), hipMemcpyHostToDevice, st));
+    If0PerArgs a;
+    a.ut = ut_all;
+    a.ur = ut_all + (size_t)nframes * n2;
+    a.ud = a.ur + (size_t)per_grid * n2;
+    a.n = n2;
+    a.fs = (double)fs;
+    a.K = (double)p.frame_size / (double)fs;
+    a.wsize = (double)p.frame_size;
+    a.max_voices = p.max_voices;
+    a.note_names = p.note_names;
+    a.Q = p.Q;
+    a.M = p.M;
+    a.tau_min = p.tau_min;
+    a.tau_max = p.tau_max;
+    a.tau_prec = p.tau_prec;
+    a.epsilon1 = p.epsilon1;
+    a.epsilon2 = p.epsilon2;
+    a.gamma = p.gamma;
+    a.chroma = (double*)ctx->d_frames_out.p;
+    a.out_row = nullptr;
+    a.num_frames = nframes;
+    if (ctx->d_queue.bytes < (size_t)per_grid * sizeof(unsigned)) {
+        if ((rc = ensure(ctx, ctx->d_queue, (size_t)per_grid * sizeof(unsigned) + 4096))) return rc;
+        MPX_HIP(ctx, hipMemsetAsync(ctx->d_queue.p, 0, ctx->d_queue.bytes, st));   // every launch leaves its slots free
+    }
+    a.slot_busy = (unsigned*)ctx->d_queue.p;
+    a.num_slots = (int)per_grid;
+    prof_mark(ctx, st, "if0_periodicity_kernel");
+    hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    prof_mark(ctx, st, nullptr);
+    MPX_HIP(ctx, hipGetLastError());
+    MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nframes * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     MPX_HIP(ctx, hipStreamSynchronize(st));
     return MPX_OK;
 }

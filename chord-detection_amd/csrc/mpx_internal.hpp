@@ -47,6 +47,7 @@ struct HePlan {
     int wins_per_note = 0;
     int num_harmonic = 0;
     int kmin = 0, kmax = 0;  // bins needed: [kmin, kmax)
+    bool wrapped = false;    // some window starts below bin 0 and wraps to the top of the spectrum (he_windows, mpx_he.hip)
 };
 
 }  // namespace mpx
@@ -121,6 +122,8 @@ inline void prof_mark(mpx_ctx* ctx, hipStream_t st, const char* name) {
     } while (0)
 
 // he
+int he_argmax_run(mpx_ctx* ctx, const float* d_signal, int64_t n, int64_t num_frames, int fs, const mpx_he_params* params,
+                  int frame, int hop, int* d_argmax, int* h_bounds, hipStream_t stream);
 int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
            int fs, const mpx_he_params* params, int frame, int hop, double* d_chroma_frames,
            double* d_chroma_sum, hipStream_t stream);
@@ -135,6 +138,8 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
 int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                  const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out,
                  bool dev_io = false, hipStream_t stream = nullptr);
+int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes, int n2, int fs, const mpx_if0_params* params,
+                         double* chroma_frames);
 int if0_warmup_samples(mpx_ctx* ctx, int fs, const mpx_if0_params* params, long long* samples, double* rho);
 int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                    const mpx_prime_params* params, double* chroma_sums, bool dev_io = false, hipStream_t stream = nullptr);

@@ -115,9 +115,13 @@ class Engine:
     def set_option(self, name, value):
         """mpx_set_option: "if0_workspace_bytes" (cap of one Iterative-F0 pass' hand-off buffer) or "he_kernel"
         (0 auto, 1 workgroup-per-frame kernel for every shape).  Results do not depend on either."""
+        if not hasattr(self.lib, "mpx_set_option"):
+            raise MpxError("the loaded library (MPX_LIB_PATH, an earlier ABI) has no mpx_set_option")
         self._check(self.lib.mpx_set_option(self.ctx, _lib.OPTIONS[name], int(value)))
 
     def get_option(self, name):
+        if not hasattr(self.lib, "mpx_get_option"):
+            raise MpxError("the loaded library (MPX_LIB_PATH, an earlier ABI) has no mpx_get_option")
         v = C.c_int64(0)
         self._check(self.lib.mpx_get_option(self.ctx, _lib.OPTIONS[name], C.byref(v)))
         return int(v.value)
@@ -144,6 +148,25 @@ class Engine:
             self.ctx, flat.ctypes.data_as(_lib._fp), offsets.ctypes.data_as(_lib._ip), len(offsets) - 1, int(fs),
             C.byref(p), int(frame), int(hop or frame), out.ctypes.data_as(_lib._dp)))
         return out
+
+    def harmonic_energy_argmax(self, x, fs, frame=8192, hop=None, num_harmonic=2, num_octave=2, num_bins=2):
+        """[F, 12 * num_octave * num_harmonic] int32: bin of each window's first maximum, counted like the reference does
+        (negative inside a wrapped window; INT32_MIN: empty window), and the windows' [k0, k1) bounds [windows, 2] --
+        mpx_harmonic_energy_argmax, the dft_maxes tap."""
+        x = self._sig(x)
+        if isinstance(x, _DevFlat):
+            raise ValueError("harmonic_energy_argmax takes a host signal")
+        hop = int(hop or frame)
+        p = _lib.HeParams(num_harmonic, num_octave, num_bins)
+        nf = max(self.num_frames(x.shape[0], frame, hop), 0)
+        nwin = 12 * int(num_octave) * int(num_harmonic)
+        out = np.zeros((nf, nwin), dtype=np.int32)
+        bounds = np.zeros((nwin, 2), dtype=np.int32)
+        i32 = C.POINTER(C.c_int32)
+        self._check(self.lib.mpx_harmonic_energy_argmax(
+            self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p), int(frame), hop,
+            out.ctypes.data_as(i32), bounds.ctypes.data_as(i32)))
+        return out, bounds
 
     def harmonic_energy_dev(self, d_signal, n, fs, frame, hop, d_frames, d_sum, stream=None,
                             num_harmonic=2, num_octave=2, num_bins=2):
@@ -260,6 +283,19 @@ class Engine:
             self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p),
             frames.ctypes.data_as(_lib._dp) if return_frames and nf else None, total.ctypes.data_as(_lib._dp)))
         return (total, frames) if return_frames else total
+
+    def iterative_f0_periodicity(self, spectra, fs, **kw):
+        """The period search alone on summary spectra [F, 2 * frame_size] (or one row): per-frame chroma [F, 12] --
+        mpx_iterative_f0_periodicity (periodicity.py:48-163)."""
+        u = np.ascontiguousarray(np.atleast_2d(np.asarray(spectra, dtype=np.float64)))
+        if u.ndim != 2:
+            raise ValueError("spectra must be [frames, 2 * frame_size]")
+        kw.setdefault("frame_size", u.shape[1] // 2)
+        p = self._if0_params(**kw)
+        out = np.zeros((u.shape[0], 12), dtype=np.float64)
+        self._check(self.lib.mpx_iterative_f0_periodicity(self.ctx, u.ctypes.data_as(_lib._dp), u.shape[0], u.shape[1], int(fs),
+                                                          C.byref(p), out.ctypes.data_as(_lib._dp)))
+        return out
 
     def iterative_f0_batch(self, clips, fs, **kw):
         flat, offsets = self._pack(clips)

@@ -17,6 +17,7 @@ class MultipitchHarmonicEnergy(Multipitch):
         self.num_octave = num_octave
         self.num_bins = num_bins
         self.hop = hop  # extension: overlapped frames (reference: hop == frame_size)
+        self.record_dft_maxes = True   # fill `dft_maxes` in compute_pitches like the reference does (a second, untuned launch)
 
     @staticmethod
     def display_name():
@@ -28,8 +29,20 @@ class MultipitchHarmonicEnergy(Multipitch):
 
     def compute_pitches(self, display_plot_frame=-1):
         # display_plot_frame: accepted and ignored (matplotlib debugging aid in the reference)
-        total = get_engine(self.device).harmonic_energy(
+        eng = get_engine(self.device)
+        total = eng.harmonic_energy(
             self.x, self.fs, self.frame_size, self.hop, self.num_harmonic, self.num_octave, self.num_bins)
+        # harmonic_energy.py:36,65: one (k0, best_ind, k1) per frame and window, in loop order; its only reader is the
+        # reference's plot.  Filled from the debug tap of the C ABI (mpx_harmonic_energy_argmax); switch it off with
+        # `record_dft_maxes = False` where only the chromagram is wanted.
+        self.dft_maxes = []
+        if self.record_dft_maxes and not hasattr(self.x, "is_cuda"):
+            best, bounds = eng.harmonic_energy_argmax(self.x, self.fs, self.frame_size, self.hop, self.num_harmonic,
+                                                      self.num_octave, self.num_bins)
+            none = -2 ** 31
+            for row in best:
+                self.dft_maxes.extend((int(k0), None if int(b) == none else int(b), int(k1))
+                                      for b, (k0, k1) in zip(row, bounds))
         return Chromagram(total)
 
     @classmethod

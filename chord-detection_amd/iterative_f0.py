@@ -6,6 +6,29 @@ from .engine import get_engine
 from .multipitch import Multipitch
 
 
+class IterativeF0PeriodicityAnalysis:
+    """periodicity.py:8-47: the period-search object the reference keeps in MultipitchIterativeF0.periodicity_estimator.
+    `compute(Uk)` runs the HIP period search on ONE summary spectrum of 2 x window_size bins (mpx_iterative_f0_periodicity)
+    and returns (Chromagram, salience_plots) like periodicity.py:48,163 -- the salience curves are plot-only and come back
+    empty."""
+
+    def __init__(self, fs, window_size, max_voices=4, tau_min=1.0 / 2100.0, tau_max=1.0 / 40.0, tau_prec=0.0000001, Q=20,
+                 M=20, epsilon1=20, epsilon2=320, gamma=0.66, device=0, note_names="unicode"):
+        self.fs = fs
+        self.window_size = window_size
+        self.K = window_size / fs
+        self.max_voices, self.tau_min, self.tau_max, self.tau_prec = max_voices, tau_min, tau_max, tau_prec
+        self.Q, self.M, self.epsilon1, self.epsilon2, self.gamma = Q, M, epsilon1, epsilon2, gamma
+        self.device, self.note_names = device, note_names
+
+    def compute(self, Uk):
+        rows = get_engine(self.device).iterative_f0_periodicity(
+            Uk, self.fs, frame_size=self.window_size, max_voices=self.max_voices, tau_min=self.tau_min, tau_max=self.tau_max,
+            tau_prec=self.tau_prec, Q=self.Q, M=self.M, epsilon1=self.epsilon1, epsilon2=self.epsilon2, gamma=self.gamma,
+            note_names=self.note_names)
+        return Chromagram(rows[0]), []
+
+
 class MultipitchIterativeF0(Multipitch):
     def __init__(
         self,
@@ -35,6 +58,8 @@ class MultipitchIterativeF0(Multipitch):
         self.peak_thresh = peak_thresh
         self.peak_min_dist = peak_min_dist
         self.harmonic_multiples_elim = harmonic_multiples_elim
+        self.periodicity_estimator = IterativeF0PeriodicityAnalysis(self.fs, self.frame_size, device=device,
+                                                                    note_names=note_names)   # iterative_f0.py:44
 
     @staticmethod
     def display_name():

@@ -189,9 +189,9 @@ def run_stream_rank(read, n, fs, rank=0, world=1, frame_size=8192, device=0, sub
     return parts[0][0], parts[-1][1], np.concatenate([p[2] for p in parts], axis=0)
 
 
-def gather_frames(block, total_frames, world, rank, device=None):
+def gather_frames(block, total_frames, world, rank, device=None, force=False):
     """all_gather of the per-rank `[frames, 12]` blocks -> `[total_frames, 12]` on every rank."""
-    return gather_blocks(block[:, None, :], total_frames, world, rank, device)[:, 0, :]
+    return gather_blocks(block[:, None, :], total_frames, world, rank, device, force=force)[:, 0, :]
 
 
 def chroma_of(frames):
@@ -246,20 +246,19 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
                     help="time shards in flight on each GPU, own context each; 0 (default): one engine call over the rank's "
                          "share when its front-end output fits 90 GiB, else 3 (1 h @44.1 kHz on one MI355X, round 3: "
                          "0.13-0.14 s in one call, 0.145-0.15 s with 3 shards)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="create the process group and run the closing all_gather even with ONE rank (RCCL on a one-GPU box)")
     args = ap.parse_args(argv)
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    from . import launch
+    rank, world, local = launch.rank_world_local()
     import torch
     on_gpu = device == "cuda"
     dev = torch.device("cuda", local) if on_gpu else torch.device(device)
+    use_dist = launch.wants_collective(world, args.force_collective)
+    if use_dist:   # before anything else touches the GPU: the communicator is bound to the device here
+        dist = launch.init_group(backend, dev if on_gpu else None)
     if on_gpu:
         torch.cuda.set_device(dev)
-    if world > 1:
-        import torch.distributed as dist
-        if on_gpu:
-            dist.init_process_group(backend, device_id=dev)
-        else:
-            dist.init_process_group(backend)
     n = int(round(args.seconds * args.fs))
     total_frames = num_frames(n, args.frame_size)
 
@@ -273,7 +272,7 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     if compute is None:
         for j in range(max(1, args.shards_per_gpu or 3)):   # plans, tables, clocks -- of every context
             _engine_frames_on(j)(read(0, min(n, 4 * args.frame_size)), args.fs, args.frame_size, local)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dev_sync()
     t0 = time.perf_counter()
@@ -299,25 +298,26 @@ def main(argv=None, compute=None, device="cuda", backend="nccl"):
     # driver is in), the second is what a service that processes one stream after the other sees
     block = compute_block()
     t_cold = time.perf_counter() - t1
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t1 = time.perf_counter()
     block = compute_block()
     t2 = time.perf_counter()
-    frames = gather_frames(block, total_frames, world, rank, dev if (world > 1 and on_gpu) else None)
+    frames = gather_frames(block, total_frames, world, rank, dev if (use_dist and on_gpu) else None, force=use_dist)
     spent = torch.tensor([t_synth, t2 - t1, t_cold], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(spent, op=dist.ReduceOp.MAX)
     if rank == 0:
         c = chroma_of(frames)
         synth_s, compute_s, cold_s = (float(v) for v in spent.cpu())
         print(json.dumps({"workload": "Iterative-F0, %.0f s stream @%d Hz (BASELINE configs[4])" % (args.seconds, args.fs),
-                          "n_gpus": world, "frames": total_frames, "frames_per_rank": f1 - f0,
+                          "n_gpus": world, "collective": ("%s all_gather over %d rank(s)" % (backend, world)) if use_dist else None,
+                          "frames": total_frames, "frames_per_rank": f1 - f0,
                           "synthesis_seconds_rank_max": synth_s, "compute_seconds_rank_max": compute_s,
                           "x_realtime_compute": args.seconds / compute_s if compute_s > 0 else None,
                           "compute_seconds_first_pass": cold_s, "shards_in_flight_per_gpu": args.shards_per_gpu or "auto (one call when the share fits 90 GiB of front-end output, else 3)",
                           "chroma": repr(c), "key": c.key()}))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     return 0
 

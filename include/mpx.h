@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPX_ABI_VERSION 3
+#define MPX_ABI_VERSION 4
 
 typedef enum mpx_status {
     MPX_OK = 0,
@@ -144,6 +144,15 @@ int mpx_harmonic_energy_batch(mpx_ctx* ctx, const float* signals, const int64_t*
 int mpx_harmonic_energy_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs,
                             const mpx_he_params* params, int frame, int hop,
                             double* d_chroma_frames, double* d_chroma_sum, void* stream);
+
+/* Debug tap: what MultipitchHarmonicEnergy.dft_maxes records (harmonic_energy.py:36,57-65; its only consumer is the
+ * reference's plot).  best_ind[F, 12 * num_octave * num_harmonic] int32, window order n x octave x harmonic: the bin k
+ * of the FIRST maximum of x_dft[k], k in range(k0, k1), counted like the reference does -- NEGATIVE inside a window that
+ * starts below bin 0 (Python's x_dft[k] wraps to the top of the spectrum there; the chroma entry points wrap the same way) --
+ * and INT32_MIN for an empty window (None in the reference).  bounds (may be NULL): [windows, 2] the k0, k1 of every
+ * window (harmonic_energy.py:50-55).  Host buffers; every frame size runs the chirp-z kernels here (untuned: a plot aid). */
+int mpx_harmonic_energy_argmax(mpx_ctx* ctx, const float* signal, int64_t n, int fs,
+                               const mpx_he_params* params, int frame, int hop, int32_t* best_ind, int32_t* bounds);
 
 /* ---- note spelling of librosa.hz_to_note (methods 1, 3, 4) ---------------------
  * The reference adds a detected pitch with `chromagram[librosa.hz_to_note(f, octave=False)] += v`
@@ -275,6 +284,13 @@ int mpx_iterative_f0_warmup(mpx_ctx* ctx, int fs, const mpx_if0_params* params, 
 /* Debug tap: summary spectra Ut [F, 2*frame_size] (iterative_f0.py:80-85), host buffers. */
 int mpx_iterative_f0_spectra(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_if0_params* params,
                              double* ut);
+
+/* The period search alone (periodicity.py:48-163, IterativeF0PeriodicityAnalysis.compute -- what the reference keeps in
+ * MultipitchIterativeF0.periodicity_estimator, iterative_f0.py:44): spectra[num_frames, bins] summary spectra in HOST memory,
+ * bins == 2 * params->frame_size (the window size the estimator was built with); chroma_frames[num_frames, 12] out.
+ * Of `params` the period-search fields, frame_size and note_names are read. */
+int mpx_iterative_f0_periodicity(mpx_ctx* ctx, const double* spectra, int64_t num_frames, int bins, int fs,
+                                 const mpx_if0_params* params, double* chroma_frames);
 
 /* Debug taps for parity tests: per-frame intermediates of the ESACF chain,
  * host buffers, each [F, len]:

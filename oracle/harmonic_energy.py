@@ -50,9 +50,33 @@ def he_chroma_from_spectrum(x_dft, fs, frame_size, num_harmonic=2, num_octave=2,
                 # empty python range: nothing is indexed, the -inf sentinel survives (harmonic_energy.py:49,57)
                 out[:, n] += -np.inf * w[n, j]
                 continue
-            if a < 0 or b > nbins:
+            if a < -nbins or b > nbins:
                 raise IndexError("harmonic-energy window [%d,%d) outside spectrum of %d bins" % (a, b, nbins))
+            if a < 0:
+                # the reference indexes x_dft[k] for k in range(k0, k1) (harmonic_energy.py:58-59): a negative k is plain
+                # Python indexing and wraps to the top of the spectrum, x_dft[nbins + k]
+                idx = [k + nbins if k < 0 else k for k in range(a, b)]
+                out[:, n] += x_dft[:, idx].max(axis=-1) * w[n, j]
+                continue
             out[:, n] += x_dft[:, a:b].max(axis=-1) * w[n, j]
+    return out
+
+
+def he_argmax(x, fs, frame_size=8192, hop=None, num_harmonic=2, num_octave=2, num_bins=2):
+    """best_ind of every window and frame [F, 12 * num_octave * num_harmonic]: the k (as the reference counts it: negative in
+    a wrapped window) of the FIRST maximum of x_dft[k], k in range(k0, k1) -- the middle entry of the (k0, best_ind, k1)
+    tuples in MultipitchHarmonicEnergy.dft_maxes (harmonic_energy.py:57-65); -1 - nbins for an empty window (None there)."""
+    spec = np.atleast_2d(he_spectrum(dsp.frame_matrix(x, frame_size, hop)))
+    k0, k1, _ = he_windows(fs, frame_size, num_harmonic, num_octave, num_bins)
+    nbins = spec.shape[-1]
+    out = np.full((spec.shape[0], k0.size), -1 - nbins, dtype=np.int64)
+    for j, (a, b) in enumerate(zip(k0.reshape(-1), k1.reshape(-1))):
+        if b <= a:
+            continue
+        if a < -nbins or b > nbins:
+            raise IndexError("harmonic-energy window [%d,%d) outside spectrum of %d bins" % (a, b, nbins))
+        idx = [k + nbins if k < 0 else k for k in range(int(a), int(b))]
+        out[:, j] = int(a) + np.argmax(spec[:, idx], axis=-1)   # numpy.argmax: first maximum, like the strict > of the loop
     return out
 
 

@@ -15,7 +15,8 @@ def configure(bench):
     bench.PREHEAT_MS = 0
     bench.NSIG = 2
     bench.CFG.update(esacf_clips=3, esacf_fs=22050, esacf_clip_seconds=0.25, corpus_clips_per_gpu=3, corpus_fs=22050,
-                     stream_seconds=9.0, stream_fs=22050, if0_frame=8192)
+                     stream_seconds=9.0, stream_fs=22050, if0_frame=8192, he_default_clips=2, he_default_fs=22050,
+                     he_default_frame=1024)
 
 
 def _f32(ptr, n):
@@ -75,6 +76,11 @@ class Engine:
             _f64(d_sum, 12)[:] = acc
         if self._prof is not None:
             self._prof["he_kernel"] = (1, 0.05)
+
+    def harmonic_energy_batch(self, clips, fs, frame=8192, hop=None, **kw):
+        from oracle import harmonic_energy as o_he
+        clips = clips.numpy() if hasattr(clips, "numpy") else np.asarray(clips)
+        return np.stack([o_he.he_frames(c, fs, frame, hop or frame).sum(axis=0) for c in clips])
 
     def esacf_dev(self, d_signal, n, fs, frame, hop, d_frames, d_sum, stream=None, **kw):
         rows = _fake_rows(_f32(d_signal, n), frame, hop)

@@ -27,7 +27,8 @@ Provenance labels stored with every array:
                  expected values: keys `<clip>/sum` ... are the unicode
                  spelling, `<clip>/sum_ascii` ... the ASCII one.
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py            (every fixture)
+        python tests/golden/make_golden.py he_wrap esacf_frames   (only the named round-5 sections; the others stay as committed)
 """
 import json
 import os
@@ -153,6 +154,66 @@ def make_clips():
     return clips
 
 
+# ---------------------------------------------------------------- round 5 sections (files of their own)
+def golden_he_wrap(chord_detection, clips, fs):
+    """harmonic_energy.py:53-61 with windows that start BELOW bin 0: `x_dft[k]` with a negative k is plain Python indexing and
+    wraps to the top of the spectrum.  Reached with large `num_bins` (k' - num_bins * harmonic < 0).  ref-code."""
+    from oracle import harmonic_energy as o_he
+    he = {"provenance": np.array("ref-code")}
+    cases = [("N1024_b30", dict(frame_size=1024, num_bins=30), "poly_seed1"),
+             ("N4096_b110_h2_o2", dict(frame_size=4096, num_bins=110), "piano_like_Cmaj"),
+             ("N8192_b200", dict(frame_size=8192, num_bins=200), "poly_seed2"),
+             ("N2048_b55_h3_o1", dict(frame_size=2048, num_bins=55, num_harmonic=3, num_octave=1), "tones_G2_B2_Gsharp3"),
+             ("N1000_b27", dict(frame_size=1000, num_bins=27), "short_ragged")]
+    for key, kw, clip in cases:
+        x = clips[clip][:4 * kw["frame_size"] + 77]
+        _CLIPS["__wrap__"] = (x, fs)
+        obj = chord_detection.MultipitchHarmonicEnergy("__wrap__", **kw)
+        total = obj.compute_pitches()
+        assert min(k0 for k0, _, _ in obj.dft_maxes) < 0, key          # the case does wrap
+        he[key + "/clip"] = np.array(clip)
+        he[key + "/n"] = np.array(x.shape[0])
+        he[key + "/kwargs"] = np.array(json.dumps(kw))
+        he[key + "/sum"] = np.array([total[i] for i in range(12)])
+        F = int(np.ceil(len(x) / kw["frame_size"]))
+        per = []
+        for f in range(F):
+            _CLIPS["__frame__"] = (x[f * kw["frame_size"]:(f + 1) * kw["frame_size"]], fs)
+            c = chord_detection.MultipitchHarmonicEnergy("__frame__", **kw).compute_pitches()
+            per.append([c[i] for i in range(12)])
+        he[key + "/frames"] = np.array(per)
+        # (k0, best_ind, k1) of the first frame's windows: what MultipitchHarmonicEnergy.dft_maxes holds (harmonic_energy.py:65)
+        he[key + "/dft_maxes_frame0"] = np.array(obj.dft_maxes[:len(obj.dft_maxes) // F], dtype=np.int64)
+        okw = {k: v for k, v in kw.items() if k != "frame_size"}
+        np.testing.assert_allclose(o_he.he_frames(x, fs, kw["frame_size"], **okw), np.array(per), rtol=1e-12, atol=0)
+    np.savez_compressed(os.path.join(HERE, "harmonic_energy_wrap.npz"), **he)
+
+
+def golden_esacf_frames(chord_detection, clips, fs):
+    """ESACF per FRAME for the clips whose sums hold ill-conditioned fits (poly_seed2: tests/test_gpu_esacf.py): the
+    reference run on one frame at a time, both note spellings.  ref-code+stub (a7-a8 go through the stand-ins)."""
+    es = {"provenance": np.array("ref-code+stub")}
+    N = int(fs * 46.4 / 1000)
+    for mode, sfx in SPELLINGS:
+        set_spelling(mode)
+        for name in ("poly_seed2", "poly_seed1", "piano_like_Cmaj"):
+            x = clips[name]
+            F = int(np.ceil(len(x) / N))
+            per = []
+            for f in range(F):
+                _CLIPS["__frame__"] = (x[f * N:(f + 1) * N], fs)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    c = chord_detection.MultipitchESACF("__frame__").compute_pitches()
+                per.append([c[i] for i in range(12)])
+            es[name + "/frames" + sfx] = np.array(per)
+    set_spelling("unicode")
+    np.savez_compressed(os.path.join(HERE, "esacf_frames.npz"), **es)
+
+
+ROUND5 = {"he_wrap": golden_he_wrap, "esacf_frames": golden_esacf_frames}
+
+
 def main():
     install_stubs()
     import chord_detection
@@ -166,6 +227,15 @@ def main():
     clips = make_clips()
     for name, x in clips.items():
         _CLIPS[name] = (x, fs)
+    only = [a for a in sys.argv[1:] if a in ROUND5]
+    if only:   # the named sections alone; the clips are regenerated in memory (same seeds) and checked against the committed file
+        committed = np.load(os.path.join(HERE, "clips.npz"))
+        for name, x in clips.items():
+            np.testing.assert_array_equal(committed[name], x)
+        for a in only:
+            ROUND5[a](chord_detection, clips, fs)
+        print("golden fixtures written:", ", ".join(only))
+        return
     np.savez_compressed(os.path.join(HERE, "clips.npz"), fs=fs, **clips)
 
     # ------------------------------------------------------ G7 constants
@@ -384,6 +454,8 @@ def main():
             it[name + "/frames" + sfx] = per
     set_spelling("unicode")
     np.savez_compressed(os.path.join(HERE, "iterative_f0.npz"), **it)
+    for fn in ROUND5.values():
+        fn(chord_detection, clips, fs)
     print("golden fixtures written to", HERE)
 
 

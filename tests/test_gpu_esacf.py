@@ -39,8 +39,9 @@ def _oracle_sum(x, fs, **kw):
 
 
 # Ill-conditioned frames SEEN by each check (fixed seeds and a deterministic engine => fixed numbers): the table lives in
-# tests/golden/esacf_fragile_frames.json, measured on MI355X (gfx950), and is asserted as <= measured + 1 by default
-# (MPX_TEST_FRAGILE_SLACK=0: exactly -- the form the table is re-measured with; a last-bit change of a kernel may move one frame):
+# tests/golden/esacf_fragile_frames.json, measured on MI355X (gfx950).  By default `fragile` is asserted as <= measured + 1
+# and `loose` EXACTLY (MPX_TEST_FRAGILE_SLACK=0: the whole table exactly; scripts/gpu_suite.sh runs the suite that way a second
+# time and prints the table diff, so a one-frame move is visible):
 #   key -> [frames, fragile, loose]: `fragile` = frames on which the reference algorithm itself is ill-conditioned
 #   (oracle.frame_fragility: a 1e-12 relative perturbation of the ESACF row changes its chroma), compared with the oracle
 #   fed the GPU's own ESACF row; `loose` = the ones among them that differ EVEN THEN, which is only accepted in bins an
@@ -51,7 +52,7 @@ def _oracle_sum(x, fs, **kw):
 FRAGILE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "esacf_fragile_frames.json")
 with open(FRAGILE_TABLE) as _fh:
     MEASURED = {k: tuple(v) for k, v in json.load(_fh)["checks"].items()}
-SLACK = int(os.environ.get("MPX_TEST_FRAGILE_SLACK", "1"))   # default: <= measured + 1; MPX_TEST_FRAGILE_SLACK=0 asserts the table exactly
+SLACK = int(os.environ.get("MPX_TEST_FRAGILE_SLACK", "1"))   # `fragile` <= measured + SLACK (default 1); `loose` -- the frames that DIFFER from the oracle -- always exactly; 0: the whole table exactly
 SEEN = {}
 RECORD = os.environ.get("MPX_TEST_FRAGILE_RECORD")   # re-measuring: path of a JSON that receives what this run saw
 
@@ -109,7 +110,10 @@ def _check_frames(eng, x, fs, frame, per, hop=None, key=None, **kw):
         if RECORD:
             pass
         elif SLACK:
-            assert fragile <= MEASURED[key][1] + SLACK and loose <= MEASURED[key][2] + SLACK, (key, fragile, loose, MEASURED[key])
+            # `fragile` counts frames on which the REFERENCE is ill-conditioned (a last-bit change of a kernel may move one
+            # across the detector's threshold); `loose` counts frames whose result differs from the oracle's on the same
+            # input -- a new one is a regression until the table is re-measured on purpose (MPX_TEST_FRAGILE_RECORD)
+            assert fragile <= MEASURED[key][1] + SLACK and loose <= MEASURED[key][2], (key, fragile, loose, MEASURED[key])
         else:
             assert (int(per.shape[0]), fragile, loose) == MEASURED[key], (key, (int(per.shape[0]), fragile, loose), MEASURED[key])
     return fragile
@@ -225,6 +229,35 @@ def test_end_to_end_golden_strings_and_keys(eng, clips, golden_dir):
     # frame by frame in test_enhancement_and_full_frames_vs_oracle); measured on MI355X: see E2E_FRAGILE_CLIPS
     print("esacf end-to-end: strict %d of %d, clips with an ill-conditioned frame: %s" % (strict, len(clips), fragile_clips))
     assert set(fragile_clips) <= E2E_FRAGILE_CLIPS, fragile_clips
+
+
+def test_per_frame_fixture_pins_the_clip_with_the_ill_conditioned_frame(eng, clips, golden_dir):
+    """poly_seed2's SUM cannot be pinned (one of its 44 frames holds a runaway gaussian fit whose landing place is chaotic):
+    its FRAMES can.  tests/golden/esacf_frames.npz is the reference run on one frame at a time (make_golden.py
+    esacf_frames; ref-code+stub, both spellings): every frame that is not ill-conditioned must match the fixture at the
+    north-star tolerance; the ill-conditioned ones are named, must be the frames the table knows, and may differ only
+    within one peak height.  The two clean clips next to it must match on every frame."""
+    from oracle import esacf as o_esacf
+    d = np.load(os.path.join(golden_dir, "esacf_frames.npz"))
+    assert str(d["provenance"]) == "ref-code+stub"
+    for name in ("poly_seed2", "poly_seed1", "piano_like_Cmaj"):
+        x = clips[name]
+        e_gpu = eng.esacf_stage("esacf", x, FS, 1023)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fragile = [f for f in range(e_gpu.shape[0]) if o_esacf.frame_fragility(e_gpu[f], FS)]
+        assert (len(fragile) <= 2) if name == "poly_seed2" else not fragile, (name, fragile)
+        for mode, sfx in SPELLINGS:
+            want = d[name + "/frames" + sfx]
+            _, per = eng.esacf(x, FS, 1023, return_frames=True, note_names=mode)
+            assert per.shape == want.shape == (44, 12)
+            differ = [f for f in range(44) if not np.allclose(per[f], want[f], rtol=RTOL_CHROMA, atol=1e-9)]
+            warnings.warn("esacf per-frame fixture %-16s %-8s ill-conditioned frames %s, frames differing from the fixture %s"
+                          % (name, mode, fragile, differ))
+            assert set(differ) <= set(fragile), (name, mode, differ, fragile)
+            for f in differ:
+                cap = float(np.max(e_gpu[f])) * (1.0 + 1e-9) + 1e-9
+                assert float(np.max(np.abs(per[f] - want[f]))) <= cap and abs(float(per[f].sum() - want[f].sum())) <= cap
 
 
 def test_note_names_ascii_keeps_the_sharps(eng, clips, golden_dir):

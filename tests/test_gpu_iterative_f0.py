@@ -83,6 +83,32 @@ def test_spectra_and_batch_vs_oracle(eng, clips):
         eng.iterative_f0(np.zeros((2, 2), dtype=np.float32), FS)
 
 
+def test_periodicity_estimator_attribute(eng, clips):
+    """iterative_f0.py:44: MultipitchIterativeF0.periodicity_estimator is an IterativeF0PeriodicityAnalysis whose
+    compute(Uk) -> (Chromagram, salience_plots) runs the period search on one summary spectrum (periodicity.py:48-163):
+    here on the oracle's summary spectra, frame by frame, against the oracle's period search, both spellings; and on the
+    engine's own spectra against the engine's per-frame rows."""
+    import chord_detection_amd as cd
+    from oracle import iterative_f0 as o_if0
+    x = clips["poly_seed1"]
+    for mode, _ in SPELLINGS:
+        obj = cd.MultipitchIterativeF0((x, FS), note_names=mode)
+        est = obj.periodicity_estimator
+        assert est.fs == FS and est.window_size == 8192 and est.max_voices == 4 and est.Q == 20
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            wper, wut = o_if0.iterative_f0_frames(x, FS, note_names=mode)
+        for f in range(wut.shape[0]):
+            c, plots = est.compute(wut[f])
+            assert plots == [] and len(c) == 12
+            np.testing.assert_allclose(c.as_array(), wper[f], rtol=1e-5, atol=1e-300)
+        ut = eng.iterative_f0_spectra(x, FS)
+        _, per = eng.iterative_f0(x, FS, return_frames=True, note_names=mode)
+        np.testing.assert_array_equal(eng.iterative_f0_periodicity(ut, FS, note_names=mode), per)
+    with pytest.raises(ValueError):
+        eng.iterative_f0_periodicity(np.ones((1, 1000)), FS, frame_size=8192)
+
+
 def test_chunked_front_end_matches_sequential_filtering(eng):
     """A signal longer than one 262144-sample chunk: chunks start from zero state mpx_iterative_f0_warmup (40960) samples early.
     The reference filters sequentially; the oracle does too.  Agreement shows the run-in is long enough."""
@@ -242,6 +268,29 @@ def test_any_frame_size_by_chirp_z_vs_oracle(eng, frame_size, power, channels):
         np.testing.assert_allclose(got[0], o_if0.iterative_f0_compute(batch[0], FS, **kw), rtol=1e-5, atol=1e-300)
         np.testing.assert_allclose(got[2], o_if0.iterative_f0_compute(batch[2], FS, **kw), rtol=1e-5, atol=1e-300)
     assert np.all(got[1] == 0)
+
+
+@pytest.mark.parametrize("frame_size,nfr,channels", [(900, 49, 70), (1000, 13, 70), (777, 30, 64), (1500, 9, 33)])
+def test_chirp_z_sequential_front_end_flushes_the_last_partial_tile(eng, frame_size, nfr, channels):
+    """Packed clips whose length is an exact multiple of a chirp-z frame size that is not a multiple of 16: the clip's last
+    chunk ends inside a 16-sample tile.  With more waves than SIMDs (640 clips) the front end is the SEQUENTIAL kernel
+    (if0_frontend2_kernel), which once dropped that tile (round-4 advisor finding): every row against the single-clip call
+    (pipelined kernel), and against the oracle for the distinct clips (iterative_f0.py:54-96)."""
+    from oracle import iterative_f0 as o_if0
+    rng = np.random.default_rng(frame_size)
+    n = frame_size * nfr
+    assert n % 16 != 0
+    base = [_poly(rng, n) + (1e-3 * rng.standard_normal(n)).astype(np.float32) for _ in range(4)]
+    kw = dict(frame_size=frame_size, channels=channels)
+    packed = np.stack([base[i % 4] for i in range(640)])
+    got = eng.iterative_f0_batch(packed, FS, **kw)
+    for i in range(4):
+        one = eng.iterative_f0(base[i], FS, **kw)
+        np.testing.assert_allclose(got[i::4], np.broadcast_to(one, got[i::4].shape), rtol=1e-12, atol=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i in (0, 3):
+            np.testing.assert_allclose(got[636 + i], o_if0.iterative_f0_compute(base[i], FS, **kw), rtol=1e-5, atol=1e-300)
 
 
 @pytest.mark.parametrize("frame_size", [1024, 2048, 4096])

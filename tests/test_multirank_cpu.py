@@ -57,7 +57,9 @@ def test_bench_py_two_ranks():
     assert np.isclose(d["value_one_in_flight"], 2 * 8 * 5 / (d["ms_per_step_one_in_flight"] * 5e-3), rtol=1e-9)
     assert "cpu_baseline" not in d                                # rank 0 at N = 1 only
     w = d["workloads"]
-    assert set(w) == {"esacf_clips_4096", "esacf_stft_8192", "corpus_4096_all_methods", "if0_stream_1h"}
+    assert set(w) == {"esacf_clips_4096", "esacf_stft_8192", "corpus_4096_all_methods", "if0_stream_1h", "he_default_8192"}
+    assert d["config"]["collective"].startswith("gloo all_gather") and d["config"]["repeats"] == 25   # K < 200: 25 repeats
+    assert w["esacf_stft_8192"]["value_one_call"] == w["esacf_stft_8192"]["value"]
     assert w["esacf_clips_4096"]["scaling"] == "weak" and w["corpus_4096_all_methods"]["scaling"] == "weak"
     assert w["if0_stream_1h"]["scaling"] == "strong" and w["if0_stream_1h"]["frames"] == -(-int(9.0 * 22050) // 8192)
     assert w["corpus_4096_all_methods"]["nonzero_rows"] == 2 * 3 * 4      # both ranks' clips arrived through the gather
@@ -80,6 +82,47 @@ def test_bench_py_one_rank_stub_matches_contract():
     assert c["cores"] == 1 and c["value"] > 0 and c["host"]["workers"] >= 1 and c["host"]["model"]
     if c["host"]["workers"] > 1:
         assert c["all_cores"]["cores"] == c["host"]["workers"]
+
+
+def test_one_rank_runs_the_collective_when_forced_or_launched():
+    """One rank has nothing to gather, but `--force-collective` -- or a one-rank launch through torch.distributed.run --
+    creates the process group and runs the job's all_gather / all_reduce over it all the same (on a GPU box: RCCL comm
+    init + collective on the one MI355X, tests/test_gpu_collective.py).  Here over gloo: bench.py both ways, and the
+    corpus and stream drivers."""
+    import tempfile
+    env = dict(os.environ, PYTHONPATH=ROOT, MPX_BENCH_STUB="tests.bench_stub")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    with tempfile.TemporaryDirectory(dir=ROOT) as tmp:
+        out = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--force-collective",
+                              "--workloads", "corpus_4096_all_methods,if0_stream_1h", "--full-json", os.path.join(tmp, "f.json")],
+                             cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        d = _bench_full(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0]))
+        assert d["n_gpus"] == 1 and d["config"]["collective"] == "gloo all_gather of [steps, 12] inside every timed repeat, 1 rank(s)"
+        assert d["workloads"]["corpus_4096_all_methods"]["nonzero_rows"] == 3 * 4
+        c = _torchrun(1, ["bench.py", "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--headline-only",
+                          "--full-json", os.path.join(tmp, "g.json")], {"MPX_BENCH_STUB": "tests.bench_stub"})
+        assert _bench_full(c)["config"]["collective"].endswith("1 rank(s)")
+        plain = subprocess.run([sys.executable, "bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--headline-only",
+                                "--full-json", os.path.join(tmp, "h.json")], cwd=ROOT, env=env, capture_output=True, text=True,
+                               timeout=600)
+        assert plain.returncode == 0, plain.stderr[-3000:]
+        assert _bench_full(json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][0]))["config"]["collective"] is None
+    env.pop("MPX_BENCH_STUB")
+    for what, args in (("corpus", ["--clips", "3", "--seconds", "0.25", "--chunk", "2", "--methods", "2"]),
+                       ("stream", ["--seconds", "9", "--fs", "22050", "--frame-size", "8192"])):
+        res = {}
+        for flag in ([], ["--force-collective"]):
+            one = subprocess.run([sys.executable, "tests/tools/launch_cpu_rank.py", what] + args + flag, cwd=ROOT, env=env,
+                                 capture_output=True, text=True, timeout=600)
+            assert one.returncode == 0, one.stderr[-3000:]
+            res[bool(flag)] = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+        assert res[False]["collective"] is None and res[True]["collective"] == "gloo all_gather over 1 rank(s)"
+        if what == "corpus":
+            assert res[False]["methods"]["2"]["mean_chroma"] == res[True]["methods"]["2"]["mean_chroma"]
+        else:
+            assert res[False]["chroma"] == res[True]["chroma"]
 
 
 def test_run_corpus_script_two_ranks():

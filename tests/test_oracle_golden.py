@@ -118,6 +118,43 @@ def test_harmonic_energy(golden_dir, clips):
         d["kwargs_N2048_h3_o3_b1/sum"], rtol=1e-12)
 
 
+def test_harmonic_energy_windows_below_bin_zero_wrap_like_python_indexing(golden_dir, clips):
+    """harmonic_energy.py:53-61: `x_dft[k]` with a negative k wraps to the top of the spectrum (large num_bins).  Fixture
+    made by the reference's own code (make_golden.py he_wrap); also dft_maxes' (k0, best_ind, k1) of frame 0."""
+    d = np.load(os.path.join(golden_dir, "harmonic_energy_wrap.npz"))
+    assert str(d["provenance"]) == "ref-code"
+    keys = sorted(k[:-7] for k in d.files if k.endswith("/kwargs"))
+    assert len(keys) == 5
+    for key in keys:
+        kw = json.loads(str(d[key + "/kwargs"]))
+        x = clips[str(d[key + "/clip"])][:int(d[key + "/n"])]
+        n = kw.pop("frame_size")
+        np.testing.assert_allclose(o_he.he_frames(x, FS, n, **kw), d[key + "/frames"], rtol=1e-12)
+        np.testing.assert_allclose(o_he.he_compute(x, FS, n, **kw), d[key + "/sum"], rtol=1e-12)
+        k0, k1, _ = o_he.he_windows(FS, n, **kw)
+        assert k0.min() < 0
+        np.testing.assert_array_equal(d[key + "/dft_maxes_frame0"][:, 0], k0.reshape(-1))
+        np.testing.assert_array_equal(d[key + "/dft_maxes_frame0"][:, 2], k1.reshape(-1))
+        np.testing.assert_array_equal(o_he.he_argmax(x[:n], FS, n, **kw)[0], d[key + "/dft_maxes_frame0"][:, 1])
+    with pytest.raises(IndexError):   # past the last bin: the reference's x_dft[k] raises
+        o_he.he_frames(clips["poly_seed1"][:1024], FS, 1024, num_bins=200)
+
+
+def test_esacf_per_frame_fixture(golden_dir, clips):
+    """ESACF frame by frame against the reference run on one frame at a time (make_golden.py esacf_frames; ref-code+stub):
+    poly_seed2 holds the one ill-conditioned frame of the golden clips, so its SUM cannot separate a real regression from
+    the fit's chaos -- its frames can.  Both spellings."""
+    d = np.load(os.path.join(golden_dir, "esacf_frames.npz"))
+    e = np.load(os.path.join(golden_dir, "esacf_e2e.npz"))
+    for mode, sfx in SPELLINGS:
+        for name in ("poly_seed2", "poly_seed1", "piano_like_Cmaj"):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                per = o_esacf.esacf_frames(clips[name], FS, frame_size=1023, note_names=mode)
+            np.testing.assert_allclose(per, d[name + "/frames" + sfx], rtol=1e-6, atol=1e-9)
+            np.testing.assert_allclose(d[name + "/frames" + sfx].sum(0), e[name + "/sum" + sfx], rtol=1e-12, atol=1e-12)
+
+
 def test_he_windows_T_shape():
     k0, k1, w = o_he.he_windows(44100, 4096)
     assert k0.min() == 47 and k1.max() == 371  # k' in [49, 367], +-2h bins
