@@ -49,12 +49,22 @@ __host__ __device__ inline size_t band_index(long long f, int n, int N) {
     return (((size_t)(f >> 6) * ntiles + (n >> 4)) * 64 + (size_t)(f & 63)) * BS_TILE + (n & 15);
 }
 
+// A frame CUT IN TIME (BandCut, chosen by the host from the frame length and the filters alone -- never from the batch, so
+// a frame's bits do not depend on what it is batched with): gridDim.y pieces, piece 0 = tiles [0, p0), piece p >= 1 =
+// tiles [p0 + (p - 1) pt, p0 + p pt); a piece other than the first starts `rt` tiles early from ZERO state and throws that
+// run-in away.  Every stage is a stable linear filter (the rectifier between them has no memory), so what the true state
+// at the piece's start would have added has decayed below 2^-60 of the filters' gain by the time the piece's own samples
+// begin (band_cut: the run-in is sized from the simulated impulse responses).  Piece 0 is the reference's zero-state start.
+struct BandCut {
+    int p0, pt, rt;   // tiles of 16 samples; one piece: p0 = all tiles
+};
+
 template <bool XW>
 __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__ sig, long long n,
                                                        const FrameDesc* __restrict__ desc, long long frame0,
                                                        long long num_frames, int N, int hop, BandCoef k,
                                                        cx<double>* __restrict__ xb,
-                                                       double* __restrict__ xw) {
+                                                       double* __restrict__ xw, BandCut cut) {
     __shared__ float tin[64][BS_TILE + 1];
     __shared__ double tlo[64][BS_TILE + 1];
     __shared__ double thi[64][BS_TILE + 1];
@@ -123,6 +133,11 @@ __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__
         }
     };
     const int ntiles = (N + BS_TILE - 1) / BS_TILE;
+    // this wave's piece of the frames: output tiles [tile_lo, tile_hi), filtering from tile_in (zero state there)
+    const int piece = blockIdx.y;
+    const int tile_lo = piece == 0 ? 0 : cut.p0 + (piece - 1) * cut.pt;
+    const int tile_hi = piece == 0 ? cut.p0 : (tile_lo + cut.pt < ntiles ? tile_lo + cut.pt : ntiles);
+    const int tile_in = tile_lo - cut.rt > 0 && piece > 0 ? tile_lo - cut.rt : 0;
     // stage out: a tile goes out exactly as it lies, (x_lo, x_hi) pairs, 16 KB contiguous per wave:
     // band layout [block of 64 frames][tile of 16 samples][frame][sample] (band_index above)
     auto flush = [&](int tile) {
@@ -137,11 +152,11 @@ __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__
             }
         }
     };
-    fetch(0);
+    fetch(tile_in * BS_TILE);
     // block tb runs iterations tau = tb .. tb + 15: it takes in the samples tb .. tb + 15 and puts out the samples
     // tb - 12 .. tb + 3, i.e. columns 4 .. 15 of output tile tb / 16 - 1 (complete after iteration tb + 11: flushed there)
     // and columns 0 .. 3 of the next one.  One block past the last input tile drains the pipeline (its input is zeros).
-    for (int tb = 0; tb <= ntiles * BS_TILE; tb += BS_TILE) {
+    for (int tb = tile_in * BS_TILE; tb <= tile_hi * BS_TILE; tb += BS_TILE) {
         // ---- stage in: 4 frame rows x 16 samples per instruction
 #pragma unroll
         for (int q = 0; q < BS_TILE; ++q) {
@@ -198,7 +213,7 @@ __global__ __launch_bounds__(64) void bandsplit_kernel(const float* __restrict__
                 pxh[1] = xhat0 + k.c[1] * o;
                 xr[q] = xf;
             }
-            if (q == 11 && tb >= BS_TILE) {   // output tile tb / 16 - 1 is complete
+            if (q == 11 && tb > tile_lo * BS_TILE) {   // output tile tb / 16 - 1 is complete (and this piece's to write)
                 wave_lds_fence();
                 flush(tb / BS_TILE - 1);
                 wave_lds_fence();
@@ -1895,6 +1910,18 @@ __global__ __launch_bounds__(T) void peakpick_kernel(SacfArgs a) {
 // (noise ~1e-8) and the tolerances (1.5e-8) resolve.
 constexpr int FIT_THREADS = 128;
 constexpr int FIT_WAVES_PER_SIMD = 2;
+#if defined(MPX_DEV_KNOBS) && defined(MPX_FIT_STATS)
+// statistics of the fit kernels (builds with -DMPX_DEV_KNOBS -DMPX_FIT_STATS only -- `make stats` -> libmpx_hip_stats.so; the
+// counters are global atomics in the trip loop and slow the kernels down thirty-fold; read with mpx_dev_fit_hist, scripts/dev/fit_hist.py):
+// [0..11] lane kernel: lmpar iterations per trial (11 = the trial took no lmpar: FIT_INIT); [12] INNER sections run (waves),
+// [13] lanes in them, [14] sum of the wave maximum of the lmpar iterations, [15] sum of the lanes' iterations, [16] OUTER
+// sections run (waves), [17] lanes in them, [18] trips (waves); [20..30] cooperative kernels: lmpar iterations per trial and
+// fit; [32] their trips (waves), [33] sum of the wave maximum, [34] fits in those trips, [35] inner-loop repeats
+__device__ unsigned long long g_fit_hist[64];
+#define FIT_STAT(i, v) atomicAdd(&g_fit_hist[i], (unsigned long long)(v))
+#else
+#define FIT_STAT(i, v) ((void)0)
+#endif
 enum { FIT_NEED_WORK = 0, FIT_OUTER = 1, FIT_INNER = 2, FIT_DONE = 3, FIT_INIT = 4 };
 
 // exp(x) for x <= 0 (the gaussian's argument; NaN propagates): x = (64 e + j) ln2/64 + r, |r| <= ln2/128, so
@@ -2585,7 +2612,27 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                 double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
 #pragma unroll
                 for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
+#if defined(MPX_DEV_KNOBS) && defined(MPX_FIT_STATS)
+                int lm_it = 0;
+                par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd, &lm_it);
+                if (l == 0) {
+                    FIT_STAT(20 + lm_it, 1);
+                    FIT_STAT(35, 1);
+                }
+                {
+                    int wmax = 0;
+                    for (int k = 1; k <= 10; ++k)
+                        if (__ballot(lm_it >= k)) wmax = k;
+                    const unsigned long long act = __ballot(1);
+                    if ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) {
+                        FIT_STAT(32, 1);
+                        FIT_STAT(33, wmax);
+                        FIT_STAT(34, __popcll(act) >> 3);
+                    }
+                }
+#else
                 par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
+#endif
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     p[j] = -p[j];
@@ -2806,6 +2853,16 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         if (__all(phase == FIT_DONE)) break;
 
         int info = 0;
+#if defined(MPX_DEV_KNOBS) && defined(MPX_FIT_STATS)
+        if (lane == 0) FIT_STAT(18, 1);
+        {
+            const int no = __popcll(__ballot(phase == FIT_OUTER));
+            if (lane == 0 && no) {
+                FIT_STAT(16, 1);
+                FIT_STAT(17, no);
+            }
+        }
+#endif
         // ---------------- OUTER: jacobian, QR, Q^T f
         if (phase == FIT_OUTER) {
             double a[MAXM][NP], r[NP * NP], qtf[NP];
@@ -2977,11 +3034,18 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             r[3] = r[6] = r[7] = 0.0;  // below the diagonal: scratch of lmpar / qrsolv, never read
 #pragma unroll
             for (int j = 0; j < NP; ++j) qtf[j] = rq[(6 + j) * 64];
+#if defined(MPX_DEV_KNOBS) && defined(MPX_FIT_STATS)
+            int lm_it = 11;
+#endif
             if (!fresh) {
                 double rr[NP * NP], sd[NP];
 #pragma unroll
                 for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
+#if defined(MPX_DEV_KNOBS) && defined(MPX_FIT_STATS)
+                par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd, &lm_it);
+#else
                 par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
+#endif
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
                     p[j] = -p[j];
@@ -2992,6 +3056,33 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             }
 #pragma unroll
             for (int j = 0; j < NP; ++j) xnew[j] = x[j] + p[j];
+#if defined(MPX_DEV_KNOBS) && defined(MPX_FIT_STATS)
+            {
+                FIT_STAT(lm_it, 1);
+                const int its = lm_it == 11 ? 0 : lm_it;
+                int mx = its, sm = its;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const int o = __shfl_xor(mx, off), q = __shfl_xor(sm, off);   // (inactive lanes return their own value: see below)
+                    mx = o > mx ? o : mx;
+                    sm += q;
+                }
+                const unsigned long long act = __ballot(1);
+                if (lane == __ffsll((long long)act) - 1) {
+                    FIT_STAT(12, 1);
+                    FIT_STAT(13, __popcll(act));
+                }
+                FIT_STAT(15, its);
+                // wave maximum over the ACTIVE lanes: by atomicMax into LDS would be exact; the shuffle above reads inactive
+                // lanes' stale registers, so take the maximum through a ballot per iteration count instead
+                int wmax = 0;
+                for (int k = 1; k <= 10; ++k)
+                    if (__ballot(its >= k)) wmax = k;
+                if (lane == __ffsll((long long)act) - 1) FIT_STAT(14, wmax);
+                (void)mx;
+                (void)sm;
+            }
+#endif
             double rn[MAXM];  // residuals at the trial point (MINPACK's wa4)
             {
                 double ys_g[MAXM];
@@ -3085,6 +3176,20 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 }
 
 #pragma clang fp contract(fast)
+
+#if defined(MPX_DEV_KNOBS) && defined(MPX_FIT_STATS)
+}  // namespace mpx
+// statistics builds only: read (and clear) the fit kernels' statistics, 64 counters (see g_fit_hist)
+extern "C" int mpx_dev_fit_hist(unsigned long long* out64, int clear) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(mpx::g_fit_hist), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (clear) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mpx::g_fit_hist), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace mpx {
+#endif
 
 // ------------------------------------------------------------------ kernel 4
 __global__ __launch_bounds__(64) void scatter_kernel(long long frame0, long long num_frames, int fs, int Mh, int maxp,
@@ -3353,6 +3458,86 @@ static int band_coefs_rest(int fs, BandCoef& k) {
     return MPX_OK;
 }
 
+// How a frame of N samples is cut in time for bandsplit_kernel (BandCut).  The run-in a later piece needs is read off the
+// filters themselves: the impulse responses of input -> residual -> high-pass, input -> residual -> low-pass and of the
+// low-pass alone (it follows the rectifier) are simulated, and the run-in is the first multiple of 16 samples t at which
+// what a forgotten past can still contribute -- sum_{n >= t} |h[n]|, for the rectified band the low-pass's tail plus the
+// high-pass's tail smeared by the low-pass -- is below 2^-60 of sum |h|.  1 kHz Butterworth poles at 44.1 kHz have radius
+// 0.904: 512 samples; at 22.05 kHz 0.818: 272.  A frame is cut when it is at least four run-ins long (the reference's own
+// 46.4 ms frames -- 1023 / 2046 samples -- are not: their batches are thousands of frames and fill the chip uncut), into
+// BS_PIECES pieces of equal WORK: the first one, without run-in, is longer by it.  Nothing here looks at the batch.
+constexpr int BS_PIECES = 8;
+static BandCut band_cut(mpx_ctx* ctx, int fs, int N, const BandCoef& k) {
+    const int ntiles = (N + BS_TILE - 1) / BS_TILE;
+    BandCut one{ntiles, 0, 0};
+    const int pieces = dev_env_int("MPX_BS_PIECES", BS_PIECES);
+    if (pieces <= 1) return one;
+    const std::string key = "bs_runin_" + std::to_string(fs);
+    auto it = ctx->host_blobs.find(key);
+    if (it == ctx->host_blobs.end()) {
+        constexpr int T = 16384;
+        std::vector<double> hr(T), hhp(T), hlo(T), hlp(T);
+        {   // dsp/wfir.py:25-43 on a unit impulse, then the three biquads (esacf.py:47-51)
+            double z[12] = {0}, h1 = 0, h2 = 0, l1 = 0, l2 = 0, g1 = 0, g2 = 0;
+            for (int t = 0; t < T; ++t) {
+                const double x = t == 0 ? 1.0 : 0.0;
+                double in = x, xh = k.c[0] * x;
+                for (int i = 0; i < 12; ++i) {
+                    const double o = -k.a * in + z[i];
+                    z[i] = in + k.a * o;
+                    xh += k.c[i + 1] * o;
+                    in = o;
+                }
+                const double r = x - xh;
+                hr[t] = r;
+                const double yh = k.hpb[0] * r + h1;
+                h1 = (h2 + k.hpb[1] * r) - k.hpa[1] * yh;
+                h2 = k.hpb[2] * r - k.hpa[2] * yh;
+                hhp[t] = yh;
+                const double yl = k.lpb[0] * r + l1;
+                l1 = (l2 + k.lpb[1] * r) - k.lpa[1] * yl;
+                l2 = k.lpb[2] * r - k.lpa[2] * yl;
+                hlo[t] = yl;
+                const double yp = k.lpb[0] * x + g1;
+                g1 = (g2 + k.lpb[1] * x) - k.lpa[1] * yp;
+                g2 = k.lpb[2] * x - k.lpa[2] * yp;
+                hlp[t] = yp;
+            }
+        }
+        auto tails = [&](const std::vector<double>& h) {   // tail[t] = sum_{n >= t} |h[n]| / sum |h|
+            std::vector<double> tl(T + 1, 0.0);
+            for (int t = T - 1; t >= 0; --t) tl[t] = tl[t + 1] + std::fabs(h[t]);
+            const double tot = tl[0] > 0 ? tl[0] : 1.0;
+            for (double& v : tl) v /= tot;
+            return tl;
+        };
+        const std::vector<double> thp = tails(hhp), tlo = tails(hlo), tlp = tails(hlp);
+        double glp = 0.0;
+        for (double v : hlp) glp += std::fabs(v);
+        const double eps = std::ldexp(1.0, -60);
+        int runin = -1;
+        for (int t = BS_TILE; t <= T / 2 && runin < 0; t += BS_TILE) {
+            if (tlo[t] >= eps || tlp[t] >= eps || thp[t] >= eps) continue;
+            double smear = 0.0;   // the rectified band: the high-pass's leftover at t - j through tap j of the low-pass
+            for (int j = 0; j <= t; ++j) smear += std::fabs(hlp[j]) * thp[t - j];
+            if (smear / glp + tlp[t] < eps && tlo[T / 2] < eps * 1e-3) runin = t;
+        }
+        std::vector<unsigned char> blob(sizeof(int));
+        std::memcpy(blob.data(), &runin, sizeof(int));
+        it = ctx->host_blobs.emplace(key, std::move(blob)).first;
+    }
+    int runin;
+    std::memcpy(&runin, it->second.data(), sizeof(int));
+    if (runin < 0 || N < 4 * runin) return one;
+    BandCut c;
+    c.rt = runin / BS_TILE;
+    c.pt = (ntiles - c.rt + pieces - 1) / pieces;
+    c.p0 = ntiles - (pieces - 1) * c.pt;
+    if (c.pt < 1 || c.p0 < 1) return one;
+    return c;
+}
+static int band_cut_pieces(const BandCut& c, int N) { return c.pt ? 1 + ((N + BS_TILE - 1) / BS_TILE - c.p0 + c.pt - 1) / c.pt : 1; }
+
 template <int L, bool BLUE>
 static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStream_t st) {
     const size_t lds = sizeof(cx<double>) * L + sizeof(double) * (size_t)(a.Mh + 2);
@@ -3397,6 +3582,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     BandCoef coef;
     int rc = band_coefs(ctx, fs, coef);
     if (rc) return rc;
+    const BandCut bcut = band_cut(ctx, fs, N, coef);
     EsacfPlan plan;
     HugeArgs hg{};
     if (huge) {
@@ -3532,12 +3718,13 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
         double* xw = (stage == MPX_STAGE_WFIR) ? d_stage_out + (size_t)f0 * N : nullptr;
         prof_mark(ctx, st, "bandsplit_kernel");
+        const dim3 bs_grid((unsigned)((nf + 63) / 64), (unsigned)band_cut_pieces(bcut, N));
         if (xw)
-            hipLaunchKernelGGL(bandsplit_kernel<true>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
-                               (long long)n, d_desc, f0, nf, N, hop, coef, xb, xw);
+            hipLaunchKernelGGL(bandsplit_kernel<true>, bs_grid, dim3(64), 0, st, d_signal,
+                               (long long)n, d_desc, f0, nf, N, hop, coef, xb, xw, bcut);
         else
-            hipLaunchKernelGGL(bandsplit_kernel<false>, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, st, d_signal,
-                               (long long)n, d_desc, f0, nf, N, hop, coef, xb, xw);
+            hipLaunchKernelGGL(bandsplit_kernel<false>, bs_grid, dim3(64), 0, st, d_signal,
+                               (long long)n, d_desc, f0, nf, N, hop, coef, xb, xw, bcut);
         MPX_HIP(ctx, hipGetLastError());
         if (stage == MPX_STAGE_XLO || stage == MPX_STAGE_XHI)
             hipLaunchKernelGGL(band_unpack_kernel, dim3((unsigned)nf), dim3(256), 0, st, xb, nf, N, stage == MPX_STAGE_XHI ? 1 : 0,
@@ -3724,6 +3911,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             // persistent grid filling every SIMD with FIT_WAVES_PER_SIMD waves; lanes pull peaks until the list is empty
             long long blocks = (slots + FIT_THREADS - 1) / FIT_THREADS;
             if (blocks > fit_resident) blocks = fit_resident;
+            if (dev_env_int("MPX_FIT_BLOCKS", 0) > 0 && blocks > dev_env_int("MPX_FIT_BLOCKS", 0)) blocks = dev_env_int("MPX_FIT_BLOCKS", 0);
             // MINPACK: maxfev = 200 (n + 1); the env knobs are for profiling
             const int maxfev = dev_env_int("MPX_FIT_MAXFEV", 200 * (lm::NP + 1));
             const bool park = !deterministic && !dev_env_on("MPX_FIT_NOPARK");

@@ -937,7 +937,7 @@ struct HeBlueSplitArgs {
     const cx<double>* coef;  // [R][nb] W_N^(r k) conj(chirp[k]) at the window bins
 };
 
-template <int L, int T>
+template <int L, int T, int PB>   // PB: window bins per thread (nb <= PB * T, checked by the host)
 __global__ __launch_bounds__(T) void he_blue_split_kernel(HeBlueSplitArgs sa) {
     const HeBlueArgs& a = sa.b;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -958,7 +958,6 @@ __global__ __launch_bounds__(T) void he_blue_split_kernel(HeBlueSplitArgs sa) {
     }
     const float* __restrict__ x = a.sig + start;
     cx<double> regs[L / T];
-    constexpr int PB = 2;   // window bins per thread (nb <= PB * T, checked by the host)
     cx<double> acc[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) acc[j] = {0.0, 0.0};
@@ -1064,7 +1063,7 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
         // beyond 8192 points: decimate the input by R (he_blue_split_kernel), R passes of ceil(N / R) + K - 1 <= 8192 points
         int R = 1;
         while ((N + R - 1) / R + K - 1 > 8192 && R < 64) ++R;
-        if ((N + R - 1) / R + K - 1 > 8192 || (R > 1 && bins.size() > 1024))
+        if ((N + R - 1) / R + K - 1 > 8192 || (R > 1 && bins.size() > 4096))
             return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame size %d with %zu window bins up to bin %d does not fit "
                              "64 passes of the 8192-point chirp-z", N, bins.size(), K - 1);
         const int n1 = (N + R - 1) / R;
@@ -1168,7 +1167,8 @@ static int he_blue_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const Fra
         sa.coef = (const cx<double>*)it->second[8];
         const size_t lds = sizeof(cx<double>) * lds_slots(8192) + extra;
         if (lds > 160 * 1024) return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: frame %d needs %zu B of LDS", N, lds);
-        auto kern = he_blue_split_kernel<8192, 512>;
+        // two window bins per thread (the shapes the chroma path sends here), eight for the bin lists of very wide windows
+        auto kern = a.nb <= 1024 ? he_blue_split_kernel<8192, 512, 2> : he_blue_split_kernel<8192, 512, 8>;
         MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         prof_mark(ctx, stream, "he_blue_kernel");
         hipLaunchKernelGGL(kern, dim3((unsigned)num_frames), dim3(512), lds, stream, sa);

@@ -193,7 +193,7 @@ MPX_HD inline void qrsolv(double* r, const int* ipvt, const double* diag, const 
 }
 
 MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const double* qtb, double delta,
-                           double par, double* x, double* sdiag) {
+                           double par, double* x, double* sdiag, int* iters = nullptr) {
     double wa1[NP], wa2[NP];
     int nsing = NP;
 #pragma unroll
@@ -220,6 +220,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
     for (int j = 0; j < NP; ++j) wa2[j] = diag[j] * x[j];
     double dxnorm = enorm3(wa2);
     double fp = dxnorm - delta;
+    if (iters) *iters = 0;   // (statistics of development builds; dead code otherwise)
     if (fp <= 0.1 * delta) return 0.0;
     double parl = 0.0;
     if (nsing >= NP) {
@@ -308,6 +309,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
         if (fp < 0.0) paru = paru < par ? paru : par;
         par = parl > par + parc ? parl : par + parc;
     }
+    if (iters) *iters = it;
     return par;
 }
 

@@ -98,8 +98,9 @@ def test_bench_line_has_the_contract_fields():
     assert (d["n_gpus"], d["steps"], d["warmup"]) == (1, 60, 6)
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f64" and d["data"] == "synthetic" and "model" not in d["config"]
-    assert d["engine"] == "hip" and d["config"]["repeats"] == 5 and len(d["ms_per_step_repeats"]) == 5
-    assert sorted(d["ms_per_step_repeats"])[2] == pytest.approx(d["ms_per_step"], rel=1e-9)     # the median of the repeats
+    # K = 60 < 200 steps: 25 repeats of exactly K steps (a short run's five-sample median was thin), the median is reported
+    assert d["engine"] == "hip" and d["config"]["repeats"] == 25 and len(d["ms_per_step_repeats"]) == 25
+    assert sorted(d["ms_per_step_repeats"])[12] == pytest.approx(d["ms_per_step"], rel=1e-9)     # the median of the repeats
     assert "configs[1]" in d["config"]["workload"] and d["config"]["frames_per_gpu"] == 8192
     assert d["value"] == pytest.approx(8192 / (d["ms_per_step"] * 1e-3), rel=1e-6)
     assert d["value_one_in_flight"] == pytest.approx(8192 / (d["ms_per_step_one_in_flight"] * 1e-3), rel=1e-6)
