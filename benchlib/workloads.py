@@ -382,7 +382,7 @@ def wl_he_default(c):
                       "frames_per_gpu": frames, "entry": "mpx_harmonic_energy_batch, clips in HBM; kernel_ms: mpx_harmonic_energy_dev"},
            "kernels_ms": {"he_kernel": kern_ms}, "oracle_spot_check": ok,
            "roofline": {"bound": "hbm", "achieved": hbm / 1e9, "peak": K.HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm / K.HBM_PEAK,
-                        "kernel": "he_kernel<8192>", "kernel_ms": kern_ms, "units_per_launch": frames, "unit_of_work": "frame",
+                        "kernel": "he_wave_kernel<7,4,...,2> (two passes per 8192-sample frame)", "kernel_ms": kern_ms, "units_per_launch": frames, "unit_of_work": "frame",
                         "bytes_per_unit": b_alg, "flops_per_unit": f_alg, "hbm_frac": hbm / K.HBM_PEAK,
                         "valu_f64_frac": fl / K.F64_PEAK, "compulsory_bytes": b_alg * frames, "traffic": None},
            "hbm_frac_whole_path": b_alg * frames / wall / K.HBM_PEAK}

@@ -616,19 +616,29 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
     return MPX_OK;
 }
 
-// The wave-per-frame kernel (mpx_he_wave.hpp) for the headline shape: 4096-sample frames, fp64, at most 256 window bins.
+// The wave-per-frame kernel (mpx_he_wave.hpp): 4096-sample frames (the headline shape) and, two passes per frame, the
+// reference's default 8192; fp64, at most 256 window bins.
 constexpr int HEW_WAVES = 8, HEW_ROUNDS = 4;
+constexpr int HEW_WAVES2 = 7;   // 8192-sample frames: the window table is 32 KB, seven transpose buffers fit next to it
 static bool he_wave_applies(const mpx_ctx* ctx, const HePlan& plan) {
     if (ctx->he_kernel == MPX_HE_KERNEL_WORKGROUP) return false;   // mpx_set_option: the workgroup-per-frame kernel below
     if (plan.wrapped) return false;   // windows that wrap to the top of the spectrum: rows the pruned bin copy does not hold
     return plan.nb <= 64 * HEW_ROUNDS && plan.nwin <= 192;
 }
+template <int HALVES>
 static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n, const FrameDesc* d_desc,
                           int64_t num_frames, int hop, double* d_out, double* d_sum, hipStream_t stream) {
-    constexpr int N = 4096, M = N / 2;
+    constexpr int N = 4096 * HALVES, WAVES = HALVES == 1 ? HEW_WAVES : HEW_WAVES2;
     if (!plan.whalf) {
-        std::vector<double> wh(M);
-        for (int i = 0; i < M; ++i) wh[i] = (double)(0.54L - 0.46L * cosl(2.0L * M_PIl * i / (long double)(N - 1)));   // scipy.signal.hamming(N), harmonic_energy.py:42
+        // scipy.signal.hamming(N), harmonic_energy.py:42, as the kernel reads it: [pass h][pair pm < 1024] = the window at the
+        // samples 2 HALVES pm + 2 h and the next one (the upper half of a pass is the mirror image of pass HALVES - 1 - h)
+        std::vector<double> wh((size_t)2048 * HALVES);
+        for (int h = 0; h < HALVES; ++h)
+            for (int pm = 0; pm < 1024; ++pm)
+                for (int j = 0; j < 2; ++j) {
+                    const int i = 2 * HALVES * pm + 2 * h + j;
+                    wh[(size_t)h * 2048 + 2 * pm + j] = (double)(0.54L - 0.46L * cosl(2.0L * M_PIl * i / (long double)(N - 1)));
+                }
         std::vector<unsigned> sl(2 * plan.h_bins.size());
         for (size_t i = 0; i < plan.h_bins.size(); ++i) {
             const int kp = plan.h_bins[i] & 1023, km = (1024 - kp) & 1023;
@@ -655,7 +665,8 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
     a.wk1 = plan.wk1;
     a.ww = (const double*)plan.ww;
     a.slots = plan.wslots;
-    a.twnb = (const cx<double>*)plan.twnb;
+    a.twnb = (const cx<double>*)plan.twnb;   // W_N^k
+    a.escratch = nullptr;
     a.nb = plan.nb;
     a.nwin = plan.nwin;
     a.wins_per_note = plan.wins_per_note;
@@ -668,7 +679,7 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
     }
     a.out = d_out;
     a.partial = nullptr;
-    // one workgroup of eight waves per CU, each owning a contiguous run of frames
+    // one workgroup per CU, each owning a contiguous run of frames
     long long g = ctx->num_cus < num_frames ? ctx->num_cus : num_frames;
     const long long per = (num_frames + g - 1) / g;
     g = (num_frames + per - 1) / per;
@@ -677,26 +688,44 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
         if (rc) return rc;
         a.partial = (double*)ctx->d_partials.p;
     }
-    const size_t lds = (size_t)hw_shared_bytes(HEW_ROUNDS, plan.nwin) + (size_t)HEW_WAVES * HW_XBUF;
-    // every frame whole, inside the signal and 8-byte aligned: the instantiation without the ragged loader (no scratch)
-    const bool all_fast = !d_desc && (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0 &&
-                          (num_frames - 1) * (long long)hop + 4096 <= n;
-    // rows of ZA / ZB the window bins (and their mirrors) live in: the 44.1 kHz instantiation when they fit its 22 rows
-    unsigned k2 = 0;
-    for (int k : plan.h_bins) k2 |= hw_k2_bits(k);
-    const bool k44 = (k2 & ~HW_K2_44K) == 0;
-    using kern_t = void (*)(HeWaveArgs, cx<double>*);
-    const kern_t kerns[4] = {he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false, HW_K2_ALL>,
-                             he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true, HW_K2_ALL>,
-                             he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false, HW_K2_44K>,
-                             he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true, HW_K2_44K>};
-    const kern_t kern = kerns[(k44 ? 2 : 0) + (all_fast ? 1 : 0)];
-    if (!ctx->occupancy.count("he_wave_lds")) {
-        for (kern_t k : kerns) MPX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ctx->occupancy["he_wave_lds"] = 1;
+    if (HALVES == 2) {   // pass 0's spectrum at the window bins, 4 KB per wave (d_ws4 is the ESACF path's: not in use here)
+        int rc = ensure(ctx, ctx->d_ws4, (size_t)g * WAVES * 64 * HEW_ROUNDS * sizeof(cx<double>));
+        if (rc) return rc;
+        a.escratch = (cx<double>*)ctx->d_ws4.p;
     }
+    const size_t lds = (size_t)hw_shared_bytes(HEW_ROUNDS, plan.nwin, HALVES) + (size_t)WAVES * HW_XBUF;
+    // every frame whole, inside the signal and (float2 loads of the 4096 kernel) 8-byte aligned: the instantiation without the
+    // ragged loader (no scratch)
+    const bool all_fast = !d_desc && (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0 &&
+                          (num_frames - 1) * (long long)hop + N <= n;
+    using kern_t = void (*)(HeWaveArgs, cx<double>*);
+    kern_t kern;
+    const char* okey;
+    if constexpr (HALVES == 1) {
+        // rows of ZA / ZB the window bins (and their mirrors) live in: the 44.1 kHz instantiation when they fit its 22 rows
+        unsigned k2 = 0;
+        for (int k : plan.h_bins) k2 |= hw_k2_bits(k);
+        const bool k44 = (k2 & ~HW_K2_44K) == 0;
+        static const kern_t kerns[4] = {he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false, HW_K2_ALL>,
+                                        he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true, HW_K2_ALL>,
+                                        he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, false, HW_K2_44K>,
+                                        he_wave_kernel<HEW_WAVES, HEW_ROUNDS, false, true, HW_K2_44K>};
+        kern = kerns[(k44 ? 2 : 0) + (all_fast ? 1 : 0)];
+        okey = "he_wave_lds";
+        if (!ctx->occupancy.count(okey))
+            for (kern_t k : kerns) MPX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    } else {
+        static const kern_t kerns[2] = {he_wave_kernel<HEW_WAVES2, HEW_ROUNDS, false, false, HW_K2_ALL, 2>,
+                                        he_wave_kernel<HEW_WAVES2, HEW_ROUNDS, false, true, HW_K2_ALL, 2>};
+        kern = kerns[all_fast ? 1 : 0];
+        okey = "he_wave2_lds";
+        if (!ctx->occupancy.count(okey))
+            for (kern_t k : kerns) MPX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    ctx->occupancy[okey] = 1;
+    if (lds > 160 * 1024) return set_error(ctx, MPX_EUNSUPPORTED, "harmonic energy: the wave kernel needs %zu B of LDS", lds);
     prof_mark(ctx, stream, "he_wave_kernel");
-    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(HEW_WAVES * 64), lds, stream, a, (cx<double>*)nullptr);
+    hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(WAVES * 64), lds, stream, a, (cx<double>*)nullptr);
     prof_mark(ctx, stream, nullptr);
     MPX_HIP(ctx, hipGetLastError());
     if (d_sum) {
@@ -712,8 +741,9 @@ template <int N, int T, typename Real>
 static int he_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n,
                      const FrameDesc* d_desc, int64_t num_frames, int hop, double* d_out, double* d_sum,
                      hipStream_t stream) {
-    if constexpr (N == 4096 && std::is_same<Real, double>::value) {
-        if (he_wave_applies(ctx, plan)) return he_wave_launch(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
+    if constexpr ((N == 4096 || N == 8192) && std::is_same<Real, double>::value) {
+        if (he_wave_applies(ctx, plan))
+            return he_wave_launch<N / 4096>(ctx, plan, d_signal, n, d_desc, num_frames, hop, d_out, d_sum, stream);
     }
     HeArgs<Real> a;
     a.sig = d_signal;

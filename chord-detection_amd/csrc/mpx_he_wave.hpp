@@ -17,6 +17,22 @@
 // The price is 2 waves per SIMD (<= 256 VGPRs); the long register-resident runs have the instruction-level
 // parallelism to cover fp64 latency without more waves.
 //
+// HALVES = 2 (round 5): the reference's own default frame, 8192 samples (harmonic_energy.py:14-16).  x[8m + r], r < 8, are
+// eight real sequences with 1024-point transforms T_r, X[k] = sum_r W_8192^(r k) T_r[k]: the wave runs the pipeline above
+// TWICE per frame, pass h on zA[m] = x[8m + 2h] + i x[8m + 2h + 1] and zB[m] = x[8m + 4 + 2h] + i x[8m + 5 + 2h] (sample
+// pairs 4 (L + 64 n1) + 2h: the same coalesced 8-byte loads), and gets
+//   X_h[k] = (T_2h + W^k T_2h+1) + W^4k (T_4+2h + W^k T_5+2h),   W = W_8192,       X[k] = X_0[k] + W^2k X_1[k]:
+// phase D with W_8192^k where the 4096-sample frame has W_4096^k (the group factor is its FOURTH power), pass 0's X_0 at
+// the window bins parked (4 KB per wave, through global memory: registers and LDS are full) and folded in at the end of
+// pass 1.  The window table is 32 KB then ([pass][pair]; the mirror image of pass h is pass 1 - h), which leaves room for
+// seven waves per CU.  Each pass uses 8 of every 16 bytes of the frame: fetched pass by pass, every cache line of the signal
+// comes in twice, the second time seven microseconds later and no longer from the L2: 127 us per 8196 frames streamed from
+// HBM against 90 with the input resident in L2 (scripts/dev/he8192_ab.py).  Three ways around it were built and measured in
+// round 5, none kept: both passes' pairs fetched together into the registers the spectrum leaves (312 bytes per lane of
+// scratch), the two passes unrolled into separate code (240), pass 1's pairs fetched at the start of pass 0 and parked in a
+// global buffer of the wave's own (scratch-free with ONE load sequence over run-time strides, but the wait for those loads
+// at the top of the pass costs more than the second fetch: 153 us streamed, 108 resident).
+//
 // Same arithmetic contract as he_kernel (harmonic_energy.py:42-67): x * hamming_sym(N) in fp64, real-split on the
 // window bins only, |X|^2 maxima, fourth root of the 48 maxima, the reference's summation order inside a frame.
 #pragma once
@@ -49,7 +65,8 @@ struct HeWaveArgs {
     const double* ww;         // 1/harmonic per window
     const unsigned* slots;    // [nb][2] per window bin k, k' = k mod 1024: (ZA[k'] | ZA[-k'] << 16), (ZB[k'] | ZB[-k'] << 16): double
                               // indices into the bin-ordered LDS copy (hw_slot)
-    const cx<double>* twnb;   // W_4096^k per window bin
+    const cx<double>* twnb;   // W_N^k per window bin (N = 4096, or 8192 with HALVES == 2)
+    cx<double>* escratch;     // HALVES == 2: [gridDim.x * WAVES][64 * ROUNDS] pass 0's spectrum at the window bins
     int nb, nwin, wins_per_note, num_harmonic;
     int quad_tail;            // host: nwin == 48, 4 windows per note, 2 harmonics, every window 1..8 bins wide
     double* out;              // [F,12] per-frame chroma, never null: the sums over frames are taken over these rows
@@ -251,25 +268,26 @@ __device__ __forceinline__ double hw_quad_xor(double v) {
 }
 
 // This lane's 32 sample pairs of one frame: pair n1 starts at sample 2*(lane + 64*n1)
-template <bool FAST>
+// (HALVES == 2: of one PASS over an 8192-sample frame -- x points at sample 2h of the frame, pair n1 starts 4*(lane + 64*n1) on)
+template <bool FAST, int HALVES = 1>
 __device__ __forceinline__ void hw_load_frame(float2* raw, const float* __restrict__ x, int lane, int valid) {
-    const float* p = x + 2 * lane;
+    const float* p = x + 2 * HALVES * lane;
     if (FAST) {
 #pragma unroll
-        for (int e = 0; e < 32; ++e) raw[e] = *reinterpret_cast<const float2*>(p + 128 * e);
+        for (int e = 0; e < 32; ++e) raw[e] = *reinterpret_cast<const float2*>(p + 128 * HALVES * e);
     } else {
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
-            const int s = 2 * lane + 128 * e;
-            raw[e].x = s < valid ? p[128 * e] : 0.f;
-            raw[e].y = s + 1 < valid ? p[128 * e + 1] : 0.f;
+            const int s = HALVES * (2 * lane + 128 * e);   // (valid counts from x: the caller has taken 2h off)
+            raw[e].x = s < valid ? p[128 * HALVES * e] : 0.f;
+            raw[e].y = s + 1 < valid ? p[128 * HALVES * e + 1] : 0.f;
         }
     }
 }
 
 // shared LDS tables in front of the waves' buffers (bytes): whalf | slots | twnb | ww | wk | theta powers | frame counter
-__host__ __device__ constexpr int hw_shared_bytes(int rounds, int nwin) {
-    return 16384 + 8 * 64 * rounds + 16 * 64 * rounds + ((16 * nwin + 15) & ~15) + 5 * 32 * 16 + 16;
+__host__ __device__ constexpr int hw_shared_bytes(int rounds, int nwin, int halves = 1) {
+    return 16384 * halves + 8 * 64 * rounds + 16 * 64 * rounds + ((16 * nwin + 15) & ~15) + 5 * 32 * 16 + 16;
 }
 
 // FASTONLY: the host has checked that EVERY frame of the launch is whole, inside the signal and 8-byte aligned (one signal,
@@ -293,19 +311,20 @@ __device__ __forceinline__ void hw_store_rows(double* mine, const cx<double>* b,
     }
 }
 
-template <int WAVES, int ROUNDS, bool DEBUG, bool FASTONLY = false, unsigned K2MASK = HW_K2_ALL>
+template <int WAVES, int ROUNDS, bool DEBUG, bool FASTONLY = false, unsigned K2MASK = HW_K2_ALL, int HALVES = 1>
 __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx<double>* dbg) {
-    constexpr int N = 4096, T = WAVES * 64, NBP = 64 * ROUNDS;
+    static_assert(HALVES == 1 || HALVES == 2, "4096- or 8192-sample frames");
+    constexpr int N = 4096 * HALVES, T = WAVES * 64, NBP = 64 * ROUNDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* whalf = reinterpret_cast<double*>(smem);                            // 16 KB, shared by the waves
-    uint2* slots_lds = reinterpret_cast<uint2*>(smem + 16384);                  // [NBP]
+    double* whalf = reinterpret_cast<double*>(smem);                            // 16 KB per pass, shared by the waves
+    uint2* slots_lds = reinterpret_cast<uint2*>(smem + 16384 * HALVES);         // [NBP]
     cx<double>* twnb_lds = reinterpret_cast<cx<double>*>(slots_lds + NBP);       // [NBP]
     double* ww_lds = reinterpret_cast<double*>(twnb_lds + NBP);                 // [nwin]
     int* wk_lds = reinterpret_cast<int*>(ww_lds + a.nwin);                      // [2 nwin]
-    unsigned* next_frame = reinterpret_cast<unsigned*>(smem + hw_shared_bytes(ROUNDS, a.nwin) - 16);
-    cx<double>* theta_lds = reinterpret_cast<cx<double>*>(smem + hw_shared_bytes(ROUNDS, a.nwin) - 16 - 5 * 32 * 16);   // [5][32]
+    unsigned* next_frame = reinterpret_cast<unsigned*>(smem + hw_shared_bytes(ROUNDS, a.nwin, HALVES) - 16);
+    cx<double>* theta_lds = reinterpret_cast<cx<double>*>(smem + hw_shared_bytes(ROUNDS, a.nwin, HALVES) - 16 - 5 * 32 * 16);   // [5][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    char* xbuf = smem + hw_shared_bytes(ROUNDS, a.nwin) + wave * HW_XBUF;
+    char* xbuf = smem + hw_shared_bytes(ROUNDS, a.nwin, HALVES) + wave * HW_XBUF;
 
     // Frames of this workgroup: a contiguous run (neighbouring frames share 3/4 of their samples), handed out to its
     // waves one at a time by an LDS counter.  The two waves of a SIMD do not run at the same speed (the hardware favours the
@@ -343,13 +362,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
     }
     if (tid == 0) *next_frame = 0;
     auto fill_tables = [&]() {
-        for (int i = tid; i < 1024; i += T) reinterpret_cast<double2*>(whalf)[i] = reinterpret_cast<const double2*>(a.whalf)[i];
+        for (int i = tid; i < 1024 * HALVES; i += T) reinterpret_cast<double2*>(whalf)[i] = reinterpret_cast<const double2*>(a.whalf)[i];
         for (int i = tid; i < NBP; i += T) {   // (entries past the last bin: bin 0, results dropped)
             slots_lds[i] = reinterpret_cast<const uint2*>(a.slots)[i < a.nb ? i : 0];
             twnb_lds[i] = a.twnb[i < a.nb ? i : 0];
         }
-        // W_1024^(k1 * 16 >> s): the per-stage constants of the modulated second transform of row k1 (a.tw is W_2048^j)
-        if (tid < 160) theta_lds[tid] = a.tw[(2 * (tid & 31) * (16 >> (tid >> 5))) & 2047];
+        // W_1024^(k1 * 16 >> s): the per-stage constants of the modulated second transform of row k1
+        // (a.tw is W_(N/2)^j: W_2048 for the 4096-sample frame, W_4096 for the 8192-sample one)
+        if (tid < 160) theta_lds[tid] = a.tw[(2 * HALVES * (tid & 31) * (16 >> (tid >> 5))) & (2048 * HALVES - 1)];
         for (int i = tid; i < a.nwin; i += T) {
             ww_lds[i] = a.ww[i];
             wk_lds[2 * i] = a.wk0[i];
@@ -385,7 +405,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             long long start;
             int valid;
             frame_span(f, start, valid);
-            hw_load_frame<FAST>(raw, a.sig + start, lane, valid);
+            hw_load_frame<FAST, HALVES>(raw, a.sig + start, lane, valid);
         }
         fill_tables();
         __syncthreads();
@@ -407,12 +427,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                                                 __builtin_amdgcn_ds_bpermute(src, __double2loint(chroma)));
             if (ol < 12) a.out[pend_f * 12 + ol] = row;
         };
+        // (one loop body for both passes, the pass a run-time value: with the two passes unrolled into separate code the
+        //  register allocation of the kernel needs 240 bytes per lane of scratch)
+        [[maybe_unused]] int h = 0;   // HALVES == 2: the pass of frame f this iteration runs
         while (f < g1) {
             cx<double> z[32];
             HW_STAMP(0);
             // this wave's next frame: asked for now, read once the window reads below have drained the LDS queue anyway
             unsigned grabbed = 0;
-            if (hw_opaque(lane) == 0) grabbed = take();
+            const bool last_pass = HALVES == 1 || h == HALVES - 1;   // (uniform) the next iteration starts another frame
+            if (last_pass && hw_opaque(lane) == 0) grabbed = take();
 #if defined(HW_FFT_A_GS) || defined(HW_WINDOW_SEPARATE)
             {
                 // window pairs through LDS, eight at a time and one group ahead of their use (the scheduler, left alone,
@@ -454,9 +478,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 // b wb is not rounded on its own).  Window pairs through LDS, four points (e, e + 16) at a time and one group
                 // ahead of their use (the scheduler, left alone, requests each pair right before its product and eats the LDS
                 // latency 32 times): pair index m = lane + 64 n1 below 1024, the mirrored pair 2047 - m (values swapped) above.
+                // (HALVES == 2: the table is [pass][pair]; the mirror image of pass h's upper half lies in pass 1 - h)
                 const int ol = hw_opaque(lane);
-                const char* wlo = reinterpret_cast<const char*>(whalf) + 16 * ol;
-                const char* whi = reinterpret_cast<const char*>(whalf) + 16 * (63 - ol);
+                const char* wlo = reinterpret_cast<const char*>(whalf) + 16 * ol + (HALVES == 2 ? 16384 * h : 0);
+                const char* whi = reinterpret_cast<const char*>(whalf) + 16 * (63 - ol) + (HALVES == 2 ? 16384 * (1 - h) : 0);
                 auto wload = [&](int e) -> double2 {
                     return e < 16 ? *reinterpret_cast<const double2*>(wlo + 1024 * e)
                                   : *reinterpret_cast<const double2*>(whi + 1024 * (31 - e));
@@ -492,7 +517,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 }
             }
 #endif
-            long long fn = g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed);
+            long long fn = last_pass ? g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed) : f;
             HW_STAMP(1);
             // A: DFT over n1 in registers; z[p] = A[k1 = br5(p)]
 #if defined(HW_FFT_A_GS)
@@ -503,7 +528,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             hw_fft32_ct_after_first_level(z);
 #endif
             hw_phase();
-            if (pend_f >= 0) finish_tail();
+            if (pend_f >= 0) {
+                finish_tail();
+                if constexpr (HALVES == 2) pend_f = -1;   // (a frame is two iterations here: once is enough)
+            }
             hw_phase();
             HW_STAMP(2);
             // B: the twiddles W_1024^(column * k1) between the two transforms are not applied here: the reader of row k1 sees
@@ -599,7 +627,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 long long start;
                 int valid;
                 frame_span(fn < g1 ? fn : f, start, valid);
-                hw_load_frame<FAST>(raw, a.sig + start, ol, valid);
+                if constexpr (HALVES == 1) {
+                    hw_load_frame<FAST>(raw, a.sig + start, ol, valid);
+                } else {   // the other pass of this frame, or pass 0 of the next one
+                    const int hn = last_pass ? 0 : h + 1;
+                    hw_load_frame<FAST, HALVES>(raw, a.sig + start + 2 * hn, ol, valid - 2 * hn);
+                }
+            }
+            // pass 1: what pass 0 parked, asked for once the spectrum's registers are free (behind the next pass's samples in
+            // the memory queue: they were requested above)
+            [[maybe_unused]] cx<double> e_parked[HALVES == 2 ? ROUNDS : 1];
+            [[maybe_unused]] cx<double>* mine_e = nullptr;
+            if constexpr (HALVES == 2) {   // scalar base + a 32-bit lane offset rebuilt on the spot: nothing lives across the transforms
+                const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane(hw_opaque(tid) >> 6);
+                mine_e = a.escratch + (size_t)(blockIdx.x * (unsigned)WAVES + wv) * NBP + (unsigned)ol;
             }
             double re[ROUNDS][4], mg[ROUNDS];
 #pragma unroll
@@ -617,6 +658,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
 #endif
             wave_lds_fence();
             hw_phase();
+            if constexpr (HALVES == 2) {
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r)
+                    e_parked[r] = mine_e[64 * r];
+            }
             HW_STAMP(6);
             // Y0 + W^k Y1 = E - i W^k D with E = (Z[k'] + conj Z[-k']) / 2, D = (Z[k'] - conj Z[-k']) / 2 (ZA), likewise
             // Y2 + W^k Y3 (ZB); X[k] = (Y0 + W^k Y1) + W^2k (Y2 + W^k Y3).  Lanes past the last bin redo bin 0.
@@ -628,12 +674,29 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 const cx<double> EB = {0.5 * (B.x + Bm.x), 0.5 * (B.y + Bm.y)}, DB = {0.5 * (B.x - Bm.x), 0.5 * (B.y - Bm.y)};
                 const cx<double> PA = cadd(EA, mul_mi(cmul(twk[r], DA)));
                 const cx<double> PB = cadd(EB, mul_mi(cmul(twk[r], DB)));
-                const cx<double> X = cadd(PA, cmul(cmul(twk[r], twk[r]), PB));
+                const cx<double> tw2 = cmul(twk[r], twk[r]);
+                cx<double> X;
+                if constexpr (HALVES == 1) {
+                    X = cadd(PA, cmul(tw2, PB));
+                } else {
+                    // this pass's four sequences: the second group is four samples on (W^4k); pass 0 parks its sum, pass 1
+                    // adds its own, two samples on (W^2k)
+                    X = cadd(PA, cmul(cmul(tw2, tw2), PB));
+                    if (h == 0) mine_e[64 * r] = X;
+                    else X = cadd(e_parked[r], cmul(tw2, X));
+                }
                 mg[r] = X.x * X.x + X.y * X.y;
             }
             wave_lds_fence();
             hw_phase();
             HW_STAMP(7);
+            if constexpr (HALVES == 2) {
+                if (h == 0) {   // (uniform) the frame's other pass comes next; nothing to reduce yet
+                    h = 1;
+                    continue;
+                }
+                h = 0;
+            }
             double* mag = xb;              // |X|^2 per window bin, over the dead spectrum
             double* winmax = xb + NBP;
 #pragma unroll
@@ -680,7 +743,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 const int base = ol * a.wins_per_note;
                 for (int oc = 0; oc < a.wins_per_note; oc += a.num_harmonic) {
                     double note_sum = 0.0;
-                    for (int h = 0; h < a.num_harmonic; ++h) note_sum += winmax[base + oc + h] * ww_lds[base + oc + h];
+                    for (int hh = 0; hh < a.num_harmonic; ++hh) note_sum += winmax[base + oc + hh] * ww_lds[base + oc + hh];
                     chroma += note_sum;
                 }
                 a.out[f * 12 + ol] = chroma;

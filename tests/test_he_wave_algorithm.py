@@ -73,6 +73,43 @@ def test_two_1024_point_transforms_and_pruned_combination_equal_rfft():
         assert abs(combine(Z, k) - X[k]) < 1e-10, k
 
 
+def test_8192_sample_frame_as_two_passes_of_the_4096_pipeline():
+    """HALVES = 2 of the kernel (the reference's default frame, harmonic_energy.py:14-16): x[8m + r], r < 8, as two passes,
+    pass h on zA[m] = x[8m + 2h] + i x[8m + 2h + 1] and zB[m] = x[8m + 4 + 2h] + i x[8m + 5 + 2h] (sample pairs 4 pm + 2h for the
+    pair index pm the lanes already use); phase D with W_8192^k, the group factor its fourth power, pass 1 folded in with its
+    square -- and the window table [pass][pair] whose upper half is the mirror image of the OTHER pass."""
+    import scipy.signal.windows
+    n8 = 8192
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(n8).astype(np.float32).astype(np.float64)
+    win = scipy.signal.windows.hamming(n8)
+    # the window as the kernel reads it: table[h][pm < 1024] = (w[4 pm + 2h], w[4 pm + 2h + 1]); pm >= 1024 mirrored from pass 1 - h
+    table = np.array([[(win[4 * pm + 2 * h], win[4 * pm + 2 * h + 1]) for pm in range(1024)] for h in range(2)])
+    X = np.fft.rfft(x * win)
+    Xh = []
+    for h in range(2):
+        sw = np.empty(4096)
+        for pm in range(2048):
+            w0, w1 = table[h][pm] if pm < 1024 else table[1 - h][2047 - pm][::-1]
+            sw[2 * pm], sw[2 * pm + 1] = x[4 * pm + 2 * h] * w0, x[4 * pm + 2 * h + 1] * w1
+        np.testing.assert_allclose(sw[0::2], (x * win)[2 * h::4], rtol=1e-14)      # the mirrored table IS the window (to the
+        np.testing.assert_allclose(sw[1::2], (x * win)[2 * h + 1::4], rtol=1e-14)  # ulp by which scipy's is not symmetric)
+        Z = wave_kernel_spectrum(sw)                                       # the same two 1024-point transforms per pass
+        np.testing.assert_allclose(Z[0], np.fft.fft(sw[0::4] + 1j * sw[1::4]), atol=1e-10)
+        Xh.append(Z)
+    for k in list(range(0, 40)) + list(range(180, 1500, 7)) + [1023, 1024, 1025, 2047, 2048, 4095, 4096]:
+        kp, km = k % 1024, (1024 - k % 1024) % 1024
+        w = _w(n8, k)
+        acc = []
+        for h in range(2):
+            Z = Xh[h]
+            a, am, b, bm = Z[0, kp], np.conj(Z[0, km]), Z[1, kp], np.conj(Z[1, km])
+            pa = (a + am) / 2 - 1j * w * (a - am) / 2
+            pb = (b + bm) / 2 - 1j * w * (b - bm) / 2
+            acc.append(pa + w ** 4 * pb)
+        assert abs(acc[0] + w * w * acc[1] - X[k]) < 1e-9, k
+
+
 def test_lds_layout_is_lane_consecutive():
     """Transpose buffer and bin-ordered copy (HW_PAIR, hw_slot): every store instruction of a wave covers 64 consecutive
     doubles, and the 64 readers of one column start in 64 different 8-byte slots of the bank sweep."""
