@@ -275,25 +275,28 @@ def wl_if0_stream(c):
             return stream.run_stream_rank(lambda a, b: x[a - s0:b - s0], n, fs, rank, world, nf_size, local)[2]
         return stream.run_stream_shard(lambda a, b: x.numpy(), n, fs, rank, world, nf_size, local, **kw)[2]
 
+    # Both timed passes run WITH the library's kernel profile on (two event records per launch, 42 over the hour): the
+    # record's kernel times and roofline fractions are those of the timed calls themselves, not of a side run.
+    prof_eng = c["cd"].get_engine(local) if c["stub"] is None else None
+    if prof_eng is not None:
+        prof_eng.profile_begin()
     t0 = time.perf_counter()
     block = compute_block()           # first pass: grows the contexts' workspaces (tens of GB of hipMalloc)
     cold = time.perf_counter() - t0
+    prof = prof_eng.profile_end() if prof_eng is not None else {}
     c["barrier"]()
+    if prof_eng is not None:
+        prof_eng.profile_begin()
     t0 = time.perf_counter()
     block = compute_block()
+    t_warm_engine = time.perf_counter() - t0
+    prof_warm = prof_eng.profile_end() if prof_eng is not None else {}
     ud = c.get("use_dist", world > 1)
     frames = stream.gather_frames(block, total_frames, world, rank, c["dev"] if ud and c["stub"] is None else None, force=ud)
     c["barrier"]()
     wall = _max_over_ranks(c, time.perf_counter() - t0)
     cold = _max_over_ranks(c, cold)
-    prof = {}
-    if c["stub"] is None:   # kernel breakdown: one context, this rank's first <= 10 minutes
-        e = c["cd"].get_engine(local)
-        m = min(x.numel(), int(600 * fs))
-        e.profile_begin()
-        e.iterative_f0(x[:m], fs, frame_size=nf_size)
-        prof = e.profile_end()
-        prof_samples = m
+    prof_samples = int(x.numel())   # this rank's share of the stream, run-in halo included
     if rank != 0:
         return None
     assert frames.shape == (total_frames, 12)
@@ -317,11 +320,16 @@ def wl_if0_stream(c):
         units = {"if0_frontend_kernel": prof_samples, "if0_spectrum_kernel": -(-prof_samples // nf_size),
                  "if0_periodicity_kernel": -(-prof_samples // nf_size)}
         rec["kernels_ms"] = kms
-        rec["kernels_ms_note"] = "one context, first %.0f s of this rank's shard" % (prof_samples / fs)
+        rec["kernels_ms_warm_pass"] = {k: v[1] for k, v in prof_warm.items()}
+        rec["kernels_ms_note"] = ("HIP-event times of the kernels INSIDE the timed first pass (`value`), this rank's whole share "
+                                  "(%.0f s of audio, %d time slices' launches summed); kernels_ms_warm_pass: the same inside "
+                                  "the timed second pass (`value_warm`)" % (prof_samples / fs, max(v[0] for v in prof.values())))
+        rec["warm_pass_engine_call_s"] = t_warm_engine
         rec["roofline"] = roofline_of(dom, kms[dom], units[dom], models[dom])
         rec["rooflines"] = {k: roofline_of(k, ms, units[k], models[k]) for k, ms in kms.items() if k in units}
         for k, r in list(rec["rooflines"].items()) + [(dom, rec["roofline"])]:
-            with_traffic(r, "if0_stream", k)
+            # (the PMC passes ran a 600 s stream, scripts/pmc_workloads.py: scaled to this rank's share)
+            with_traffic(r, "if0_stream", k, launches=prof_samples / (600.0 * fs))
         rec["hbm_frac_whole_path"] = (4.0 * n + 96.0 * total_frames) / wall / K.HBM_PEAK   # samples in once, 12 doubles per frame out (warm pass)
     if _cpu_rec(c, "if0"):
         rec["cpu_baseline"] = _cpu_rec(c, "if0")
