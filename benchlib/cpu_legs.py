@@ -69,6 +69,18 @@ def _cpu_he(budget_s, worker):
     return done, time.perf_counter() - t0
 
 
+def _cpu_he_default(budget_s, worker):
+    """Harmonic Energy at the reference's default shape: 8192-sample frames, hop = frame, 22.05 kHz clips, 6 frames per call."""
+    from oracle import harmonic_energy as o_he
+    clips, fs, nfr = _CPU_INPUT["clips22x6"], K.CFG["he_default_fs"], K.CFG["he_default_frame"]
+    done, t0, f = 0, time.perf_counter(), worker
+    while time.perf_counter() - t0 < budget_s:
+        o_he.he_frames(clips[f % clips.shape[0]], fs, nfr)
+        done += clips.shape[1] // nfr
+        f += 1
+    return done, time.perf_counter() - t0
+
+
 def _cpu_esacf(budget_s, worker, frame, hop, fs):
     import warnings
     from oracle import esacf as o_esacf
@@ -130,7 +142,7 @@ def _cpu_if0(budget_s, worker):
 
 
 _CPU_LEGS = {"he": _cpu_he, "esacf_clips": _cpu_esacf_clips, "esacf_stft": _cpu_esacf_stft, "corpus": _cpu_corpus,
-             "if0": _cpu_if0}
+             "if0": _cpu_if0, "he_default": _cpu_he_default}
 
 
 def _cpu_worker(arg):
@@ -143,7 +155,7 @@ def _cpu_worker(arg):
     return _CPU_LEGS[name](budget, worker)
 
 
-def cpu_baselines(budget_s=6.0, legs=("he", "esacf_clips", "esacf_stft", "corpus", "if0")):
+def cpu_baselines(budget_s=6.0, legs=("he", "esacf_clips", "esacf_stft", "corpus", "if0", "he_default")):
     """Every leg twice: one process on one core, then one process per physical core (multiprocessing, fork): units
     done / wall clock of the slowest worker.  Bounded samples of the same workloads the GPU legs run."""
     import multiprocessing as mp
@@ -151,15 +163,17 @@ def cpu_baselines(budget_s=6.0, legs=("he", "esacf_clips", "esacf_stft", "corpus
     _CPU_INPUT["he"] = synth_signal(20260101, frames=2048)
     _CPU_INPUT["clips22"] = synth_clips_numpy(16, K.CFG["corpus_fs"], 2.0)
     _CPU_INPUT["clip44"] = synth_clips_numpy(4, K.CFG["esacf_fs"], 2.0).reshape(-1)
+    _CPU_INPUT["clips22x6"] = synth_clips_numpy(8, K.CFG["he_default_fs"], 6.0 * K.CFG["he_default_frame"] / K.CFG["he_default_fs"])
     from oracle import esacf, harmonic_energy, iterative_f0, prime_multif0  # noqa: F401  (imported before the fork)
     units = {"he": "frames/s", "esacf_clips": "frames/s", "esacf_stft": "frames/s", "corpus": "clips/s",
-             "if0": "x real time"}
+             "if0": "x real time", "he_default": "frames/s"}
     samples = {
         "he": "N=4096 hop=1024 frames of a 47 s stretch of the bench signal through oracle/harmonic_energy.py (numpy.fft.rfft, float64, 128 frames per call)",
         "esacf_clips": "46.4 ms frames of 44.1 kHz polyphonic clips through oracle/esacf.py (4 frames per call)",
         "esacf_stft": "N=4096 hop=1024 frames of the bench signal through oracle/esacf.py (phase-vocoder regime, 4 frames per call)",
         "corpus": "2 s clips @22.05 kHz through all four oracle methods, one clip after the other",
         "if0": "32768-sample pieces of a 44.1 kHz signal through oracle/iterative_f0.py",
+        "he_default": "clips of six 8192-sample frames @22.05 kHz through oracle/harmonic_energy.py (hop = frame, one clip per call)",
     }
     out = {}
     ctx = mp.get_context("fork")

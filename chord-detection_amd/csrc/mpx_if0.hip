@@ -825,17 +825,18 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
         const int topm = (int)(tau * (a.fs / a.wsize) * n);  // periodicity.py:78
         const double srovertau = a.fs / tau;
         const double weight = srovertau + a.epsilon1;
-        // The 9-bin windows of neighbouring partials are m K / tau bins apart: below nine bins (f0 under ~48 Hz at the default
-        // frame size) they overlap, and two threads adding into one bin would race.  Wave 0 then takes all partials alone:
-        // its lanes' read-modify-writes of one bin fall into different iterations of the window loop, which a wave issues
-        // in order.  (Until round 4 all four waves scattered in every case: a lost update at m = 64 k was possible.)
+        // The 9-bin windows of neighbouring partials are K / tau bins apart: below nine bins (f0 under ~48 Hz at the default
+        // frame size; ordinary bass notes at small chirp-z frames, where the spacing can fall below ONE bin) they overlap, and
+        // threads scattering their partials would race on the shared bins -- across waves, between the lanes of a wave
+        // (loads hoisted over another lane's store), and inside one store instruction when two lanes hit the same bin.  The
+        // overlapping case is therefore a GATHER: a thread owns bins, and adds the contributions of the partials that cover a
+        // bin in ascending m -- the order of the reference's sequential loop (periodicity.py:83-96), so the sums round alike.
         const bool overlap = a.K / tau < 9.0;   // uniform
         // partials whose window lies below nl: m K / tau + 0.5 < nl - 4 (checked exactly per partial below)
         const int mlim = (int)((nl - 4.5) * tau / a.K) + 2;
         const int mend = nl < n && mlim < topm ? mlim : topm;
-        const int mstep = overlap ? 64 : PER_T;
-        if (!overlap || wave == 0) {
-            for (int m = 1 + (overlap ? lane : tid); m < mend; m += mstep) {
+        if (!overlap) {
+            for (int m = 1 + tid; m < mend; m += PER_T) {
                 const double partialK = m * a.K / tau + 0.5;
                 if (partialK <= n && partialK < nl - 4) {
                     const int ip = (int)partialK;
@@ -849,6 +850,32 @@ __global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
                         for (int j = lowk; j <= highk && j < n; ++j) ud[j] += IF0_HAMMING9[(int)(j - partialK + 4)] * urw;
                     }
                 }
+            }
+        } else {
+            const double spacing = a.K / tau;   // bins between neighbouring partials
+            const int jend = nl < n ? nl : n;   // (a window below nl ends below nl)
+            for (int j = tid; j < jend; j += PER_T) {
+                // partials whose window [int(pK - 4), int(pK + 4)] can hold bin j have pK in (j - 5, j + 5): a superset of m,
+                // every candidate checked with the reference's own integer arithmetic
+                int m0 = (int)floor((j - 5.5) / spacing), m1 = (int)ceil((j + 4.5) / spacing);
+                if (m0 < 1) m0 = 1;
+                if (m1 > mend - 1) m1 = mend - 1;
+                double acc = ud[j];
+                for (int m = m0; m <= m1; ++m) {
+                    const double partialK = m * a.K / tau + 0.5;
+                    if (!(partialK <= n && partialK < nl - 4)) continue;
+                    const int ip = (int)partialK;
+                    if (ip >= n) continue;
+                    int lowk = (int)(partialK - 4);
+                    if (lowk < 0) lowk = 0;
+                    int highk = (int)(partialK + 4);
+                    if (highk > n) highk = n;
+                    if (j < lowk || j > highk) continue;
+                    double urw = ur[ip];
+                    urw *= weight / (m * srovertau + a.epsilon2);
+                    acc += IF0_HAMMING9[(int)(j - partialK + 4)] * urw;
+                }
+                ud[j] = acc;
             }
         }
         __syncthreads();
@@ -1697,9 +1724,25 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         if (blue_chunk > IF0_CHUNK) blue_chunk = base;   // (64 x 8191 = 524 224 samples at most: the one case above IF0_CHUNK)
         while ((1LL << blue_lgp) < blue_chunk) ++blue_lgp;
     }
+    // the clip list in two halves, one call each (above the workspace cap, or the 96 GiB bound further down)
+    auto run_halves = [&]() -> int {
+        const int mid = num_clips / 2;
+        std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
+        for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
+        size_t frames_first = 0;
+        for (int c = 0; c < mid; ++c) {
+            const int64_t len = offsets[c + 1] - offsets[c];
+            if (len > 0) frames_first += (size_t)((len + NF - 1) / NF);
+        }
+        int rc1 = if0_run_host(ctx, signals, offsets, mid, fs, &p, chroma_frames, chroma_sums, ut_out, dev_io, stream);
+        if (rc1) return rc1;
+        return if0_run_host(ctx, signals + (offsets[mid] - offsets[0]), off2.data(), num_clips - mid, fs, &p,
+                            chroma_frames ? chroma_frames + frames_first * 12 : nullptr,
+                            chroma_sums ? chroma_sums + (size_t)mid * 12 : nullptr,
+                            ut_out ? ut_out + frames_first * n2 : nullptr, dev_io, stream);
+    };
     {
         size_t rows = 0;
-        const int mid = num_clips / 2;
         for (int c = 0; c < num_clips; ++c) {
             const int64_t len = offsets[c + 1] - offsets[c];
             if (len < 0) return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
@@ -1719,21 +1762,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             if (len > 0) est_chunks += (size_t)((len + IF0_CHUNK - 1) / IF0_CHUNK);   // (the planner may cut finer: the cap is soft)
         }
         const bool slices_fit = !blue && est_chunks * (size_t)NF * p.channels * sizeof(double) <= ws_cap;
-        if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap && !slices_fit) {
-            std::vector<int64_t> off2((size_t)(num_clips - mid) + 1);
-            for (int i = 0; i <= num_clips - mid; ++i) off2[i] = offsets[mid + i] - offsets[mid];
-            size_t frames_first = 0;
-            for (int c = 0; c < mid; ++c) {
-                const int64_t len = offsets[c + 1] - offsets[c];
-                if (len > 0) frames_first += (size_t)((len + NF - 1) / NF);
-            }
-            int rc1 = if0_run_host(ctx, signals, offsets, mid, fs, &p, chroma_frames, chroma_sums, ut_out, dev_io, stream);
-            if (rc1) return rc1;
-            return if0_run_host(ctx, signals + (offsets[mid] - offsets[0]), off2.data(), num_clips - mid, fs, &p,
-                                chroma_frames ? chroma_frames + frames_first * 12 : nullptr,
-                                chroma_sums ? chroma_sums + (size_t)mid * 12 : nullptr,
-                                ut_out ? ut_out + frames_first * n2 : nullptr, dev_io, stream);
-        }
+        if (num_clips > 1 && rows * p.channels * sizeof(double) > ws_cap && !slices_fit) return run_halves();
     }
     If0Plan plan;
     int rc = if0_plan(ctx, fs, p, plan);
@@ -1957,6 +1986,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     for (size_t i = 0; i + 1 < sl_off.size(); ++i) max_slice_frames = std::max(max_slice_frames, sl_off[i + 1] - sl_off[i]);
     const std::vector<If0Frame>& up_frames = sliced ? sl_frames : frames;
     const size_t yc_bytes = (size_t)(sliced ? nchunks * slice : yc_rows) * p.channels * sizeof(double);
+    // (the estimate above counts chunks of IF0_CHUNK samples; the planner may have cut finer -- the cap is soft -- and a list
+    //  that then needs more than 96 GiB even in time slices is halved like one above the cap)
+    if (yc_bytes > ((size_t)96 << 30) && num_clips > 1) return run_halves();
     if (yc_bytes > ((size_t)96 << 30))
         return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: %lld chunks need %zu GiB of workspace; split the call", nchunks,
                          yc_bytes >> 30);

@@ -81,13 +81,16 @@ void* mpx_stream(mpx_ctx* ctx);
  * Settings of a context that are not kwargs of the reference's constructors: how much device memory one pass may take and
  * which of two equivalent kernels runs.  None of them changes what is computed (tests/ compare every setting with the
  * oracle); they replace what rounds 1-3 read from the environment in development builds only.
- *   MPX_OPT_IF0_WORKSPACE_BYTES  upper bound, in bytes, of the Iterative-F0 front-end hand-off buffer of ONE pass
- *                                (8 B x channels per sample).  A clip batch that needs more is cut in halves that run one
- *                                after the other; a single clip / stream that needs more runs in time slices of whole
- *                                frames whose filter state is carried over.  Default 32 GiB, minimum 64 MiB.
- *   MPX_OPT_HE_KERNEL            MPX_HE_KERNEL_AUTO (default): 4096-sample fp64 frames with <= 256 window bins run on the
- *                                wave-per-frame kernel (csrc/mpx_he_wave.hpp), everything else on the workgroup-per-frame
- *                                kernel.  MPX_HE_KERNEL_WORKGROUP: the workgroup-per-frame kernel for every shape (A/B).
+ *   MPX_OPT_IF0_WORKSPACE_BYTES  target size, in bytes, of the Iterative-F0 front-end hand-off buffer of ONE pass
+ *                                (8 B x channels per sample).  A single clip / stream that needs more runs in time slices
+ *                                of whole frames whose filter state is carried over; so does a clip list while one frame of
+ *                                every chunk fits (counted in chunks of 262144 samples: a SOFT bound, the planner may cut a
+ *                                list into finer chunks and hold up to 16 x as many frames); a list beyond that -- or beyond
+ *                                96 GiB whatever the setting -- is cut in halves that run one after the other.
+ *                                Default 32 GiB, minimum 64 MiB.
+ *   MPX_OPT_HE_KERNEL            MPX_HE_KERNEL_AUTO (default): 4096- and 8192-sample fp64 frames with <= 256 window bins (none of
+ *                                them wrapping below bin 0) run on the wave-per-frame kernel (csrc/mpx_he_wave.hpp),
+ *                                everything else on the workgroup-per-frame kernel.  MPX_HE_KERNEL_WORKGROUP: the workgroup-per-frame kernel for every shape (A/B).
  * mpx_set_option returns MPX_EINVAL for an unknown option or a value out of range. */
 #define MPX_OPT_IF0_WORKSPACE_BYTES 1
 #define MPX_OPT_HE_KERNEL 2

@@ -2,7 +2,7 @@
 # usage (on the GPU box, from the repo root): bash scripts/pmc_collect.sh <tag> [workloads]
 # One rocprofv3 pass per counter group over scripts/pmc_workloads.py (counters never share a pass with tracing other than
 # --kernel-trace), then scripts/pmc_report.py -> gpurun_out/<tag>/pmc.json + pmc.txt; a --kernel-trace --stats pass first.
-TAG=${1:-pmc}; WL=${2:-he,esacf_clips,esacf_1023,esacf_stft,prime,if0_clips,if0_stream}
+TAG=${1:-pmc}; WL=${2:-he,he_default,esacf_clips,esacf_1023,esacf_stft,prime,if0_clips,if0_stream}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/pw_stats; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pw_stats -- python3 $GRAFT_REPO_ROOT/scripts/pmc_workloads.py $WL > $OUT/stats.log 2>&1

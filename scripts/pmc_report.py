@@ -21,7 +21,7 @@ def short(name):
     return name.replace("mpx::", "")
 
 
-ORDER = ["he", "esacf_stft", "esacf_clips", "esacf_1023", "prime", "if0_clips", "if0_stream"]
+ORDER = ["he", "he_default", "esacf_stft", "esacf_clips", "esacf_1023", "prime", "if0_clips", "if0_stream"]
 order_file = os.path.join(d, "order.txt")
 if os.path.exists(order_file):
     ORDER = open(order_file).read().strip().split(",")

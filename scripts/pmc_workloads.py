@@ -16,7 +16,7 @@ import chord_detection_amd as cd
 from chord_detection_amd import corpus, stream
 import bench
 
-want = (sys.argv[1] if len(sys.argv) > 1 else "he,esacf_clips,esacf_1023,esacf_stft,prime,if0_clips,if0_stream").split(",")
+want = (sys.argv[1] if len(sys.argv) > 1 else "he,he_default,esacf_clips,esacf_1023,esacf_stft,prime,if0_clips,if0_stream").split(",")
 reps = int(os.environ.get("PMC_REPS", "2"))
 eng = cd.Engine(0)
 dev = torch.device("cuda", 0)
@@ -35,13 +35,23 @@ def mark(name):
     torch.cuda.synchronize()
 
 
-order = [w for w in ("he", "esacf_stft", "esacf_clips", "esacf_1023", "prime", "if0_clips", "if0_stream") if w in want]
+order = [w for w in ("he", "he_default", "esacf_stft", "esacf_clips", "esacf_1023", "prime", "if0_clips", "if0_stream") if w in want]
 print("pmc_workloads order:", ",".join(order), flush=True)
 if "he" in want:
     mark("he")
     for r in range(9 * reps):
         eng.harmonic_energy_dev(sigs[r % 9].data_ptr(), n, FS, N, HOP, rows.data_ptr(), None)
         eng.synchronize()
+if "he_default" in want:   # the reference's default shape: 8196 frames of 8192 samples, hop = frame, two 268 MB signals in turn
+    g = torch.Generator(device="cpu"); g.manual_seed(7)
+    big = [(0.3 * torch.randn(8196 * 8192, generator=g)).to(dev) for _ in range(2)]
+    rows8 = torch.empty((8196, 12), dtype=torch.float64, device=dev)
+    mark("he_default")
+    for r in range(4 * reps):
+        eng.harmonic_energy_dev(big[r & 1].data_ptr(), big[0].numel(), 22050, 8192, 8192, rows8.data_ptr(), None)
+        eng.synchronize()
+    del big, rows8
+    torch.cuda.empty_cache()
 if "esacf_stft" in want:
     mark("esacf_stft")
     for r in range(1 + reps):

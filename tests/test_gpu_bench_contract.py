@@ -123,7 +123,9 @@ def test_bench_line_has_the_contract_fields():
         assert c["all_cores"]["cores"] == c["host"]["workers"] and c["all_cores"]["value"] > 0
     # every BASELINE workload and the north star's Target are in the same line, each with its own roofline and CPU leg
     w = d["workloads"]
-    assert set(w) == {"esacf_clips_4096", "esacf_stft_8192", "corpus_4096_all_methods", "if0_stream_1h"}
+    assert set(w) == {"esacf_clips_4096", "esacf_stft_8192", "corpus_4096_all_methods", "if0_stream_1h", "he_default_8192"}
+    assert w["he_default_8192"]["config"]["frames_per_gpu"] == 1366 * 6 and w["he_default_8192"]["oracle_spot_check"] is True
+    assert w["esacf_stft_8192"]["value_one_call"] == w["esacf_stft_8192"]["value"]
     assert w["esacf_clips_4096"]["unit"] == "frames/s" and w["esacf_clips_4096"]["config"]["frames_per_gpu"] == 4096 * 44
     assert w["esacf_clips_4096"]["oracle_spot_check"] is True and w["esacf_stft_8192"]["oracle_spot_check"] is True
     assert w["esacf_stft_8192"]["config"]["frames_per_gpu"] == 8192

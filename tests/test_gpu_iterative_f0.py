@@ -109,6 +109,33 @@ def test_periodicity_estimator_attribute(eng, clips):
         eng.iterative_f0_periodicity(np.ones((1, 1000)), FS, frame_size=8192)
 
 
+@pytest.mark.parametrize("fs,frame_size,f0s", [(44100, 1024, (41.2, 43.0)), (22050, 512, (55.0, 82.4)), (22050, 300, (65.4, 98.0)),
+                                                (44100, 8192, (41.2, 46.2))])
+def test_harmonic_cancellation_with_overlapping_partial_windows(eng, fs, frame_size, f0s):
+    """periodicity.py:83-96 adds the 9-bin windows of the partials one after the other.  When the partials are less than
+    nine bins apart (K / tau < 9: f0 below ~48 Hz at the default frame, ordinary bass notes at small frames -- below ONE
+    bin at 300 / 512 samples) the windows overlap; the kernel then gathers per bin in ascending m (round-4 advisor
+    finding: the scatter it replaced could lose updates).  Low tones, against the oracle's sequential loop."""
+    from oracle import iterative_f0 as o_if0
+    rng = np.random.default_rng(int(fs + frame_size))
+    n = 6 * frame_size + 17
+    t = np.arange(n) / fs
+    x = np.zeros(n)
+    for f0 in f0s:
+        for h in range(1, 9):
+            x += 0.7 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+    x = (0.15 * x + 1e-3 * rng.standard_normal(n)).astype(np.float32)
+    kw = dict(frame_size=frame_size)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wper, wut = o_if0.iterative_f0_frames(x, fs, note_names="ascii", **kw)
+    tot, per = eng.iterative_f0(x, fs, return_frames=True, note_names="ascii", **kw)
+    assert per.shape == wper.shape and np.abs(wper).sum() > 0
+    np.testing.assert_allclose(per, wper, rtol=1e-5, atol=1e-300)
+    # the estimator alone on the oracle's spectra: the cancellation is all that differs between voices
+    np.testing.assert_allclose(eng.iterative_f0_periodicity(wut, fs, note_names="ascii", **kw), wper, rtol=1e-5, atol=1e-300)
+
+
 def test_chunked_front_end_matches_sequential_filtering(eng):
     """A signal longer than one 262144-sample chunk: chunks start from zero state mpx_iterative_f0_warmup (40960) samples early.
     The reference filters sequentially; the oracle does too.  Agreement shows the run-in is long enough."""
