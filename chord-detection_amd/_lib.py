@@ -16,7 +16,7 @@ MPX_FLAG_DETERMINISTIC = 0x2
 MPX_ENHANCE_LIBROSA010, MPX_ENHANCE_NOOP = 0, 1
 MPX_NOTES_UNICODE, MPX_NOTES_ASCII = 0, 1
 MPX_OPT_IF0_WORKSPACE_BYTES, MPX_OPT_HE_KERNEL = 1, 2
-MPX_HE_KERNEL_AUTO, MPX_HE_KERNEL_WORKGROUP = 0, 1
+MPX_HE_KERNEL_AUTO, MPX_HE_KERNEL_WORKGROUP, MPX_HE_KERNEL_WAVE_PAIRS = 0, 1, 2
 OPTIONS = {"if0_workspace_bytes": MPX_OPT_IF0_WORKSPACE_BYTES, "he_kernel": MPX_OPT_HE_KERNEL}
 NOTE_NAMES = {"unicode": MPX_NOTES_UNICODE, "ascii": MPX_NOTES_ASCII}
 STAGES = {"wfir": 0, "x_lo": 1, "x_hi": 2, "sacf": 3, "esacf": 4}

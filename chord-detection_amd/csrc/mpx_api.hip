@@ -192,7 +192,7 @@ int mpx_set_option(mpx_ctx* ctx, int option, int64_t value) {
             ctx->if0_ws_cap = (size_t)value;
             return MPX_OK;
         case MPX_OPT_HE_KERNEL:
-            if (value != MPX_HE_KERNEL_AUTO && value != MPX_HE_KERNEL_WORKGROUP)
+            if (value != MPX_HE_KERNEL_AUTO && value != MPX_HE_KERNEL_WORKGROUP && value != MPX_HE_KERNEL_WAVE_PAIRS)
                 return set_error(ctx, MPX_EINVAL, "MPX_OPT_HE_KERNEL: unknown kernel %lld", (long long)value);
             ctx->he_kernel = (int)value;
             return MPX_OK;

@@ -620,6 +620,7 @@ static int he_build_plan(mpx_ctx* ctx, int fs, int N, const mpx_he_params& p, He
 // reference's default 8192; fp64, at most 256 window bins.
 constexpr int HEW_WAVES = 8, HEW_ROUNDS = 4;
 constexpr int HEW_WAVES2 = 7;   // 8192-sample frames: the window table is 32 KB, seven transpose buffers fit next to it
+constexpr int HEW_WAVES2P = 6;  // ... or three PAIRS of waves, a frame per pair, and 4 KB per pair for the spectrum pass 0 hands over
 static bool he_wave_applies(const mpx_ctx* ctx, const HePlan& plan) {
     if (ctx->he_kernel == MPX_HE_KERNEL_WORKGROUP) return false;   // mpx_set_option: the workgroup-per-frame kernel below
     if (plan.wrapped) return false;   // windows that wrap to the top of the spectrum: rows the pruned bin copy does not hold
@@ -628,7 +629,14 @@ static bool he_wave_applies(const mpx_ctx* ctx, const HePlan& plan) {
 template <int HALVES>
 static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n, const FrameDesc* d_desc,
                           int64_t num_frames, int hop, double* d_out, double* d_sum, hipStream_t stream) {
-    constexpr int N = 4096 * HALVES, WAVES = HALVES == 1 ? HEW_WAVES : HEW_WAVES2;
+    constexpr int N = 4096 * HALVES;
+    // 8192-sample frames: both passes of a frame on ONE wave (seven per CU) by default; MPX_OPT_HE_KERNEL =
+    // MPX_HE_KERNEL_WAVE_PAIRS gives a frame to TWO waves (three pairs per CU), one per pass -- same bits.  Measured (round 5,
+    // 8196 frames from two 268 MB inputs in turn, scripts/dev/he8192_ab.py, he8192_pmc.py): pairs fetch 1.2 x the compulsory
+    // bytes where one wave fetches 2.2 x (every line twice), but take 121-126 us against 122 (106 against 88 with the input
+    // resident in L2: six waves per CU instead of seven) -- the second fetch is not what the streamed case waits for.
+    const bool paired = HALVES == 2 && ctx->he_kernel == MPX_HE_KERNEL_WAVE_PAIRS;
+    const int WAVES = HALVES == 1 ? HEW_WAVES : (paired ? HEW_WAVES2P : HEW_WAVES2);
     if (!plan.whalf) {
         // scipy.signal.hamming(N), harmonic_energy.py:42, as the kernel reads it: [pass h][pair pm < 1024] = the window at the
         // samples 2 HALVES pm + 2 h and the next one (the upper half of a pass is the mirror image of pass HALVES - 1 - h)
@@ -688,12 +696,13 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
         if (rc) return rc;
         a.partial = (double*)ctx->d_partials.p;
     }
-    if (HALVES == 2) {   // pass 0's spectrum at the window bins, 4 KB per wave (d_ws4 is the ESACF path's: not in use here)
+    if (HALVES == 2 && !paired) {   // pass 0's spectrum at the window bins, 4 KB per wave (d_ws4 is the ESACF path's: not in use here)
         int rc = ensure(ctx, ctx->d_ws4, (size_t)g * WAVES * 64 * HEW_ROUNDS * sizeof(cx<double>));
         if (rc) return rc;
         a.escratch = (cx<double>*)ctx->d_ws4.p;
     }
-    const size_t lds = (size_t)hw_shared_bytes(HEW_ROUNDS, plan.nwin, HALVES) + (size_t)WAVES * HW_XBUF;
+    const size_t lds = (size_t)hw_shared_bytes(HEW_ROUNDS, plan.nwin, HALVES) + (size_t)WAVES * HW_XBUF +
+                       (paired ? (size_t)(WAVES / 2) * 64 * HEW_ROUNDS * sizeof(cx<double>) + 64 : 0);
     // every frame whole, inside the signal and (float2 loads of the 4096 kernel) 8-byte aligned: the instantiation without the
     // ragged loader (no scratch)
     const bool all_fast = !d_desc && (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0 &&
@@ -715,9 +724,11 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
         if (!ctx->occupancy.count(okey))
             for (kern_t k : kerns) MPX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     } else {
-        static const kern_t kerns[2] = {he_wave_kernel<HEW_WAVES2, HEW_ROUNDS, false, false, HW_K2_ALL, 2>,
-                                        he_wave_kernel<HEW_WAVES2, HEW_ROUNDS, false, true, HW_K2_ALL, 2>};
-        kern = kerns[all_fast ? 1 : 0];
+        static const kern_t kerns[4] = {he_wave_kernel<HEW_WAVES2, HEW_ROUNDS, false, false, HW_K2_ALL, 2>,
+                                        he_wave_kernel<HEW_WAVES2, HEW_ROUNDS, false, true, HW_K2_ALL, 2>,
+                                        he_wave_kernel<HEW_WAVES2P, HEW_ROUNDS, false, false, HW_K2_ALL, 2, true>,
+                                        he_wave_kernel<HEW_WAVES2P, HEW_ROUNDS, false, true, HW_K2_ALL, 2, true>};
+        kern = kerns[(paired ? 2 : 0) + (all_fast ? 1 : 0)];
         okey = "he_wave2_lds";
         if (!ctx->occupancy.count(okey))
             for (kern_t k : kerns) MPX_HIP(ctx, hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -311,9 +311,16 @@ __device__ __forceinline__ void hw_store_rows(double* mine, const cx<double>* b,
     }
 }
 
-template <int WAVES, int ROUNDS, bool DEBUG, bool FASTONLY = false, unsigned K2MASK = HW_K2_ALL, int HALVES = 1>
+// PAIRED (8192-sample frames): TWO WAVES PER FRAME -- the waves 2j and 2j + 1 of a workgroup take the same frames, wave 2j
+// pass 0 and wave 2j + 1 pass 1, at the same time: their loads hit the same cache lines within a fraction of a frame (one
+// fetch from HBM serves both; with one wave running the passes one after the other every line came in twice, 127 against 90 us
+// per 8196 frames).  Pass 0's spectrum at the window bins goes to its partner through 4 KB of LDS per pair, guarded by two
+// LDS counters (written: frames published by pass 0 / consumed by pass 1); a wave that gets ahead of its partner waits there,
+// so the two stay within one frame of each other.  Frames are dealt to the pairs round-robin (no LDS frame counter).
+template <int WAVES, int ROUNDS, bool DEBUG, bool FASTONLY = false, unsigned K2MASK = HW_K2_ALL, int HALVES = 1, bool PAIRED = false>
 __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx<double>* dbg) {
     static_assert(HALVES == 1 || HALVES == 2, "4096- or 8192-sample frames");
+    static_assert(!PAIRED || (HALVES == 2 && WAVES % 2 == 0), "pairs of waves: one per pass of an 8192-sample frame");
     constexpr int N = 4096 * HALVES, T = WAVES * 64, NBP = 64 * ROUNDS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* whalf = reinterpret_cast<double*>(smem);                            // 16 KB per pass, shared by the waves
@@ -325,6 +332,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
     cx<double>* theta_lds = reinterpret_cast<cx<double>*>(smem + hw_shared_bytes(ROUNDS, a.nwin, HALVES) - 16 - 5 * 32 * 16);   // [5][32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char* xbuf = smem + hw_shared_bytes(ROUNDS, a.nwin, HALVES) + wave * HW_XBUF;
+    // PAIRED: behind the waves' buffers, per pair [64 ROUNDS complex: pass 0's spectrum] and (at the very end) two counters
+    // (addresses rebuilt from a scalar pair index where they are used: nothing of them lives in vector registers)
+    auto pair_index = [&]() -> int { return __builtin_amdgcn_readfirstlane(hw_opaque(tid) >> 7); };
+    auto pair_buf_of = [&](int pr) -> cx<double>* {
+        return reinterpret_cast<cx<double>*>(smem + hw_shared_bytes(ROUNDS, a.nwin, HALVES) + WAVES * HW_XBUF) + pr * NBP;
+    };
+    auto pair_flag_of = [&](int pr) -> volatile unsigned* {
+        return reinterpret_cast<volatile unsigned*>(smem + hw_shared_bytes(ROUNDS, a.nwin, HALVES) + WAVES * HW_XBUF + (WAVES / 2) * NBP * 16) + 2 * pr;
+    };
 
     // Frames of this workgroup: a contiguous run (neighbouring frames share 3/4 of their samples), handed out to its
     // waves one at a time by an LDS counter.  The two waves of a SIMD do not run at the same speed (the hardware favours the
@@ -361,6 +377,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
         }
     }
     if (tid == 0) *next_frame = 0;
+    if (PAIRED && tid < WAVES) const_cast<unsigned*>(pair_flag_of(0))[tid] = 0;   // (wave 0's lanes: every pair's two counters)
     auto fill_tables = [&]() {
         for (int i = tid; i < 1024 * HALVES; i += T) reinterpret_cast<double2*>(whalf)[i] = reinterpret_cast<const double2*>(a.whalf)[i];
         for (int i = tid; i < NBP; i += T) {   // (entries past the last bin: bin 0, results dropped)
@@ -395,17 +412,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
 #define HW_STAMP(pt) do {} while (0)
 #endif
     const bool quad_tail = a.quad_tail != 0;
-    auto run = [&](auto fast_tag) {
+    auto run = [&](auto fast_tag, auto pass_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int PASS = decltype(pass_tag)::value;   // PAIRED: this wave's pass, a compile-time constant of its loop
         float2 raw[32];
-        long long f = grab();
+        long long f = PAIRED ? g0 + (wave >> 1) : grab();
         const long long f0 = f;
         (void)f0;
         if (f < g1) {   // the first frame is on its way while the tables are filled
             long long start;
             int valid;
             frame_span(f, start, valid);
-            hw_load_frame<FAST, HALVES>(raw, a.sig + start, lane, valid);
+            const int h0 = PAIRED ? PASS : 0;
+            hw_load_frame<FAST, HALVES>(raw, a.sig + start + 2 * h0, lane, valid - 2 * h0);
         }
         fill_tables();
         __syncthreads();
@@ -417,7 +436,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
         long long pend_f = -1;
         auto finish_tail = [&]() {
             const int ol = hw_opaque(lane);
-            const double t = sqrt(sqrt(pend_m)) * pend_w;   // sqrt(|X|) of the maximum, times 1/harmonic
+            // (PAIRED: the weight is read again here instead of travelling round the loop -- that kernel is two registers short)
+            const double wgt = PAIRED ? ww_lds[ol < 48 ? ol : 47] : pend_w;
+            const double t = sqrt(sqrt(pend_m)) * wgt;   // sqrt(|X|) of the maximum, times 1/harmonic
             // chroma = (max_0 + max_1/2) + (max_2 + max_3/2) over the quad: the reference's association (its sums start at 0.0)
             const double u = t + hw_quad_xor<1>(t);
             const double chroma = u + hw_quad_xor<2>(u);
@@ -429,14 +450,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
         };
         // (one loop body for both passes, the pass a run-time value: with the two passes unrolled into separate code the
         //  register allocation of the kernel needs 240 bytes per lane of scratch)
-        [[maybe_unused]] int h = 0;   // HALVES == 2: the pass of frame f this iteration runs
+        [[maybe_unused]] int h = PAIRED ? PASS : 0;   // HALVES == 2: the pass of frame f this iteration runs (PAIRED: this wave's, always)
+        [[maybe_unused]] unsigned pair_seq = 0;   // PAIRED: frames this wave has finished
         while (f < g1) {
             cx<double> z[32];
             HW_STAMP(0);
             // this wave's next frame: asked for now, read once the window reads below have drained the LDS queue anyway
             unsigned grabbed = 0;
-            const bool last_pass = HALVES == 1 || h == HALVES - 1;   // (uniform) the next iteration starts another frame
-            if (last_pass && hw_opaque(lane) == 0) grabbed = take();
+            const bool last_pass = PAIRED || HALVES == 1 || h == HALVES - 1;   // (uniform) the next iteration starts another frame
+            if (!PAIRED && last_pass && hw_opaque(lane) == 0) grabbed = take();
 #if defined(HW_FFT_A_GS) || defined(HW_WINDOW_SEPARATE)
             {
                 // window pairs through LDS, eight at a time and one group ahead of their use (the scheduler, left alone,
@@ -517,7 +539,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 }
             }
 #endif
-            long long fn = last_pass ? g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed) : f;
+            long long fn = PAIRED ? f + WAVES / 2 : (last_pass ? g0 + (long long)__builtin_amdgcn_readfirstlane((int)grabbed) : f);
             HW_STAMP(1);
             // A: DFT over n1 in registers; z[p] = A[k1 = br5(p)]
 #if defined(HW_FFT_A_GS)
@@ -630,7 +652,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 if constexpr (HALVES == 1) {
                     hw_load_frame<FAST>(raw, a.sig + start, ol, valid);
                 } else {   // the other pass of this frame, or pass 0 of the next one
-                    const int hn = last_pass ? 0 : h + 1;
+                    const int hn = PAIRED ? h : (last_pass ? 0 : h + 1);
                     hw_load_frame<FAST, HALVES>(raw, a.sig + start + 2 * hn, ol, valid - 2 * hn);
                 }
             }
@@ -638,10 +660,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             // the memory queue: they were requested above)
             [[maybe_unused]] cx<double> e_parked[HALVES == 2 ? ROUNDS : 1];
             [[maybe_unused]] cx<double>* mine_e = nullptr;
-            if constexpr (HALVES == 2) {   // scalar base + a 32-bit lane offset rebuilt on the spot: nothing lives across the transforms
+            if constexpr (HALVES == 2 && !PAIRED) {   // scalar base + a 32-bit lane offset rebuilt on the spot: nothing lives across the transforms
                 const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane(hw_opaque(tid) >> 6);
                 mine_e = a.escratch + (size_t)(blockIdx.x * (unsigned)WAVES + wv) * NBP + (unsigned)ol;
             }
+            if constexpr (PAIRED) mine_e = pair_buf_of(pair_index()) + ol;   // (LDS)
             double re[ROUNDS][4], mg[ROUNDS];
 #pragma unroll
             for (int r = 0; r < ROUNDS; ++r) {
@@ -658,10 +681,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
 #endif
             wave_lds_fence();
             hw_phase();
-            if constexpr (HALVES == 2) {
+            if constexpr (HALVES == 2 && !PAIRED) {
 #pragma unroll
                 for (int r = 0; r < ROUNDS; ++r)
                     e_parked[r] = mine_e[64 * r];
+            }
+            if constexpr (PAIRED) {
+                // pass 0 may overwrite the pair's buffer once its partner has taken the frame before; pass 1 needs this
+                // frame's to be there.  (LDS executes a wave's instructions in order: data, then counter.)
+                const unsigned want = h == 0 ? pair_seq : pair_seq + 1;
+                volatile unsigned* pair_flag = pair_flag_of(pair_index());
+                volatile unsigned* flag = pair_flag + (h == 0 ? 1 : 0);   // [0] published by pass 0, [1] consumed by pass 1
+                while (*flag < want) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (h == 1) {
+#pragma unroll
+                    for (int r = 0; r < ROUNDS; ++r) e_parked[r] = mine_e[64 * r];
+                    wave_lds_fence();
+                    if (hw_opaque(lane) == 0) pair_flag[1] = pair_seq + 1;
+                }
             }
             HW_STAMP(6);
             // Y0 + W^k Y1 = E - i W^k D with E = (Z[k'] + conj Z[-k']) / 2, D = (Z[k'] - conj Z[-k']) / 2 (ZA), likewise
@@ -690,7 +728,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
             wave_lds_fence();
             hw_phase();
             HW_STAMP(7);
-            if constexpr (HALVES == 2) {
+            if constexpr (PAIRED) {
+                ++pair_seq;
+                if (h == 0) {   // (uniform) publish: the stores above are in the LDS queue ahead of the counter
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (hw_opaque(lane) == 0) pair_flag_of(pair_index())[0] = pair_seq;
+                    f = fn;
+                    continue;
+                }
+            } else if constexpr (HALVES == 2) {
                 if (h == 0) {   // (uniform) the frame's other pass comes next; nothing to reduce yet
                     h = 1;
                     continue;
@@ -716,7 +762,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
 #pragma unroll
                 for (int j = 1; j < 8; ++j) m = v[j] > m ? v[j] : m;   // in bin order, like the reference's loop
                 pend_m = m;
-                pend_w = wweight;
+                if constexpr (!PAIRED) pend_w = wweight;
                 pend_f = f;
                 wave_lds_fence();
                 HW_STAMP(9);
@@ -755,13 +801,27 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
         }
         if (pend_f >= 0) finish_tail();
     };
-    if constexpr (FASTONLY) {
-        run(std::true_type{});
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    if constexpr (PAIRED) {   // (two loops, one per pass: what a pass keeps alive does not burden the other's registers)
+        const bool odd = __builtin_amdgcn_readfirstlane(wave & 1) != 0;
+        if constexpr (FASTONLY) {
+            if (odd) run(std::true_type{}, P1{});
+            else run(std::true_type{}, P0{});
+        } else if (fast) {
+            if (odd) run(std::true_type{}, P1{});
+            else run(std::true_type{}, P0{});
+        } else {
+            if (odd) run(std::false_type{}, P1{});
+            else run(std::false_type{}, P0{});
+        }
+    } else if constexpr (FASTONLY) {
+        run(std::true_type{}, P0{});
     } else {
         if (fast)
-            run(std::true_type{});
+            run(std::true_type{}, P0{});
         else
-            run(std::false_type{});
+            run(std::false_type{}, P0{});
     }
 
     // Which wave computed a frame is decided at run time, so the sum over frames is taken over the rows, in row order:

@@ -12,7 +12,7 @@ g = torch.Generator(device="cpu"); g.manual_seed(1)
 xs = [(0.3 * torch.randn(frames * N, generator=g)).to(dev) for _ in range(2)]   # 2 x 268 MB > the Infinity Cache
 rows = torch.zeros((frames, 12), dtype=torch.float64, device=dev)
 res = {}
-for name, opt in (("wave", 0), ("workgroup", 1), ("wave", 0), ("workgroup", 1)):
+for name, opt in (("wave", 0), ("pairs", 2), ("workgroup", 1), ("wave", 0), ("pairs", 2), ("workgroup", 1)):
     e = cd.Engine(0); e.set_option("he_kernel", opt)
     for _ in range(5):
         e.harmonic_energy_dev(xs[0].data_ptr(), xs[0].numel(), 22050, N, N, rows.data_ptr(), None)
@@ -28,7 +28,7 @@ for name, opt in (("wave", 0), ("workgroup", 1), ("wave", 0), ("workgroup", 1)):
     e.close()
 # the same launches on a signal that stays in L2 (hop 8: 8196 frames inside 74 KB): what the arithmetic alone takes
 small = xs[0][:8196 * 8 + N].contiguous()
-for name, opt in (("wave", 0), ("workgroup", 1)):
+for name, opt in (("wave", 0), ("pairs", 2), ("workgroup", 1)):
     e = cd.Engine(0); e.set_option("he_kernel", opt)
     for _ in range(5):
         e.harmonic_energy_dev(small.data_ptr(), small.numel(), 22050, N, 8, rows.data_ptr(), None)
@@ -38,3 +38,4 @@ for name, opt in (("wave", 0), ("workgroup", 1)):
     print("%-10s %.2f us per %d frames, input resident in L2 (hop 8)" % (name, 1e3 * e.timer_end() / 40, frames))
     e.close()
 print("max relative difference wave vs workgroup:", float(np.max(np.abs(res["wave_out"] - res["workgroup_out"]) / np.abs(res["workgroup_out"]))))
+print("one wave per frame == a pair of waves per frame, bit for bit:", bool(np.array_equal(res["wave_out"], res["pairs_out"])))

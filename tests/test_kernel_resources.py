@@ -22,10 +22,10 @@ def table():
 
 
 SCRATCH_FREE = [
-    "mpx::he_wave_kernel<8, 4, false, true, 2146439166u, 1>",    # headline: every frame whole and aligned, 22 of 32 rows (HW_K2_44K)
-    "mpx::he_wave_kernel<8, 4, false, true, 4294967295u, 1>",    # the same loader, window shapes / sample rates that need every row
-    "mpx::he_wave_kernel<8, 4, false, false, 2146439166u, 1>",   # ragged / unaligned frames at 44.1 kHz
-    "mpx::he_wave_kernel<7, 4, false, true, 4294967295u, 2>",    # 8192-sample frames (the reference's default), whole and aligned: two passes per frame
+    "mpx::he_wave_kernel<8, 4, false, true, 2146439166u, 1, false>",    # headline: every frame whole and aligned, 22 of 32 rows (HW_K2_44K)
+    "mpx::he_wave_kernel<8, 4, false, true, 4294967295u, 1, false>",    # the same loader, window shapes / sample rates that need every row
+    "mpx::he_wave_kernel<8, 4, false, false, 2146439166u, 1, false>",   # ragged / unaligned frames at 44.1 kHz
+    "mpx::he_wave_kernel<7, 4, false, true, 4294967295u, 2, false>",    # 8192-sample frames (the reference's default), whole and aligned: two passes per frame
     "mpx::he_kernel<4096, 256, double>",
     "mpx::sacf_pfa_kernel<1>", "mpx::sacf_pfa_kernel<2>",
     "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
@@ -49,13 +49,15 @@ SCRATCH_FREE = [
 SCRATCH_CEILING = {
     "mpx::coopfit_kernel": 36,                         # a 36-byte stack slot is reserved since the two-pass form; the ISA holds no scratch instruction
     "mpx::coopfit8_kernel": 36,                        # the same kernel with eight lanes per fit
-    "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
-    "mpx::he_wave_kernel<7, 4, false, false, 4294967295u, 2>": 32,   # 8192-sample frames, ragged / unaligned (clips: the last frame of each)
+    "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1, false>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
+    "mpx::he_wave_kernel<7, 4, false, false, 4294967295u, 2, false>": 32,
+    "mpx::he_wave_kernel<6, 4, false, true, 4294967295u, 2, true>": 20,     # the pairs-of-waves arrangement (an option, not the default)
+    "mpx::he_wave_kernel<6, 4, false, false, 4294967295u, 2, true>": 44,   # 8192-sample frames, ragged / unaligned (clips: the last frame of each)
 }
 # occupancy (waves per SIMD) the launch geometry of the host code counts on
 OCCUPANCY = {
-    "mpx::he_wave_kernel<8, 4, false, true, 2146439166u, 1>": 2,
-    "mpx::he_wave_kernel<7, 4, false, true, 4294967295u, 2>": 2,
+    "mpx::he_wave_kernel<8, 4, false, true, 2146439166u, 1, false>": 2,
+    "mpx::he_wave_kernel<7, 4, false, true, 4294967295u, 2, false>": 2,
     "mpx::sacf_pfa_kernel<2>": 4,
     "mpx::if0_spectrum_split_kernel<8192, true, 1>": 4,
     "mpx::prime_pers_kernel<1024>": 2,
