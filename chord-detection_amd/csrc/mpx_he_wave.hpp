@@ -636,6 +636,47 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 wlast = wk_lds[2 * wi + 1] - 1;
                 wweight = ww_lds[wi];
             }
+#ifdef HW_ABL_DPP_MODEL
+            // COST MODEL (tests/tools/he_wave_check.hip only; results are garbage): what phase D would execute with a bin and its
+            // mirror in neighbouring lanes (rows k1 and 32 - k1 of one quad) and the conjugate split by DPP -- no bin-ordered copy,
+            // no gathers.  Per lane and row k2 = 1..11: the partner's mirror value (4 quad_perm moves), the fix for the two
+            // self-mirrored rows of quad 0 (8 selects), E / D without the halves (4), W^k D from an LDS twiddle (4 + a read),
+            // P (2), the pair's other parity by DPP (4 moves), W^2k (3), X (6), |X|^2 / 4 (3), a store of the result.
+            double re[ROUNDS][4], mg[ROUNDS];
+            (void)re;
+            {
+                const bool is0 = (ol >> 1) == 0, is16 = (ol >> 1) == 1;
+                double accm = 0.0;
+                {
+                    long long start;
+                    int valid;
+                    frame_span(fn < g1 ? fn : f, start, valid);
+                    hw_load_frame<FAST>(raw, a.sig + start, ol, valid);
+                }
+#pragma unroll
+                for (int k2 = 1; k2 <= 11; ++k2) {
+                    constexpr int dummy = 0;
+                    (void)dummy;
+                    const int p = hw_br5(k2), pm = 31 - p, p0 = k2 == 1 ? pm : hw_br5(32 - k2);
+                    double mx = hw_quad_xor<2>(b[pm].x), my = hw_quad_xor<2>(b[pm].y);
+                    mx = is16 ? b[pm].x : mx;
+                    my = is16 ? b[pm].y : my;
+                    mx = is0 ? b[p0].x : mx;
+                    my = is0 ? b[p0].y : my;
+                    const cx<double> E = {b[p].x + mx, b[p].y - my}, D = {b[p].x - mx, b[p].y + my};
+                    const cx<double> w = twnb_lds[(ol >> 1) + 32 * (k2 & 7)];
+                    const cx<double> P = cadd(E, mul_mi(cmul(w, D)));
+                    const cx<double> Q = {hw_quad_xor<1>(P.x), hw_quad_xor<1>(P.y)};
+                    const cx<double> X = cadd(P, cmul(cmul(w, w), Q));
+                    const double m2 = 0.25 * (X.x * X.x + X.y * X.y);
+                    xb[ol + 64 * k2] = m2;
+                    accm += m2;
+                }
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) mg[r] = accm;
+            }
+            wave_lds_fence();
+#else
 #ifndef HW_ABL_NO_BINCOPY
             hw_store_rows<K2MASK, 0>(mine, b, false);   // only the rows a window bin or its mirror lives in
 #else
@@ -726,6 +767,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
                 mg[r] = X.x * X.x + X.y * X.y;
             }
             wave_lds_fence();
+#endif   // HW_ABL_DPP_MODEL
             hw_phase();
             HW_STAMP(7);
             if constexpr (PAIRED) {
