@@ -11,7 +11,7 @@ cd $R
 timeout 1500 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gputest.txt; cat $O/gputest.txt
 export PMC_REPS=1
 bash scripts/pmc_collect.sh $TAG/pmc_after > $O/pmc.log 2>&1
-python3 scripts/pmc_to_traffic.py $O/pmc_after/pmc.json 4 > /dev/null
+python3 scripts/pmc_to_traffic.py $O/pmc_after/pmc.json 5 > /dev/null
 cp profiles/traffic_latest.json $O/traffic_latest.json
 timeout 900 python3 bench.py --steps 2000 --warmup 200 --full-json $O/bench_plain_full.json > $O/bench_plain.json 2> $O/bench_plain.err
 cd /tmp; export TMPDIR=/tmp
