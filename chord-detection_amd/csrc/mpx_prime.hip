@@ -20,6 +20,7 @@
 
 #include "mpx_fft.hpp"
 #include "mpx_fft_dif.hpp"
+#include "mpx_he_wave.hpp"
 #include "mpx_internal.hpp"
 
 namespace mpx {
@@ -36,6 +37,12 @@ struct PrimeCand {          // per candidate frequency, device resident
     const cx<double>* tw;     // [L] W_L
     int R, n1;                // prime_kernel, frames whose chirp-z does not fit 8192 points: input decimated by R, n1 = ceil(N / R)
     const cx<double>* coef;   // [R][half] W_N^(r k) conj(chirp[k]) (R > 1; chirp is then exp(i pi R j^2 / N), j < max(n1, half))
+    // prime_wave_kernel (L <= 2048), WD = L / 32 lanes per transform:
+    const cx<double>* wv_wc;  // [22][WD] window x conj(chirp) at n = lane + WD n1 (0 from N on)
+    const cx<double>* wv_fr;  // [32][WD] bhat where the wave's forward transform leaves it: register p, lane
+    const cx<double>* wv_oc;  // [6][WD]  conj(chirp[k]), k = lane + WD q (0 from `half` on)
+    const cx<double>* wv_theta;   // [5][32] W_1024^(k1 (16 >> s)): the stage constants of the modulated transform of row k1
+    const cx<double>* wv_tw2;     // [32][32] W_2048^(k1 + 32 br5(p)) at [p][k1] (L = 2048)
 };
 
 struct PrimeItem {
@@ -420,6 +427,342 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
     }
 }
 
+// ---- wave kernel ---------------------------------------------------------------------------------------------------
+// prime_wave_kernel<L> (round 5; chirp-z lengths 1024 and 2048: every candidate of 22.05 kHz input, the upper octave of
+// 44.1 kHz): the structure of he_wave_kernel.  A chirp-z is a forward and an inverse transform of L points; here both are
+// 1024-point transforms of one LANE CLASS (the 32 lanes of one parity, 32 complex points per lane in registers): a 32-point
+// DFT in registers, one transpose through LDS inside the class, a second, modulated 32-point DFT (mpx_he_wave.hpp).  In:
+// lane l, register n1 = point l + 32 n1; out: lane k1, register p = frequency k1 + 32 br5(p) -- which, read as "lane,
+// br5(register)", is the input layout again: the inverse transform (the forward one on swapped components) starts from a
+// renaming of registers, the filter spectrum is multiplied on where it stands (table in register order), and nothing but
+// the two transposes of each transform touches LDS.
+//   L = 1024: the two lane classes of a wave run two ITEMS (pairs of frames of the same candidate) side by side;
+//   L = 2048: one item on both classes -- even lanes transform u[2m], odd lanes u[2m + 1]; the radix-2 step that joins them
+//             (U[k], U[k + 1024] = E[k] +- W_2048^k O[k]) and its mirror image in front of the inverse transform pair lanes
+//             2 k1 and 2 k1 + 1 on the same register: quad-permute DPP, no LDS.
+// A wave never waits for another wave: no workgroup barrier in the loop (prime_pers_kernel: seven per item), the arg-max
+// is DPP + ballot inside the wave.  Per lane six output bins k = lane + WD q (half <= 6 WD) and their mirrors -k, which the
+// inverse transform leaves in registers 26..31 of the mirrored lane (one 6-register exchange through the wave's buffer).
+// The arg-max runs on |X|^2 (monotone in the magnitude the reference compares, prime_multif0.py:68); the square root is
+// taken of the winner only.
+constexpr int PW_NR = 22;   // registers that can hold samples: 22 WD >= the longest frame of a class (684 / 1366)
+constexpr int PW_NQ = 6;    // output bins per lane: 6 WD >= half
+constexpr int PW_WAVES_1024 = 7, PW_WAVES_2048 = 4;   // what 160 KB of LDS hold next to the tables (33 / 80 KB)
+template <int L>
+__host__ __device__ constexpr int pw_table_elems() {
+    return (PW_NR + 32 + PW_NQ) * (L / 32) + 160 + (L == 2048 ? 1024 : 0);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double pw_dpp(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+// maximum over the lanes of the caller's class (L = 1024: its parity; L = 2048: the wave) of values that are never NaN
+template <int L>
+__device__ __forceinline__ double pw_class_max(double v, int parity) {
+    v = fmax(v, pw_dpp<0x4E>(v));                        // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (L == 2048) v = fmax(v, pw_dpp<0xB1>(v));   // quad_perm [1,0,3,2]: lane ^ 1
+    v = fmax(v, pw_dpp<0x124>(v));                       // row_ror:4
+    v = fmax(v, pw_dpp<0x128>(v));                       // row_ror:8: the lanes of a row that agree modulo 4 (2) agree
+    const double e = fmax(fmax(prime_readlane(v, 0), prime_readlane(v, 16)), fmax(prime_readlane(v, 32), prime_readlane(v, 48)));
+    if constexpr (L == 2048) return e;
+    const double o = fmax(fmax(prime_readlane(v, 1), prime_readlane(v, 17)), fmax(prime_readlane(v, 33), prime_readlane(v, 49)));
+    return parity ? o : e;
+}
+
+// one transform of 1024 points per lane class, in place: z[n1] = point l + 32 n1 (l = lane >> 1) in, z[p] = frequency
+// (lane >> 1) + 32 br5(p) out
+__device__ __forceinline__ void pw_fft1024(cx<double>* z, char* xbuf, const cx<double>* theta_lds) {
+    hw_fft32_ct(z);
+    hw_phase();
+    cx<double> th[5];
+    const int ol = hw_opaque((int)(threadIdx.x & 63));
+    char* wr = xbuf + 8 * ol;
+    const char* rd = xbuf + HW_PAIR * (ol >> 1) + 8 * (ol & 1);
+#pragma unroll
+    for (int st = 0; st < 5; ++st) th[st] = theta_lds[32 * st + (ol >> 1)];
+    cx<double> b[32];
+#pragma unroll
+    for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].x;
+    wave_lds_fence();
+#pragma unroll
+    for (int c = 0; c < 32; ++c) b[c].x = *reinterpret_cast<const double*>(rd + 16 * c);
+    wave_lds_fence();
+#pragma unroll
+    for (int p = 0; p < 32; ++p) *reinterpret_cast<double*>(wr + HW_PAIR * hw_br5(p)) = z[p].y;
+    wave_lds_fence();
+#pragma unroll
+    for (int c = 0; c < 32; ++c) b[c].y = *reinterpret_cast<const double*>(rd + 16 * c);
+    wave_lds_fence();
+    hw_phase();
+    hw_fft32_modulated(b, th);
+    hw_phase();
+#pragma unroll
+    for (int p = 0; p < 32; ++p) z[p] = b[p];
+}
+
+template <int L, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* __restrict__ sig, const PrimeItem* __restrict__ items,
+                                                                    const PrimeWork* __restrict__ work, const PrimeCand* __restrict__ cands,
+                                                                    int runs, int elim, int note_names, int* out_pc, double* out_val,
+                                                                    int uniform_clips, long long clip_len, long long clip_slots) {
+    constexpr int WD = L / 32, T = WAVES * 64, TAB = pw_table_elems<L>();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<double>* wc_lds = reinterpret_cast<cx<double>*>(smem);   // [PW_NR][WD]
+    cx<double>* fr_lds = wc_lds + PW_NR * WD;                   // [32][WD]
+    cx<double>* oc_lds = fr_lds + 32 * WD;                      // [PW_NQ][WD]
+    cx<double>* theta_lds = oc_lds + PW_NQ * WD;                // [5][32]
+    [[maybe_unused]] cx<double>* tw2_lds = theta_lds + 160;     // [32][32] (L = 2048)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* xbuf = smem + (size_t)TAB * 16 + wave * HW_XBUF;
+    const PrimeWork wk = work[blockIdx.x];
+    const PrimeCand c = cands[wk.cand];
+    const int N = c.N, half = c.half;
+    for (int i = tid; i < PW_NR * WD; i += T) wc_lds[i] = c.wv_wc[i];
+    for (int i = tid; i < 32 * WD; i += T) fr_lds[i] = c.wv_fr[i];
+    for (int i = tid; i < PW_NQ * WD; i += T) oc_lds[i] = c.wv_oc[i];
+    for (int i = tid; i < 160; i += T) theta_lds[i] = c.wv_theta[i];
+    if constexpr (L == 2048)
+        for (int i = tid; i < 1024; i += T) tw2_lds[i] = c.wv_tw2[i];
+    __syncthreads();   // the only one
+
+    const int parity = lane & 1;
+    const int lw = L == 1024 ? lane >> 1 : lane;   // this lane's index inside its transform
+    constexpr int PER = L == 1024 ? 2 : 1;         // items per wave and iteration
+    const int count = wk.count;
+    const int worker = wk.worker + __builtin_amdgcn_readfirstlane(wave);
+    const int stride = wk.workers * PER;           // (the host keeps count + stride below 2^31)
+    // Position of this lane's class: item i of the candidate's list, or -- equal-length clips -- item j of clip `clip`,
+    // which follows from the first clip's first item (frames 2j and 2j + 1 of the clip)
+    int i = worker * PER + (L == 1024 ? parity : 0), clip = 0;
+    int dclip = 0, dj = 0;
+    long long start0 = 0, slot0 = 0;
+    if (uniform_clips) {
+        clip = i / count;
+        i -= clip * count;
+        dclip = stride / count;
+        dj = stride - dclip * count;
+        start0 = items[wk.item0].start;
+        slot0 = items[wk.item0].slot;
+    }
+    struct Cur {
+        const float* xa;
+        int va, vb;
+        long long slot;
+    };
+    auto live_here = [&]() -> bool { return uniform_clips ? clip < uniform_clips : i < count; };
+    auto item_here = [&]() -> Cur {
+        Cur it{sig, 0, 0, -1};
+        if (live_here()) {
+            long long start;
+            if (uniform_clips) {
+                const long long s = (long long)i * 2 * N, left = clip_len - s, lb = left - N;
+                it.va = (int)(left >= N ? N : left);
+                it.vb = lb > 0 ? (int)(lb >= N ? N : lb) : 0;
+                start = start0 + clip * clip_len + s;
+                it.slot = slot0 + clip * clip_slots + 2 * i;
+            } else {
+                const PrimeItem p = items[wk.item0 + i];
+                start = p.start;
+                it.va = p.valid;
+                it.vb = p.valid_b;
+                it.slot = p.slot;
+            }
+            it.xa = sig + start;
+        }
+        return it;
+    };
+    auto advance = [&]() {
+        i += stride;
+        if (uniform_clips) {
+            i -= stride - dj;
+            clip += dclip;
+            if (i >= count) {
+                i -= count;
+                ++clip;
+            }
+        }
+    };
+    // a frame's samples: clamped position and a select (no branch per register); frame b starts N samples after frame a
+    auto fetch = [&](const Cur& it, float* xa, float* xb) {
+        const float* pb = it.vb > 0 ? it.xa + N : it.xa;
+#pragma unroll
+        for (int n1 = 0; n1 < PW_NR; ++n1) {
+            const int n = lw + WD * n1;
+            int ia = n < it.va ? n : it.va - 1, ib = n < it.vb ? n : it.vb - 1;
+            ia = ia < 0 ? 0 : ia;
+            ib = ib < 0 ? 0 : ib;
+            const float ta = it.xa[ia], tb = pb[ib];
+            xa[n1] = n < it.va ? ta : 0.0f;
+            xb[n1] = n < it.vb ? tb : 0.0f;
+        }
+    };
+
+    if (__builtin_amdgcn_readfirstlane((int)!live_here())) return;   // (lane 0: the even class; wave-uniform)
+    Cur it = item_here();
+    float xa[PW_NR], xb[PW_NR];
+    fetch(it, xa, xb);
+    for (;;) {
+        cx<double> z[32];
+        bool nza = false, nzb = false;
+        {
+            const int ol = hw_opaque(lw);
+#pragma unroll
+            for (int n1 = 0; n1 < PW_NR; ++n1) {
+                const cx<double> w = wc_lds[n1 * WD + ol];
+                const double a = (double)xa[n1], b = (double)xb[n1];
+                nza |= xa[n1] != 0.0f;
+                nzb |= xb[n1] != 0.0f;
+                z[n1] = {a * w.x - b * w.y, a * w.y + b * w.x};   // (a + i b) x window x conj(chirp)
+                if ((n1 & 7) == 7) hw_phase();
+            }
+#pragma unroll
+            for (int n1 = PW_NR; n1 < 32; ++n1) z[n1] = {0.0, 0.0};
+        }
+        // An all-zero frame has an all-zero spectrum in the reference; next to a loud partner it would come out as that
+        // partner's rounding noise, so such a frame is flagged and its magnitudes are the exact zeros (as in prime_pers_kernel).
+        const unsigned long long class_mask = L == 1024 ? (parity ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull) : ~0ull;
+        const bool live_a = (__ballot(nza) & class_mask) != 0, live_b = (__ballot(nzb) & class_mask) != 0;
+        const long long cur_slot = it.slot;
+        const bool cur_b = it.vb > 0;
+        // the next item's samples travel under this item's transforms
+        advance();
+        const bool more = __builtin_amdgcn_readfirstlane((int)live_here()) != 0;   // (lane 0: the even class's item; wave-uniform)
+        it = item_here();
+        fetch(it, xa, xb);
+        hw_phase();
+        pw_fft1024(z, xbuf, theta_lds);   // z[p] = U_class[(lane >> 1) + 32 br5(p)]
+        hw_phase();
+        {
+            const int ol = hw_opaque(lw);
+            [[maybe_unused]] const int k1 = hw_opaque(lane) >> 1;
+            [[maybe_unused]] const double sgn = parity ? -1.0 : 1.0;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) {
+                const cx<double> f = fr_lds[p * WD + ol];
+                if constexpr (L == 1024) {
+                    z[p] = cmul(z[p], f);
+                } else {
+                    // even lane: E, odd lane: O of the same frequency.  s = E | W^k O;  U = E +- W^k O;  V = U x filter;
+                    // then the mirror image for the inverse transform: G_even = V_lo + V_hi, G_odd = (V_lo - V_hi) conj(W^k)
+                    const cx<double> tw = tw2_lds[p * 32 + k1];
+                    const cx<double> s = parity ? cmul(z[p], tw) : z[p];
+                    const cx<double> o = {hw_quad_xor<1>(s.x), hw_quad_xor<1>(s.y)};
+                    const cx<double> u = parity ? csub(o, s) : cadd(s, o);
+                    const cx<double> v = cmul(u, f);
+                    const cx<double> ov = {hw_quad_xor<1>(v.x), hw_quad_xor<1>(v.y)};
+                    const cx<double> g = parity ? csub(ov, v) : cadd(v, ov);
+                    z[p] = parity ? cmul(g, cx<double>{tw.x, -tw.y}) : g;
+                }
+                if ((p & 7) == 7) hw_phase();
+            }
+        }
+        // inverse transform = the forward one on swapped components; register p holds k2 = br5(p): a renaming
+        cx<double> w[32];
+#pragma unroll
+        for (int n1 = 0; n1 < 32; ++n1) w[n1] = {z[hw_br5(n1)].y, z[hw_br5(n1)].x};
+        hw_phase();
+        pw_fft1024(w, xbuf, theta_lds);   // (swapped) w[p] = y[lw + WD br5(p)]
+        hw_phase();
+        // the mirrors: y[-k] for k = lw + WD q sits in register br5(31 - q) of lane WD - lw (lane 0: register br5(32 - q) of its own)
+        cx<double> yp[PW_NQ], ym[PW_NQ];
+        {
+            const int ol = hw_opaque(lane);
+            cx<double>* ex = reinterpret_cast<cx<double>*>(xbuf);   // [7][64]; row 6 is never written and never used
+#pragma unroll
+            for (int r = 0; r < 6; ++r) ex[r * 64 + ol] = {w[hw_br5(26 + r)].y, w[hw_br5(26 + r)].x};
+            wave_lds_fence();
+            const int olw = L == 1024 ? ol >> 1 : ol;
+            const int mlw = (WD - olw) & (WD - 1);
+            const int mol = L == 1024 ? 2 * mlw + (ol & 1) : mlw;
+            const int first = olw == 0 ? 1 : 0;
+#pragma unroll
+            for (int q = 0; q < PW_NQ; ++q) {
+                yp[q] = {w[hw_br5(q)].y, w[hw_br5(q)].x};
+                const cx<double> m = ex[(5 - q + first) * 64 + mol];
+                ym[q] = (q == 0 && first) ? yp[0] : m;
+            }
+            wave_lds_fence();
+        }
+        double ma[PW_NQ], mb[PW_NQ];   // |X_a[k]|^2, |X_b[k]|^2; -inf from `half` on
+        {
+            const int ol = hw_opaque(lw);
+#pragma unroll
+            for (int q = 0; q < PW_NQ; ++q) {
+                const cx<double> oc = oc_lds[q * WD + ol];
+                const cx<double> xp = cmul(yp[q], oc), xm = cmul(ym[q], oc);
+                const cx<double> sa = {0.5 * (xp.x + xm.x), 0.5 * (xp.y - xm.y)};    // X_a = (X[k] + conj X[-k]) / 2
+                const cx<double> sb = {0.5 * (xp.y + xm.y), 0.5 * (xm.x - xp.x)};    // X_b = (X[k] - conj X[-k]) / 2i
+                const bool in = ol + WD * q < half;
+                const double a2 = live_a ? fma(sa.x, sa.x, sa.y * sa.y) : 0.0, b2 = live_b ? fma(sb.x, sb.x, sb.y * sb.y) : 0.0;
+                ma[q] = in ? a2 : -INFINITY;
+                mb[q] = in ? b2 : -INFINITY;
+            }
+        }
+        const bool has_item = cur_slot >= 0;
+        for (int run = 0; run < runs; ++run) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                double* m = f ? mb : ma;
+                // numpy argmax: first index of the maximum, NaN never wins
+                double bv = -INFINITY;
+#pragma unroll
+                for (int q = 0; q < PW_NQ; ++q)
+                    if (m[q] > bv) bv = m[q];
+                const double wmax = pw_class_max<L>(bv, parity);
+                int i0 = 0x7fffffff, i1 = 0x7fffffff;
+#pragma unroll
+                for (int q = 0; q < PW_NQ; ++q) {
+                    const unsigned long long bq = __ballot(m[q] == wmax && wmax > -INFINITY);
+                    if constexpr (L == 1024) {
+                        const unsigned long long b0 = bq & 0x5555555555555555ull, b1 = bq & 0xAAAAAAAAAAAAAAAAull;
+                        if (i0 == 0x7fffffff && b0) i0 = (__builtin_ctzll(b0) >> 1) + 32 * q;
+                        if (i1 == 0x7fffffff && b1) i1 = (__builtin_ctzll(b1) >> 1) + 32 * q;
+                    } else {
+                        if (i0 == 0x7fffffff && bq) i0 = __builtin_ctzll(bq) + 64 * q;
+                    }
+                }
+                int idx = (L == 1024 && parity) ? i1 : i0;
+                int pc = -1;
+                double val = 0.0;
+                if (half > 0) {
+                    const bool none = idx == 0x7fffffff;   // nothing compared greater than -inf: every magnitude is NaN
+                    if (none) idx = 0;
+                    const double max_f = (double)idx * c.val;
+                    const double midi = 12.0 * (log2(max_f) - log2(440.0)) + 69.0;
+                    // hz_to_note raises on NaN (ValueError) and on +-inf (OverflowError, e.g. the DC bin): the
+                    // reference `continue`s: nothing is added and nothing is eliminated (prime_multif0.py:73-74)
+                    if (midi == midi && !isinf(midi)) {
+                        const long long note = (long long)nearbyint(midi);
+                        pc = (int)(((note % 12) + 12) % 12);
+                        val = none ? __builtin_nan("") : sqrt(wmax) / c.wsum;   // mlab: np.abs(result) / window.sum()
+                        if (run + 1 < runs) {   // (what the last round eliminates nobody looks at)
+#pragma unroll
+                            for (int q = 0; q < PW_NQ; ++q) {
+                                const int jb = lw + WD * q;
+                                for (int k = 1; k < elim; ++k) {   // f == k * max_f, exact comparison (:80), among bins k idx - 1 .. k idx + 1
+                                    const int d = jb - k * idx;
+                                    if (jb < half && d >= -1 && d <= 1 && (double)jb * c.val == (double)k * max_f) m[q] = 0.0;
+                                }
+                            }
+                        }
+                        // unicode-sharp quirk A.18 (MPX_NOTES_UNICODE): sharps land in a stray key and are lost, but the
+                        // elimination above has happened; ASCII note names (librosa < 0.8) keep every pitch class
+                        if (note_names == MPX_NOTES_UNICODE && (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) pc = -1;
+                    }
+                }
+                if (lw == 0 && has_item && (f == 0 || cur_b)) {
+                    out_pc[(cur_slot + f) * PRIME_MAX_RUNS + run] = pc;
+                    out_val[(cur_slot + f) * PRIME_MAX_RUNS + run] = val;
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
 // one workgroup per clip: chroma[clip] = sum over its item slots, in slot order per pitch class
 __global__ __launch_bounds__(64) void prime_sum_kernel(const long long* __restrict__ seg, int runs,
                                                        const int* __restrict__ pc, const double* __restrict__ val,
@@ -473,7 +816,7 @@ struct PrimePlan {
 // Plans live in the context (host copy of the candidate records in ctx->host_blobs, device tables in
 // ctx->owned) and die with it.
 static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan& plan) {
-    const std::string key = "prime4_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
+    const std::string key = "prime5_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
                             std::to_string(p.num_octave);
     auto bit = ctx->host_blobs.find(key);
     if (bit != ctx->host_blobs.end()) {
@@ -555,6 +898,7 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                     c.bhat = (const cx<double>*)upload(ctx, filt.data(), filt.size() * sizeof(cx<double>));
                     c.coef = (const cx<double>*)upload(ctx, coef.data(), coef.size() * sizeof(cx<double>));
                     c.bhat_r = nullptr;
+                    c.wv_wc = c.wv_fr = c.wv_oc = c.wv_theta = c.wv_tw2 = nullptr;
                     if (!c.win || !c.chirp || !c.bhat || !c.coef) return MPX_ENOMEM;
                     plan.cands.push_back(c);
                     continue;
@@ -616,6 +960,41 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                     if (!c.bhat_r) return MPX_ENOMEM;
                 }
                 if (!c.win || !c.chirp || !c.bhat) return MPX_ENOMEM;
+                c.wv_wc = c.wv_fr = c.wv_oc = c.wv_theta = c.wv_tw2 = nullptr;
+                if (c.L <= 2048) {   // prime_wave_kernel's tables (tests/test_prime_wave_algorithm.py restates them)
+                    const int WD = c.L / 32;
+                    if (PW_NR * WD < N || PW_NQ * WD < half || !c.paired)
+                        return set_error(ctx, MPX_EUNSUPPORTED, "prime-multiF0: frame of %d samples does not fit its wave class", N);
+                    std::vector<cx<double>> wc((size_t)PW_NR * WD, cx<double>{0.0, 0.0}), oc((size_t)PW_NQ * WD, cx<double>{0.0, 0.0}),
+                        fr((size_t)32 * WD);
+                    for (int i = 0; i < N; ++i) wc[i] = {win[i] * chirp[i].x, -(win[i] * chirp[i].y)};     // [n1][lane]: n = lane + WD n1
+                    for (int k = 0; k < half; ++k) oc[k] = {chirp[k].x, -chirp[k].y};                      // [q][lane]: k = lane + WD q
+                    for (int p = 0; p < 32; ++p)
+                        for (int l = 0; l < WD; ++l)
+                            fr[(size_t)p * WD + l] = c.L == 1024 ? filt[l + 32 * hw_br5(p)] : filt[(l >> 1) + 32 * hw_br5(p) + 1024 * (l & 1)];
+                    if (!twl.count(-1)) {
+                        std::vector<cx<double>> th(160), tw2(1024);
+                        for (int st = 0; st < 5; ++st)
+                            for (int k1 = 0; k1 < 32; ++k1) {
+                                const long double ang = -2.0L * M_PIl * (long double)(k1 * (16 >> st)) / 1024.0L;
+                                th[32 * st + k1] = {(double)cosl(ang), (double)sinl(ang)};
+                            }
+                        for (int p = 0; p < 32; ++p)
+                            for (int k1 = 0; k1 < 32; ++k1) {
+                                const long double ang = -2.0L * M_PIl * (long double)(k1 + 32 * hw_br5(p)) / 2048.0L;
+                                tw2[32 * p + k1] = {(double)cosl(ang), (double)sinl(ang)};
+                            }
+                        twl[-1] = upload(ctx, th.data(), th.size() * sizeof(cx<double>));
+                        twl[-2] = upload(ctx, tw2.data(), tw2.size() * sizeof(cx<double>));
+                        if (!twl[-1] || !twl[-2]) return MPX_ENOMEM;
+                    }
+                    c.wv_theta = (const cx<double>*)twl[-1];
+                    c.wv_tw2 = (const cx<double>*)twl[-2];
+                    c.wv_wc = (const cx<double>*)upload(ctx, wc.data(), wc.size() * sizeof(cx<double>));
+                    c.wv_oc = (const cx<double>*)upload(ctx, oc.data(), oc.size() * sizeof(cx<double>));
+                    c.wv_fr = (const cx<double>*)upload(ctx, fr.data(), fr.size() * sizeof(cx<double>));
+                    if (!c.wv_wc || !c.wv_oc || !c.wv_fr) return MPX_ENOMEM;
+                }
                 plan.cands.push_back(c);
             }
     }
@@ -648,6 +1027,18 @@ static int prime_pers_launch(mpx_ctx* ctx, const float* d_sig, const PrimeItem* 
     auto kern = prime_pers_kernel<L>;
     if (lds > 48 * 1024) MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(L / 8), lds, st, d_sig, d_items, d_work, d_cands, runs, elim, note_names,
+                       d_pc, d_val, uniform_clips, clip_len, clip_slots);
+    return MPX_OK;
+}
+template <int L, int WAVES>
+static int prime_wave_launch(mpx_ctx* ctx, const float* d_sig, const PrimeItem* d_items, const PrimeWork* d_work, size_t groups,
+                             const PrimeCand* d_cands, int runs, int elim, int note_names, int* d_pc, double* d_val, hipStream_t st,
+                             int uniform_clips, long long clip_len, long long clip_slots) {
+    if (!groups) return MPX_OK;
+    const size_t lds = (size_t)pw_table_elems<L>() * 16 + (size_t)WAVES * HW_XBUF;
+    auto kern = prime_wave_kernel<L, WAVES>;
+    MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(WAVES * 64), lds, st, d_sig, d_items, d_work, d_cands, runs, elim, note_names,
                        d_pc, d_val, uniform_clips, clip_len, clip_slots);
     return MPX_OK;
 }
@@ -756,19 +1147,29 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     }
     // work table of the persistent kernel: the resident workgroups of a class are shared out among its candidates in
     // proportion to their items (equal cost inside a class), so that every workgroup walks about the same number of frames
+    // (prime_wave_kernel, classes 0 and 1: one workgroup per CU -- its tables and its waves' buffers fill the LDS -- and a
+    //  worker is a WAVE: workgroup g of a candidate holds the workers g WAVES ... g WAVES + WAVES - 1, each taking one item
+    //  (two in the 1024-point class) per iteration)
     std::vector<PrimeWork> work[3];
-    const int slots_of[3] = {prime_pers_slots<1024>(ctx), prime_pers_slots<2048>(ctx), prime_pers_slots<4096>(ctx)};
+    const bool wave_path = !dev_env_on("MPX_PRIME_PERS");
+    const int wave_waves[2] = {PW_WAVES_1024, PW_WAVES_2048}, wave_per[2] = {2, 1};
+    const int slots_of[3] = {wave_path ? ctx->num_cus : prime_pers_slots<1024>(ctx), wave_path ? ctx->num_cus : prime_pers_slots<2048>(ctx),
+                             prime_pers_slots<4096>(ctx)};
     for (int cls = 0; cls < 3; ++cls) {
         const long long mult = uniform ? num_clips : 1;
         const long long class_items = (long long)items[cls].size() * mult;
         if (!class_items) continue;
+        const bool wv = wave_path && cls < 2;
         for (size_t k = 0; k < plan->cands.size(); ++k) {
             if (class_of(plan->cands[k].L) != cls || by_cand[k].empty()) continue;
             const long long mine = (long long)by_cand[k].size() * mult;
             long long w = (long long)((double)slots_of[cls] * (double)mine / (double)class_items + 0.5);
-            w = w < 1 ? 1 : (w > mine ? mine : w);
+            const long long per_group = wv ? wave_waves[cls] * wave_per[cls] : 1;   // items a workgroup takes per iteration
+            const long long cap = (mine + per_group - 1) / per_group;
+            w = w < 1 ? 1 : (w > cap ? cap : w);
             for (long long i = 0; i < w; ++i)
-                work[cls].push_back(PrimeWork{(int)k, (int)i, (int)w, cand_item0[k], (int)by_cand[k].size()});
+                work[cls].push_back(wv ? PrimeWork{(int)k, (int)(i * wave_waves[cls]), (int)(w * wave_waves[cls]), cand_item0[k], (int)by_cand[k].size()}
+                                       : PrimeWork{(int)k, (int)i, (int)w, cand_item0[k], (int)by_cand[k].size()});
         }
     }
     const size_t work_bytes = (work[0].size() + work[1].size() + work[2].size()) * sizeof(PrimeWork);
@@ -792,8 +1193,10 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         if (cls < 3) {
             const PrimeWork* dw = (const PrimeWork*)((char*)ctx->d_ws1.p + woff);
             const size_t groups = work[cls].size();
-            if (cls == 0) rc = prime_pers_launch<1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
-            if (cls == 1) rc = prime_pers_launch<2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 0 && wave_path) rc = prime_wave_launch<1024, PW_WAVES_1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 1 && wave_path) rc = prime_wave_launch<2048, PW_WAVES_2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 0 && !wave_path) rc = prime_pers_launch<1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+            if (cls == 1 && !wave_path) rc = prime_pers_launch<2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
             if (cls == 2) rc = prime_pers_launch<4096>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
             if (rc) return rc;
             woff += groups * sizeof(PrimeWork);
