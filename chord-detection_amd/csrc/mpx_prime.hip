@@ -585,18 +585,34 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
             }
         }
     };
-    // a frame's samples: clamped position and a select (no branch per register); frame b starts N samples after frame a
-    auto fetch = [&](const Cur& it, float* xa, float* xb) {
-        const float* pb = it.vb > 0 ? it.xa + N : it.xa;
+    // A frame's samples through a buffer descriptor of exactly the samples that exist (base = the frame, size = 4 x valid):
+    // positions past them -- the zero padding of a last frame, the registers past N, a frame b that is not there, an item
+    // past the end of the list -- come back as zeros from the hardware's range check: no clamp, no select, no branch.
+    // Frame b starts N samples after frame a.  The two lane classes of the 1024-point kernel hold different items: one
+    // descriptor pair per class, each class's loads under its own half of EXEC into the same registers.
+    auto fetch_class = [&](int src_lane, float* xa, float* xb, const Cur& it) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)(uintptr_t)it.xa & 0xffffffffull), src_lane);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)(uintptr_t)it.xa >> 32), src_lane);
+        const int va = __builtin_amdgcn_readlane(it.va, src_lane), vb = __builtin_amdgcn_readlane(it.vb, src_lane);
+        const float* pa = reinterpret_cast<const float*>((uintptr_t)(((unsigned long long)hi << 32) | lo));
+        const auto ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa), 0, 4 * va, 0x00020000);
+        const auto rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa + (vb > 0 ? N : 0)), 0, 4 * vb, 0x00020000);
+        // (the register's part of the position travels in the instruction's offset field or the vector offset: the range
+        //  check does not see a scalar offset)
+        const int voff = 4 * hw_opaque(lw);
 #pragma unroll
         for (int n1 = 0; n1 < PW_NR; ++n1) {
-            const int n = lw + WD * n1;
-            int ia = n < it.va ? n : it.va - 1, ib = n < it.vb ? n : it.vb - 1;
-            ia = ia < 0 ? 0 : ia;
-            ib = ib < 0 ? 0 : ib;
-            const float ta = it.xa[ia], tb = pb[ib];
-            xa[n1] = n < it.va ? ta : 0.0f;
-            xb[n1] = n < it.vb ? tb : 0.0f;
+            xa[n1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, voff + 4 * WD * n1, 0, 0));
+            xb[n1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, voff + 4 * WD * n1, 0, 0));
+        }
+    };
+    auto fetch = [&](const Cur& it, float* xa, float* xb) {
+        if constexpr (L == 1024) {   // (two ifs, not if / else: the compiler merges the arms of an if / else into one load with a per-lane descriptor and serialises it)
+            if (parity == 0) fetch_class(0, xa, xb, it);
+            hw_phase();
+            if (parity == 1) fetch_class(1, xa, xb, it);
+        } else {
+            fetch_class(0, xa, xb, it);
         }
     };
 
@@ -1186,7 +1202,10 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     off = 0;
     size_t woff = 0;
     prof_mark(ctx, st, "prime_kernel");
+    const bool class_marks = dev_env_on("MPX_PRIME_CLASS_MARKS");   // development: a profile entry per chirp-z class
+    static const char* const class_names[4] = {"prime_kernel_1024", "prime_kernel_2048", "prime_kernel_4096", "prime_kernel_8192"};
     for (int cls = 0; cls < 4; ++cls) {
+        if (class_marks) prof_mark(ctx, st, class_names[cls]);
         const size_t bytes = items[cls].size() * sizeof(PrimeItem);
         const PrimeItem* di = (const PrimeItem*)(d_items + off);
         const int uclips = uniform ? num_clips : 0;
