@@ -40,9 +40,10 @@ struct PrimeCand {          // per candidate frequency, device resident
     // prime_wave_kernel (L <= 2048), WD = L / 32 lanes per transform:
     const cx<double>* wv_wc;  // [22][WD] window x conj(chirp) at n = lane + WD n1 (0 from N on)
     const cx<double>* wv_fr;  // [32][WD] bhat where the wave's forward transform leaves it: register p, lane
-    const cx<double>* wv_oc;  // [6][WD]  conj(chirp[k]), k = lane + WD q (0 from `half` on)
+    const cx<double>* wv_oc;  // [6][WD]  conj(chirp[k])^2, k = lane + WD q (0 from `half` on)
+    const int* wv_pc;         // [6 WD]   pitch class of bin k (before the note-name quirk), -2: its frequency has none (bin 0)
     const cx<double>* wv_theta;   // [5][32] W_1024^(k1 (16 >> s)): the stage constants of the modulated transform of row k1
-    const cx<double>* wv_tw2;     // [32][32] W_2048^(k1 + 32 br5(p)) at [p][k1] (L = 2048)
+    const cx<double>* wv_tw2;     // [32][33] W_2048^(k1 + 32 br5(p)) at [p][k1], 1 at [p][32] (L = 2048)
 };
 
 struct PrimeItem {
@@ -447,10 +448,14 @@ __global__ __launch_bounds__(L / 8) void prime_pers_kernel(const float* __restri
 // taken of the winner only.
 constexpr int PW_NR = 22;   // registers that can hold samples: 22 WD >= the longest frame of a class (684 / 1366)
 constexpr int PW_NQ = 6;    // output bins per lane: 6 WD >= half
-constexpr int PW_WAVES_1024 = 7, PW_WAVES_2048 = 4;   // what 160 KB of LDS hold next to the tables (33 / 80 KB)
+// Waves per workgroup = per CU: what 160 KB of LDS hold next to the tables (33 / 80 KB).  Measured (4096 clips, profiles/r5/prime_wave_ab.txt):
+// 1024 points: 4 / 6 / 7 waves 16.1 / 16.0 / 13.9 ms; 2048 points: 2 / 3 / 4 waves 31.6 / 21.2 / 16.0 ms (a wave per SIMD scales, the
+// kernel is then bound by one wave's issue rate); a fifth wave -- output chirp from global memory, every wave back under 256
+// registers -- 19.7 ms.
+constexpr int PW_WAVES_1024 = 7, PW_WAVES_2048 = 4;
 template <int L>
 __host__ __device__ constexpr int pw_table_elems() {
-    return (PW_NR + 32 + PW_NQ) * (L / 32) + 160 + (L == 2048 ? 1024 : 0);
+    return (PW_NR + 32 + PW_NQ) * (L / 32) + 160 + (L == 2048 ? 32 * 33 : 0) + PW_NQ * (L / 32) / 4;   // (the last: PW_NQ WD ints)
 }
 
 template <int CTRL>
@@ -472,10 +477,26 @@ __device__ __forceinline__ double pw_class_max(double v, int parity) {
     return parity ? o : e;
 }
 
+template <int CTRL>
+__device__ __forceinline__ int pw_dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+template <int L>
+__device__ __forceinline__ int pw_class_min(int v, int parity) {
+    v = min(v, pw_dpp_i<0x4E>(v));
+    if constexpr (L == 2048) v = min(v, pw_dpp_i<0xB1>(v));
+    v = min(v, pw_dpp_i<0x124>(v));
+    v = min(v, pw_dpp_i<0x128>(v));
+    const int e = min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+    if constexpr (L == 2048) return e;
+    const int o = min(min(__builtin_amdgcn_readlane(v, 1), __builtin_amdgcn_readlane(v, 17)), min(__builtin_amdgcn_readlane(v, 33), __builtin_amdgcn_readlane(v, 49)));
+    return parity ? o : e;
+}
+
 // one transform of 1024 points per lane class, in place: z[n1] = point l + 32 n1 (l = lane >> 1) in, z[p] = frequency
 // (lane >> 1) + 32 br5(p) out
+template <bool FIRST_LEVEL_DONE = false>
 __device__ __forceinline__ void pw_fft1024(cx<double>* z, char* xbuf, const cx<double>* theta_lds) {
-    hw_fft32_ct(z);
+    if constexpr (FIRST_LEVEL_DONE) hw_fft32_ct_after_first_level(z);
+    else hw_fft32_ct(z);
     hw_phase();
     cx<double> th[5];
     const int ol = hw_opaque((int)(threadIdx.x & 63));
@@ -512,9 +533,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* wc_lds = reinterpret_cast<cx<double>*>(smem);   // [PW_NR][WD]
     cx<double>* fr_lds = wc_lds + PW_NR * WD;                   // [32][WD]
-    cx<double>* oc_lds = fr_lds + 32 * WD;                      // [PW_NQ][WD]
+    cx<double>* oc_lds = fr_lds + 32 * WD;                      // [PW_NQ][WD] conj(chirp[k])^2
     cx<double>* theta_lds = oc_lds + PW_NQ * WD;                // [5][32]
-    [[maybe_unused]] cx<double>* tw2_lds = theta_lds + 160;     // [32][32] (L = 2048)
+    [[maybe_unused]] cx<double>* tw2_lds = theta_lds + 160;     // [32][33] (L = 2048)
+    int* pc_lds = reinterpret_cast<int*>(tw2_lds + (L == 2048 ? 32 * 33 : 0));   // [PW_NQ WD] pitch class of bin k, -2: none
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     char* xbuf = smem + (size_t)TAB * 16 + wave * HW_XBUF;
     const PrimeWork wk = work[blockIdx.x];
@@ -523,13 +545,15 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
     for (int i = tid; i < PW_NR * WD; i += T) wc_lds[i] = c.wv_wc[i];
     for (int i = tid; i < 32 * WD; i += T) fr_lds[i] = c.wv_fr[i];
     for (int i = tid; i < PW_NQ * WD; i += T) oc_lds[i] = c.wv_oc[i];
+    for (int i = tid; i < PW_NQ * WD; i += T) pc_lds[i] = c.wv_pc[i];
     for (int i = tid; i < 160; i += T) theta_lds[i] = c.wv_theta[i];
     if constexpr (L == 2048)
-        for (int i = tid; i < 1024; i += T) tw2_lds[i] = c.wv_tw2[i];
+        for (int i = tid; i < 32 * 33; i += T) tw2_lds[i] = c.wv_tw2[i];
     __syncthreads();   // the only one
 
     const int parity = lane & 1;
     const int lw = L == 1024 ? lane >> 1 : lane;   // this lane's index inside its transform
+    const double scale = 0.5 / c.wsum;
     constexpr int PER = L == 1024 ? 2 : 1;         // items per wave and iteration
     const int count = wk.count;
     const int worker = wk.worker + __builtin_amdgcn_readfirstlane(wave);
@@ -634,8 +658,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
                 z[n1] = {a * w.x - b * w.y, a * w.y + b * w.x};   // (a + i b) x window x conj(chirp)
                 if ((n1 & 7) == 7) hw_phase();
             }
+            // registers 22 .. 31 are zeros: the transform's first level (points n1 and n1 + 16, twiddle 1) copies where it would add
 #pragma unroll
-            for (int n1 = PW_NR; n1 < 32; ++n1) z[n1] = {0.0, 0.0};
+            for (int n1 = 0; n1 < 16; ++n1) {
+                if (n1 + 16 < PW_NR) {
+                    const cx<double> u = z[n1], v = z[n1 + 16];
+                    z[n1] = cadd(u, v);
+                    z[n1 + 16] = csub(u, v);
+                } else {
+                    z[n1 + 16] = z[n1];
+                }
+            }
         }
         // An all-zero frame has an all-zero spectrum in the reference; next to a loud partner it would come out as that
         // partner's rounding noise, so such a frame is flagged and its magnitudes are the exact zeros (as in prime_pers_kernel).
@@ -649,12 +682,19 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
         it = item_here();
         fetch(it, xa, xb);
         hw_phase();
-        pw_fft1024(z, xbuf, theta_lds);   // z[p] = U_class[(lane >> 1) + 32 br5(p)]
+        pw_fft1024<true>(z, xbuf, theta_lds);   // z[p] = U_class[(lane >> 1) + 32 br5(p)]
         hw_phase();
         {
             const int ol = hw_opaque(lw);
-            [[maybe_unused]] const int k1 = hw_opaque(lane) >> 1;
-            [[maybe_unused]] const double sgn = parity ? -1.0 : 1.0;
+            // L = 2048: the twiddle of this lane's row -- W_2048^k in the odd lanes, 1 in the even ones (entry 32 of every
+            // table row), so that both kinds run the same instructions: no select on data
+            int twi = 0;
+            double sgn = 1.0;
+            if constexpr (L == 2048) {
+                const int ol2 = hw_opaque(lane);
+                twi = (ol2 & 1) ? ol2 >> 1 : 32;
+                sgn = (ol2 & 1) ? -1.0 : 1.0;
+            }
 #pragma unroll
             for (int p = 0; p < 32; ++p) {
                 const cx<double> f = fr_lds[p * WD + ol];
@@ -663,14 +703,14 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
                 } else {
                     // even lane: E, odd lane: O of the same frequency.  s = E | W^k O;  U = E +- W^k O;  V = U x filter;
                     // then the mirror image for the inverse transform: G_even = V_lo + V_hi, G_odd = (V_lo - V_hi) conj(W^k)
-                    const cx<double> tw = tw2_lds[p * 32 + k1];
-                    const cx<double> s = parity ? cmul(z[p], tw) : z[p];
+                    const cx<double> tw = tw2_lds[p * 33 + twi];
+                    const cx<double> s = cmul(z[p], tw);
                     const cx<double> o = {hw_quad_xor<1>(s.x), hw_quad_xor<1>(s.y)};
-                    const cx<double> u = parity ? csub(o, s) : cadd(s, o);
+                    const cx<double> u = {fma(sgn, s.x, o.x), fma(sgn, s.y, o.y)};        // E + t | E - t
                     const cx<double> v = cmul(u, f);
                     const cx<double> ov = {hw_quad_xor<1>(v.x), hw_quad_xor<1>(v.y)};
-                    const cx<double> g = parity ? csub(ov, v) : cadd(v, ov);
-                    z[p] = parity ? cmul(g, cx<double>{tw.x, -tw.y}) : g;
+                    const cx<double> g = {fma(sgn, v.x, ov.x), fma(sgn, v.y, ov.y)};      // V_lo + V_hi | V_lo - V_hi
+                    z[p] = {fma(g.x, tw.x, g.y * tw.y), fma(g.y, tw.x, -(g.x * tw.y))};  // g conj(tw)
                 }
                 if ((p & 7) == 7) hw_phase();
             }
@@ -702,15 +742,18 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
             }
             wave_lds_fence();
         }
-        double ma[PW_NQ], mb[PW_NQ];   // |X_a[k]|^2, |X_b[k]|^2; -inf from `half` on
+        // 4 |X_a[k]|^2 and 4 |X_b[k]|^2 (-inf from `half` on).  X[k] = conj(chirp[k]) y[k] and X[-k] = conj(chirp[k]) y[-k] (the
+        // chirp is even); X_a = (X[k] + conj X[-k]) / 2, X_b = (X[k] - conj X[-k]) / 2i.  Times conj(chirp[k]) once more -- a
+        // factor of modulus 1 -- the two are t +- conj(y[-k]) with t = conj(chirp[k])^2 y[k]: one complex product per bin; the
+        // halves wait for the winner (a power of two commutes with the square root).
+        double ma[PW_NQ], mb[PW_NQ];
         {
             const int ol = hw_opaque(lw);
 #pragma unroll
             for (int q = 0; q < PW_NQ; ++q) {
-                const cx<double> oc = oc_lds[q * WD + ol];
-                const cx<double> xp = cmul(yp[q], oc), xm = cmul(ym[q], oc);
-                const cx<double> sa = {0.5 * (xp.x + xm.x), 0.5 * (xp.y - xm.y)};    // X_a = (X[k] + conj X[-k]) / 2
-                const cx<double> sb = {0.5 * (xp.y + xm.y), 0.5 * (xm.x - xp.x)};    // X_b = (X[k] - conj X[-k]) / 2i
+                const cx<double> oc2 = oc_lds[q * WD + ol];
+                const cx<double> t = cmul(yp[q], oc2);
+                const cx<double> sa = {t.x + ym[q].x, t.y - ym[q].y}, sb = {t.x - ym[q].x, t.y + ym[q].y};
                 const bool in = ol + WD * q < half;
                 const double a2 = live_a ? fma(sa.x, sa.x, sa.y * sa.y) : 0.0, b2 = live_b ? fma(sb.x, sb.x, sb.y * sb.y) : 0.0;
                 ma[q] = in ? a2 : -INFINITY;
@@ -728,45 +771,42 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
                 for (int q = 0; q < PW_NQ; ++q)
                     if (m[q] > bv) bv = m[q];
                 const double wmax = pw_class_max<L>(bv, parity);
-                int i0 = 0x7fffffff, i1 = 0x7fffffff;
+                const int olw = hw_opaque(lw);
+                int key = 0x7fffffff;   // this lane's first bin that holds the maximum
 #pragma unroll
-                for (int q = 0; q < PW_NQ; ++q) {
-                    const unsigned long long bq = __ballot(m[q] == wmax && wmax > -INFINITY);
-                    if constexpr (L == 1024) {
-                        const unsigned long long b0 = bq & 0x5555555555555555ull, b1 = bq & 0xAAAAAAAAAAAAAAAAull;
-                        if (i0 == 0x7fffffff && b0) i0 = (__builtin_ctzll(b0) >> 1) + 32 * q;
-                        if (i1 == 0x7fffffff && b1) i1 = (__builtin_ctzll(b1) >> 1) + 32 * q;
-                    } else {
-                        if (i0 == 0x7fffffff && bq) i0 = __builtin_ctzll(bq) + 64 * q;
-                    }
-                }
-                int idx = (L == 1024 && parity) ? i1 : i0;
+                for (int q = PW_NQ - 1; q >= 0; --q) key = m[q] == wmax ? olw + WD * q : key;
+                int idx = pw_class_min<L>(key, parity);
+                if (!(wmax > -INFINITY)) idx = 0x7fffffff;
                 int pc = -1;
                 double val = 0.0;
                 if (half > 0) {
                     const bool none = idx == 0x7fffffff;   // nothing compared greater than -inf: every magnitude is NaN
                     if (none) idx = 0;
-                    const double max_f = (double)idx * c.val;
-                    const double midi = 12.0 * (log2(max_f) - log2(440.0)) + 69.0;
-                    // hz_to_note raises on NaN (ValueError) and on +-inf (OverflowError, e.g. the DC bin): the
-                    // reference `continue`s: nothing is added and nothing is eliminated (prime_multif0.py:73-74)
-                    if (midi == midi && !isinf(midi)) {
-                        const long long note = (long long)nearbyint(midi);
-                        pc = (int)(((note % 12) + 12) % 12);
-                        val = none ? __builtin_nan("") : sqrt(wmax) / c.wsum;   // mlab: np.abs(result) / window.sum()
+                    // the bin's pitch class from the host's table (12 (log2(k val) - log2 440) + 69, rounded, modulo 12); -2: hz_to_note
+                    // raises on NaN (ValueError) and on +-inf (OverflowError, e.g. the DC bin): the reference `continue`s: nothing is
+                    // added and nothing is eliminated (prime_multif0.py:73-74)
+                    pc = pc_lds[idx];
+                    if (pc >= 0) {
+                        val = none ? __builtin_nan("") : sqrt(wmax) * scale;   // mlab: np.abs(result) / window.sum()
                         if (run + 1 < runs) {   // (what the last round eliminates nobody looks at)
-#pragma unroll
-                            for (int q = 0; q < PW_NQ; ++q) {
-                                const int jb = lw + WD * q;
-                                for (int k = 1; k < elim; ++k) {   // f == k * max_f, exact comparison (:80), among bins k idx - 1 .. k idx + 1
-                                    const int d = jb - k * idx;
-                                    if (jb < half && d >= -1 && d <= 1 && (double)jb * c.val == (double)k * max_f) m[q] = 0.0;
-                                }
+                            // f == k * max_f, exact comparison (:80).  Two bins' frequencies differ by `val`, far more than a
+                            // rounding error: only bin k idx can compare equal (and does not always).  Its owner notes it.
+                            const double max_f = (double)idx * c.val;
+                            int zero = 0;   // bit q: this lane's bin lw + WD q goes
+#pragma nounroll
+                            for (int k = 1; k < elim; ++k) {
+                                const int t = k * idx;
+                                const bool eq = (double)t * c.val == (double)k * max_f;
+                                if (eq && t < half && (t & (WD - 1)) == olw) zero |= 1 << (t / WD);
                             }
+#pragma unroll
+                            for (int q = 0; q < PW_NQ; ++q) m[q] = ((zero >> q) & 1) ? 0.0 : m[q];
                         }
                         // unicode-sharp quirk A.18 (MPX_NOTES_UNICODE): sharps land in a stray key and are lost, but the
                         // elimination above has happened; ASCII note names (librosa < 0.8) keep every pitch class
-                        if (note_names == MPX_NOTES_UNICODE && (pc == 1 || pc == 3 || pc == 6 || pc == 8 || pc == 10)) pc = -1;
+                        if (note_names == MPX_NOTES_UNICODE && ((0x54A >> pc) & 1)) pc = -1;
+                    } else {
+                        pc = -1;
                     }
                 }
                 if (lw == 0 && has_item && (f == 0 || cur_b)) {
@@ -832,7 +872,7 @@ struct PrimePlan {
 // Plans live in the context (host copy of the candidate records in ctx->host_blobs, device tables in
 // ctx->owned) and die with it.
 static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan& plan) {
-    const std::string key = "prime5_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
+    const std::string key = "prime6_" + std::to_string(fs) + "_" + std::to_string(p.num_harmonic) + "_" +
                             std::to_string(p.num_octave);
     auto bit = ctx->host_blobs.find(key);
     if (bit != ctx->host_blobs.end()) {
@@ -915,6 +955,7 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                     c.coef = (const cx<double>*)upload(ctx, coef.data(), coef.size() * sizeof(cx<double>));
                     c.bhat_r = nullptr;
                     c.wv_wc = c.wv_fr = c.wv_oc = c.wv_theta = c.wv_tw2 = nullptr;
+                c.wv_pc = nullptr;
                     if (!c.win || !c.chirp || !c.bhat || !c.coef) return MPX_ENOMEM;
                     plan.cands.push_back(c);
                     continue;
@@ -984,12 +1025,23 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                     std::vector<cx<double>> wc((size_t)PW_NR * WD, cx<double>{0.0, 0.0}), oc((size_t)PW_NQ * WD, cx<double>{0.0, 0.0}),
                         fr((size_t)32 * WD);
                     for (int i = 0; i < N; ++i) wc[i] = {win[i] * chirp[i].x, -(win[i] * chirp[i].y)};     // [n1][lane]: n = lane + WD n1
-                    for (int k = 0; k < half; ++k) oc[k] = {chirp[k].x, -chirp[k].y};                      // [q][lane]: k = lane + WD q
+                    std::vector<int> pcs((size_t)PW_NQ * WD, -2);
+                    for (long long k = 0; k < half; ++k) {                                                   // [q][lane]: k = lane + WD q
+                        const long long q2 = (2 * k * k) % (2LL * N);
+                        const long double ang = -M_PIl * (long double)q2 / (long double)N;
+                        oc[k] = {(double)cosl(ang), (double)sinl(ang)};                                      // conj(chirp[k])^2
+                        const double max_f = (double)k * c.val;
+                        const double midi = 12.0 * (std::log2(max_f) - std::log2(440.0)) + 69.0;
+                        if (midi == midi && !std::isinf(midi)) {
+                            const long long note = (long long)std::nearbyint(midi);
+                            pcs[k] = (int)(((note % 12) + 12) % 12);
+                        }
+                    }
                     for (int p = 0; p < 32; ++p)
                         for (int l = 0; l < WD; ++l)
                             fr[(size_t)p * WD + l] = c.L == 1024 ? filt[l + 32 * hw_br5(p)] : filt[(l >> 1) + 32 * hw_br5(p) + 1024 * (l & 1)];
                     if (!twl.count(-1)) {
-                        std::vector<cx<double>> th(160), tw2(1024);
+                        std::vector<cx<double>> th(160), tw2(32 * 33, cx<double>{1.0, 0.0});
                         for (int st = 0; st < 5; ++st)
                             for (int k1 = 0; k1 < 32; ++k1) {
                                 const long double ang = -2.0L * M_PIl * (long double)(k1 * (16 >> st)) / 1024.0L;
@@ -998,7 +1050,7 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                         for (int p = 0; p < 32; ++p)
                             for (int k1 = 0; k1 < 32; ++k1) {
                                 const long double ang = -2.0L * M_PIl * (long double)(k1 + 32 * hw_br5(p)) / 2048.0L;
-                                tw2[32 * p + k1] = {(double)cosl(ang), (double)sinl(ang)};
+                                tw2[33 * p + k1] = {(double)cosl(ang), (double)sinl(ang)};
                             }
                         twl[-1] = upload(ctx, th.data(), th.size() * sizeof(cx<double>));
                         twl[-2] = upload(ctx, tw2.data(), tw2.size() * sizeof(cx<double>));
@@ -1009,7 +1061,8 @@ static int prime_plan(mpx_ctx* ctx, int fs, const mpx_prime_params& p, PrimePlan
                     c.wv_wc = (const cx<double>*)upload(ctx, wc.data(), wc.size() * sizeof(cx<double>));
                     c.wv_oc = (const cx<double>*)upload(ctx, oc.data(), oc.size() * sizeof(cx<double>));
                     c.wv_fr = (const cx<double>*)upload(ctx, fr.data(), fr.size() * sizeof(cx<double>));
-                    if (!c.wv_wc || !c.wv_oc || !c.wv_fr) return MPX_ENOMEM;
+                    c.wv_pc = (const int*)upload(ctx, pcs.data(), pcs.size() * sizeof(int));
+                    if (!c.wv_wc || !c.wv_oc || !c.wv_fr || !c.wv_pc) return MPX_ENOMEM;
                 }
                 plan.cands.push_back(c);
             }
@@ -1168,7 +1221,15 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     //  (two in the 1024-point class) per iteration)
     std::vector<PrimeWork> work[3];
     const bool wave_path = !dev_env_on("MPX_PRIME_PERS");
-    const int wave_waves[2] = {PW_WAVES_1024, PW_WAVES_2048}, wave_per[2] = {2, 1};
+    int wave_waves[2] = {PW_WAVES_1024, PW_WAVES_2048};
+    const int wave_per[2] = {2, 1};
+#ifdef MPX_DEV_KNOBS   // development: other workgroup sizes (scripts/dev/prime_time.py)
+    {
+        const int w0 = dev_env_int("MPX_PRIME_WAVES_1024", PW_WAVES_1024), w1 = dev_env_int("MPX_PRIME_WAVES_2048", PW_WAVES_2048);
+        if (w0 == 4 || w0 == 6) wave_waves[0] = w0;
+        if (w1 == 2 || w1 == 3) wave_waves[1] = w1;
+    }
+#endif
     const int slots_of[3] = {wave_path ? ctx->num_cus : prime_pers_slots<1024>(ctx), wave_path ? ctx->num_cus : prime_pers_slots<2048>(ctx),
                              prime_pers_slots<4096>(ctx)};
     for (int cls = 0; cls < 3; ++cls) {
@@ -1212,8 +1273,16 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         if (cls < 3) {
             const PrimeWork* dw = (const PrimeWork*)((char*)ctx->d_ws1.p + woff);
             const size_t groups = work[cls].size();
-            if (cls == 0 && wave_path) rc = prime_wave_launch<1024, PW_WAVES_1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
-            if (cls == 1 && wave_path) rc = prime_wave_launch<2048, PW_WAVES_2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+#define PW_ARGS ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots
+            if (cls == 0 && wave_path && wave_waves[0] == PW_WAVES_1024) rc = prime_wave_launch<1024, PW_WAVES_1024>(PW_ARGS);
+            if (cls == 1 && wave_path && wave_waves[1] == PW_WAVES_2048) rc = prime_wave_launch<2048, PW_WAVES_2048>(PW_ARGS);
+#ifdef MPX_DEV_KNOBS
+            if (cls == 0 && wave_path && wave_waves[0] == 4) rc = prime_wave_launch<1024, 4>(PW_ARGS);
+            if (cls == 0 && wave_path && wave_waves[0] == 6) rc = prime_wave_launch<1024, 6>(PW_ARGS);
+            if (cls == 1 && wave_path && wave_waves[1] == 2) rc = prime_wave_launch<2048, 2>(PW_ARGS);
+            if (cls == 1 && wave_path && wave_waves[1] == 3) rc = prime_wave_launch<2048, 3>(PW_ARGS);
+#endif
+#undef PW_ARGS
             if (cls == 0 && !wave_path) rc = prime_pers_launch<1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
             if (cls == 1 && !wave_path) rc = prime_pers_launch<2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
             if (cls == 2) rc = prime_pers_launch<4096>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);

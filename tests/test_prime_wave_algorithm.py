@@ -49,11 +49,11 @@ def candidate_tables(N, L):
         idx = np.arange(wd) + wd * n1
         ok = idx < N
         wc[n1, ok] = win[idx[ok]] * np.conj(chirp[idx[ok]])
-    oc = np.zeros((6, wd), dtype=complex)               # [q][lane]: conj(chirp[k]), k = lane + wd q
+    oc = np.zeros((6, wd), dtype=complex)               # [q][lane]: conj(chirp[k])^2, k = lane + wd q
     for q in range(6):
         idx = np.arange(wd) + wd * q
         ok = idx < half
-        oc[q, ok] = np.conj(chirp[idx[ok]])
+        oc[q, ok] = np.exp(-1j * np.pi * ((2 * idx[ok] * idx[ok]) % (2 * N)) / N)
     fr = np.empty((32, wd), dtype=complex)              # [p][lane]: the filter spectrum where the forward transform leaves it
     for p in range(32):
         if L == 1024:
@@ -75,11 +75,11 @@ def mirror_and_split(y, t, wd):
                 ym = y[wd - lane, BR[31 - q]]
             else:
                 ym = y[0, BR[0]] if q == 0 else y[0, BR[32 - q]]
-            xp, xm = yp * t["oc"][q, lane], ym * t["oc"][q, lane]
-            sa = 0.5 * (xp + np.conj(xm))
-            sb = (xp - np.conj(xm)) / 2j
-            ma[lane, q], mb[lane, q] = abs(sa), abs(sb)
-    return ma / t["wsum"], mb / t["wsum"]
+            # X[k] = conj(chirp[k]) y[k], X[-k] = conj(chirp[k]) y[-k]; X_a = (X[k] + conj X[-k]) / 2, X_b = (X[k] - conj X[-k]) / 2i:
+            # times conj(chirp[k]) once more (modulus 1) they are (tt +- conj(y[-k])) / 2 with tt = conj(chirp[k])^2 y[k]
+            tt = yp * t["oc"][q, lane]
+            ma[lane, q], mb[lane, q] = abs(tt + np.conj(ym)), abs(tt - np.conj(ym))
+    return 0.5 * ma / t["wsum"], 0.5 * mb / t["wsum"]
 
 
 def wave_item_1024(a, b, t):
