@@ -7,7 +7,8 @@
 // (prime_multif0.py:66-82).  Every item writes its <= runs (pitch class, value) pairs to a fixed slot;
 // one workgroup per clip adds them up in item order (deterministic).
 //
-// prime_pers_kernel (chirp-z lengths up to 4096): PERSISTENT workgroups, each bound to one candidate frequency.  What
+// prime_wave_kernel (chirp-z lengths 1024 and 2048, round 5): a WAVE per item, the item in registers -- see the kernel.
+// prime_pers_kernel (chirp-z length 4096; 1024 and 2048 in development builds): PERSISTENT workgroups, each bound to one candidate frequency.  What
 // depends on the candidate only -- window x chirp, the filter spectrum in the register order of the DIF engine, the
 // twiddle bases, the output chirp -- is loaded into registers once; the workgroup then walks that candidate's frames
 // across all clips with a stride, the next frame's samples in flight under the current frame's transforms.  The two
@@ -1220,7 +1221,11 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     //  worker is a WAVE: workgroup g of a candidate holds the workers g WAVES ... g WAVES + WAVES - 1, each taking one item
     //  (two in the 1024-point class) per iteration)
     std::vector<PrimeWork> work[3];
+#ifdef MPX_DEV_KNOBS
     const bool wave_path = !dev_env_on("MPX_PRIME_PERS");
+#else
+    constexpr bool wave_path = true;
+#endif
     int wave_waves[2] = {PW_WAVES_1024, PW_WAVES_2048};
     const int wave_per[2] = {2, 1};
 #ifdef MPX_DEV_KNOBS   // development: other workgroup sizes (scripts/dev/prime_time.py)
@@ -1230,8 +1235,13 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
         if (w1 == 2 || w1 == 3) wave_waves[1] = w1;
     }
 #endif
-    const int slots_of[3] = {wave_path ? ctx->num_cus : prime_pers_slots<1024>(ctx), wave_path ? ctx->num_cus : prime_pers_slots<2048>(ctx),
-                             prime_pers_slots<4096>(ctx)};
+    int slots_of[3] = {ctx->num_cus, ctx->num_cus, prime_pers_slots<4096>(ctx)};
+#ifdef MPX_DEV_KNOBS
+    if (!wave_path) {
+        slots_of[0] = prime_pers_slots<1024>(ctx);
+        slots_of[1] = prime_pers_slots<2048>(ctx);
+    }
+#endif
     for (int cls = 0; cls < 3; ++cls) {
         const long long mult = uniform ? num_clips : 1;
         const long long class_items = (long long)items[cls].size() * mult;
@@ -1283,8 +1293,10 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
             if (cls == 1 && wave_path && wave_waves[1] == 3) rc = prime_wave_launch<2048, 3>(PW_ARGS);
 #endif
 #undef PW_ARGS
+#ifdef MPX_DEV_KNOBS   // round 3's kernel for these classes: A / B only (MPX_PRIME_PERS=1)
             if (cls == 0 && !wave_path) rc = prime_pers_launch<1024>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
             if (cls == 1 && !wave_path) rc = prime_pers_launch<2048>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
+#endif
             if (cls == 2) rc = prime_pers_launch<4096>(ctx, d_in, di, dw, groups, plan->d_cands, p.harmonic_elim_runs, p.harmonic_multiples_elim, p.note_names, d_pc, d_val, st, uclips, clip_len, clip_slots);
             if (rc) return rc;
             woff += groups * sizeof(PrimeWork);

@@ -33,7 +33,8 @@ SCRATCH_FREE = [
     "mpx::pv_enhance_kernel<true, 2>", "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
     "mpx::sacf_huge_kernel<512>", "mpx::pv_enhance_big_kernel<8>", "mpx::enhance_pick_big_kernel<512>",   # frames of odd length above 4096 / above 8192 samples
     "mpx::peakfit_kernel<true>",                      # samples in LDS, fvec recomputed: every batch (the round-2 arrangement, 40 B of scratch, is a development-build option)
-    "mpx::prime_pers_kernel<1024>", "mpx::prime_pers_kernel<2048>", "mpx::prime_pers_kernel<4096>",
+    "mpx::prime_wave_kernel<2048, 4>",                # Prime-multiF0, 2048-point chirp-z: a wave per SIMD, 512 registers each
+    "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
     # ... and every other instantiation a caller can reach through frame_size / power (iterative_f0.py:22-33); round 3 shipped
     # these with 96-324 bytes per lane of scratch under a four-waves-per-SIMD limit (if0_split_waves)
@@ -47,6 +48,7 @@ SCRATCH_FREE = [
 ]
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
+    "mpx::prime_wave_kernel<1024, 7>": 36,             # two items per wave at two waves per SIMD: loop-carried item state (slots, pointers), touched once per iteration outside the transforms
     "mpx::coopfit_kernel": 36,                         # a 36-byte stack slot is reserved since the two-pass form; the ISA holds no scratch instruction
     "mpx::coopfit8_kernel": 36,                        # the same kernel with eight lanes per fit
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1, false>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
@@ -60,7 +62,8 @@ OCCUPANCY = {
     "mpx::he_wave_kernel<7, 4, false, true, 4294967295u, 2, false>": 2,
     "mpx::sacf_pfa_kernel<2>": 4,
     "mpx::if0_spectrum_split_kernel<8192, true, 1>": 4,
-    "mpx::prime_pers_kernel<1024>": 2,
+    "mpx::prime_wave_kernel<1024, 7>": 2,
+    "mpx::prime_wave_kernel<2048, 4>": 1,
     "mpx::peakfit_kernel<true>": 2,
 }
 
@@ -81,7 +84,9 @@ def test_release_build_has_no_development_only_kernels(table):
     """if0_spectrum_kernel / if0_spectrum_dif_kernel and the prefetch variants of the split kernel are reachable only through
     dev_env knobs, which are constants in the release build: they are compiled under MPX_DEV_KNOBS only."""
     dead = [k for k in table if "if0_spectrum_kernel<" in k or "if0_spectrum_dif_kernel<" in k
-            or ("if0_spectrum_split_kernel<" in k and not (k.endswith("true, 1>") or k.endswith("false, 0>")))]
+            or ("if0_spectrum_split_kernel<" in k and not (k.endswith("true, 1>") or k.endswith("false, 0>")))
+            or "prime_pers_kernel<1024>" in k or "prime_pers_kernel<2048>" in k        # round 3's Prime-multiF0 kernel where the wave kernel runs
+            or ("prime_wave_kernel<" in k and k not in ("mpx::prime_wave_kernel<1024, 7>", "mpx::prime_wave_kernel<2048, 4>"))]
     assert not dead, dead
 
 
