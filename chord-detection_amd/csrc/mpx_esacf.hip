@@ -1501,6 +1501,9 @@ __global__ __launch_bounds__(T) void sacf_huge_kernel(SacfArgs a, HugeArgs h) {
 //   -> ISTFT (overlap-add / window sum-square, drop 1024, length round(Mh/r)) -> subtract -> clip.
 // Two real frames share one complex 2048-point LDS FFT in both directions (re/im packing).
 constexpr int PV_T = 256, PV_NFFT = 2048, PV_HOP = 512, PV_BINS = PV_NFFT / 2 + 1;
+#ifndef PV_WGS
+#define PV_WGS 3
+#endif
 
 struct PvArgs {
     double* y;                 // [F, Mh] SACF in, enhanced SACF out
@@ -1518,7 +1521,7 @@ __device__ __forceinline__ double pv_hann(const cx<double>* __restrict__ tw, int
 // MAXS: output frames of the vocoder this instantiation can hold (2: rows up to 2047 lags, everything until round 3;
 // 4: rows up to 4095 lags, ESACF frames up to 8192 samples -- the phase is then carried as a unit vector per bin, see there).
 template <bool PICK, int MAXS>
-__global__ __launch_bounds__(PV_T, MAXS > 2 ? 1 : 2) void pv_enhance_kernel(PvArgs a, SacfArgs sa) {
+__global__ __launch_bounds__(PV_T, MAXS > 2 ? 1 : PV_WGS) void pv_enhance_kernel(PvArgs a, SacfArgs sa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cx<double>* buf = reinterpret_cast<cx<double>*>(smem);                       // 2048 complex (padded)
     double* x = reinterpret_cast<double*>(buf + lds_slots(PV_NFFT));             // [Mh] working copy of the SACF
