@@ -30,7 +30,7 @@ SCRATCH_FREE = [
     "mpx::sacf_pfa_kernel<1>", "mpx::sacf_pfa_kernel<2>",
     "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
     "mpx::bandsplit_kernel<false>", "mpx::bandsplit_kernel<true>",
-    "mpx::pv_enhance_kernel<true, 2>", "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
+    "mpx::pv_enhance_kernel<true, 4>", "mpx::sacf_split_kernel<8192, 512>", "mpx::sacf_rz_kernel<4096>", "mpx::scatter_kernel",
     "mpx::sacf_huge_kernel<512>", "mpx::pv_enhance_big_kernel<8>", "mpx::enhance_pick_big_kernel<512>",   # frames of odd length above 4096 / above 8192 samples
     "mpx::peakfit_kernel<true>",                      # samples in LDS, fvec recomputed: every batch (the round-2 arrangement, 40 B of scratch, is a development-build option)
     "mpx::prime_wave_kernel<2048, 4>",                # Prime-multiF0, 2048-point chirp-z: a wave per SIMD, 512 registers each
@@ -49,6 +49,7 @@ SCRATCH_FREE = [
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane)
 SCRATCH_CEILING = {
     "mpx::prime_wave_kernel<1024, 7>": 36,             # two items per wave at two waves per SIMD: loop-carried item state (slots, pointers), touched once per iteration outside the transforms
+    "mpx::pv_enhance_kernel<true, 2>": 24,             # three workgroups per CU since round 5 (168 registers): 0.85 -> 0.66 ms per 8192 frames with the spill
     "mpx::coopfit_kernel": 36,                         # a 36-byte stack slot is reserved since the two-pass form; the ISA holds no scratch instruction
     "mpx::coopfit8_kernel": 36,                        # the same kernel with eight lanes per fit
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1, false>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
@@ -65,6 +66,7 @@ OCCUPANCY = {
     "mpx::prime_wave_kernel<1024, 7>": 2,
     "mpx::prime_wave_kernel<2048, 4>": 1,
     "mpx::peakfit_kernel<true>": 2,
+    "mpx::pv_enhance_kernel<true, 2>": 3,
 }
 
 
