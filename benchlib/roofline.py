@@ -31,7 +31,7 @@ def kernel_models(n, mh, channels=70, nf=8192):
 
 
 # profile marks of the library (mpx_profile_*) -> kernels they cover, as the profiler names them
-MARK_KERNELS = {"prime_kernel": ("prime_pers_kernel", "prime_kernel"),
+MARK_KERNELS = {"prime_kernel": ("prime_wave_kernel", "prime_pers_kernel", "prime_kernel"),   # wave per item (chirp-z of 1024 / 2048 points) | persistent workgroups | workgroup per item
                 "if0_frontend_kernel": ("if0_frontend_kernel", "if0_frontend2_kernel"),   # pipelined | sequential (mpx_if0.hip)
                 "if0_spectrum_kernel": ("if0_spectrum_split_kernel", "if0_spectrum_dif_kernel", "if0_spectrum_kernel"),
                 "he_kernel": ("he_wave_kernel", "he_kernel", "he_blue_kernel"),

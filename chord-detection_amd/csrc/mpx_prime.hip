@@ -820,18 +820,33 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
     }
 }
 
-// one workgroup per clip: chroma[clip] = sum over its item slots, in slot order per pitch class
+// one wave per clip: chroma[clip] = sum over its item slots.  Lane l adds up the slots l, l + 64, ... (twelve sums in
+// registers: a slot holds up to PRIME_MAX_RUNS (pitch class, value) pairs), then lane n < 12 adds the 64 partial sums of
+// pitch class n in lane order: a fixed order that depends on nothing but the clip's own slot count.  (Until round 5 twelve
+// lanes walked all the slots one after the other: 0.85 ms per 4096 clips, 3.5 % of the method once its transforms took 24 ms.)
 __global__ __launch_bounds__(64) void prime_sum_kernel(const long long* __restrict__ seg, int runs,
                                                        const int* __restrict__ pc, const double* __restrict__ val,
                                                        double* out) {
+    __shared__ double part[64][13];
     const int lane = threadIdx.x;
     const long long s0 = seg[blockIdx.x], s1 = seg[blockIdx.x + 1];
+    double acc[12];
+#pragma unroll
+    for (int n = 0; n < 12; ++n) acc[n] = 0.0;
+    for (long long s = s0 + lane; s < s1; s += 64)
+        for (int r = 0; r < runs; ++r) {
+            const int p = pc[s * PRIME_MAX_RUNS + r];
+            const double v = val[s * PRIME_MAX_RUNS + r];
+#pragma unroll
+            for (int n = 0; n < 12; ++n) acc[n] += p == n ? v : 0.0;
+        }
+#pragma unroll
+    for (int n = 0; n < 12; ++n) part[lane][n] = acc[n];
+    __syncthreads();
     if (lane < 12) {
-        double acc = 0.0;
-        for (long long s = s0; s < s1; ++s)
-            for (int r = 0; r < runs; ++r)
-                if (pc[s * PRIME_MAX_RUNS + r] == lane) acc += val[s * PRIME_MAX_RUNS + r];
-        out[(long long)blockIdx.x * 12 + lane] = acc;
+        double t = 0.0;
+        for (int l = 0; l < 64; ++l) t += part[l][lane];
+        out[(long long)blockIdx.x * 12 + lane] = t;
     }
 }
 

@@ -32,7 +32,7 @@ out = {"round": rnd, "source": os.path.relpath(src),
                  "correction; calibrated 1.995-1.998 on he_wave / sacf_pfa known bytes), 1 for 4-byte and scattered reads (calibrated "
                  "0.89-1.01 on bandsplit / peakfit known bytes): scripts/pmc_to_traffic.py; median per launch shape",
        "kernels": {}}
-FACTOR_ONE = ("bandsplit_kernel", "peakfit_kernel", "coopfit_kernel", "coopfit8_kernel", "scatter_kernel", "if0_frontend_kernel", "if0_frontend2_kernel", "prime_pers_kernel",
+FACTOR_ONE = ("bandsplit_kernel", "peakfit_kernel", "coopfit_kernel", "coopfit8_kernel", "scatter_kernel", "if0_frontend_kernel", "if0_frontend2_kernel", "prime_pers_kernel", "prime_wave_kernel",
               "prime_kernel", "prime_sum_kernel", "sum_segments_kernel", "sum_chunks_kernel", "sum_all_kernel", "peakpick_kernel")
 for key, rec in pmc.items():
     if "hbm_bytes_per_launch" not in rec:
