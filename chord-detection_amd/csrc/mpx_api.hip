@@ -391,11 +391,17 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     int rc = check_common(ctx, signals, total, frame, hop);
     if (rc) return rc;
     if (offsets[0] != 0) return set_error(ctx, MPX_EINVAL, "offsets[0] must be 0");
+    // the frame descriptors and the segment table of this layout may still be on the device from the previous call
+    std::vector<int64_t> layout(offsets, offsets + num_clips + 1);
+    layout.push_back(frame);
+    layout.push_back(hop);
+    const bool cached = layout == ctx->batch_layout && ctx->d_desc.p && ctx->d_offsets.p;
     std::vector<FrameDesc> descs;
     std::vector<long long> seg;
-    if (build_descs(offsets, num_clips, frame, hop, descs, seg))
+    if (!cached && build_descs(offsets, num_clips, frame, hop, descs, seg))
         return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
-    const int64_t nf = (int64_t)descs.size();
+    const int64_t nf = cached ? ctx->batch_layout_frames : (int64_t)descs.size();
+    ctx->batch_layout.clear();
     // where the samples live (include/mpx.h): clips already in HBM are read IN PLACE, no copy into the context's buffer
     bool on_device = false;
     {
@@ -409,17 +415,21 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     const float* d_in = on_device ? signals : (const float*)ctx->d_signal.p;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_desc, (size_t)(nf ? nf : 1) * sizeof(FrameDesc)))) return rc;
-    if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_offsets, (size_t)(num_clips + 1) * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
     hipStream_t st = ctx->stream;
-    if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
-    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    if (!cached) {   // (the buffers only grow: a layout that was cached fits them as they are)
+        if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+    }
     bool did_sum = false;
     // A large batch in HOST memory goes over PCIe in pieces on a second stream, the kernels of piece k running next to
     // the copy of piece k+1 (ESACF, 4096 clips: the 1.4 GB copy and the 27 ms of kernels take about as long as each
     // other).  Device-resident batches and small ones: one copy, one pass.
     int pieces = 1;
     if (!on_device && (size_t)total * sizeof(float) >= (size_t(64) << 20) && num_clips >= 8) pieces = ctx->copy_pieces;
+    if (pieces > 1 && cached && build_descs(offsets, num_clips, frame, hop, descs, seg))   // the pieces' frame ranges come from the host's table
+        return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
     if (pieces > 1 && !ctx->copy_ready) {
         // the copy stream and its eight events exist together or not at all: a partial failure is undone, and the batch
         // (and the next one: it tries again) goes in one piece
@@ -477,6 +487,8 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double),
                                 hipMemcpyDeviceToHost, st));
     MPX_HIP(ctx, hipStreamSynchronize(st));
+    ctx->batch_layout.swap(layout);   // d_desc / d_offsets hold this layout now (a failed call leaves the cache empty)
+    ctx->batch_layout_frames = nf;
     return MPX_OK;
 }
 

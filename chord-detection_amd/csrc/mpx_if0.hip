@@ -2009,6 +2009,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + up_frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
                                        tail_groups.size() * sizeof(If0TailGroup) + sl_rows.size() * sizeof(int) + 256))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * 12 * sizeof(double)))) return rc;
+    ctx->batch_layout.clear();   // d_desc / d_offsets are about to hold this call's tables (method_batch's cache)
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
     If0Chunk* d_chunks = (If0Chunk*)ctx->d_desc.p;

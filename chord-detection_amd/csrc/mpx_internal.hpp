@@ -72,6 +72,10 @@ struct mpx_ctx {
     std::map<std::string, std::vector<unsigned char>> host_blobs;  // host copies of plan records, per context
     std::map<std::string, int> occupancy;      // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answers
     std::map<int, std::vector<double>> remez;  // user-registered warped-FIR taps per sample rate
+    // method_batch: the clip layout (offsets, frame, hop) whose frame descriptors and segment table d_desc / d_offsets hold --
+    // a corpus driver calls with the same layout chunk after chunk; empty: they hold something else (Iterative-F0, Prime-multiF0)
+    std::vector<int64_t> batch_layout;
+    int64_t batch_layout_frames = 0;
     std::vector<void*> owned;  // plan tables, freed in mpx_destroy
     // per-kernel timing (mpx_profile_begin / mpx_profile_end): an event in front of every launch while enabled
     struct ProfMark {

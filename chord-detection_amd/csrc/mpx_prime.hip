@@ -1214,6 +1214,7 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     const size_t nitems = (size_t)slot;
     size_t item_bytes = 0;
     for (auto& v : items) item_bytes += v.size() * sizeof(PrimeItem);
+    ctx->batch_layout.clear();   // d_desc / d_offsets are about to hold this call's tables (method_batch's cache)
     if ((rc = ensure(ctx, ctx->d_desc, item_bytes + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, (nitems + 1) * PRIME_MAX_RUNS * (sizeof(int) + sizeof(double)) + 64))) return rc;
