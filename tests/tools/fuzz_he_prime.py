@@ -54,15 +54,18 @@ with warnings.catch_warnings():
         # A row entry is sqrt|X| of a window maximum: a transform's rounding error in |X| scales with the FRAME's largest bin
         # (eps * peak), so an entry far below the row maximum carries eps * rowmax^2 / (2 entry) of it (seed 551, case 214: an
         # entry 1e-4 of its row maximum, 1.9e-9 from NumPy's and 1.8e-9 from a long-double DFT, the round-4 library alike)
-        rowmax = np.abs(want).max(axis=-1, keepdims=True)
-        floor_ = 8 * np.finfo(np.float64).eps * rowmax ** 2 / np.maximum(np.abs(want), 1e-6 * rowmax + 1e-300)
-        if not np.all(np.abs(per - want) <= 1e-9 * np.abs(want) + 1e-12 + floor_):
+        ok = np.allclose(per, want, rtol=1e-9, atol=1e-12)
+        if not ok and np.all(np.isfinite(want)) and np.all(np.isfinite(per)):   # (empty windows: -inf entries, compared by allclose alone)
+            rowmax = np.abs(want).max(axis=-1, keepdims=True)
+            floor_ = 8 * np.finfo(np.float64).eps * rowmax ** 2 / np.maximum(np.abs(want), 1e-6 * rowmax + 1e-300)
+            ok = bool(np.all(np.abs(per - want) <= 1e-9 * np.abs(want) + 1e-12 + floor_))
+        if not ok:
             bad += 1
             print("HE MISMATCH", case, fs, N, hop, n, kw, float(np.max(np.abs(per - want) / np.maximum(np.abs(want), 1e-300))))
     for case in range(cases // 3):
-        fs = int(rng.choice([22050, 22050, 44100, 48000, 96000, 120000, 192000]))   # above ~107 kHz: decimated chirp-z passes
+        fs = int(rng.choice([22050, 22050, 44100, 48000, 96000, 120000, 192000] + ([8000, 11025, 16000, 32000] if os.environ.get("FUZZ_PRIME_LOW_RATES") else [])))   # above ~107 kHz: decimated chirp-z passes
         n = int(rng.choice([3000, 22050, 44100, 50001])) * (1 if fs <= 48000 else 2)
-        kw = dict(num_harmonic=int(rng.integers(1, 3)), num_octave=int(rng.integers(1, 3)),
+        kw = dict(num_harmonic=int(rng.integers(1, 3)), num_octave=int(rng.integers(1, 4 if os.environ.get("FUZZ_PRIME_LOW_RATES") else 3)),
                   harmonic_multiples_elim=int(rng.integers(1, 7)), harmonic_elim_runs=int(rng.integers(1, 4)))
         x = signal(n, fs)
         got = eng.prime_multif0(x, fs, **kw)
