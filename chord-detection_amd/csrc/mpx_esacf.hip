@@ -2027,6 +2027,56 @@ __device__ __forceinline__ double gauss_resid(const GaussEval& g, double xi, dou
     const double d = xi - g.mu;
     return fma_as_written(g.ampl, exp_nonpos(prod(d, d) * g.ninv, g.tab), -yi);
 }
+// ---- forward-difference columns of the centre and the width without their exponentials (round 5) -----------------------
+// MINPACK's fdjac2 column j is (f(x + h e_j) - f(x)) / h.  For the gaussian f(x) + y = A e^u, u = d^2 ninv (d = x_i - centre), and
+// the perturbed argument is u + t with
+//   centre:  t = ((d - h)^2 - d^2) ninv = h (h - 2 d) ninv;       width:  t = d^2 (ninv' - ninv),  ninv' - ninv = 2 h (2 s + h) ninv ninv'
+// (h the step as taken, fl(x_j + h) - x_j), so f(x + h e_j) - f(x) = (f + y)(e^t - 1) -- the amplitude column's own f + y, one
+// exponential per row instead of three.  e^t - 1 by its series while |t| <= 2^-6 (relative error 1.3e-12: four orders below the
+// rounding noise eps / h = 1e-8 of the difference it replaces); a fit with a row outside that range takes the two
+// exponentials as before (fd_big, decided per FIT from its own scalars: the three fit kernels agree on it and stay bit-equal).
+constexpr double FD_SERIES_MAX = 0.015625;
+__device__ __forceinline__ double expm1_small(double t) {
+    double p = fma_as_written(t, 1.0 / 120.0, 1.0 / 24.0);
+    p = fma_as_written(t, p, 1.0 / 6.0);
+    p = fma_as_written(t, p, 0.5);
+    p = fma_as_written(t, p, 1.0);
+    return prod(t, p);
+}
+struct FdStep {
+    double h1, k1, inv_h1;   // centre: the step as taken, h1 ninv, 1 / the nominal step (what fdjac2 divides by)
+    double dn, inv_h2;       // width: ninv' - ninv, 1 / the nominal step
+    double mu1, ninv2;       // the perturbed centre and -1 / (2 s'^2 + eps) themselves (slow path)
+};
+__device__ __forceinline__ FdStep fd_prep(const double* x, double ninv, double eps) {
+    FdStep s;
+    double h1 = eps * fabs(x[1]), h2 = eps * fabs(x[2]);
+    if (h1 == 0.0) h1 = eps;
+    if (h2 == 0.0) h2 = eps;
+    s.mu1 = x[1] + h1;
+    s.h1 = s.mu1 - x[1];
+    s.k1 = prod(s.h1, ninv);
+    s.inv_h1 = 1.0 / h1;
+    const double s2 = x[2] + h2, h2e = s2 - x[2];
+    s.ninv2 = -1.0 / fma_as_written(2.0, prod(s2, s2), lm::EPSMCH);
+    s.dn = prod(prod(prod(2.0, h2e), x[2] + s2), prod(ninv, s.ninv2));
+    s.inv_h2 = 1.0 / h2;
+    return s;
+}
+// one row: t = f + y, d = x_i - centre
+__device__ __forceinline__ void fd_row(const FdStep& s, double d, double t, double& j1, double& j2) {
+    const double t1 = prod(fma_as_written(-2.0, d, s.h1), s.k1), t2 = prod(prod(d, d), s.dn);
+    j1 = prod(prod(t, expm1_small(t1)), s.inv_h1);
+    j2 = prod(prod(t, expm1_small(t2)), s.inv_h2);
+}
+// Does some row of the fit leave the series' range?  |t| is largest at the first or the last row (|linear| and a square are
+// convex in d): decided from the fit's own scalars, the same in every kernel and in every lane of a cooperative fit.  (NaN: yes.)
+__device__ __forceinline__ bool fd_big(const FdStep& s, double d_first, double d_last) {
+    const double a = fmax(fabs(prod(fma_as_written(-2.0, d_first, s.h1), s.k1)), fabs(prod(fma_as_written(-2.0, d_last, s.h1), s.k1)));
+    const double b = fmax(fabs(prod(prod(d_first, d_first), s.dn)), fabs(prod(prod(d_last, d_last), s.dn)));
+    return !(a <= FD_SERIES_MAX && b <= FD_SERIES_MAX);
+}
+
 __device__ __forceinline__ void load_samples(const double* __restrict__ row, int m, double* ys) {
 #pragma unroll
     for (int q = 0; q < lm::MAXM; ++q) ys[q] = q < m ? row[q] : 0.0;
@@ -2173,20 +2223,23 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                     J0 = {(w.a - f.a) * (1.0 / eps), (w.b - f.b) * (1.0 / eps)};
                     x[0] = 0.0;
                 }
-                D2 jj[NP];
-#pragma unroll
-                for (int j = 1; j < NP; ++j) {
-                    const double temp = x[j];
-                    double h = eps * fabs(temp);
-                    if (h == 0.0) h = eps;
-                    x[j] = temp + h;
-                    const D2 w = resid(x);
-                    x[j] = temp;
-                    const double inv_h = 1.0 / h;
-                    jj[j] = {(w.a - f.a) * inv_h, (w.b - f.b) * inv_h};
+                const FdStep fs = fd_prep(x, gauss_prep(x, exp_tab).ninv, eps);
+                if (!fd_big(fs, pf.x0 - x[1], pf.x0 + (double)(pf.m - 1) - x[1])) {
+                    fd_row(fs, px.a - x[1], f.a + py.a, J1.a, J2.a);
+                    fd_row(fs, px.b - x[1], f.b + py.b, J1.b, J2.b);
+                    J1 = {ona ? J1.a : 0.0, onb ? J1.b : 0.0};
+                    J2 = {ona ? J2.a : 0.0, onb ? J2.b : 0.0};
+                } else {   // a row outside the series' range (a width far below a lag): the two exponentials per row
+                    const double keep1 = x[1], keep2 = x[2];
+                    x[1] = fs.mu1;
+                    const D2 w1 = resid(x);
+                    x[1] = keep1;
+                    x[2] = keep2 + (eps * fabs(keep2) == 0.0 ? eps : eps * fabs(keep2));
+                    const D2 w2 = resid(x);
+                    x[2] = keep2;
+                    J1 = {(w1.a - f.a) * fs.inv_h1, (w1.b - f.b) * fs.inv_h1};
+                    J2 = {(w2.a - f.a) * fs.inv_h2, (w2.b - f.b) * fs.inv_h2};
                 }
-                J1 = jj[1];
-                J2 = jj[2];
             }
             nfev += NP;
             int ipvt[NP] = {0, 1, 2};
@@ -2488,20 +2541,24 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                     J0 = {(w.a - f.a) * (1.0 / eps), (w.b - f.b) * (1.0 / eps), (w.c - f.c) * (1.0 / eps)};
                     x[0] = 0.0;
                 }
-                D3 jj[NP];
-#pragma unroll
-                for (int j = 1; j < NP; ++j) {
-                    const double temp = x[j];
-                    double h = eps * fabs(temp);
-                    if (h == 0.0) h = eps;
-                    x[j] = temp + h;
-                    const D3 w = resid(x);
-                    x[j] = temp;
-                    const double inv_h = 1.0 / h;
-                    jj[j] = {(w.a - f.a) * inv_h, (w.b - f.b) * inv_h, (w.c - f.c) * inv_h};
+                const FdStep fs = fd_prep(x, gauss_prep(x, exp_tab).ninv, eps);
+                if (!fd_big(fs, pf.x0 - x[1], pf.x0 + (double)(pf.m - 1) - x[1])) {
+                    fd_row(fs, px.a - x[1], f.a + py.a, J1.a, J2.a);
+                    fd_row(fs, px.b - x[1], f.b + py.b, J1.b, J2.b);
+                    fd_row(fs, px.c - x[1], f.c + py.c, J1.c, J2.c);
+                    J1 = {ona ? J1.a : 0.0, onb ? J1.b : 0.0, onc ? J1.c : 0.0};
+                    J2 = {ona ? J2.a : 0.0, onb ? J2.b : 0.0, onc ? J2.c : 0.0};
+                } else {   // a row outside the series' range (a width far below a lag): the two exponentials per row
+                    const double keep1 = x[1], keep2 = x[2];
+                    x[1] = fs.mu1;
+                    const D3 w1 = resid(x);
+                    x[1] = keep1;
+                    x[2] = keep2 + (eps * fabs(keep2) == 0.0 ? eps : eps * fabs(keep2));
+                    const D3 w2 = resid(x);
+                    x[2] = keep2;
+                    J1 = {(w1.a - f.a) * fs.inv_h1, (w1.b - f.b) * fs.inv_h1, (w1.c - f.c) * fs.inv_h1};
+                    J2 = {(w2.a - f.a) * fs.inv_h2, (w2.b - f.b) * fs.inv_h2, (w2.c - f.c) * fs.inv_h2};
                 }
-                J1 = jj[1];
-                J2 = jj[2];
             }
             nfev += NP;
             int ipvt[NP] = {0, 1, 2};
@@ -2881,12 +2938,12 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                 const double inv_a = a_nonzero ? 1.0 / x[0] : 0.0;
                 double xa[NP] = {eps, x[1], x[2]};
                 const GaussEval ga = gauss_prep(xa, exp_tab);   // only used when A == 0
-                double h1 = eps * fabs(x[1]), h2 = eps * fabs(x[2]);
-                if (h1 == 0.0) h1 = eps;
-                if (h2 == 0.0) h2 = eps;
-                double x1[NP] = {x[0], x[1] + h1, x[2]}, x2[NP] = {x[0], x[1], x[2] + h2};
-                const GaussEval g1 = gauss_prep(x1, exp_tab), g2 = gauss_prep(x2, exp_tab);
-                const double inv_h1 = 1.0 / h1, inv_h2 = 1.0 / h2, inv_ha = 1.0 / eps;
+                const FdStep fs = fd_prep(x, g0.ninv, eps);
+                const double inv_ha = 1.0 / eps;
+                // (rare: a width far below a lag) this fit takes the two exponentials per row, in place: a branch per row that a
+                // wave without such a fit skips
+                const bool big = fd_big(fs, x0 - x[1], x0 + (double)(m - 1) - x[1]);
+                const GaussEval g1 = {x[0], fs.mu1, g0.ninv, exp_tab}, g2 = {x[0], x[1], fs.ninv2, exp_tab};
 #pragma unroll
                 for (int i = 0; i < MAXM; ++i) {
                     const double yi = SAMPLES_IN_LDS ? ysl[i * 64] : ys_g[i], xi = x0 + (double)i;
@@ -2895,8 +2952,14 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                         a[i][0] = keep_if(i < m, (fi + yi) * inv_a);
                     else
                         a[i][0] = i < m ? (gauss_resid(ga, xi, yi) - fi) * inv_ha : 0.0;
-                    a[i][1] = keep_if(i < m, (gauss_resid(g1, xi, yi) - fi) * inv_h1);
-                    a[i][2] = keep_if(i < m, (gauss_resid(g2, xi, yi) - fi) * inv_h2);
+                    double j1, j2;
+                    fd_row(fs, xi - x[1], fi + yi, j1, j2);
+                    if (big) {
+                        j1 = (gauss_resid(g1, xi, yi) - fi) * fs.inv_h1;
+                        j2 = (gauss_resid(g2, xi, yi) - fi) * fs.inv_h2;
+                    }
+                    a[i][1] = keep_if(i < m, j1);
+                    a[i][2] = keep_if(i < m, j2);
                     w[i] = keep_if(i < m, fi);
                 }
             }
