@@ -1200,6 +1200,8 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     std::vector<int> cand_item0(plan->cands.size(), 0);
     for (size_t k = 0; k < plan->cands.size(); ++k) {
         auto& v = items[class_of(plan->cands[k].L)];
+        if (by_cand[k].size() > (size_t)0x7fff0000u)   // prime_wave_kernel walks a candidate's items with a 32-bit index + stride
+            return set_error(ctx, MPX_EUNSUPPORTED, "prime-multiF0: %zu frame pairs of one candidate frequency in one call", by_cand[k].size());
         cand_item0[k] = (int)v.size();
         v.insert(v.end(), by_cand[k].begin(), by_cand[k].end());
     }
