@@ -217,3 +217,29 @@ def test_paired_frames_with_a_large_level_difference(eng, drop_db):
             want = o_prime.prime_compute(x, FS, note_names=mode)
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-13 * np.abs(want).max())
         assert np.abs(want).max() > 0
+
+
+@pytest.mark.parametrize("fs,kw", [(8000, dict(num_octave=3)), (16000, dict(num_harmonic=2, num_octave=2)),
+                                   (11025, dict(harmonic_multiples_elim=3, harmonic_elim_runs=3)), (32000, dict(num_octave=1))])
+def test_wave_kernel_classes_at_other_rates_and_parameters(eng, fs, kw):
+    """Round 5: prime_wave_kernel runs every candidate whose chirp-z fits 1024 or 2048 points (a wave per pair of frames, both
+    transforms in registers): short frames at low rates and higher octaves, more elimination rounds, single clips and batches
+    of equal and of ragged lengths -- against the oracle and against each other."""
+    from oracle import prime_multif0 as o_prime
+    rng = np.random.default_rng(fs)
+    n = int(1.3 * fs)
+    t = np.arange(n) / fs
+    xs = []
+    for f0s in ((196.0, 246.94), (261.63, 329.63, 392.0), (146.83,)):
+        x = sum(0.6 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6)) for f0 in f0s for h in (1, 2, 3) if f0 * h < fs / 2)
+        xs.append((0.3 * x + 1e-3 * rng.standard_normal(n)).astype(np.float32))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = [o_prime.prime_compute(x.astype(np.float64), fs, **kw) for x in xs]
+    same = eng.prime_multif0_batch(np.stack(xs), fs, **kw)                     # equal lengths: items from (clip, pair)
+    ragged = eng.prime_multif0_batch([xs[0], xs[1][: n - 777], xs[2]], fs, **kw)   # the general item list
+    for i, x in enumerate(xs):
+        np.testing.assert_allclose(same[i], want[i], rtol=1e-7, atol=1e-6)
+        np.testing.assert_array_equal(same[i], eng.prime_multif0(x, fs, **kw))
+    np.testing.assert_array_equal(ragged[0], same[0])
+    np.testing.assert_array_equal(ragged[2], same[2])
