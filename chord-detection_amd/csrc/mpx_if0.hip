@@ -616,7 +616,7 @@ __device__ __forceinline__ double if0_wave_max(double v) {
 // per lane (two divisions in all instead of two per range) and handed out by v_readlane.  Same operations on the same
 // operands: bit-identical chroma (checked against that kernel on a 600 s stream, 1024 clips and two other parameter sets:
 // scripts/dev/if0_ab.py); 4.75 -> 3.8 ms per 3230 frames, 8.2 -> 6.6 ms per 6144.
-__global__ __launch_bounds__(PER_T) void if0_periodicity_kernel(If0PerArgs a) {
+__global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a) {   // (four workgroups per CU = 128 registers: the gather of the overlapping-window case had taken the kernel to 129 and three -- 2.61 -> 3.05 ms per 600 s; a register cap brings 2.70 back, the gather as a function of its own the same)
     __shared__ double tau_low[32], tau_up[32], smax[32];
     __shared__ double um[128];    // [interval * 64 + harmonic]: range maxima
     __shared__ double wts[128];   // [interval * 64 + harmonic]: m fs / tau_up + epsilon2

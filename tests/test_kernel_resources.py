@@ -67,6 +67,7 @@ OCCUPANCY = {
     "mpx::prime_wave_kernel<2048, 4>": 1,
     "mpx::peakfit_kernel<true>": 2,
     "mpx::pv_enhance_kernel<true, 2>": 3,
+    "mpx::if0_periodicity_kernel": 4,                  # round 5 shipped it at 129 registers = 3 for a while: 17 % slower
 }
 
 
