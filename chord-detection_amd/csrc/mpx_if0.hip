@@ -616,11 +616,31 @@ __device__ __forceinline__ double if0_wave_max(double v) {
 // per lane (two divisions in all instead of two per range) and handed out by v_readlane.  Same operations on the same
 // operands: bit-identical chroma (checked against that kernel on a 600 s stream, 1024 clips and two other parameter sets:
 // scripts/dev/if0_ab.py); 4.75 -> 3.8 ms per 3230 frames, 8.2 -> 6.6 ms per 6144.
+// maxima of a wave's 64 consecutive bins (lane = bin i0 + lane, -inf past nl): the eight 8-bin blocks into e8, the 64-bin block into b64
+__device__ __forceinline__ void if0_block_maxima(double m, int lane, int i0, int nl, double* e8, double* b64) {
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const double o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if ((lane & 7) == 0 && i0 + lane < nl) e8[(i0 + lane) >> 3] = m;
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const double o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if (lane == 0 && i0 + 64 <= nl) b64[i0 >> 6] = m;
+}
+
 __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a) {   // (four workgroups per CU = 128 registers: the gather of the overlapping-window case had taken the kernel to 129 and three -- 2.61 -> 3.05 ms per 600 s; a register cap brings 2.70 back, the gather as a function of its own the same)
     __shared__ double tau_low[32], tau_up[32], smax[32];
     __shared__ double um[128];    // [interval * 64 + harmonic]: range maxima
     __shared__ double wts[128];   // [interval * 64 + harmonic]: m fs / tau_up + epsilon2
-    __shared__ double bmax[256];  // maxima of the 64-bin blocks of ur (n <= 16384)
+    // Range maxima in O(1) loads per range (round 5): e8 = maxima of the 8-bin blocks of the residual, st[k][b] = maximum of the 64-bin
+    // blocks b .. b + 2^k - 1 (a sparse table; st[0] is what bmax was).  A range [lo, hi] is at most 7 + 7 bins, 7 + 7 entries of e8
+    // and two entries of st -- few enough for ONE LANE per range (see lane_range_max).
+    __shared__ double e8[2048];      // n <= 16384
+    __shared__ double st[8][256];
     __shared__ int qbest_sh;
     __shared__ unsigned char dirty[256];   // 64-bin blocks of the residual a cancellation step has changed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -665,86 +685,94 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
             ur[i] = m;
             ud[i] = 0.0;
         }
-        if (i0 + 64 <= nl) {
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_xor(m, off);
-                m = o > m ? o : m;
-            }
-            if (lane == 0) bmax[i0 >> 6] = m;
-        }
+        if0_block_maxima(m, lane, i0, nl, e8, st[0]);
     }
     if (tid < 256) dirty[tid] = 0;
     __syncthreads();
     __threadfence_block();
+    const int nb64 = nl >> 6;   // whole 64-bin blocks (what a range's block part can reach: hi < nl)
+    auto build_levels = [&]() {   // st[k] from st[k - 1]; one barrier per level (eight per voice at most)
+        for (int k = 1; k < 8; ++k) {
+            const int half = 1 << (k - 1);
+            if (tid + 2 * half <= nb64) {
+                const double x = st[k - 1][tid], y = st[k - 1][tid + half];
+                st[k][tid] = y > x ? y : x;
+            }
+            __syncthreads();
+        }
+    };
+    build_levels();
 
-    // periodicity.py:144-163, the range maxima of TWO intervals (a halving step of min_search evaluates the new interval
-    // and the best one so far): one wave per harmonic m and both intervals per pass; the loads -- the ragged ends from ur,
-    // the whole 64-bin blocks from bmax -- are issued unconditionally (clamped positions, -inf by select), the wave maxima
-    // are DPP row steps + v_readlane.  A maximum does not depend on the order: the results are the same bits.
-    auto range_maxima = [&](double tl0, double tl1, double tu0, double tu1) {
-        int plo[2], phi[2];   // pair p = 2 (m - 1) + interval of lane p (and p + 64 when M > 33)
+    // periodicity.py:144-163, the range maxima of TWO intervals (a halving step of min_search evaluates the new interval and the
+    // best one so far): 2 (M - 1) ranges, ONE LANE each (pair p = 2 (m - 1) + interval in lane p of wave 0, and p + 64 when M > 33).
+    // Until round 5 a wave took a range at a time -- 64 lanes on its ragged ends and block maxima, a wave-wide maximum, ten ranges
+    // per wave and step: 17-19 k of a step's 24 k clocks (s_memtime stamps) at four resident workgroups per CU.  A maximum does
+    // not depend on the order it is taken in: the same bits.  (Loads unconditional: clamped positions, -inf by select.)
+    auto lane_range_max = [&](int lo, int hi) -> double {
+        double mm = -INFINITY;
+        const int a8 = (lo + 7) >> 3, z8 = (hi + 1) >> 3;
+        const bool whole8 = z8 > a8;
+        const int le = whole8 ? 8 * a8 : hi + 1, rs = whole8 ? 8 * z8 : hi + 1;   // bins [lo, le) and [rs, hi]
+        // (seven loads at a time: all 21 in flight at once cost the kernel its four workgroups per CU in spills)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            double v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = ur[lo + 7 * g + j < le ? lo + 7 * g + j : 0];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) mm = lo + 7 * g + j < le && v[j] > mm ? v[j] : mm;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            double v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = ur[rs + j <= hi ? rs + j : 0];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) mm = rs + j <= hi && v[j] > mm ? v[j] : mm;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int a64 = (a8 + 7) >> 3, z64 = z8 >> 3;
+        const bool whole64 = whole8 && z64 > a64;
+        const int le8 = whole64 ? 8 * a64 : z8, rs8 = whole64 ? 8 * z64 : z8;     // 8-bin blocks [a8, le8) and [rs8, z8)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            double v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = e8[whole8 && a8 + 7 * g + j < le8 ? a8 + 7 * g + j : 0];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) mm = whole8 && a8 + 7 * g + j < le8 && v[j] > mm ? v[j] : mm;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            double v[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] = e8[whole8 && rs8 + j < z8 ? rs8 + j : 0];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) mm = whole8 && rs8 + j < z8 && v[j] > mm ? v[j] : mm;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const int cnt = whole64 ? z64 - a64 : 1;
+            const int k = 31 - __builtin_clz(cnt);
+            const double v1 = st[k][whole64 ? a64 : 0], v2 = st[k][whole64 ? z64 - (1 << k) : 0];
+            mm = whole64 && v1 > mm ? v1 : mm;
+            mm = whole64 && v2 > mm ? v2 : mm;
+        }
+        return mm;
+    };
+    auto range_maxima = [&](double tl0, double tl1, double tu0, double tu1) {   // wave 0
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            plo[h] = phi[h] = 0;
             if (h == 0 || 2 * (a.M - 1) > 64) {
                 const int pidx = lane + 64 * h, m = 1 + (pidx >> 1);
                 const double tlw = (pidx & 1) ? tl1 : tl0, tuw = (pidx & 1) ? tu1 : tu0;
                 const double tau = 0.5 * (tlw + tuw), deltatau = tuw - tlw;
-                plo[h] = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
+                const int lo = (int)(m * a.K / (tau + 0.5 * deltatau) + 0.5);
                 int hi = (int)(m * a.K / (tau - 0.5 * deltatau) + 0.5);
                 if (hi > n - 1) hi = n - 1;  // numpy slicing clips silently
-                phi[h] = hi;
-            }
-        }
-        for (int m = 1 + wave; m < a.M; m += PER_T / 64) {
-            double mx[2];
-#pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                const int pidx = 2 * (m - 1) + w;   // wave-uniform
-                const int lo = __builtin_amdgcn_readlane(pidx < 64 ? plo[0] : plo[1], pidx & 63);
-                const int hi = __builtin_amdgcn_readlane(pidx < 64 ? phi[0] : phi[1], pidx & 63);
-                // lo and hi are wave-uniform (scalar registers): what a range does not need is skipped by a scalar branch --
-                // from the fifth halving step on the ranges are a few bins wide and one load per range is all there is
-                const int span = hi - lo;
-                const bool wide = span >= 192;
-                const int i0 = lo + lane;
-                double mm;
-                if (!wide) {
-                    // a narrow range is lo + lane + 64 j, j < 3
-                    const bool ok0 = i0 <= hi;
-                    const double v0 = ur[ok0 ? i0 : 0];
-                    mm = ok0 ? v0 : -INFINITY;
-                    if (span >= 64) {
-                        const int i1 = i0 + 64, i2 = i0 + 128;
-                        const bool ok1 = i1 <= hi, ok2 = i2 <= hi;
-                        const double v1 = ur[ok1 ? i1 : 0], v2 = ur[ok2 ? i2 : 0];
-                        mm = ok1 && v1 > mm ? v1 : mm;
-                        mm = ok2 && v2 > mm ? v2 : mm;
-                    }
-                } else {
-                    // a wide one: its two ragged ends from ur, the whole 64-bin blocks [b0, b1) from bmax
-                    const int b0 = (lo + 63) >> 6, b1 = (hi + 1) >> 6;
-                    const int i1 = b1 * 64 + lane;
-                    const bool ok0 = i0 < b0 * 64, ok1 = i1 <= hi;
-                    const double v0 = ur[ok0 ? i0 : 0], v1 = ur[ok1 ? i1 : 0];
-                    mm = ok0 ? v0 : -INFINITY;
-                    mm = ok1 && v1 > mm ? v1 : mm;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {   // n <= 16384: at most 256 blocks
-                        const int b = b0 + lane + 64 * j;
-                        const bool okb = b < b1;
-                        const double vb = bmax[okb ? b : 0];
-                        mm = okb && vb > mm ? vb : mm;
-                    }
-                }
-                mx[w] = mm;
-            }
-            mx[0] = if0_wave_max(mx[0]);
-            mx[1] = if0_wave_max(mx[1]);
-            if (lane == 0) {
-                um[m] = mx[0];
-                um[64 + m] = mx[1];
+                const bool live = pidx < 2 * (a.M - 1);
+                const double mm = lane_range_max(live ? lo : 0, live ? hi : 0);
+                if (live) um[(pidx & 1) * 64 + m] = mm;
             }
         }
     };
@@ -762,6 +790,8 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
             qbest_sh = 0;
         }
         __syncthreads();
+        // wave 0 runs the whole search alone, without a workgroup barrier: it holds every range of a step, and the serial part was its already
+        if (wave == 0) {
         int q = 0;
         for (;;) {
             const int qbest = qbest_sh;
@@ -771,8 +801,8 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
             // the new interval q is the upper half of the best one, which keeps its lower half
             const double tlq = (tlb + tub) * 0.5;
             range_maxima(tlq, tlb, tub, tlq);
-            __syncthreads();   // the maxima are complete, and everybody has read the interval table
-            if (wave == 0) {
+            wave_lds_fence();
+            {
                 if (lane >= 1 && lane < a.M) {
                     wts[lane] = lane * a.fs / tub + a.epsilon2;        // interval q:     tau_up = tub
                     wts[64 + lane] = lane * a.fs / tlq + a.epsilon2;   // interval qbest: tau_up = tlq
@@ -801,8 +831,10 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
                     qbest_sh = whichq;
                 }
             }
-            __syncthreads();
+            wave_lds_fence();
         }
+        }
+        __syncthreads();
         const int qbest = qbest_sh;
         const double tau = (tau_low[qbest] + tau_up[qbest]) * 0.5;
         const double best = smax[qbest];
@@ -894,25 +926,20 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
                 for (int j = lowk; j <= highk && j < n; ++j) {
                     const double d = uk[j] - 1.0 * ud[j];  // cancellation_weight = 1.0
                     ur[j] = d > 0.0 ? d : 0.0;
-                    dirty[j >> 6] = 1;   // (bins past the last whole block: no block maximum to refresh; index <= 255 for n <= 16384)
+                    dirty[j >> 6] = 1;   // (index <= 255 for n <= 16384)
                 }
             }
         }
         __syncthreads();
         __threadfence_block();
-        for (int b = wave; b < (nl >> 6); b += PER_T / 64) {
+        for (int b = wave; b < ((nl + 63) >> 6); b += PER_T / 64) {
             if (!dirty[b]) continue;   // uniform over the wave
-            double m = ur[b * 64 + lane];
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double o = __shfl_xor(m, off);
-                m = o > m ? o : m;
-            }
-            if (lane == 0) {
-                bmax[b] = m;
-                dirty[b] = 0;
-            }
+            const int i = b * 64 + lane;
+            if0_block_maxima(i < nl ? ur[i] : -INFINITY, lane, b * 64, nl, e8, st[0]);
+            if (lane == 0) dirty[b] = 0;
         }
+        __syncthreads();
+        build_levels();
         __syncthreads();
     }
     if (tid == 0) {
