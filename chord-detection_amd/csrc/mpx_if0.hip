@@ -677,15 +677,26 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
     const double* __restrict__ uk = a.ut + f * (long long)n;
     // residual = spectrum, detected = 0, and the block maxima of the residual in the same pass (a wave copies whole 64-bin
     // blocks, so it holds each block's maximum: until round 4 build_bmax read the row back) -- for the bins below nl only
-    for (int i0 = wave * 64; i0 < nl; i0 += PER_T) {
-        const int i = i0 + lane;
-        const bool ok = i < nl;
-        double m = ok ? uk[i] : -INFINITY;
-        if (ok) {
-            ur[i] = m;
-            ud[i] = 0.0;
+    // (four blocks per pass: the stamps had this loop at 80 k clocks per frame -- thirty rounds of one load and its six dependent
+    //  exchange steps per wave)
+    for (int i0 = wave * 64; i0 < nl; i0 += 4 * PER_T) {
+        double m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PER_T + lane;
+            m[u] = i < nl ? uk[i] : -INFINITY;
         }
-        if0_block_maxima(m, lane, i0, nl, e8, st[0]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PER_T + lane;
+            if (i < nl) {
+                ur[i] = m[u];
+                ud[i] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * PER_T < nl) if0_block_maxima(m[u], lane, i0 + u * PER_T, nl, e8, st[0]);   // (uniform)
     }
     if (tid < 256) dirty[tid] = 0;
     __syncthreads();
@@ -810,7 +821,8 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
                 wave_lds_fence();
                 if (lane == 0) {
                     double s0 = 0.0, s1 = 0.0;
-                    for (int m = 1; m < a.M; ++m) {
+#pragma unroll 4
+                    for (int m = 1; m < a.M; ++m) {   // (unrolled: the LDS reads of four harmonics in flight, the sums in order)
                         s0 = __builtin_fma(wts[m], um[m], s0);
                         s1 = __builtin_fma(wts[64 + m], um[64 + m], s1);
                     }
@@ -821,6 +833,7 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
                     smax[qbest] = s1 * (a.fs / tlb + a.epsilon1);
                     int whichq = 0;
                     double maxval = smax[0];
+#pragma unroll 4
                     for (int j = 1; j <= q; ++j) {
                         const double valnow = smax[j];
                         if (valnow > maxval) {
