@@ -723,43 +723,40 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
         double mm = -INFINITY;
         const int a8 = (lo + 7) >> 3, z8 = (hi + 1) >> 3;
         const bool whole8 = z8 > a8;
-        const int le = whole8 ? 8 * a8 : hi + 1, rs = whole8 ? 8 * z8 : hi + 1;   // bins [lo, le) and [rs, hi]
-        // (seven loads at a time: all 21 in flight at once cost the kernel its four workgroups per CU in spills)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            double v[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) v[j] = ur[lo + 7 * g + j < le ? lo + 7 * g + j : 0];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) mm = lo + 7 * g + j < le && v[j] > mm ? v[j] : mm;
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // bins [lo, le) and [rs, hi]: the ragged ends of the whole 8-bin blocks [a8, z8) -- or, without a whole block, the range
+        // itself (at most 14 bins) in two sevens.  Fourteen loads in flight, one wait.
+        const int le = whole8 ? 8 * a8 : hi + 1, rs = whole8 ? 8 * z8 : lo + 7;
         {
-            double v[7];
+            double v[14];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) v[j] = ur[rs + j <= hi ? rs + j : 0];
+            for (int j = 0; j < 7; ++j) {
+                // (32-bit byte offsets from the row's uniform base: one address register per load)
+                v[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ur) + (unsigned)((lo + j < le ? lo + j : 0) << 3));
+                v[7 + j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ur) + (unsigned)((rs + j <= hi ? rs + j : 0) << 3));
+            }
 #pragma unroll
-            for (int j = 0; j < 7; ++j) mm = rs + j <= hi && v[j] > mm ? v[j] : mm;
+            for (int j = 0; j < 7; ++j) {
+                mm = lo + j < le && v[j] > mm ? v[j] : mm;
+                mm = rs + j <= hi && v[7 + j] > mm ? v[7 + j] : mm;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         const int a64 = (a8 + 7) >> 3, z64 = z8 >> 3;
         const bool whole64 = whole8 && z64 > a64;
-        const int le8 = whole64 ? 8 * a64 : z8, rs8 = whole64 ? 8 * z64 : z8;     // 8-bin blocks [a8, le8) and [rs8, z8)
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            double v[7];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) v[j] = e8[whole8 && a8 + 7 * g + j < le8 ? a8 + 7 * g + j : 0];
-#pragma unroll
-            for (int j = 0; j < 7; ++j) mm = whole8 && a8 + 7 * g + j < le8 && v[j] > mm ? v[j] : mm;
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        // 8-bin blocks [a8, le8) and [rs8, z8), likewise
+        const int le8 = whole64 ? 8 * a64 : z8, rs8 = whole64 ? 8 * z64 : a8 + 7;
         {
-            double v[7];
+            double v[14];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) v[j] = e8[whole8 && rs8 + j < z8 ? rs8 + j : 0];
+            for (int j = 0; j < 7; ++j) {
+                v[j] = e8[whole8 && a8 + j < le8 ? a8 + j : 0];
+                v[7 + j] = e8[whole8 && rs8 + j < z8 ? rs8 + j : 0];
+            }
 #pragma unroll
-            for (int j = 0; j < 7; ++j) mm = whole8 && rs8 + j < z8 && v[j] > mm ? v[j] : mm;
+            for (int j = 0; j < 7; ++j) {
+                mm = whole8 && a8 + j < le8 && v[j] > mm ? v[j] : mm;
+                mm = whole8 && rs8 + j < z8 && v[7 + j] > mm ? v[7 + j] : mm;
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         {
@@ -788,9 +785,8 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
         }
     };
 
-    double voice_sal[8], voice_per[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) voice_sal[i] = voice_per[i] = 0.0;
+    __shared__ double voice_sal[8], voice_per[8];   // (LDS: in every thread's registers they cost the search its loads in flight)
+    if (tid < 8) voice_sal[tid] = voice_per[tid] = 0.0;
     int voices = 0;
     double prevmix = 0.0, mix = 0.0;
     for (;;) {
@@ -852,14 +848,9 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
         const double tau = (tau_low[qbest] + tau_up[qbest]) * 0.5;
         const double best = smax[qbest];
         __syncthreads();
-        if (voices < 8) {
-            // static indexing of the per-voice registers
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (i == voices) {
-                    voice_sal[i] = best;
-                    voice_per[i] = tau;
-                }
+        if (voices < 8 && tid == 0) {
+            voice_sal[voices] = best;
+            voice_per[voices] = tau;
         }
         ++voices;
         mix += best;

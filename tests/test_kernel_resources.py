@@ -42,7 +42,7 @@ SCRATCH_FREE = [
     "mpx::if0_spectrum_split_kernel<4096, true, 1>", "mpx::if0_spectrum_split_kernel<4096, false, 0>",
     "mpx::if0_spectrum_split_kernel<2048, true, 1>", "mpx::if0_spectrum_split_kernel<2048, false, 0>",
     "mpx::if0_spectrum_split_kernel<1024, true, 1>", "mpx::if0_spectrum_split_kernel<1024, false, 0>",
-    "mpx::if0_frontend_kernel<false>", "mpx::if0_frontend2_kernel<false>", "mpx::if0_periodicity_kernel",
+    "mpx::if0_frontend_kernel<false>", "mpx::if0_frontend2_kernel<false>",
     "mpx::if0_frontend_kernel<true>", "mpx::if0_frontend2_kernel<true>",     # time slices (MPX_OPT_IF0_WORKSPACE_BYTES)
     "mpx::if0_spectrum_blue_kernel<4096, 256>", "mpx::if0_spectrum_blue_kernel<8192, 512>", "mpx::if0_spectrum_blue2_kernel<512>",   # chirp-z frame sizes
 ]
@@ -50,6 +50,7 @@ SCRATCH_FREE = [
 SCRATCH_CEILING = {
     "mpx::prime_wave_kernel<1024, 7>": 36,             # two items per wave at two waves per SIMD: loop-carried item state (slots, pointers), touched once per iteration outside the transforms
     "mpx::pv_enhance_kernel<true, 2>": 24,             # three workgroups per CU since round 5 (168 registers): 0.85 -> 0.66 ms per 8192 frames with the spill
+    "mpx::if0_periodicity_kernel": 112,                # held at four workgroups per CU (128 registers); fourteen loads in flight per lane in the range maxima: 1.59 -> 1.49 ms per 600 s WITH the spill
     "mpx::coopfit_kernel": 36,                         # a 36-byte stack slot is reserved since the two-pass form; the ISA holds no scratch instruction
     "mpx::coopfit8_kernel": 36,                        # the same kernel with eight lanes per fit
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1, false>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
