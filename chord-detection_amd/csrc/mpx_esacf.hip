@@ -2205,8 +2205,19 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
         D2 f = resid(x);
         int trips = 0;
         bool again = false;
+        // A trip = at most one OUTER step (jacobian, QR: only the fits whose last trial was accepted) and ONE trial (round 5).
+        // Until then a trip ran the trial loop to acceptance for every fit of the wave: one fit's rejected trial (21 % of the
+        // trials) made the other fits wait for a second `lmpar` -- 9 k of a trip's 26 k clocks on 85 % of the trips at eight fits
+        // to a wave.  The same operations per fit in the same order: the same bits.  What a trial needs of the OUTER step (R, Q^T f,
+        // the pivots, gnorm) stays in registers across trips.
+        bool need_outer = true;
+        int ipvt[NP] = {0, 1, 2};
+        double qtf[NP] = {0.0, 0.0, 0.0}, r[NP * NP], gnorm = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP * NP; ++i) r[i] = 0.0;
         for (;;) {
-            if (repark != nullptr && trips >= max_trips) {   // (uniform in the row)
+            if (need_outer) {
+            if (repark != nullptr && trips >= max_trips) {   // (uniform in the row; a fit is parked again at the top of lmdif's outer loop only)
                 again = true;
                 break;
             }
@@ -2242,14 +2253,15 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                 }
             }
             nfev += NP;
-            int ipvt[NP] = {0, 1, 2};
+            ipvt[0] = 0;
+            ipvt[1] = 1;
+            ipvt[2] = 2;
             double acnorm[NP], rdiag[NP], wa[NP];
             acnorm[0] = sqrt(row_sum(coop_leaf(l, 0, J0, J0)));
             acnorm[1] = sqrt(row_sum(coop_leaf(l, 0, J1, J1)));
             acnorm[2] = sqrt(row_sum(coop_leaf(l, 0, J2, J2)));
 #pragma unroll
             for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
-            double qtf[NP];
             D2 w4 = f;  // becomes Q^T fvec
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -2319,14 +2331,13 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                 if (delta == 0.0) delta = factor;
             }
             // replicate the 3x3 upper triangle R (row i lives in lane i, first slot; its diagonal is rdiag)
-            double r[NP * NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 r[i * NP + 0] = i == 0 ? rdiag[0] : row_bcast(J0.a, i);
                 r[i * NP + 1] = i == 1 ? rdiag[1] : row_bcast(J1.a, i);
                 r[i * NP + 2] = i == 2 ? rdiag[2] : row_bcast(J2.a, i);
             }
-            double gnorm = 0.0;
+            gnorm = 0.0;
             if (fnorm != 0.0) {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
@@ -2346,7 +2357,8 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
             }
 #pragma unroll
             for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
-            for (;;) {
+            }
+            {
                 double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
 #pragma unroll
                 for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
@@ -2411,9 +2423,8 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                 if (delta <= EPSMCH * xnorm) info = 7;
                 if (gnorm <= EPSMCH) info = 8;
                 if (info != 0) break;
-                if (ratio >= 1e-4) break;
+                need_outer = ratio >= 1e-4;   // accepted: a new jacobian next trip; rejected: the next trial with the same R
             }
-            if (info != 0) break;
         }
         if (l == 0) {
             if (again) {
@@ -2523,8 +2534,19 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
         D3 f = resid(x);
         int trips = 0;
         bool again = false;
+        // A trip = at most one OUTER step (jacobian, QR: only the fits whose last trial was accepted) and ONE trial (round 5).
+        // Until then a trip ran the trial loop to acceptance for every fit of the wave: one fit's rejected trial (21 % of the
+        // trials) made the other fits wait for a second `lmpar` -- 9 k of a trip's 26 k clocks on 85 % of the trips at eight fits
+        // to a wave.  The same operations per fit in the same order: the same bits.  What a trial needs of the OUTER step (R, Q^T f,
+        // the pivots, gnorm) stays in registers across trips.
+        bool need_outer = true;
+        int ipvt[NP] = {0, 1, 2};
+        double qtf[NP] = {0.0, 0.0, 0.0}, r[NP * NP], gnorm = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP * NP; ++i) r[i] = 0.0;
         for (;;) {
-            if (repark != nullptr && trips >= max_trips) {   // (uniform in the row)
+            if (need_outer) {
+            if (repark != nullptr && trips >= max_trips) {   // (uniform in the row; a fit is parked again at the top of lmdif's outer loop only)
                 again = true;
                 break;
             }
@@ -2561,14 +2583,15 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                 }
             }
             nfev += NP;
-            int ipvt[NP] = {0, 1, 2};
+            ipvt[0] = 0;
+            ipvt[1] = 1;
+            ipvt[2] = 2;
             double acnorm[NP], rdiag[NP], wa[NP];
             acnorm[0] = sqrt(coop8_sum(l, 0, J0, J0));
             acnorm[1] = sqrt(coop8_sum(l, 0, J1, J1));
             acnorm[2] = sqrt(coop8_sum(l, 0, J2, J2));
 #pragma unroll
             for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
-            double qtf[NP];
             D3 w4 = f;  // becomes Q^T fvec
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -2641,14 +2664,13 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                 if (delta == 0.0) delta = factor;
             }
             // replicate the 3x3 upper triangle R (row i lives in lane i of the fit's eight, first slot; its diagonal is rdiag)
-            double r[NP * NP];
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 r[i * NP + 0] = i == 0 ? rdiag[0] : half_bcast(J0.a, i);
                 r[i * NP + 1] = i == 1 ? rdiag[1] : half_bcast(J1.a, i);
                 r[i * NP + 2] = i == 2 ? rdiag[2] : half_bcast(J2.a, i);
             }
-            double gnorm = 0.0;
+            gnorm = 0.0;
             if (fnorm != 0.0) {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) {
@@ -2668,7 +2690,8 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
             }
 #pragma unroll
             for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
-            for (;;) {
+            }
+            {
                 double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
 #pragma unroll
                 for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
@@ -2753,9 +2776,8 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                 if (delta <= EPSMCH * xnorm) info = 7;
                 if (gnorm <= EPSMCH) info = 8;
                 if (info != 0) break;
-                if (ratio >= 1e-4) break;
+                need_outer = ratio >= 1e-4;   // accepted: a new jacobian next trip; rejected: the next trial with the same R
             }
-            if (info != 0) break;
         }
         if (l == 0) {
             if (again) {
