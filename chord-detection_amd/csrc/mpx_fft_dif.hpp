@@ -210,6 +210,30 @@ __device__ __forceinline__ void dif_fft_keep_last(cx<Real>* buf, const DifTwiddl
         dif_butterfly<M, PL::n - 1, true, false, Real>(buf, twd, regs + h * RL, dif_bid<M, PL::n - 1>(tid, h));
 }
 
+// The same transform with the caller's barrier moved INSIDE: the first pass's butterflies are computed in registers, then the
+// workgroup barrier that protects `buf` from this transform's first stores (everybody has finished reading the previous
+// contents), then the stores.  What a caller would otherwise wait for in front of the transform overlaps the butterfly arithmetic.
+template <int M, typename Real>
+__device__ __forceinline__ void dif_fft_keep_last_barrier_before_stores(cx<Real>* buf, const DifTwiddles<M, Real>& twd, cx<Real>* regs,
+                                                                        int tid) {
+    using PL = DifPlan<M>;
+    static_assert(PL::n >= 2 && PL::radix(0) == 8, "plan");
+    const int base = dif_butterfly<M, 0, false, false, Real>(buf, twd, regs, tid);
+    __syncthreads();
+    {
+        constexpr int S = PL::stride(0);
+        const int sb = sigma<M>(base);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) buf[dif_addr<M, S>(sb, q)] = regs[q];
+    }
+    __syncthreads();
+    dif_middle<M, 1, Real>(buf, twd, regs, tid);
+    constexpr int RL = PL::radix(PL::n - 1);
+#pragma unroll
+    for (int h = 0; h < 8 / RL; ++h)
+        dif_butterfly<M, PL::n - 1, true, false, Real>(buf, twd, regs + h * RL, dif_bid<M, PL::n - 1>(tid, h));
+}
+
 template <int M>
 __host__ __device__ __forceinline__ int dif_last_pos(int tid, int h, int q) {
     using PL = DifPlan<M>;

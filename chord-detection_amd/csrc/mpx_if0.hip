@@ -1382,7 +1382,8 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
         if (IF0_PF == 2)
         // the next channel's samples travel under this channel's transform (the last channel re-reads itself)
         fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
-        dif_fft_keep_last<H, double>(buf, twd, regs, tid);
+        // (the barrier behind the previous channel's mirror reads sits inside, between the first pass's arithmetic and its stores)
+        dif_fft_keep_last_barrier_before_stores<H, double>(buf, twd, regs, tid);
 #pragma unroll
         for (int e = PAIR ? 4 : 0; e < 8; ++e) buf[sigma<H>(dif_last_pos<H>(tid, e / RL, e % RL))] = regs[e];
         if (IF0_PF == 1)
@@ -1443,7 +1444,6 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
         }
         if (IF0_PF == 0)
         fetch(src + (size_t)(ch + 1 < channels ? ch + 1 : ch) * fr.ch_stride, tid);
-        __syncthreads();  // the mirror reads are done before the next transform writes buf
     }
     if constexpr (PAIR) {
         const int j0 = dif_freq<H>(dif_last_pos<H>(tid0, 0, 0));
