@@ -761,7 +761,8 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
         }
         {
             const int cnt = whole64 ? z64 - a64 : 1;
-            const int k = 31 - __builtin_clz(cnt);
+            const int kk = 31 - __builtin_clz(cnt);
+            const int k = kk < 7 ? kk : 7;   // (256 blocks -- n = 16384, a range over all of them -- are two windows of 128)
             const double v1 = st[k][whole64 ? a64 : 0], v2 = st[k][whole64 ? z64 - (1 << k) : 0];
             mm = whole64 && v1 > mm ? v1 : mm;
             mm = whole64 && v2 > mm ? v2 : mm;
