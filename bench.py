@@ -185,8 +185,12 @@ def main():
             dist.all_gather(gathered, d_sums)          # one RCCL gather of the 12-vectors, at the end
         else:
             sync_engines()
-        barrier()
+        # the clock stops when THIS rank's K steps (and its part of the gather) are done; the closing barrier + synchronize
+        # follow, and the maximum over the ranks is when the job was done -- the barrier's own latency (tens of microseconds
+        # of a 0.8 ms region at the driver's K = 20) is not part of the steps
+        dev_sync()
         el = time.perf_counter() - t0
+        barrier()
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -202,8 +206,9 @@ def main():
         for i in range(steps):
             step(i, eng)
         eng.synchronize()
+        el1 = time.perf_counter() - t1
         barrier()
-        one = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        one = torch.tensor([el1], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(one, op=dist.ReduceOp.MAX)
         one_s.append(float(one.item()))

@@ -6,6 +6,7 @@ unless the caller asks for it (`--force-collective`, or a launch through `torch.
 which case the communicator is created and the collective runs over the one rank: the same RCCL code path a multi-GPU
 launch takes, exercised on a one-GPU box."""
 import os
+import sys
 import socket
 
 
@@ -41,8 +42,27 @@ def init_group(backend, device=None):
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("LOCAL_RANK", "0")
-    if device is not None and device.type == "cuda":
-        dist.init_process_group(backend, device_id=device)
-    else:
-        dist.init_process_group(backend)
+    # RCCL prints its version banner (library path, HIP / ROCm versions, host name) to STDOUT when the communicator is
+    # created; the drivers' contract is ONE JSON line there.  File descriptor 1 points at stderr while the group comes up.
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        if device is not None and device.type == "cuda":
+            dist.init_process_group(backend, device_id=device)
+            import torch
+            t = torch.zeros(1, device=device)
+            dist.all_reduce(t)          # (the first collective: whatever the library still has to say)
+            torch.cuda.synchronize(device)
+        else:
+            dist.init_process_group(backend)
+    finally:
+        sys.stdout.flush()
+        try:   # the banner sits in the C library's buffer when stdout is a pipe: out with it while descriptor 1 is still stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
     return dist
