@@ -172,6 +172,7 @@ def main():
     # each repeat, and the median of the repeats is what `value` is computed from (every repeat is listed in the output).
     repeats = args.repeats if args.repeats > 0 else (25 if steps < 200 else 5)
     rep_s, host_enqueue_ms, gathered = [], 0.0, None
+    gather_out = torch.empty((world,) + tuple(d_sums.shape), dtype=d_sums.dtype, device=dev) if use_dist and backend == "nccl" else None
     for rep in range(repeats):
         barrier()
         t0 = time.perf_counter()
@@ -181,8 +182,12 @@ def main():
         host_enqueue_ms = 1e3 * (time.perf_counter() - th0) / max(steps, 1)
         if use_dist:
             sync_engines()
-            gathered = [torch.empty_like(d_sums) for _ in range(world)]
-            dist.all_gather(gathered, d_sums)          # one RCCL gather of the 12-vectors, at the end
+            if gather_out is not None:                 # RCCL: into one preallocated tensor (no list of outputs to build per repeat)
+                dist.all_gather_into_tensor(gather_out, d_sums)
+                gathered = gather_out
+            else:
+                gathered = [torch.empty_like(d_sums) for _ in range(world)]
+                dist.all_gather(gathered, d_sums)      # one gather of the 12-vectors, at the end
         else:
             sync_engines()
         # the clock stops when THIS rank's K steps (and its part of the gather) are done; the closing barrier + synchronize
