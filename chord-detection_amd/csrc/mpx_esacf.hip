@@ -301,16 +301,43 @@ __device__ __forceinline__ void dft_regs(cx<double>* buf, const DifTwiddles<L, d
     }
 }
 
-// workgroup max and min of one double per thread; result in every thread
+// a lane's view of another lane's double through DPP (register to register, ~8 cycles; a shuffle is two ds_bpermute
+// round trips through the LDS crossbar with a wait)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// workgroup max and min of one double per thread; result in every thread.  Within a wave: four DPP steps make the 16
+// lanes of a row agree, four v_readlane join the rows (until round 5: twelve shuffles of two ds_bpermute each)
 template <int T>
 __device__ __forceinline__ void block_minmax(double* sh, double& mx, double& mn) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#define MPX_MINMAX_STEP(CTRL)                                        \
+    {                                                                \
+        const double a_ = dpp_f64<CTRL>(mx), b_ = dpp_f64<CTRL>(mn); \
+        mx = a_ > mx ? a_ : mx;                                      \
+        mn = b_ < mn ? b_ : mn;                                      \
+    }
+    MPX_MINMAX_STEP(0xB1)   // quad_perm [1,0,3,2]
+    MPX_MINMAX_STEP(0x4E)   // quad_perm [2,3,0,1]
+    MPX_MINMAX_STEP(0x141)  // row_half_mirror
+    MPX_MINMAX_STEP(0x140)  // row_mirror
+#undef MPX_MINMAX_STEP
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const double a = __shfl_xor(mx, off), b = __shfl_xor(mn, off);
+    for (int r = 16; r < 64; r += 16) {
+        const double a = readlane_f64(mx, r), b = readlane_f64(mn, r);
         mx = a > mx ? a : mx;
         mn = b < mn ? b : mn;
     }
+    mx = readlane_f64(mx, 0);  // lanes of the rows 1..3 have not seen row 0's values the way lane 0 has
+    mn = readlane_f64(mn, 0);
     if (lane == 0) {
         sh[wave] = mx;
         sh[T / 64 + wave] = mn;
@@ -345,32 +372,89 @@ __host__ __device__ inline size_t peak_scratch_bytes(int Mh) {
 
 // exclusive prefix sums over up to 64 (WIDE: 128) per-word counts held as c0 = count(word lane), c1 = count(word lane + 64);
 // word_base() reads the sum in front of word w (wave-uniform w)
+// (inclusive sums by DPP: row_shr 1, 2, 4, 8 inside the rows of 16 lanes, row_bcast:15 / row_bcast:31 across them -- six
+// register-to-register steps; until round 5 six __shfl_up, a ds_bpermute round trip each)
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1 (lanes without a source add 0)
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+    return v;
+}
 template <bool WIDE>
 struct WordScan {
     int e0, e1, total;
     __device__ __forceinline__ WordScan(int c0, int c1, int lane) {
-        int incl = c0;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(incl, off);
-            if (lane >= off) incl += o;
-        }
+        const int incl = wave_inclusive_sum(c0);
         e0 = incl - c0;
-        total = __shfl(incl, 63);
+        total = __builtin_amdgcn_readlane(incl, 63);
         e1 = 0;
         if (WIDE) {
-            int incl1 = c1;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl1, off);
-                if (lane >= off) incl1 += o;
-            }
+            const int incl1 = wave_inclusive_sum(c1);
             e1 = total + incl1 - c1;
-            total += __shfl(incl1, 63);
+            total += __builtin_amdgcn_readlane(incl1, 63);
         }
     }
-    __device__ __forceinline__ int word_base(int w) const { return (WIDE && w >= 64) ? __shfl(e1, w - 64) : __shfl(e0, w); }
+    // w is the same in every lane of the wave: a v_readlane
+    __device__ __forceinline__ int word_base(int w) const {
+        w = __builtin_amdgcn_readfirstlane(w);
+        return (WIDE && w >= 64) ? __builtin_amdgcn_readlane(e1, w - 64) : __builtin_amdgcn_readlane(e0, w);
+    }
 };
+
+// The minimum-distance rounds of peak_pick for a frame of at most 64 candidates (the usual frame has a few dozen), one
+// candidate per lane of wave 0 and no LDS inside the rounds.  Candidates are in ascending position, so the ones within
+// min_dist of lane c are lanes c - 1, c - 2, ... and c + 1, c + 2, ... up to the first one too far away: d wave shifts
+// (DPP wave_shr:1 / wave_shl:1) bring the d-th neighbour's position and height, once, for the masks "left neighbour d
+// is higher" / "right neighbour d is higher or equal" (ties go to the larger index); a round then shifts the states
+// along and applies the rule of the LDS version below -- removed if a higher neighbour is kept, kept if none is
+// undecided -- whose fixed point does not depend on the order of the updates.  Returns false (nothing written) when a
+// candidate has more than 31 neighbours on a side in range: the LDS version takes the frame.
+__device__ __forceinline__ bool peak_rounds_in_lanes(const int* cand, const double* yv, volatile int* state, int ncand, int md, int lane) {
+    const bool on = lane < ncand;
+    const int pos = on ? cand[lane] : 0x3fffffff;
+    const double v = on ? yv[pos] : 0.0;
+    int pl = pos, pr = pos, vl_lo = __double2loint(v), vl_hi = __double2hiint(v), vr_lo = vl_lo, vr_hi = vl_hi;
+    unsigned hl = 0, hr = 0;
+    int dmax = 0;
+    for (int d = 1;; ++d) {
+        pl = __builtin_amdgcn_update_dpp(-0x3fffffff, pl, 0x138, 0xf, 0xf, false);  // wave_shr:1: lane c sees lane c - d
+        vl_lo = __builtin_amdgcn_update_dpp(0, vl_lo, 0x138, 0xf, 0xf, false);
+        vl_hi = __builtin_amdgcn_update_dpp(0, vl_hi, 0x138, 0xf, 0xf, false);
+        pr = __builtin_amdgcn_update_dpp(0x7fffffff, pr, 0x130, 0xf, 0xf, false);   // wave_shl:1: lane c sees lane c + d
+        vr_lo = __builtin_amdgcn_update_dpp(0, vr_lo, 0x130, 0xf, 0xf, false);
+        vr_hi = __builtin_amdgcn_update_dpp(0, vr_hi, 0x130, 0xf, 0xf, false);
+        const bool in_l = on && pos - pl <= md, in_r = on && pr - pos <= md;
+        if (!__any(in_l || in_r)) break;
+        if (d > 31) return false;
+        if (in_l && __hiloint2double(vl_hi, vl_lo) > v) hl |= 1u << d;
+        if (in_r && __hiloint2double(vr_hi, vr_lo) >= v) hr |= 1u << d;
+        dmax = d;
+    }
+    int st = on ? 0 : 2;
+    for (;;) {
+        int sl = st, sr = st;
+        bool any_kept = false, any_open = false;
+        for (int d = 1; d <= dmax; ++d) {
+            sl = __builtin_amdgcn_update_dpp(2, sl, 0x138, 0xf, 0xf, false);
+            sr = __builtin_amdgcn_update_dpp(2, sr, 0x130, 0xf, 0xf, false);
+            if ((hl >> d) & 1u) {
+                any_kept |= sl == 1;
+                any_open |= sl == 0;
+            }
+            if ((hr >> d) & 1u) {
+                any_kept |= sr == 1;
+                any_open |= sr == 0;
+            }
+        }
+        if (st == 0) st = any_kept ? 2 : (any_open ? 0 : 1);
+        if (!__any(st == 0)) break;
+    }
+    if (on) state[lane] = st;
+    return true;
+}
 
 template <int T, bool WIDE = false>
 __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double* yv, char* scratch, int tid) {
@@ -460,7 +544,9 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     if (ncand > 1 && md > 1) {
         // a frame has a few dozen candidates: wave 0 runs the rounds alone, ordered by its own in-order LDS queue
         // instead of a workgroup barrier per round
-        if (wave == 0) {
+        if (wave == 0 && ncand <= 64 && peak_rounds_in_lanes(cand, yv, state, ncand, md, lane)) {
+            // (decided in registers: see peak_rounds_in_lanes)
+        } else if (wave == 0) {
             const int Q0 = (ncand + 63) / 64;
             for (;;) {
                 bool undecided = false;
@@ -2103,13 +2189,7 @@ constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked
 // (~100 cycles through the LDS crossbar): a fit owns one 16-lane DPP row, so its all-reduce is four mirror /
 // quad-permute steps.  Every step pairs lanes symmetrically (i <-> partner(i)), so both partners add the same
 // two numbers and all 16 lanes end with identical bits.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
+// (dpp_f64: above block_minmax)
 __device__ __forceinline__ double row_sum(double v) {
     v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
     v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
