@@ -285,6 +285,53 @@ def test_note_names_ascii_keeps_the_sharps(eng, clips, golden_dir):
         eng.esacf(x, FS, 1023, note_names="latin1")
 
 
+def test_minimum_distance_rounds_in_lanes_and_in_lds(eng):
+    """peak_pick's minimum-distance rounds run in the lanes of one wave when a frame has at most 64 candidates with at
+    most 31 of them within min_dist on a side, in LDS otherwise (csrc/mpx_esacf.hip: peak_rounds_in_lanes): parameter
+    sets on both sides of both limits, each frame against the oracle's peak picking + fits ON THE GPU'S OWN ESACF ROW
+    (identical input: what is compared is the set of kept peaks and their fits)."""
+    from oracle import esacf as o_esacf
+
+    def signal(n, noise):
+        rng = np.random.default_rng(77)
+        t = np.arange(n) / 44100.0
+        x = np.zeros(n)
+        for f0 in (110.0, 196.0, 261.63, 329.63):
+            for h in range(1, 8):
+                x += 0.7 ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6))
+        return (0.2 * x + noise * rng.standard_normal(n)).astype(np.float32)
+
+    # candidates per frame (oracle, min_dist 1): 4096 / 0.05 -> 36..56, 4096 / 0.5 -> 86..189, 2046 / 1.0 -> 45..120 (on both
+    # sides of 64); min_dist 1000 puts every candidate in range of every other (more than 31 on a side from 33 candidates up)
+    cases = (dict(enhance_mode="noop", peak_thresh=0.0, peak_min_dist=2),
+             dict(enhance_mode="librosa010", peak_thresh=0.02, peak_min_dist=1000),
+             dict(enhance_mode="librosa010", peak_thresh=0.02, peak_min_dist=300),
+             dict(enhance_mode="librosa010", peak_thresh=0.1, peak_min_dist=3))
+    seen = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for frame, noise in ((4096, 0.05), (4096, 0.5), (2046, 1.0)):
+            x = signal(6 * frame, noise)
+            for kw in cases:
+                _, per = eng.esacf(x, 44100, frame, return_frames=True, note_names="ascii", **kw)
+                rows = eng.esacf_stage("esacf", x, 44100, frame, **kw)
+                okw = dict(peak_thresh=kw["peak_thresh"], peak_min_dist=kw["peak_min_dist"])
+                exact = 0
+                for f in range(per.shape[0]):
+                    want = o_esacf.frame_chroma(rows[f], 44100, note_names="ascii", **okw)
+                    if np.allclose(per[f], want, rtol=RTOL_CHROMA, atol=1e-12):
+                        exact += 1
+                        continue
+                    # a fit that ran away (the reference is ill-conditioned there) may move ONE peak height between bins or
+                    # drop it; a different set of kept peaks is not that
+                    assert o_esacf.frame_fragility(rows[f], 44100, **okw), (frame, noise, kw, f, per[f], want)
+                    cap = float(np.max(rows[f])) * (1.0 + 1e-9) + 1e-12
+                    assert abs(float(per[f].sum()) - float(want.sum())) <= cap, (frame, noise, kw, f, per[f], want)
+                seen.append((frame, noise, kw["peak_min_dist"], exact, per.shape[0]))
+    warnings.warn("peak rounds: (frame, noise, min_dist, frames equal to the oracle on the same row, frames) %s" % (seen,))
+    assert sum(e for *_, e, _n in seen) * 2 >= sum(n for *_, n in seen), seen
+
+
 def test_parameters_and_44100_default_frame(eng):
     rng = np.random.default_rng(9)
     n = 6 * 2046 + 100
