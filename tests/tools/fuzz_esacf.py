@@ -12,6 +12,9 @@ if os.environ.get("FUZZ_DEFAULT_MODE") != "1":   # FUZZ_DEFAULT_MODE=1: the libr
 import chord_detection_amd as cd
 from oracle import esacf as o_esacf
 
+# FUZZ_WIDE=1: loud noise (more than 64 peak candidates per frame) and minimum distances up to 1000 lags (more than 31 candidates
+# in range of one another): both sides of the limits of peak_pick's in-lane rounds
+WIDE = os.environ.get("FUZZ_WIDE") == "1"
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 eng = cd.get_engine(0)
@@ -32,7 +35,7 @@ with warnings.catch_warnings():
             for h in range(1, int(rng.integers(2, 9))):
                 if f0 * h < fs / 2:
                     x += rng.uniform(0.3, 1.0) ** h * np.sin(2 * np.pi * f0 * h * t + rng.uniform(0, 6.28))
-        x += rng.choice([0.0, 1e-3, 0.05]) * rng.standard_normal(n)
+        x += rng.choice([0.0, 1e-3, 0.05, 0.5, 2.0] if WIDE else [0.0, 1e-3, 0.05]) * rng.standard_normal(n)
         x *= rng.uniform(0.05, 1.0) / max(np.abs(x).max(), 1e-9)
         if rng.random() < 0.3:                      # a silent stretch
             a = int(rng.integers(0, n)); x[a:a + int(rng.integers(10, N))] = 0.0
@@ -40,7 +43,7 @@ with warnings.catch_warnings():
             c = rng.uniform(0.2, 0.8) * np.abs(x).max(); x = np.clip(x, -c, c)
         x = x.astype(np.float32)
         kw = dict(n_peaks_elim=int(rng.integers(2, 8)), peak_thresh=float(rng.choice([0.05, 0.1, 0.3, 0.6])),
-                  peak_min_dist=int(rng.choice([1, 2, 5, 10, 25])), enhance_mode=str(rng.choice(["librosa010", "noop"])))
+                  peak_min_dist=int(rng.choice([1, 2, 5, 10, 25, 60, 300, 1000] if WIDE else [1, 2, 5, 10, 25])), enhance_mode=str(rng.choice(["librosa010", "noop"])))
         nn = str(rng.choice(["unicode", "ascii"]))
         tot, per = eng.esacf(x, fs, N, return_frames=True, note_names=nn, **kw)
         e_gpu = eng.esacf_stage("esacf", x, fs, N, **kw)
