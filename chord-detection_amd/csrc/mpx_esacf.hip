@@ -2107,7 +2107,7 @@ struct GaussEval {
     const double* tab;      // 2^(j/64), LDS
 };
 __device__ __forceinline__ GaussEval gauss_prep(const double* p, const double* tab) {
-    return {p[0], p[1], -1.0 / fma_as_written(2.0, prod(p[2], p[2]), lm::EPSMCH), tab};
+    return {p[0], p[1], -lm::lm_rcp(fma_as_written(2.0, prod(p[2], p[2]), lm::EPSMCH)), tab};
 }
 __device__ __forceinline__ double gauss_resid(const GaussEval& g, double xi, double yi) {
     const double d = xi - g.mu;
@@ -2142,11 +2142,11 @@ __device__ __forceinline__ FdStep fd_prep(const double* x, double ninv, double e
     s.mu1 = x[1] + h1;
     s.h1 = s.mu1 - x[1];
     s.k1 = prod(s.h1, ninv);
-    s.inv_h1 = 1.0 / h1;
+    s.inv_h1 = lm::lm_rcp(h1);
     const double s2 = x[2] + h2, h2e = s2 - x[2];
-    s.ninv2 = -1.0 / fma_as_written(2.0, prod(s2, s2), lm::EPSMCH);
+    s.ninv2 = -lm::lm_rcp(fma_as_written(2.0, prod(s2, s2), lm::EPSMCH));
     s.dn = prod(prod(prod(2.0, h2e), x[2] + s2), prod(ninv, s.ninv2));
-    s.inv_h2 = 1.0 / h2;
+    s.inv_h2 = lm::lm_rcp(h2);
     return s;
 }
 // one row: t = f + y, d = x_i - centre
@@ -2306,7 +2306,7 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
             D2 J0, J1, J2;
             {
                 if (x[0] != 0.0) {
-                    const double inv_a = 1.0 / x[0];
+                    const double inv_a = lm_rcp(x[0]);
                     J0 = {ona ? (f.a + py.a) * inv_a : 0.0, onb ? (f.b + py.b) * inv_a : 0.0};
                 } else {
                     x[0] = eps;
@@ -2337,9 +2337,9 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
             ipvt[1] = 1;
             ipvt[2] = 2;
             double acnorm[NP], rdiag[NP], wa[NP];
-            acnorm[0] = sqrt(row_sum(coop_leaf(l, 0, J0, J0)));
-            acnorm[1] = sqrt(row_sum(coop_leaf(l, 0, J1, J1)));
-            acnorm[2] = sqrt(row_sum(coop_leaf(l, 0, J2, J2)));
+            acnorm[0] = lm_sqrt(row_sum(coop_leaf(l, 0, J0, J0)));
+            acnorm[1] = lm_sqrt(row_sum(coop_leaf(l, 0, J1, J1)));
+            acnorm[2] = lm_sqrt(row_sum(coop_leaf(l, 0, J2, J2)));
 #pragma unroll
             for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
             D2 w4 = f;  // becomes Q^T fvec
@@ -2367,14 +2367,14 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                 }
                 D2& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
                 const bool below = l >= j;  // rows j..15 of the first slot; the second slot (rows 16..) is always below
-                double ajnorm = sqrt(row_sum(coop_leaf(l, j, cj, cj)));
+                double ajnorm = lm_sqrt(row_sum(coop_leaf(l, j, cj, cj)));
                 if (ajnorm != 0.0) {
                     if (row_bcast(cj.a, j) < 0.0) ajnorm = -ajnorm;
-                    const double inv_aj = 1.0 / ajnorm;
+                    const double inv_aj = lm_rcp(ajnorm);
                     if (below) cj.a *= inv_aj;
                     cj.b *= inv_aj;
                     if (l == j) cj.a += 1.0;
-                    const double inv_ajj = 1.0 / row_bcast(cj.a, j);
+                    const double inv_ajj = lm_rcp(row_bcast(cj.a, j));
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
                         D2& ck = k == 1 ? J1 : J2;
@@ -2382,12 +2382,12 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                         if (below) ck.a = fma_as_written(-temp, cj.a, ck.a);
                         ck.b = fma_as_written(-temp, cj.b, ck.b);
                         if (rdiag[k] != 0.0) {
-                            const double t = row_bcast(ck.a, j) / rdiag[k];
+                            const double t = lm_div(row_bcast(ck.a, j), rdiag[k]);
                             const double u = fma(-t, t, 1.0);
-                            rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
-                            const double q = rdiag[k] / wa[k];
+                            rdiag[k] *= lm_sqrt(u > 0.0 ? u : 0.0);
+                            const double q = lm_div(rdiag[k], wa[k]);
                             if (0.05 * q * q <= EPSMCH) {
-                                rdiag[k] = sqrt(row_sum(coop_leaf(l, j + 1, ck, ck)));
+                                rdiag[k] = lm_sqrt(row_sum(coop_leaf(l, j + 1, ck, ck)));
                                 wa[k] = rdiag[k];
                             }
                         }
@@ -2425,8 +2425,8 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                     if (an != 0.0) {
                         double s2 = 0.0;
 #pragma unroll
-                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], qtf[i] / fnorm, s2);
-                        const double g = fabs(s2 / an);
+                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], lm_div(qtf[i], fnorm), s2);
+                        const double g = fabs(lm_div(s2, an));
                         gnorm = g > gnorm ? g : gnorm;
                     }
                 }
@@ -2453,10 +2453,10 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
                 if (it == 1) delta = delta < pnorm ? delta : pnorm;
                 const D2 fn = resid(xnew);
                 ++nfev;
-                const double fnorm1 = sqrt(row_sum(coop_leaf(l, 0, fn, fn)));
+                const double fnorm1 = lm_sqrt(row_sum(coop_leaf(l, 0, fn, fn)));
                 double actred = -1.0;
                 if (0.1 * fnorm1 < fnorm) {
-                    const double q = fnorm1 / fnorm;
+                    const double q = lm_div(fnorm1, fnorm);
                     actred = fma(-q, q, 1.0);
                 }
 #pragma unroll
@@ -2467,17 +2467,17 @@ __global__ __launch_bounds__(256) void coopfit_kernel(const ParkedFit* __restric
 #pragma unroll
                     for (int i = 0; i <= j; ++i) wa3[i] = fma(r[i * NP + j], temp, wa3[i]);
                 }
-                const double temp1 = enorm3(wa3) / fnorm;
-                const double temp2 = (sqrt(par) * pnorm) / fnorm;
+                const double temp1 = lm_div(enorm3(wa3), fnorm);
+                const double temp2 = lm_div(lm_sqrt(par) * pnorm, fnorm);
                 const double prered = fma(temp1, temp1, temp2 * temp2 / 0.5);
                 const double dirder = -fma(temp1, temp1, temp2 * temp2);
-                const double ratio = prered != 0.0 ? actred / prered : 0.0;
+                const double ratio = prered != 0.0 ? lm_div(actred, prered) : 0.0;
                 if (ratio <= 0.25) {
-                    double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+                    double temp = actred >= 0.0 ? 0.5 : lm_div(0.5 * dirder, dirder + 0.5 * actred);
                     if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                    const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
+                    const double p10 = lm_div(pnorm, 0.1), dm = delta < p10 ? delta : p10;
                     delta = temp * dm;
-                    par = par / temp;
+                    par = lm_div(par, temp);
                 } else if (par == 0.0 || ratio >= 0.75) {
                     delta = pnorm / 0.5;
                     par = 0.5 * par;
@@ -2635,7 +2635,7 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
             D3 J0, J1, J2;
             {
                 if (x[0] != 0.0) {
-                    const double inv_a = 1.0 / x[0];
+                    const double inv_a = lm_rcp(x[0]);
                     J0 = {ona ? (f.a + py.a) * inv_a : 0.0, onb ? (f.b + py.b) * inv_a : 0.0, onc ? (f.c + py.c) * inv_a : 0.0};
                 } else {
                     x[0] = eps;
@@ -2667,9 +2667,9 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
             ipvt[1] = 1;
             ipvt[2] = 2;
             double acnorm[NP], rdiag[NP], wa[NP];
-            acnorm[0] = sqrt(coop8_sum(l, 0, J0, J0));
-            acnorm[1] = sqrt(coop8_sum(l, 0, J1, J1));
-            acnorm[2] = sqrt(coop8_sum(l, 0, J2, J2));
+            acnorm[0] = lm_sqrt(coop8_sum(l, 0, J0, J0));
+            acnorm[1] = lm_sqrt(coop8_sum(l, 0, J1, J1));
+            acnorm[2] = lm_sqrt(coop8_sum(l, 0, J2, J2));
 #pragma unroll
             for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
             D3 w4 = f;  // becomes Q^T fvec
@@ -2697,15 +2697,15 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                 }
                 D3& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
                 const bool below = l >= j;  // rows j..7 of the first slot; the other two slots (rows 8.., 16..) are always below
-                double ajnorm = sqrt(coop8_sum(l, j, cj, cj));
+                double ajnorm = lm_sqrt(coop8_sum(l, j, cj, cj));
                 if (ajnorm != 0.0) {
                     if (half_bcast(cj.a, j) < 0.0) ajnorm = -ajnorm;
-                    const double inv_aj = 1.0 / ajnorm;
+                    const double inv_aj = lm_rcp(ajnorm);
                     if (below) cj.a *= inv_aj;
                     cj.b *= inv_aj;
                     cj.c *= inv_aj;
                     if (l == j) cj.a += 1.0;
-                    const double inv_ajj = 1.0 / half_bcast(cj.a, j);
+                    const double inv_ajj = lm_rcp(half_bcast(cj.a, j));
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
                         D3& ck = k == 1 ? J1 : J2;
@@ -2714,12 +2714,12 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                         ck.b = fma_as_written(-temp, cj.b, ck.b);
                         ck.c = fma_as_written(-temp, cj.c, ck.c);
                         if (rdiag[k] != 0.0) {
-                            const double t = half_bcast(ck.a, j) / rdiag[k];
+                            const double t = lm_div(half_bcast(ck.a, j), rdiag[k]);
                             const double u = fma(-t, t, 1.0);
-                            rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
-                            const double q = rdiag[k] / wa[k];
+                            rdiag[k] *= lm_sqrt(u > 0.0 ? u : 0.0);
+                            const double q = lm_div(rdiag[k], wa[k]);
                             if (0.05 * q * q <= EPSMCH) {
-                                rdiag[k] = sqrt(coop8_sum(l, j + 1, ck, ck));
+                                rdiag[k] = lm_sqrt(coop8_sum(l, j + 1, ck, ck));
                                 wa[k] = rdiag[k];
                             }
                         }
@@ -2758,8 +2758,8 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                     if (an != 0.0) {
                         double s2 = 0.0;
 #pragma unroll
-                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], qtf[i] / fnorm, s2);
-                        const double g = fabs(s2 / an);
+                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], lm_div(qtf[i], fnorm), s2);
+                        const double g = fabs(lm_div(s2, an));
                         gnorm = g > gnorm ? g : gnorm;
                     }
                 }
@@ -2806,10 +2806,10 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
                 if (it == 1) delta = delta < pnorm ? delta : pnorm;
                 const D3 fn = resid(xnew);
                 ++nfev;
-                const double fnorm1 = sqrt(coop8_sum(l, 0, fn, fn));
+                const double fnorm1 = lm_sqrt(coop8_sum(l, 0, fn, fn));
                 double actred = -1.0;
                 if (0.1 * fnorm1 < fnorm) {
-                    const double q = fnorm1 / fnorm;
+                    const double q = lm_div(fnorm1, fnorm);
                     actred = fma(-q, q, 1.0);
                 }
 #pragma unroll
@@ -2820,17 +2820,17 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
 #pragma unroll
                     for (int i = 0; i <= j; ++i) wa3[i] = fma(r[i * NP + j], temp, wa3[i]);
                 }
-                const double temp1 = enorm3(wa3) / fnorm;
-                const double temp2 = (sqrt(par) * pnorm) / fnorm;
+                const double temp1 = lm_div(enorm3(wa3), fnorm);
+                const double temp2 = lm_div(lm_sqrt(par) * pnorm, fnorm);
                 const double prered = fma(temp1, temp1, temp2 * temp2 / 0.5);
                 const double dirder = -fma(temp1, temp1, temp2 * temp2);
-                const double ratio = prered != 0.0 ? actred / prered : 0.0;
+                const double ratio = prered != 0.0 ? lm_div(actred, prered) : 0.0;
                 if (ratio <= 0.25) {
-                    double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+                    double temp = actred >= 0.0 ? 0.5 : lm_div(0.5 * dirder, dirder + 0.5 * actred);
                     if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                    const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
+                    const double p10 = lm_div(pnorm, 0.1), dm = delta < p10 ? delta : p10;
                     delta = temp * dm;
-                    par = par / temp;
+                    par = lm_div(par, temp);
                 } else if (par == 0.0 || ratio >= 0.75) {
                     delta = pnorm / 0.5;
                     par = 0.5 * par;
@@ -3037,7 +3037,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                 if (!SAMPLES_IN_LDS) load_samples(row, m, ys_g);
                 const GaussEval g0 = gauss_prep(x, exp_tab);   // (dead code without SAMPLES_IN_LDS)
                 const bool a_nonzero = x[0] != 0.0;
-                const double inv_a = a_nonzero ? 1.0 / x[0] : 0.0;
+                const double inv_a = a_nonzero ? lm_rcp(x[0]) : 0.0;
                 double xa[NP] = {eps, x[1], x[2]};
                 const GaussEval ga = gauss_prep(xa, exp_tab);   // only used when A == 0
                 const FdStep fs = fd_prep(x, g0.ninv, eps);
@@ -3073,7 +3073,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 const double q = dot_rows(0, [&](int i) { return a[i][j]; }, [&](int i) { return a[i][j]; });
-                acnorm[j] = sqrt(q);
+                acnorm[j] = lm_sqrt(q);
                 rdiag[j] = wa[j] = acnorm[j];
             }
 #pragma unroll
@@ -3102,14 +3102,14 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     put3(ipvt, kmax, t);
                 }
                 const double q = dot_rows(j, [&](int i) { return a[i][j]; }, [&](int i) { return a[i][j]; });
-                double ajnorm = sqrt(q);
+                double ajnorm = lm_sqrt(q);
                 if (ajnorm != 0.0) {
                     if (a[j][j] < 0.0) ajnorm = -ajnorm;
-                    const double inv_aj = 1.0 / ajnorm;
+                    const double inv_aj = lm_rcp(ajnorm);
 #pragma unroll
                     for (int i = j; i < MAXM; ++i) a[i][j] *= inv_aj;
                     a[j][j] += 1.0;
-                    const double inv_ajj = 1.0 / a[j][j];
+                    const double inv_ajj = lm_rcp(a[j][j]);
 #pragma unroll
                     for (int k = j + 1; k < NP; ++k) {
                         const double sum = dot_rows(j, [&](int i) { return a[i][j]; }, [&](int i) { return a[i][k]; });
@@ -3117,13 +3117,13 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 #pragma unroll
                         for (int i = j; i < MAXM; ++i) a[i][k] = fma_as_written(-temp, a[i][j], a[i][k]);
                         if (rdiag[k] != 0.0) {
-                            const double t = a[j][k] / rdiag[k];
+                            const double t = lm_div(a[j][k], rdiag[k]);
                             const double u = fma(-t, t, 1.0);
-                            rdiag[k] *= sqrt(u > 0.0 ? u : 0.0);
-                            const double qq = rdiag[k] / wa[k];
+                            rdiag[k] *= lm_sqrt(u > 0.0 ? u : 0.0);
+                            const double qq = lm_div(rdiag[k], wa[k]);
                             if (0.05 * qq * qq <= EPSMCH) {
                                 const double s2 = dot_rows(j + 1, [&](int i) { return a[i][k]; }, [&](int i) { return a[i][k]; });
-                                rdiag[k] = sqrt(s2);
+                                rdiag[k] = lm_sqrt(s2);
                                 wa[k] = rdiag[k];
                             }
                         }
@@ -3163,8 +3163,8 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                     if (an != 0.0) {
                         double s2 = 0.0;
 #pragma unroll
-                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], qtf[i] / fnorm, s2);
-                        const double g = fabs(s2 / an);
+                        for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], lm_div(qtf[i], fnorm), s2);
+                        const double g = fabs(lm_div(s2, an));
                         gnorm = g > gnorm ? g : gnorm;
                     }
                 }
@@ -3268,7 +3268,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                         if (i < m) fvec[i * 64] = rn[i];
                 }
                 nfev = 1;
-                fnorm = sqrt(s1);
+                fnorm = lm_sqrt(s1);
                 par = 0.0;
                 it = 1;
                 diag[0] = diag[1] = diag[2] = 1.0;
@@ -3276,10 +3276,10 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
                 phase = FIT_OUTER;
             } else {
             ++nfev;
-            const double fnorm1 = sqrt(s1);
+            const double fnorm1 = lm_sqrt(s1);
             double actred = -1.0;
             if (0.1 * fnorm1 < fnorm) {
-                const double q = fnorm1 / fnorm;
+                const double q = lm_div(fnorm1, fnorm);
                 actred = fma(-q, q, 1.0);
             }
 #pragma unroll
@@ -3290,17 +3290,17 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 #pragma unroll
                 for (int i = 0; i <= j; ++i) wa3[i] = fma(r[i * NP + j], temp, wa3[i]);
             }
-            const double temp1 = enorm3(wa3) / fnorm;
-            const double temp2 = (sqrt(par) * pnorm) / fnorm;
+            const double temp1 = lm_div(enorm3(wa3), fnorm);
+            const double temp2 = lm_div(lm_sqrt(par) * pnorm, fnorm);
             const double prered = fma(temp1, temp1, temp2 * temp2 / 0.5);
             const double dirder = -fma(temp1, temp1, temp2 * temp2);
-            const double ratio = prered != 0.0 ? actred / prered : 0.0;
+            const double ratio = prered != 0.0 ? lm_div(actred, prered) : 0.0;
             if (ratio <= 0.25) {
-                double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+                double temp = actred >= 0.0 ? 0.5 : lm_div(0.5 * dirder, dirder + 0.5 * actred);
                 if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                const double dm = delta < pnorm / 0.1 ? delta : pnorm / 0.1;
+                const double p10 = lm_div(pnorm, 0.1), dm = delta < p10 ? delta : p10;
                 delta = temp * dm;
-                par = par / temp;
+                par = lm_div(par, temp);
             } else if (par == 0.0 || ratio >= 0.75) {
                 delta = pnorm / 0.5;
                 par = 0.5 * par;

@@ -24,6 +24,38 @@ constexpr int NP = 3;     // ampl, center, dev
 constexpr double EPSMCH = 2.220446049250313e-16;
 constexpr double DWARF = 2.2250738585072014e-308;
 
+// Quotients and square roots of the device code.  The compiler's IEEE sequences are 12 (division: two v_div_scale, v_rcp, seven
+// multiply-adds, v_div_fmas, v_div_fixup) and 17 instructions (square root: range scaling, v_rsq, nine multiply-adds, special cases);
+// a trip of the fit kernels runs ~90 divisions and ~35 square roots, a quarter of its instructions (a third in the cooperative
+// kernels, where they also sit on the dependent path).  These are the hardware estimate + two Newton steps: 1-2 ulp from the rounded
+// result -- the distance the shared-reciprocal quotients already keep from MINPACK's, eight orders of magnitude inside its
+// tolerances -- with zero, infinite and NaN operands answered as IEEE does (v_div_fixup; the select in lm_sqrt).  No range scaling:
+// an operand within 2^-970 of the ends of the exponent range loses bits, as the forward-difference jacobian does long before.
+MPX_HD inline double lm_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(b);       // 25 bits
+    y = fma(y, fma(-b, y, 1.0), y);           // 1 / b to ~11 ulp
+    const double q = a * y;
+    return __builtin_amdgcn_div_fixup(fma(fma(-b, q, a), y, q), b, a);   // + the residual's share
+#else
+    return a / b;
+#endif
+}
+MPX_HD inline double lm_rcp(double b) { return lm_div(1.0, b); }
+MPX_HD inline double lm_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    return (x == 0.0 || x == __builtin_inf()) ? x : g;   // (x < 0 and NaN: v_rsq returns NaN, and so does this)
+#else
+    return sqrt(x);
+#endif
+}
+
 struct Problem {
     double xs[MAXM];
     double ys[MAXM];
@@ -43,7 +75,7 @@ MPX_HD inline double enorm(const double* v, int n) {
     for (int i = 0; i < n; ++i) s += v[i] * v[i];
     return sqrt(s);
 }
-MPX_HD inline double enorm3(const double* v) { return sqrt(fma(v[2], v[2], fma(v[1], v[1], v[0] * v[0]))); }
+MPX_HD inline double enorm3(const double* v) { return lm_sqrt(fma(v[2], v[2], fma(v[1], v[1], v[0] * v[0]))); }
 
 // a: [m][NP] row-major, modified in place.
 MPX_HD inline void qrfac(double* a, int m, int* ipvt, double* rdiag, double* acnorm) {
@@ -142,7 +174,7 @@ MPX_HD inline void qrsolv(double* r, const int* ipvt, const double* diag, const 
                     // disagree no longer runs both (2 divisions + 1 square root each)
                     const double rkk = r[k * NP + k], sk = sdiag[k];
                     const bool small = fabs(rkk) < fabs(sk);
-                    const double t = (small ? rkk : sk) / (small ? sk : rkk);
+                    const double t = lm_div(small ? rkk : sk, small ? sk : rkk);
 #if defined(__HIP_DEVICE_COMPILE__)
                     // |t| <= 1, so the radicand lies in [0.25, 0.5]: no range scaling needed, and the hardware
                     // reciprocal square root + two Newton steps (~1 ulp) replaces a full sqrt and a full division
@@ -185,7 +217,7 @@ MPX_HD inline void qrsolv(double* r, const int* ipvt, const double* diag, const 
 #pragma unroll
             for (int i = j + 1; i < NP; ++i)
                 if (i < nsing) s = fma(r[i * NP + j], wa[i], s);
-            wa[j] = (wa[j] - s) / sdiag[j];
+            wa[j] = lm_div(wa[j] - s, sdiag[j]);
         }
     }
 #pragma unroll
@@ -205,7 +237,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
 #pragma unroll
     for (int j = NP - 1; j >= 0; --j) {
         if (j < nsing) {
-            wa1[j] /= r[j * NP + j];
+            wa1[j] = lm_div(wa1[j], r[j * NP + j]);
             const double temp = wa1[j];
 #pragma unroll
             for (int i = 0; i < j; ++i) wa1[i] = fma(-r[i * NP + j], temp, wa1[i]);
@@ -226,7 +258,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
     if (nsing >= NP) {
         {
 #if defined(__HIP_DEVICE_COMPILE__)
-            const double inv_dx = 1.0 / dxnorm;  // one division for the three quotients (1 ulp apart)
+            const double inv_dx = lm_rcp(dxnorm);  // one division for the three quotients (1 ulp apart)
 #endif
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -243,11 +275,11 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
             double s = 0.0;
 #pragma unroll
             for (int i = 0; i < j; ++i) s = fma(r[i * NP + j], wa1[i], s);
-            wa1[j] = (wa1[j] - s) / r[j * NP + j];
+            wa1[j] = lm_div(wa1[j] - s, r[j * NP + j]);
         }
         const double temp = enorm3(wa1);
 #if defined(__HIP_DEVICE_COMPILE__)
-        parl = fp / (delta * temp * temp);
+        parl = lm_div(fp, delta * temp * temp);
 #else
         parl = ((fp / delta) / temp) / temp;
 #endif
@@ -257,18 +289,18 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i <= j; ++i) s = fma(r[i * NP + j], qtb[i], s);
-        wa1[j] = s / sel3(diag, ipvt[j]);
+        wa1[j] = lm_div(s, sel3(diag, ipvt[j]));
     }
     const double gnorm = enorm3(wa1);
-    double paru = gnorm / delta;
-    if (paru == 0.0) paru = DWARF / (delta < 0.1 ? delta : 0.1);
+    double paru = lm_div(gnorm, delta);
+    if (paru == 0.0) paru = lm_div(DWARF, delta < 0.1 ? delta : 0.1);
     par = par > parl ? par : parl;
     par = par < paru ? par : paru;
-    if (par == 0.0) par = gnorm / dxnorm;
+    if (par == 0.0) par = lm_div(gnorm, dxnorm);
     for (;;) {
         ++it;
         if (par == 0.0) par = DWARF > 0.001 * paru ? DWARF : 0.001 * paru;
-        double temp = sqrt(par);
+        double temp = lm_sqrt(par);
 #pragma unroll
         for (int j = 0; j < NP; ++j) wa1[j] = temp * diag[j];
         qrsolv(r, ipvt, wa1, qtb, x, sdiag);
@@ -280,7 +312,7 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
         if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || it == 10) break;
         {
 #if defined(__HIP_DEVICE_COMPILE__)
-            const double inv_dx = 1.0 / dxnorm;  // one division for the three quotients (1 ulp apart)
+            const double inv_dx = lm_rcp(dxnorm);  // one division for the three quotients (1 ulp apart)
 #endif
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
@@ -294,14 +326,14 @@ MPX_HD inline double lmpar(double* r, const int* ipvt, const double* diag, const
         }
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-            wa1[j] /= sdiag[j];
+            wa1[j] = lm_div(wa1[j], sdiag[j]);
             const double t = wa1[j];
 #pragma unroll
             for (int i = j + 1; i < NP; ++i) wa1[i] = fma(-r[i * NP + j], t, wa1[i]);
         }
         temp = enorm3(wa1);
 #if defined(__HIP_DEVICE_COMPILE__)
-        const double parc = fp / (delta * temp * temp);
+        const double parc = lm_div(fp, delta * temp * temp);
 #else
         const double parc = ((fp / delta) / temp) / temp;
 #endif
