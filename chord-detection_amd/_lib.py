@@ -82,6 +82,7 @@ SIGNATURES = {
     "mpx_set_remez_taps": (C.c_int, [_vp, C.c_int, _dp]),
     "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),
     "mpx_test_pow067": (C.c_int, [_dp, C.c_int, _dp]),
+    "mpx_test_lm_div_sqrt": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int, _dp, _dp]),
     "mpx_timer_begin": (C.c_int, [_vp, _vp]),
     "mpx_timer_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "mpx_host_alloc": (_vp, [C.c_size_t]),
@@ -92,7 +93,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4   # include/mpx.h MPX_ABI_VERSION
+ABI_VERSION = 5   # include/mpx.h MPX_ABI_VERSION
 
 
 def _share_torch_hip_runtime():

@@ -114,6 +114,18 @@ static int build_descs(const int64_t* offsets, int num_clips, int frame, int hop
 
 using namespace mpx;
 
+namespace mpx {
+// the fit kernels' quotient and square root, element by element (mpx_test_lm_div_sqrt)
+__global__ __launch_bounds__(256) void lm_div_sqrt_kernel(const double* __restrict__ a, const double* __restrict__ b, int n,
+                                                          double* __restrict__ quot, double* __restrict__ root) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        quot[i] = mpx::lm::lm_div(a[i], b[i]);
+        root[i] = mpx::lm::lm_sqrt(b[i]);
+    }
+}
+}  // namespace mpx
+
 extern "C" {
 
 int mpx_abi_version(void) { return MPX_ABI_VERSION; }
@@ -671,6 +683,29 @@ int mpx_test_pow067(const double* x, int n, double* out) {
     mpx::p067::build_tables(tab);
     for (int i = 0; i < n; ++i) out[i] = mpx::p067::pow067(x[i], tab);
     return MPX_OK;
+}
+
+// the fit kernels' quotient and square root on the device, element by element (tests/test_gpu_lm_div_sqrt.py)
+int mpx_test_lm_div_sqrt(mpx_ctx* ctx, const double* a, const double* b, int n, double* quot, double* root) {
+    if (!ctx) return MPX_EINVAL;
+    if (!a || !b || !quot || !root || n < 0) return set_error(ctx, MPX_EINVAL, "NULL pointer or negative count");
+    if (n == 0) return MPX_OK;
+    const size_t bytes = (size_t)n * sizeof(double);
+    double* d = nullptr;
+    if (hipMalloc(&d, 4 * bytes) != hipSuccess) return set_error(ctx, MPX_ENOMEM, "hipMalloc(%zu) failed", 4 * bytes);
+    int rc = MPX_OK;
+    if (hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d + n, b, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        rc = set_error(ctx, MPX_EHIP, "copy to the device failed");
+    } else {
+        mpx::lm_div_sqrt_kernel<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d, d + n, n, d + 2 * (size_t)n, d + 3 * (size_t)n);
+        if (hipMemcpyAsync(quot, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(root, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = set_error(ctx, MPX_EHIP, "kernel or copy back failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    (void)hipFree(d);
+    return rc;
 }
 
 int mpx_esacf_stage(mpx_ctx* ctx, int stage, const float* signal, int64_t n, int fs,

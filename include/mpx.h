@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPX_ABI_VERSION 4
+#define MPX_ABI_VERSION 5
 
 typedef enum mpx_status {
     MPX_OK = 0,
@@ -327,6 +327,12 @@ int mpx_test_gaussian_fit(const double* xs, const double* ys, int m, double* cen
 /* Host-callable copy of the device code for |X|^0.67 (esacf.py:95-101) from x = |X|^2: out[i] = x[i]^(0.67/2) by the table
  * form the SACF kernels use (csrc/mpx_pow067.hpp), so its accuracy can be checked against long-double pow without a GPU. */
 int mpx_test_pow067(const double* x, int n, double* out);
+
+/* The quotients and square roots of the device gaussian fit (csrc/mpx_lm.hpp: lm_div, lm_sqrt -- hardware estimate, one
+ * Newton step, residual step, instead of the compiler's IEEE sequences), run ON THE GPU so that their rounding can be held
+ * against IEEE division / square root by a test (ABI 5): quot[i] = lm_div(a[i], b[i]), root[i] = lm_sqrt(b[i]); host
+ * pointers, n >= 0.  Returns MPX_EINVAL for NULL pointers, MPX_ENOMEM / MPX_EHIP when the device refuses. */
+int mpx_test_lm_div_sqrt(mpx_ctx* ctx, const double* a, const double* b, int n, double* quot, double* root);
 
 /* ---- timing helper (HIP events on the stream the kernels run on) ----------
  * mpx_timer_begin records an event on `stream` (NULL = context stream);
