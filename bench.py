@@ -36,7 +36,7 @@ from benchlib import config as K                                                
 from benchlib.config import FS, N_FFT, HOP, F_ALG, B_ALG, HBM_PEAK, F64_PEAK, CFG            # noqa: E402,F401
 from benchlib.synth import synth_signal, synth_clips_numpy, synth_signal_device              # noqa: E402,F401
 from benchlib.cpu_legs import cpu_baselines, host_cpu_info, _cpu_worker, _CPU_INPUT          # noqa: E402,F401
-from benchlib.roofline import measured_traffic, he_kernel_name                               # noqa: E402
+from benchlib.roofline import measured_traffic, he_kernel_name, traffic_from                               # noqa: E402
 from benchlib.record import compact_record, write_full_record, COMPACT_LIMIT                 # noqa: E402,F401
 from benchlib.workloads import WORKLOADS                                                     # noqa: E402
 
@@ -79,7 +79,7 @@ def main():
     # Nothing in the environment may change what is measured: the release library reads no development switches, and this
     # script refuses to run with any MPX_* variable other than its own two set (MPX_LIB_PATH would swap the library,
     # MPX_DETERMINISTIC the fit scheduling).
-    foreign = sorted(k for k in os.environ if k.startswith("MPX_") and k not in ("MPX_BENCH_STUB", "MPX_BENCH_CPU_BUDGET"))
+    foreign = sorted(k for k in os.environ if k.startswith("MPX_") and k not in ("MPX_BENCH_STUB", "MPX_BENCH_CPU_BUDGET", "MPX_BENCH_DUMP_GATHER"))
     if foreign:
         sys.exit("bench.py: unset %s (bench numbers are taken with the default library and defaults only)" % ", ".join(foreign))
 
@@ -171,7 +171,7 @@ def main():
     # The timed region, `repeats` times: EXACTLY K steps between barrier + synchronize on both sides, the rank maximum of
     # each repeat, and the median of the repeats is what `value` is computed from (every repeat is listed in the output).
     repeats = args.repeats if args.repeats > 0 else (25 if steps < 200 else 5)
-    rep_s, host_enqueue_ms, gathered = [], 0.0, None
+    rep_s, rep_steps_s, rep_gather_s, host_enqueue_ms, gathered = [], [], [], 0.0, None
     gather_out = torch.empty((world,) + tuple(d_sums.shape), dtype=d_sums.dtype, device=dev) if use_dist and backend == "nccl" else None
     for rep in range(repeats):
         barrier()
@@ -180,8 +180,10 @@ def main():
         for i in range(steps):
             step(i)
         host_enqueue_ms = 1e3 * (time.perf_counter() - th0) / max(steps, 1)
+        el_steps = None
         if use_dist:
             sync_engines()
+            el_steps = time.perf_counter() - t0        # this rank's K steps alone: the clock read before the job's one gather
             if gather_out is not None:                 # RCCL: into one preallocated tensor (no list of outputs to build per repeat)
                 dist.all_gather_into_tensor(gather_out, d_sums)
                 gathered = gather_out
@@ -196,11 +198,21 @@ def main():
         dev_sync()
         el = time.perf_counter() - t0
         barrier()
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        # [whole region, the steps alone, the gather alone]: the rank maximum of each, so that a weak-scaling loss of a short
+        # region (0.8 ms at the driver's K = 20) can be split into "the steps got slower" and "the gather's latency"
+        t = torch.tensor([el, el if el_steps is None else el_steps, 0.0 if el_steps is None else el - el_steps],
+                         dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        rep_s.append(float(t.item()))
+        rep_s.append(float(t[0].item()))
+        rep_steps_s.append(float(t[1].item()))
+        rep_gather_s.append(float(t[2].item()))
+    if rank == 0 and gathered is not None and os.environ.get("MPX_BENCH_DUMP_GATHER"):   # tests: what the gather delivered
+        g = gathered if torch.is_tensor(gathered) else torch.stack(list(gathered))
+        np.save(os.environ["MPX_BENCH_DUMP_GATHER"], g.cpu().numpy())
     elapsed = sorted(rep_s)[len(rep_s) // 2]
+    elapsed_steps = sorted(rep_steps_s)[len(rep_steps_s) // 2]
+    gather_s = sorted(rep_gather_s)[len(rep_gather_s) // 2]
     sums = d_sums[:steps].cpu().numpy()
 
     # the same K steps strictly one launch after the other on ONE context/stream (what the per-launch roofline describes)
@@ -282,6 +294,12 @@ def main():
             "data": "synthetic",
             "engine": "hip" if stub is None else "stub",
             "ms_per_step_repeats": [1e3 * v / max(steps, 1) for v in rep_s],
+            # the same timed regions with the clock read BEFORE the job's one all_gather (rank maximum, median of the repeats),
+            # and the gather + its synchronize on their own: value = frames / (steps + gather); value_steps_only = frames / steps
+            "value_steps_only": total_frames / max(elapsed_steps, 1e-12),
+            "ms_per_step_steps_only": 1e3 * elapsed_steps / max(steps, 1),
+            "gather_ms": 1e3 * gather_s if use_dist else None,
+            "gather_ms_repeats": [1e3 * v for v in rep_gather_s] if use_dist else None,
             "value_one_in_flight": total_frames / elapsed_one,
             "ms_per_step_one_in_flight": 1e3 * elapsed_one / max(steps, 1),
             "config": {"workload": "Harmonic Energy STFT->chromagram, 8192 synthetic 44.1 kHz frames per GPU, "
@@ -295,6 +313,9 @@ def main():
                        if use_dist else None},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": K.HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / K.HBM_PEAK, "traffic": traffic,
+                         # where `traffic` was read: bench.py cannot run rocprofv3 on itself, so it is the committed PMC
+                         # collection of the same launch shape (profiles/traffic_latest.json), NOT a counter of this run
+                         "traffic_from": traffic_from("he"),
                          "traffic_note": "bytes/launch; %s; algorithmic = %d" % (traffic_note, K.B_ALG * K.FRAMES),
                          "compulsory_bytes": K.B_ALG * K.FRAMES,
                          "wasted_traffic_ratio": (traffic / (K.B_ALG * K.FRAMES)) if traffic else None,

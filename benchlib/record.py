@@ -26,7 +26,7 @@ def _r(v, sig=6):
     return v
 
 
-ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "compulsory_bytes",
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_from", "kernel", "kernel_ms", "compulsory_bytes",
              "wasted_traffic_ratio")
 
 
@@ -44,7 +44,7 @@ def compact_record(out, full_path=None):
     """The driver's line: the contract's keys, the headline roofline + cpu_baseline, and one short entry per workload."""
     rec = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                       "vs_baseline", "dtype", "data", "engine", "ms_per_step_repeats", "value_one_in_flight",
-                      "ms_per_step_one_in_flight"))
+                      "ms_per_step_one_in_flight", "value_steps_only", "ms_per_step_steps_only", "gather_ms"))
     cfg = out.get("config", {})
     rec["config"] = _pick(cfg, ("frames_per_gpu", "fft", "hop", "fs", "repeats", "repeat_statistic", "batches_in_flight",
                                 "distinct_input_signals"))

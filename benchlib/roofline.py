@@ -62,6 +62,14 @@ def measured_traffic(pmc_workload, mark):
     return total, "round %s PMC, %s: %s" % (_TRAFFIC.get("round"), pmc_workload, ", ".join(sorted(hit)))
 
 
+def traffic_from(pmc_workload=None):
+    """Short provenance of every `traffic` figure in the record: which committed PMC collection it was read from."""
+    measured_traffic("he", "he_kernel")   # loads the file
+    if not _TRAFFIC:
+        return None
+    return "committed PMC pass of round %s (profiles/traffic_latest.json <- %s), not this run" % (_TRAFFIC.get("round"), _TRAFFIC.get("source"))
+
+
 def with_traffic(r, pmc_workload, mark, launches=1):
     """Fill roofline.traffic (bytes per call of the marked kernels x launches) and the ratio to the compulsory bytes."""
     if r is None:
@@ -75,6 +83,7 @@ def with_traffic(r, pmc_workload, mark, launches=1):
         tot += b
         notes.append(note)
     r["traffic"] = tot * launches
+    r["traffic_from"] = traffic_from()
     r["traffic_note"] = "HBM-side bytes (calibrated factor x FETCH_SIZE + WRITE_SIZE, scripts/pmc_to_traffic.py) of these launches; " + "; ".join(notes)
     comp = r.get("bytes_per_unit", 0) * r.get("units_per_launch", 0)
     if r.get("compulsory_bytes"):

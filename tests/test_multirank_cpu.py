@@ -67,6 +67,34 @@ def test_bench_py_two_ranks():
         assert rec["value"] > 0 and "cpu_baseline" not in rec
 
 
+def test_bench_py_eight_ranks():
+    """The shape of the driver's 8-GPU launch, over gloo on this box's 8 cores: eight ranks, seeds by rank, the job's one
+    gather of [8, steps, 12], one JSON line from rank 0, and the steps-only / gather split of the timed region."""
+    import tempfile
+    with tempfile.TemporaryDirectory(dir=ROOT) as tmp:
+        c = _torchrun(8, ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--repeats", "3", "--workloads",
+                          "corpus_4096_all_methods,if0_stream_1h", "--full-json", os.path.join(tmp, "full8.json")],
+                      {"MPX_BENCH_STUB": "tests.bench_stub", "MPX_BENCH_DUMP_GATHER": os.path.join(tmp, "gather.npy")},
+                      timeout=900)
+        d = _bench_full(c)
+        g = np.load(os.path.join(tmp, "gather.npy"))
+    assert c["n_gpus"] == d["n_gpus"] == 8 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["config"]["collective"] == "gloo all_gather of [steps, 12] inside every timed repeat, 8 rank(s)"
+    assert np.isclose(d["value"], 8 * 8 * 3 / (d["ms_per_step"] * 3e-3), rtol=1e-9)          # whole job, rank-maximum time
+    # the clock read before and after the one gather: steps-only <= whole region, and the two parts add up to about it
+    assert d["value_steps_only"] >= d["value"] * (1 - 1e-9) and d["gather_ms"] >= 0 and len(d["gather_ms_repeats"]) == 3
+    assert d["ms_per_step_steps_only"] * 3 + d["gather_ms"] <= 2.0 * d["ms_per_step"] * 3 + 1.0
+    for k in ("value_steps_only", "ms_per_step_steps_only", "gather_ms"):
+        assert k in c, k                                                                     # in the driver's line too
+    # the gathered tensor: [ranks, rows, 12], every rank's block arrived, and the ranks' signals differ (seed = f(rank))
+    assert g.shape[0] == 8 and g.shape[2] == 12 and g.shape[1] >= 3
+    assert all(np.abs(g[r, :3]).sum() > 0 for r in range(8))
+    assert len({tuple(np.round(g[r, 0], 9)) for r in range(8)}) == 8
+    w = d["workloads"]
+    assert w["corpus_4096_all_methods"]["nonzero_rows"] == 8 * 3 * 4      # eight ranks x 3 clips x 4 methods through the gather
+    assert w["if0_stream_1h"]["scaling"] == "strong" and w["if0_stream_1h"]["value"] > 0
+
+
 def test_bench_py_one_rank_stub_matches_contract():
     env = dict(os.environ, PYTHONPATH=ROOT, MPX_BENCH_STUB="tests.bench_stub", MPX_BENCH_CPU_BUDGET="0.2")
     import tempfile
