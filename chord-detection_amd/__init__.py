@@ -6,7 +6,7 @@ from .iterative_f0 import MultipitchIterativeF0
 from .prime_multif0 import MultipitchPrimeMultiF0
 from .multipitch import METHODS, Multipitch
 from .chromagram import Chromagram, detect_key
-from .engine import Engine, get_engine, device_count, pinned_empty
+from .engine import Engine, Pcm16, get_engine, device_count, pinned_empty
 
 __all__ = ["MultipitchESACF", "MultipitchHarmonicEnergy", "MultipitchIterativeF0", "MultipitchPrimeMultiF0", "METHODS", "Multipitch", "Chromagram", "detect_key",
-           "Engine", "get_engine", "device_count", "pinned_empty"]
+           "Engine", "Pcm16", "get_engine", "device_count", "pinned_empty"]

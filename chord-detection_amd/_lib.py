@@ -47,6 +47,7 @@ _fp = C.POINTER(C.c_float)
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int64)
 _vp = C.c_void_p
+_sp = C.POINTER(C.c_int16)
 
 # name -> (restype, argtypes); every symbol include/mpx.h declares
 SIGNATURES = {
@@ -78,6 +79,11 @@ SIGNATURES = {
     "mpx_iterative_f0_warmup": (C.c_int, [_vp, C.c_int, C.POINTER(If0Params), C.POINTER(C.c_int64), _dp]),
     "mpx_iterative_f0_spectra": (C.c_int, [_vp, _fp, C.c_int64, C.c_int, C.POINTER(If0Params), _dp]),
     "mpx_iterative_f0_periodicity": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, C.c_int, C.POINTER(If0Params), _dp]),
+    "mpx_iterative_f0_periodicity_voices": (C.c_int, [_vp, _dp, C.c_int64, C.c_int, C.c_int, C.POINTER(If0Params), _dp, _dp, _dp]),
+    "mpx_harmonic_energy_pcm16": (C.c_int, [_vp, _sp, C.c_int64, C.c_int, C.POINTER(HeParams), C.c_int, C.c_int, _dp, _dp]),
+    "mpx_esacf_pcm16": (C.c_int, [_vp, _sp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp, _dp]),
+    "mpx_prime_multif0_pcm16": (C.c_int, [_vp, _sp, C.c_int64, C.c_int, C.POINTER(PrimeParams), _dp]),
+    "mpx_iterative_f0_pcm16": (C.c_int, [_vp, _sp, C.c_int64, C.c_int, C.POINTER(If0Params), _dp, _dp]),
     "mpx_esacf_stage": (C.c_int, [_vp, C.c_int, _fp, C.c_int64, C.c_int, C.POINTER(EsacfParams), C.c_int, C.c_int, _dp]),
     "mpx_set_remez_taps": (C.c_int, [_vp, C.c_int, _dp]),
     "mpx_test_gaussian_fit": (C.c_int, [_dp, _dp, C.c_int, _dp]),
@@ -93,7 +99,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5   # include/mpx.h MPX_ABI_VERSION
+ABI_VERSION = 6   # include/mpx.h MPX_ABI_VERSION
 
 
 def _share_torch_hip_runtime():

@@ -30,6 +30,18 @@ def _resample(x, sr_in, sr_out):
     return scipy.signal.resample_poly(np.asarray(x, dtype=np.float64), up, down, window=h).astype(np.float32)
 
 
+def load_pcm16(path, sr=22050):
+    """(int16 samples, rate) when the file is mono PCM_16 already at `sr` (or `sr` is None) -- the samples exactly as the file
+    holds them, for the library's PCM_16 entry points (include/mpx.h: x / 32768 on the device, half the bytes over PCIe) -- else
+    None: anything that has to be down-mixed or resampled goes through load()."""
+    with wave.open(str(path), "rb") as w:
+        nch, width, rate, nframes = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        if nch != 1 or width != 2 or (sr is not None and rate != sr):
+            return None
+        raw = w.readframes(nframes)
+    return np.frombuffer(raw, dtype="<i2").astype(np.int16, copy=False), int(rate)
+
+
 def load(path, sr=22050):
     """Returns (float32 mono samples, sample rate) like librosa.load(path)."""
     with wave.open(str(path), "rb") as w:

@@ -115,6 +115,25 @@ static int build_descs(const int64_t* offsets, int num_clips, int frame, int hop
 using namespace mpx;
 
 namespace mpx {
+// PCM_16 samples as a WAV file holds them -> the float32 the reference's loader hands the methods: x / 32768, exact in float32
+// (include/mpx.h "PCM_16 input").  Eight samples per lane: one 16-byte load, two 16-byte stores.
+__global__ __launch_bounds__(256) void pcm16_to_f32_kernel(const int16_t* __restrict__ pcm, long long n, float* __restrict__ out) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const int4 v = *reinterpret_cast<const int4*>(pcm + i);
+        const int w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = (float)(short)(w[k] & 0xffff) * (1.0f / 32768.0f);
+            f[2 * k + 1] = (float)(short)(w[k] >> 16) * (1.0f / 32768.0f);
+        }
+        *reinterpret_cast<float4*>(out + i) = make_float4(f[0], f[1], f[2], f[3]);
+        *reinterpret_cast<float4*>(out + i + 4) = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+        for (long long k = i; k < n; ++k) out[k] = (float)pcm[k] * (1.0f / 32768.0f);
+    }
+}
 // the fit kernels' quotient and square root, element by element (mpx_test_lm_div_sqrt)
 __global__ __launch_bounds__(256) void lm_div_sqrt_kernel(const double* __restrict__ a, const double* __restrict__ b, int n,
                                                           double* __restrict__ quot, double* __restrict__ root) {
@@ -182,7 +201,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     for (void* p : ctx->owned) hipFree(p);
-    for (DevBuf* b : {&ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
+    for (DevBuf* b : {&ctx->d_pcm, &ctx->d_pcm_f32, &ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
                       &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3, &ctx->d_ws4, &ctx->d_counter, &ctx->d_queue})
         if (b->p) hipFree(b->p);
     for (auto& m : ctx->prof_marks) hipEventDestroy(m.ev);
@@ -371,8 +390,22 @@ static int method_dev(mpx_ctx* ctx, run_fn run, const float* d_signal, int64_t n
 }
 
 // host single signal
-static int method_host(mpx_ctx* ctx, run_fn run, const float* signal, int64_t n, int fs, const void* params,
+// int16 samples (host or device memory) -> float32 in `d_out` (device), on `st`: the copy moves 2 bytes per sample
+static int pcm16_stage(mpx_ctx* ctx, const int16_t* pcm, int64_t n, float* d_out, hipStream_t st) {
+    if (!n) return MPX_OK;
+    int rc = ensure(ctx, ctx->d_pcm, (size_t)n * sizeof(int16_t) + 16);
+    if (rc) return rc;
+    if ((rc = stage_h2d(ctx, ctx->d_pcm.p, pcm, (size_t)n * sizeof(int16_t), st))) return rc;
+    const long long groups = (n + 7) / 8;
+    hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                       (const int16_t*)ctx->d_pcm.p, (long long)n, d_out);
+    MPX_HIP(ctx, hipGetLastError());
+    return MPX_OK;
+}
+
+static int method_host(mpx_ctx* ctx, run_fn run, const void* signal_any, bool pcm16, int64_t n, int fs, const void* params,
                        int frame, int hop, double* chroma_frames, double* chroma_sum) {
+    const float* signal = (const float*)signal_any;
     int rc = check_common(ctx, signal, n, frame, hop);
     if (rc) return rc;
     if (!chroma_sum) return set_error(ctx, MPX_EINVAL, "chroma_sum must not be NULL");
@@ -380,7 +413,11 @@ static int method_host(mpx_ctx* ctx, run_fn run, const float* signal, int64_t n,
     if ((rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
-    if (n && (rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) return rc;
+    if (pcm16) {
+        if ((rc = pcm16_stage(ctx, (const int16_t*)signal_any, n, (float*)ctx->d_signal.p, ctx->stream))) return rc;
+    } else if (n && (rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) {
+        return rc;
+    }
     rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
                     chroma_frames ? (double*)ctx->d_frames_out.p : nullptr, (double*)ctx->d_sum.p, ctx->stream);
     if (rc) return rc;
@@ -506,7 +543,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
 
 int mpx_harmonic_energy(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_he_params* params,
                         int frame, int hop, double* chroma_frames, double* chroma_sum) {
-    return method_host(ctx, run_he, signal, n, fs, params, frame, hop, chroma_frames, chroma_sum);
+    return method_host(ctx, run_he, signal, false, n, fs, params, frame, hop, chroma_frames, chroma_sum);
 }
 
 int mpx_harmonic_energy_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
@@ -542,7 +579,7 @@ int mpx_harmonic_energy_argmax(mpx_ctx* ctx, const float* signal, int64_t n, int
 // ------------------------------------------------------------------ method 1
 int mpx_esacf(mpx_ctx* ctx, const float* signal, int64_t n, int fs, const mpx_esacf_params* params, int frame,
               int hop, double* chroma_frames, double* chroma_sum) {
-    return method_host(ctx, run_esacf, signal, n, fs, params, frame, hop, chroma_frames, chroma_sum);
+    return method_host(ctx, run_esacf, signal, false, n, fs, params, frame, hop, chroma_frames, chroma_sum);
 }
 
 int mpx_esacf_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
@@ -553,6 +590,48 @@ int mpx_esacf_batch(mpx_ctx* ctx, const float* signals, const int64_t* offsets, 
 int mpx_esacf_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_esacf_params* params,
                   int frame, int hop, double* d_chroma_frames, double* d_chroma_sum, void* stream) {
     return method_dev(ctx, run_esacf, d_signal, n, fs, params, frame, hop, d_chroma_frames, d_chroma_sum, stream);
+}
+
+// ------------------------------------------------------------------ PCM_16 input (ABI 6): include/mpx.h
+int mpx_harmonic_energy_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_he_params* params, int frame,
+                              int hop, double* chroma_frames, double* chroma_sum) {
+    return method_host(ctx, run_he, pcm, true, n, fs, params, frame, hop, chroma_frames, chroma_sum);
+}
+
+int mpx_esacf_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_esacf_params* params, int frame, int hop,
+                    double* chroma_frames, double* chroma_sum) {
+    return method_host(ctx, run_esacf, pcm, true, n, fs, params, frame, hop, chroma_frames, chroma_sum);
+}
+
+// methods 3 and 4 take their samples wherever they live: converted into a buffer of the context's, then handed over as
+// device memory (their runners read device-resident clips in place or copy them inside HBM)
+static int pcm16_to_ctx(mpx_ctx* ctx, const int16_t* pcm, int64_t n, const float** d_out) {
+    if (!ctx) return MPX_EINVAL;
+    ctx->err.clear();
+    if (n < 0 || (n > 0 && !pcm)) return set_error(ctx, MPX_EINVAL, "signal pointer/length invalid");
+    MPX_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->d_pcm_f32, (size_t)(n ? n : 1) * sizeof(float));
+    if (rc) return rc;
+    if ((rc = pcm16_stage(ctx, pcm, n, (float*)ctx->d_pcm_f32.p, ctx->stream))) return rc;
+    MPX_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the runners' own copies are ordered on their streams, not behind this one
+    *d_out = (const float*)ctx->d_pcm_f32.p;
+    return MPX_OK;
+}
+
+int mpx_prime_multif0_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_prime_params* params,
+                            double* chroma_sum) {
+    const float* d = nullptr;
+    int rc = pcm16_to_ctx(ctx, pcm, n, &d);
+    if (rc) return rc;
+    return mpx_prime_multif0(ctx, d, n, fs, params, chroma_sum);
+}
+
+int mpx_iterative_f0_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_if0_params* params,
+                           double* chroma_frames, double* chroma_sum) {
+    const float* d = nullptr;
+    int rc = pcm16_to_ctx(ctx, pcm, n, &d);
+    if (rc) return rc;
+    return mpx_iterative_f0(ctx, d, n, fs, params, chroma_frames, chroma_sum);
 }
 
 // ------------------------------------------------------------------ method 3
@@ -591,6 +670,14 @@ int mpx_iterative_f0_periodicity(mpx_ctx* ctx, const double* spectra, int64_t nu
     ctx->err.clear();
     MPX_HIP(ctx, hipSetDevice(ctx->device));
     return if0_periodicity_host(ctx, spectra, num_frames, bins, fs, params, chroma_frames);
+}
+
+int mpx_iterative_f0_periodicity_voices(mpx_ctx* ctx, const double* spectra, int64_t num_frames, int bins, int fs,
+                                        const mpx_if0_params* params, double* chroma_frames, double* saliences, double* periods) {
+    if (!ctx) return MPX_EINVAL;
+    ctx->err.clear();
+    MPX_HIP(ctx, hipSetDevice(ctx->device));
+    return if0_periodicity_host(ctx, spectra, num_frames, bins, fs, params, chroma_frames, saliences, periods);
 }
 
 int mpx_iterative_f0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_if0_params* params,
@@ -661,6 +748,7 @@ int mpx_prime_multif0(mpx_ctx* ctx, const float* signal, int64_t n, int fs, cons
 int mpx_set_remez_taps(mpx_ctx* ctx, int fs, const double* taps13) {
     if (!ctx || !taps13 || fs <= 0) return MPX_EINVAL;
     ctx->remez[fs] = std::vector<double>(taps13, taps13 + 13);
+    ctx->host_blobs.erase("bs_runin_" + std::to_string(fs));   // the band splitter's run-in (band_cut, mpx_esacf.hip) was simulated with the taps before
     return MPX_OK;
 }
 

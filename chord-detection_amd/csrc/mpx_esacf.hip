@@ -3679,13 +3679,16 @@ static BandCut band_cut(mpx_ctx* ctx, int fs, int N, const BandCoef& k) {
             for (double& v : tl) v /= tot;
             return tl;
         };
-        const std::vector<double> thp = tails(hhp), tlo = tails(hlo), tlp = tails(hlp);
+        // (thr: the warped-FIR residual itself -- what a cut piece writes for the MPX_STAGE_WFIR tap and what feeds every later
+        // stage.  For the built-in tables its all-pass pole decays far faster than the 1 kHz biquads; for taps the caller
+        // registered for another rate (mpx_set_remez_taps, which also drops this cache entry) nothing else would bound it.)
+        const std::vector<double> thr = tails(hr), thp = tails(hhp), tlo = tails(hlo), tlp = tails(hlp);
         double glp = 0.0;
         for (double v : hlp) glp += std::fabs(v);
         const double eps = std::ldexp(1.0, -60);
         int runin = -1;
         for (int t = BS_TILE; t <= T / 2 && runin < 0; t += BS_TILE) {
-            if (tlo[t] >= eps || tlp[t] >= eps || thp[t] >= eps) continue;
+            if (thr[t] >= eps || tlo[t] >= eps || tlp[t] >= eps || thp[t] >= eps) continue;
             double smear = 0.0;   // the rectified band: the high-pass's leftover at t - j through tap j of the low-pass
             for (int j = 0; j <= t; ++j) smear += std::fabs(hlp[j]) * thp[t - j];
             if (smear / glp + tlp[t] < eps && tlo[T / 2] < eps * 1e-3) runin = t;

@@ -578,6 +578,7 @@ struct If0PerArgs {
     double tau_min, tau_max, tau_prec, epsilon1, epsilon2, gamma;
     double* chroma;     // [F, 12]
     const int* out_row; // frame f of this launch is row out_row[f] of chroma (nullptr: row f)
+    double* voices = nullptr;   // [F, 16] saliences (8) and periods (8) of the detected voices (periodicity.py:112), or nullptr
     long long num_frames;
     unsigned* slot_busy;   // [num_slots] 0 = free (all free between launches)
     int num_slots;
@@ -965,6 +966,13 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
             }
         }
         for (int i = 0; i < 12; ++i) a.chroma[(a.out_row ? (long long)a.out_row[f] : f) * 12 + i] = chroma[i];
+        if (a.voices) {   // what IterativeF0PeriodicityAnalysis.compute returns next to the chromagram (periodicity.py:112)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a.voices[(a.out_row ? (long long)a.out_row[f] : f) * 16 + i] = voice_sal[i];
+                a.voices[(a.out_row ? (long long)a.out_row[f] : f) * 16 + 8 + i] = voice_per[i];
+            }
+        }
     }
     }
     __syncthreads();   // everybody's last access to the slot's rows
@@ -2160,7 +2168,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
 // Debug tap / drop-in for IterativeF0PeriodicityAnalysis.compute (periodicity.py:48-163): the period search alone on summary
 // spectra the CALLER hands in (host memory, [F, n2] doubles, n2 = 2 x window size), per-frame chroma out.
 int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes, int n2, int fs, const mpx_if0_params* params,
-                         double* chroma_frames) {
+                         double* chroma_frames, double* saliences, double* periods) {
     mpx_if0_params p = params ? *params
                               : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
     if (fs <= 0 || nframes < 0 || n2 < 32 || (n2 & 1) || n2 != 2 * p.frame_size || !chroma_frames || (nframes && !spectra))
@@ -2185,7 +2193,7 @@ int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes,
     }
     const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy["if0_periodicity"]);
     if ((rc = ensure(ctx, ctx->d_ws1, ((size_t)nframes + 2 * (size_t)per_grid) * n2 * sizeof(double)))) return rc;   // ut | ur | ud
-    if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * 12 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * (12 + 16) * sizeof(double)))) return rc;   // chroma rows | voices rows
     double* ut_all = (double*)ctx->d_ws1.p;
     MPX_HIP(ctx, hipMemcpyAsync(ut_all, spectra, (size_t)nframes * n2 * sizeof(double), hipMemcpyHostToDevice, st));
     If0PerArgs a;
@@ -2208,6 +2216,7 @@ int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes,
     a.gamma = p.gamma;
     a.chroma = (double*)ctx->d_frames_out.p;
     a.out_row = nullptr;
+    a.voices = (saliences || periods) ? (double*)ctx->d_frames_out.p + (size_t)nframes * 12 : nullptr;
     a.num_frames = nframes;
     if (ctx->d_queue.bytes < (size_t)per_grid * sizeof(unsigned)) {
         if ((rc = ensure(ctx, ctx->d_queue, (size_t)per_grid * sizeof(unsigned) + 4096))) return rc;
@@ -2220,7 +2229,17 @@ int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes,
     prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
     MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nframes * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
+    std::vector<double> hv;
+    if (a.voices) {
+        hv.resize((size_t)nframes * 16);
+        MPX_HIP(ctx, hipMemcpyAsync(hv.data(), a.voices, hv.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
     MPX_HIP(ctx, hipStreamSynchronize(st));
+    for (long long f = 0; a.voices && f < nframes; ++f)
+        for (int i = 0; i < p.max_voices; ++i) {
+            if (saliences) saliences[f * p.max_voices + i] = hv[(size_t)f * 16 + i];
+            if (periods) periods[f * p.max_voices + i] = hv[(size_t)f * 16 + 8 + i];
+        }
     return MPX_OK;
 }
 

@@ -68,6 +68,7 @@ struct mpx_ctx {
     std::map<std::tuple<int, int, int, int, int>, mpx::HePlan> he_plans;
     std::map<std::string, std::vector<void*>> misc_plans;
     // grow-only device workspaces
+    mpx::DevBuf d_pcm, d_pcm_f32;   // PCM_16 entry points: the int16 samples as copied, and (methods 3 / 4) their float32 conversion
     mpx::DevBuf d_signal, d_frames_out, d_partials, d_sum, d_desc, d_offsets, d_ws0, d_ws1, d_ws2, d_ws3, d_ws4, d_counter, d_queue;   // (d_ws4: sacf_huge_kernel accumulators; d_counter: he_kernel's tickets, left at zero; d_queue: scratch-slot flags, all free between launches)
     std::map<std::string, std::vector<unsigned char>> host_blobs;  // host copies of plan records, per context
     std::map<std::string, int> occupancy;      // cached hipOccupancyMaxActiveBlocksPerMultiprocessor answers
@@ -143,7 +144,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                  const mpx_if0_params* params, double* chroma_frames, double* chroma_sums, double* ut_out,
                  bool dev_io = false, hipStream_t stream = nullptr);
 int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes, int n2, int fs, const mpx_if0_params* params,
-                         double* chroma_frames);
+                         double* chroma_frames, double* saliences = nullptr, double* periods = nullptr);
 int if0_warmup_samples(mpx_ctx* ctx, int fs, const mpx_if0_params* params, long long* samples, double* rho);
 int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int num_clips, int fs,
                    const mpx_prime_params* params, double* chroma_sums, bool dev_io = false, hipStream_t stream = nullptr);

@@ -27,10 +27,22 @@ constexpr double DWARF = 2.2250738585072014e-308;
 // Quotients and square roots of the device code.  The compiler's IEEE sequences are 12 (division: two v_div_scale, v_rcp, seven
 // multiply-adds, v_div_fmas, v_div_fixup) and 17 instructions (square root: range scaling, v_rsq, nine multiply-adds, special cases);
 // a trip of the fit kernels runs ~90 divisions and ~35 square roots, a quarter of its instructions (a third in the cooperative
-// kernels, where they also sit on the dependent path).  These are the hardware estimate + two Newton steps: 1-2 ulp from the rounded
-// result -- the distance the shared-reciprocal quotients already keep from MINPACK's, eight orders of magnitude inside its
-// tolerances -- with zero, infinite and NaN operands answered as IEEE does (v_div_fixup; the select in lm_sqrt).  No range scaling:
-// an operand within 2^-970 of the ends of the exponent range loses bits, as the forward-difference jacobian does long before.
+// kernels, where they also sit on the dependent path).  These are the hardware estimate (25 bits), ONE Newton step and the
+// residual step -- q = a y, then q + (a - b q) y; g = x y, then g + (x - g^2) h -- 7 and 10 instructions: correctly rounded on
+// every operand pair tried over 2^-300 ... 2^300 (tests/test_gpu_lm_div_sqrt.py holds that bit for bit), with zero, infinite and
+// NaN operands answered as IEEE does (v_div_fixup; the select in lm_sqrt).
+// NO RANGE SCALING, and two corners where the result is NOT IEEE's (asserted, not masked, by the same test):
+//   (1) a finite a / b whose quotient overflows: q = a y = +-inf, the residual step computes inf - inf, and lm_div returns NaN
+//       where IEEE returns +-inf;
+//   (2) a subnormal divisor (|b| < 2^-1022): v_rcp_f64 returns +-inf, the Newton step inf - inf, and lm_div returns NaN where
+//       IEEE returns a finite quotient or +-inf (a ZERO divisor is answered by v_div_fixup as IEEE does);
+//   and operands within ~2^-970 of the ends of the exponent range lose bits (the intermediate 1/b or x y underflows).
+// A select on the residual step would repair (1) and cost two instructions on the dependent path of each of the ~90 quotients of a
+// trip (7 -> 9: ~6 % of a cooperative trip); (2) needs the range scaling this form exists to avoid.  Neither corner is reachable
+// from a fit that MINPACK would accept: amplitudes are <= 1 lag-domain heights, widths and centres are lags (|x| < 1e6 even in
+// the runaway fits, which stop at maxfev), the smallest divisors are the jacobian steps eps |x| >= 1e-8 |x| and 2 s^2 + 2.2e-16;
+// a fit whose state reaches 1e+-300 is one the reference drops (curve_fit raises or returns a centre that maps to no pitch), and a
+// NaN here drops it as well (no convergence test passes on NaN).
 MPX_HD inline double lm_div(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rcp(b);       // 25 bits

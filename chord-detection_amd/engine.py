@@ -31,6 +31,26 @@ class _DevFlat:
         return C.cast(C.c_void_p(self._t.data_ptr()), typ)
 
 
+class Pcm16:
+    """int16 samples as a 16-bit PCM WAV file holds them.  Handed to a single-signal method of the engine they travel to the
+    device as they are -- half the PCIe bytes of float32 -- and become x / 32768 there (include/mpx.h "PCM_16 input": exact
+    in float32, results bit-equal to the float32 entry points fed `pcm / 32768`).  A plain int16 ndarray is NOT treated this
+    way (it is cast to float32 sample values like any other array): the scaling is a property of the file format, not of
+    the dtype."""
+
+    def __init__(self, a):
+        a = np.asarray(a)
+        if a.ndim != 1 or a.dtype != np.int16:
+            raise ValueError("Pcm16 takes a 1-D int16 array")
+        self.a = np.ascontiguousarray(a)
+        self.shape = self.a.shape
+        self.ctypes = self.a.ctypes
+
+    def float32(self):
+        """what librosa.load / soundfile return for these samples (multipitch.py:24-30)"""
+        return self.a.astype(np.float32) / np.float32(32768.0)
+
+
 class Engine:
     def __init__(self, device=0, f32=False, deterministic=False):
         self.lib = _lib.load()
@@ -68,6 +88,8 @@ class Engine:
 
     @staticmethod
     def _sig(x):
+        if isinstance(x, Pcm16):
+            return x
         if hasattr(x, "is_cuda") and x.is_cuda:   # 1-D float32 tensor on the device: handed over in place (include/mpx.h)
             import torch
             if x.dim() != 1 or x.dtype != torch.float32 or not x.is_contiguous():
@@ -135,8 +157,9 @@ class Engine:
         nf = max(self.num_frames(x.shape[0], frame, hop), 0)
         total = np.zeros(12, dtype=np.float64)
         frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
-        self._check(self.lib.mpx_harmonic_energy(
-            self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p), int(frame), hop,
+        fn, ptr = (self.lib.mpx_harmonic_energy_pcm16, _lib._sp) if isinstance(x, Pcm16) else (self.lib.mpx_harmonic_energy, _lib._fp)
+        self._check(fn(
+            self.ctx, x.ctypes.data_as(ptr), x.shape[0], int(fs), C.byref(p), int(frame), hop,
             frames.ctypes.data_as(_lib._dp) if return_frames and nf else None, total.ctypes.data_as(_lib._dp)))
         return (total, frames) if return_frames else total
 
@@ -154,6 +177,8 @@ class Engine:
         (negative inside a wrapped window; INT32_MIN: empty window), and the windows' [k0, k1) bounds [windows, 2] --
         mpx_harmonic_energy_argmax, the dft_maxes tap."""
         x = self._sig(x)
+        if isinstance(x, Pcm16):
+            x = x.float32()   # (a plot aid: no PCM_16 form of the tap)
         if isinstance(x, _DevFlat):
             raise ValueError("harmonic_energy_argmax takes a host signal")
         hop = int(hop or frame)
@@ -213,8 +238,9 @@ class Engine:
         nf = max(self.num_frames(x.shape[0], frame, hop), 0)
         total = np.zeros(12, dtype=np.float64)
         frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
-        self._check(self.lib.mpx_esacf(
-            self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p), int(frame), hop,
+        fn, ptr = (self.lib.mpx_esacf_pcm16, _lib._sp) if isinstance(x, Pcm16) else (self.lib.mpx_esacf, _lib._fp)
+        self._check(fn(
+            self.ctx, x.ctypes.data_as(ptr), x.shape[0], int(fs), C.byref(p), int(frame), hop,
             frames.ctypes.data_as(_lib._dp) if return_frames and nf else None, total.ctypes.data_as(_lib._dp)))
         return (total, frames) if return_frames else total
 
@@ -279,12 +305,13 @@ class Engine:
             return (total, d_frames.cpu().numpy()) if return_frames else total
         total = np.zeros(12, dtype=np.float64)
         frames = np.zeros((nf, 12), dtype=np.float64) if return_frames else None
-        self._check(self.lib.mpx_iterative_f0(
-            self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p),
+        fn, ptr = (self.lib.mpx_iterative_f0_pcm16, _lib._sp) if isinstance(x, Pcm16) else (self.lib.mpx_iterative_f0, _lib._fp)
+        self._check(fn(
+            self.ctx, x.ctypes.data_as(ptr), x.shape[0], int(fs), C.byref(p),
             frames.ctypes.data_as(_lib._dp) if return_frames and nf else None, total.ctypes.data_as(_lib._dp)))
         return (total, frames) if return_frames else total
 
-    def iterative_f0_periodicity(self, spectra, fs, **kw):
+    def iterative_f0_periodicity(self, spectra, fs, return_voices=False, **kw):
         """The period search alone on summary spectra [F, 2 * frame_size] (or one row): per-frame chroma [F, 12] --
         mpx_iterative_f0_periodicity (periodicity.py:48-163)."""
         u = np.ascontiguousarray(np.atleast_2d(np.asarray(spectra, dtype=np.float64)))
@@ -293,6 +320,13 @@ class Engine:
         kw.setdefault("frame_size", u.shape[1] // 2)
         p = self._if0_params(**kw)
         out = np.zeros((u.shape[0], 12), dtype=np.float64)
+        if return_voices:   # periodicity.py:112: (voicesaliences, voiceperiods), one row of max_voices per frame
+            sal = np.zeros((u.shape[0], p.max_voices), dtype=np.float64)
+            per = np.zeros((u.shape[0], p.max_voices), dtype=np.float64)
+            self._check(self.lib.mpx_iterative_f0_periodicity_voices(
+                self.ctx, u.ctypes.data_as(_lib._dp), u.shape[0], u.shape[1], int(fs), C.byref(p), out.ctypes.data_as(_lib._dp),
+                sal.ctypes.data_as(_lib._dp), per.ctypes.data_as(_lib._dp)))
+            return out, sal, per
         self._check(self.lib.mpx_iterative_f0_periodicity(self.ctx, u.ctypes.data_as(_lib._dp), u.shape[0], u.shape[1], int(fs),
                                                           C.byref(p), out.ctypes.data_as(_lib._dp)))
         return out
@@ -345,8 +379,8 @@ class Engine:
         p = _lib.PrimeParams(num_harmonic, num_octave, harmonic_multiples_elim, harmonic_elim_runs,
                              self._notes(note_names))
         total = np.zeros(12, dtype=np.float64)
-        self._check(self.lib.mpx_prime_multif0(self.ctx, x.ctypes.data_as(_lib._fp), x.shape[0], int(fs), C.byref(p),
-                                               total.ctypes.data_as(_lib._dp)))
+        fn, ptr = (self.lib.mpx_prime_multif0_pcm16, _lib._sp) if isinstance(x, Pcm16) else (self.lib.mpx_prime_multif0, _lib._fp)
+        self._check(fn(self.ctx, x.ctypes.data_as(ptr), x.shape[0], int(fs), C.byref(p), total.ctypes.data_as(_lib._dp)))
         return total
 
     def prime_multif0_batch(self, clips, fs, num_harmonic=1, num_octave=2, harmonic_multiples_elim=5,

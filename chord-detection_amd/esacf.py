@@ -38,7 +38,7 @@ class MultipitchESACF(Multipitch):
 
     def compute_pitches(self, display_plot_frame=-1):
         total = get_engine(self.device).esacf(
-            self.x, self.fs, self.ham_samples, self.hop, self.n_peaks_elim, self.peak_thresh,
+            self._samples(), self.fs, self.ham_samples, self.hop, self.n_peaks_elim, self.peak_thresh,
             self.peak_min_dist, self.enhance_mode, note_names=self.note_names)
         return Chromagram(total)
 

@@ -17,7 +17,13 @@ class MultipitchHarmonicEnergy(Multipitch):
         self.num_octave = num_octave
         self.num_bins = num_bins
         self.hop = hop  # extension: overlapped frames (reference: hop == frame_size)
-        self.record_dft_maxes = True   # fill `dft_maxes` in compute_pitches like the reference does (a second, untuned launch)
+        # `dft_maxes` (harmonic_energy.py:36,65; its only reader is the reference's plot) is filled LAZILY: compute_pitches notes
+        # that the list is due, and the first read of the attribute runs the debug tap of the C ABI (mpx_harmonic_energy_argmax:
+        # a second copy of the signal and an untuned one-workgroup-per-frame launch) -- a caller that only wants the chromagram
+        # never pays for it.  `record_dft_maxes = False` switches the tap off altogether.
+        self.record_dft_maxes = True
+        self._dft_maxes = []
+        self._dft_maxes_due = False
 
     @staticmethod
     def display_name():
@@ -31,24 +37,36 @@ class MultipitchHarmonicEnergy(Multipitch):
         # display_plot_frame: accepted and ignored (matplotlib debugging aid in the reference)
         eng = get_engine(self.device)
         total = eng.harmonic_energy(
-            self.x, self.fs, self.frame_size, self.hop, self.num_harmonic, self.num_octave, self.num_bins)
-        # harmonic_energy.py:36,65: one (k0, best_ind, k1) per frame and window, in loop order; its only reader is the
-        # reference's plot.  Filled from the debug tap of the C ABI (mpx_harmonic_energy_argmax); switch it off with
-        # `record_dft_maxes = False` where only the chromagram is wanted.
-        self.dft_maxes = []
-        if self.record_dft_maxes and not hasattr(self.x, "is_cuda"):
+            self._samples(), self.fs, self.frame_size, self.hop, self.num_harmonic, self.num_octave, self.num_bins)
+        self._dft_maxes = []                       # the reference appends per call; a new call starts a new list here
+        self._dft_maxes_due = bool(self.record_dft_maxes)
+        return Chromagram(total)
+
+    @property
+    def dft_maxes(self):
+        """harmonic_energy.py:36,65: one (k0, best_ind, k1) per frame and window, in loop order, of the LAST compute_pitches call.
+        Nothing the tap raises reaches the caller: the chromagram was returned already and does not depend on it."""
+        if self._dft_maxes_due:
+            self._dft_maxes_due = False
+            import warnings
+            if hasattr(self.x, "is_cuda"):
+                warnings.warn("dft_maxes not recorded: the debug tap takes a host signal and this input is device-resident")
+                return self._dft_maxes
             try:
-                best, bounds = eng.harmonic_energy_argmax(self.x, self.fs, self.frame_size, self.hop, self.num_harmonic,
-                                                          self.num_octave, self.num_bins)
-            except NotImplementedError as e:   # a shape the (untuned) tap does not reach: the chromagram does not depend on it
-                import warnings
-                warnings.warn("dft_maxes not recorded: %s" % e)
-                return Chromagram(total)
+                best, bounds = get_engine(self.device).harmonic_energy_argmax(
+                    self.x, self.fs, self.frame_size, self.hop, self.num_harmonic, self.num_octave, self.num_bins)
+            except Exception as e:   # a shape the (untuned) tap does not reach, no memory for the second copy, ...
+                warnings.warn("dft_maxes not recorded: %s: %s" % (type(e).__name__, e))
+                return self._dft_maxes
             none = -2 ** 31
             for row in best:
-                self.dft_maxes.extend((int(k0), None if int(b) == none else int(b), int(k1))
-                                      for b, (k0, k1) in zip(row, bounds))
-        return Chromagram(total)
+                self._dft_maxes.extend((int(k0), None if int(b) == none else int(b), int(k1))
+                                       for b, (k0, k1) in zip(row, bounds))
+        return self._dft_maxes
+
+    @dft_maxes.setter
+    def dft_maxes(self, value):
+        self._dft_maxes, self._dft_maxes_due = value, False
 
     @classmethod
     def compute_batch(cls, clips, fs, frame_size=8192, num_harmonic=2, num_octave=2, num_bins=2, hop=None,

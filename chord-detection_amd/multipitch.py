@@ -52,12 +52,38 @@ class Multipitch(object):
             self.clip_name = "<array>"
         else:
             from . import audio
-            x, self.fs = audio.load(audio_path)
             self.clip_name = Path(audio_path).name
+            pcm = audio.load_pcm16(audio_path)
+            if pcm is not None:
+                # a mono PCM_16 file at the methods' rate (what gen_test_clips.py writes and librosa.load reads back as
+                # int16 / 32768, multipitch.py:24-30): the int16 samples go to the device as they are and are scaled there
+                # (include/mpx.h "PCM_16 input"); `self.x` is the float32 view the reference's attribute holds, made on demand
+                from .engine import Pcm16
+                self._pcm16, self.fs = Pcm16(pcm[0]), pcm[1]
+                self._x = None
+                self.device = device
+                return
+            x, self.fs = audio.load(audio_path)
         if len(x.shape) != 1:
             raise ValueError("Only 1D numpy ndarrays are supported")
         self.x = numpy.ascontiguousarray(x, dtype=numpy.float32)
         self.device = device
+
+    _pcm16 = None
+
+    @property
+    def x(self):
+        if self._x is None and self._pcm16 is not None:
+            self._x = self._pcm16.float32()
+        return self._x
+
+    @x.setter
+    def x(self, value):
+        self._x, self._pcm16 = value, None   # samples assigned by the caller replace the file's
+
+    def _samples(self):
+        """what compute_pitches hands the engine: the file's int16 samples when there are any, else `self.x`"""
+        return self._pcm16 if self._pcm16 is not None else self._x
 
     @abstractmethod
     def compute_pitches(self):

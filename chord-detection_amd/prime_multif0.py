@@ -32,7 +32,7 @@ class MultipitchPrimeMultiF0(Multipitch):
 
     def compute_pitches(self, display_plot_frame=-1):
         total = get_engine(self.device).prime_multif0(
-            self.x, self.fs, self.num_harmonic, self.num_octave, self.harmonic_multiples_elim,
+            self._samples(), self.fs, self.num_harmonic, self.num_octave, self.harmonic_multiples_elim,
             self.harmonic_elim_runs, note_names=self.note_names)
         return Chromagram(total)
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MPX_ABI_VERSION 5
+#define MPX_ABI_VERSION 6
 
 typedef enum mpx_status {
     MPX_OK = 0,
@@ -297,6 +297,30 @@ int mpx_iterative_f0_spectra(mpx_ctx* ctx, const float* signal, int64_t n, int f
  * Of `params` the period-search fields, frame_size and note_names are read. */
 int mpx_iterative_f0_periodicity(mpx_ctx* ctx, const double* spectra, int64_t num_frames, int bins, int fs,
                                  const mpx_if0_params* params, double* chroma_frames);
+/* ABI 6: the same search, also returning what periodicity.py:112 returns next to the chromagram --
+ * `(self.voicesaliences.copy(), self.voiceperiods.copy())`: saliences[num_frames, max_voices] and
+ * periods[num_frames, max_voices] (seconds; 0 for a voice the search did not detect, periodicity.py:56-57,63-67).
+ * Either may be NULL. */
+int mpx_iterative_f0_periodicity_voices(mpx_ctx* ctx, const double* spectra, int64_t num_frames, int bins, int fs,
+                                        const mpx_if0_params* params, double* chroma_frames, double* saliences,
+                                        double* periods);
+
+/* ---- PCM_16 input (ABI 6) -------------------------------------------------------
+ * The reference's audio is 16-bit PCM: librosa.load (multipitch.py:24-30) hands the methods `int16 / 32768` as float32.
+ * These entry points take the int16 samples as the WAV file holds them (host memory, pageable or pinned; or memory of the
+ * context's device) and convert x / 32768 ON THE DEVICE -- exact in float32 (16 significant bits, a power-of-two divisor) --
+ * so HALF the bytes cross PCIe and the results are bit-equal to the float32 entry points fed `pcm / 32768.0f`
+ * (tests/test_gpu_pcm16.py).  Same arguments, outputs and errors as mpx_harmonic_energy / mpx_esacf / mpx_prime_multif0 /
+ * mpx_iterative_f0 otherwise.  Use them when the file is mono PCM_16 at the rate the method runs at; anything that has to be
+ * resampled or down-mixed goes through the float32 entry points. */
+int mpx_harmonic_energy_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_he_params* params,
+                              int frame, int hop, double* chroma_frames, double* chroma_sum);
+int mpx_esacf_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_esacf_params* params, int frame,
+                    int hop, double* chroma_frames, double* chroma_sum);
+int mpx_prime_multif0_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_prime_params* params,
+                            double* chroma_sum);
+int mpx_iterative_f0_pcm16(mpx_ctx* ctx, const int16_t* pcm, int64_t n, int fs, const mpx_if0_params* params,
+                           double* chroma_frames /* [F,12] or NULL */, double* chroma_sum /* [12] */);
 
 /* Debug taps for parity tests: per-frame intermediates of the ESACF chain,
  * host buffers, each [F, len]:

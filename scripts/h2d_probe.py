@@ -36,6 +36,16 @@ for label, src in (("pageable", x_host), ("pinned", x_pin), ("device_through_hos
     s, r = timed(lambda: eng.harmonic_energy(src, FS, N, HOP))
     assert np.array_equal(r, ref), label
     out[label] = {"ms": 1e3 * s, "frames_per_s": 8192 / s, "GB_per_s": mb / 1e3 / s}
+# the same signal as 16-bit PCM (what the reference's WAV files hold): half the bytes over PCIe, x / 32768 on the device
+# (include/mpx.h "PCM_16 input"); the chroma must equal the float32 entry point's on the same quantised samples bit for bit
+pcm = np.clip(np.round(x_host.astype(np.float64) * 32768.0), -32768, 32767).astype(np.int16)
+pcm_pin = cd.pinned_empty(pcm.shape[0], dtype=np.int16)
+pcm_pin[:] = pcm
+ref16 = eng.harmonic_energy(pcm.astype(np.float32) / np.float32(32768.0), FS, N, HOP)
+for label, src in (("pcm16_pageable", pcm), ("pcm16_pinned", pcm_pin)):
+    s, r = timed(lambda: eng.harmonic_energy(cd.Pcm16(src), FS, N, HOP))
+    assert np.array_equal(r, ref16), label
+    out[label] = {"ms": 1e3 * s, "frames_per_s": 8192 / s, "GB_per_s": pcm.nbytes / 1e9 / s, "bytes": int(pcm.nbytes)}
 d_sum = torch.zeros(12, dtype=torch.float64, device=dev)
 def resident():
     eng.harmonic_energy_dev(x_dev.data_ptr(), n, FS, N, HOP, None, d_sum.data_ptr())

@@ -35,7 +35,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_version_and_frame_math(lib):
-    assert lib.mpx_abi_version() == 5
+    assert lib.mpx_abi_version() == 6
     assert lib.mpx_dev_knobs() == 0      # the release build: no result-changing environment switches compiled in
     assert lib.mpx_num_frames(44100, 1023, 1023) == 44
     assert lib.mpx_num_frames(44100, 8192, 8192) == 6

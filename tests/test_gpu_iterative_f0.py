@@ -85,7 +85,7 @@ def test_spectra_and_batch_vs_oracle(eng, clips):
 
 def test_periodicity_estimator_attribute(eng, clips):
     """iterative_f0.py:44: MultipitchIterativeF0.periodicity_estimator is an IterativeF0PeriodicityAnalysis whose
-    compute(Uk) -> (Chromagram, salience_plots) runs the period search on one summary spectrum (periodicity.py:48-163):
+    compute(Uk) -> (Chromagram, (voicesaliences, voiceperiods)) runs the period search on one summary spectrum (periodicity.py:48-163):
     here on the oracle's summary spectra, frame by frame, against the oracle's period search, both spellings; and on the
     engine's own spectra against the engine's per-frame rows."""
     import chord_detection_amd as cd
@@ -98,10 +98,24 @@ def test_periodicity_estimator_attribute(eng, clips):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             wper, wut = o_if0.iterative_f0_frames(x, FS, note_names=mode)
+        o_est = o_if0.Periodicity(FS, 8192, note_names=mode)   # one object for the clip, like iterative_f0_frames (smax leaks)
         for f in range(wut.shape[0]):
             c, plots = est.compute(wut[f])
-            assert plots == [] and len(c) == 12
+            assert len(c) == 12
             np.testing.assert_allclose(c.as_array(), wper[f], rtol=1e-5, atol=1e-300)
+            # periodicity.py:112: (voicesaliences.copy(), voiceperiods.copy()) -- max_voices entries each, zeros for the voices
+            # the search did not find; also attributes of the estimator, like the reference's
+            sal, per = plots
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                _, wsal, wtau = o_est.compute(wut[f])
+            assert sal.shape == per.shape == (4,)
+            np.testing.assert_allclose(sal, wsal, rtol=1e-5, atol=1e-300)
+            np.testing.assert_allclose(per, wtau, rtol=1e-9, atol=0)
+            assert np.array_equal(est.voicesaliences, sal) and np.array_equal(est.voiceperiods, per)
+            assert np.array_equal(per == 0, wtau == 0) and (per[0] > 0)
+        with pytest.raises(ValueError):
+            est.compute(wut[:2])                      # periodicity.py:48 takes ONE spectrum
         ut = eng.iterative_f0_spectra(x, FS)
         _, per = eng.iterative_f0(x, FS, return_frames=True, note_names=mode)
         np.testing.assert_array_equal(eng.iterative_f0_periodicity(ut, FS, note_names=mode), per)

@@ -2,8 +2,9 @@
 one Newton step and the residual step, 7 and 10 instructions where the compiler's IEEE sequences are 12 and 17) against IEEE
 division and square root (NumPy), through the C ABI's mpx_test_lm_div_sqrt.  The reference's MINPACK divides and takes
 roots correctly rounded; these are held to: the same bits on every operand pair of a million drawn over 2^-300 ... 2^300,
-IEEE's answers for zero, infinite and NaN operands, and <= 1e-9 relative towards the ends of the exponent range (no range
-scaling: documented in the header)."""
+IEEE's answers for zero, infinite and NaN operands, <= 1e-9 relative towards the ends of the exponent range (no range
+scaling: documented in the header), and -- asserted, not masked -- the two corners where lm_div is NOT IEEE: a finite quotient
+that overflows and a subnormal divisor both give NaN."""
 import ctypes as C
 
 import numpy as np
@@ -80,3 +81,27 @@ def test_towards_the_ends_of_the_exponent_range(eng):
     assert np.all(np.abs(q[fin] - wq[fin]) <= 1e-9 * np.abs(wq[fin]))
     assert np.all(np.abs(r - wr) <= 1e-9 * wr)
     assert eng.lib.mpx_test_lm_div_sqrt(eng.ctx, None, None, 4, None, None) == -1
+
+
+def test_the_two_documented_corners_where_lm_div_is_not_ieee(eng):
+    """csrc/mpx_lm.hpp states them: (1) a finite a / b that overflows -> NaN (IEEE: +-inf); (2) a subnormal divisor -> NaN (IEEE: a
+    finite quotient or +-inf).  If either starts answering as IEEE does (a select or range scaling was added) this test says so:
+    update the header with it.  Everything next to the corners still answers as IEEE."""
+    big, tiny, sub = 1e300, 1e-300, 5e-310          # sub: subnormal (< 2.2e-308)
+    a = np.array([big, -big, 1e-300, 1.0, -2.0], dtype=np.float64)
+    b = np.array([tiny, tiny, sub, sub, -sub], dtype=np.float64)
+    with np.errstate(all="ignore"):
+        ieee = a / b
+    assert np.array_equal(np.isinf(ieee), [True, True, False, True, True]) and ieee[2] == 1e-300 / 5e-310
+    q, _ = _run(eng, a, b)
+    print("lm_div corners: a", a, "b", b, "->", q, "(IEEE:", ieee, ")")
+    assert np.all(np.isnan(q)), q                                          # the documented divergence
+    # the neighbours of the corners: quotients just inside the range, the smallest NORMAL divisor, a zero divisor
+    a2 = np.array([1e300, 1e-300, 3.0, 1.0, -1.0], dtype=np.float64)
+    b2 = np.array([1e-7, 2.3e-308, 2.3e-308 * 4, 0.0, 0.0], dtype=np.float64)
+    q2, _ = _run(eng, a2, b2)
+    with np.errstate(all="ignore"):
+        w2 = a2 / b2
+    assert np.array_equal(np.isinf(q2), np.isinf(w2)) and np.array_equal(np.signbit(q2), np.signbit(w2)), (q2, w2)
+    fin = np.isfinite(w2)
+    assert np.all(np.abs(q2[fin] - w2[fin]) <= 1e-9 * np.abs(w2[fin])), (q2, w2)
