@@ -31,18 +31,18 @@ constexpr double DWARF = 2.2250738585072014e-308;
 // residual step -- q = a y, then q + (a - b q) y; g = x y, then g + (x - g^2) h -- 7 and 10 instructions: correctly rounded on
 // every operand pair tried over 2^-300 ... 2^300 (tests/test_gpu_lm_div_sqrt.py holds that bit for bit), with zero, infinite and
 // NaN operands answered as IEEE does (v_div_fixup; the select in lm_sqrt).
-// NO RANGE SCALING, and two corners where the result is NOT IEEE's (asserted, not masked, by the same test):
-//   (1) a finite a / b whose quotient overflows: q = a y = +-inf, the residual step computes inf - inf, and lm_div returns NaN
-//       where IEEE returns +-inf;
-//   (2) a subnormal divisor (|b| < 2^-1022): v_rcp_f64 returns +-inf, the Newton step inf - inf, and lm_div returns NaN where
-//       IEEE returns a finite quotient or +-inf (a ZERO divisor is answered by v_div_fixup as IEEE does);
+// NO RANGE SCALING.  What that costs, measured on MI355X and asserted (not masked) by the same test:
+//   (1) a finite a / b whose quotient overflows: the residual step computes inf - inf = NaN, but v_div_fixup_f64 looks at the
+//       operands' exponents and returns +-inf -- as IEEE does;
+//   (2) a SUBNORMAL divisor (|b| < 2^-1022): v_rcp_f64 returns +-inf, the Newton step NaN, and v_div_fixup_f64 treats the divisor
+//       as zero: lm_div returns +-inf (the sign is IEEE's) where IEEE returns a finite quotient when the numerator is small
+//       enough (1e-300 / 5e-310 = 2e9).  THE ONE DIVERGENCE FROM IEEE DIVISION;
 //   and operands within ~2^-970 of the ends of the exponent range lose bits (the intermediate 1/b or x y underflows).
-// A select on the residual step would repair (1) and cost two instructions on the dependent path of each of the ~90 quotients of a
-// trip (7 -> 9: ~6 % of a cooperative trip); (2) needs the range scaling this form exists to avoid.  Neither corner is reachable
-// from a fit that MINPACK would accept: amplitudes are <= 1 lag-domain heights, widths and centres are lags (|x| < 1e6 even in
-// the runaway fits, which stop at maxfev), the smallest divisors are the jacobian steps eps |x| >= 1e-8 |x| and 2 s^2 + 2.2e-16;
-// a fit whose state reaches 1e+-300 is one the reference drops (curve_fit raises or returns a centre that maps to no pitch), and a
-// NaN here drops it as well (no convergence test passes on NaN).
+// (2) needs the range scaling this form exists to avoid (7 instructions where the compiler's IEEE sequence is 12, ~90 quotients on
+// the dependent path of a trip).  It is not reachable from a fit that MINPACK would accept: amplitudes are lag-domain heights
+// <= 1, widths and centres are lags (|x| < 1e6 even in the runaway fits, which stop at maxfev), the smallest divisors are the
+// jacobian steps eps |x| >= 1e-8 |x| and 2 s^2 + 2.2e-16; a fit whose state reaches 1e-308 is one the reference drops, and an
+// infinite quotient drops it here as well (no convergence test passes on inf or NaN).
 MPX_HD inline double lm_div(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rcp(b);       // 25 bits

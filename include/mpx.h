@@ -90,15 +90,19 @@ void* mpx_stream(mpx_ctx* ctx);
  *                                Default 32 GiB, minimum 64 MiB.
  *   MPX_OPT_HE_KERNEL            MPX_HE_KERNEL_AUTO (default): 4096- and 8192-sample fp64 frames with <= 256 window bins (none of
  *                                them wrapping below bin 0) run on the wave-per-frame kernel (csrc/mpx_he_wave.hpp),
- *                                everything else on the workgroup-per-frame kernel.  An 8192-sample frame is two passes of
- *                                one wave over interleaved halves of its samples; MPX_HE_KERNEL_WAVE_PAIRS gives the
- *                                passes to two waves at the same time instead (A/B; 4096-sample frames are not affected).  MPX_HE_KERNEL_WORKGROUP: the workgroup-per-frame kernel for every shape (A/B).
+ *                                everything else on the workgroup-per-frame kernel.  An 8192-sample frame is two passes
+ *                                over interleaved halves of its samples: of ONE wave when the call's samples fit the L2
+ *                                (< 32 MiB), of a PAIR of waves at the same time -- every cache line fetched once instead of
+ *                                twice, the same time -- when they are streamed.  MPX_HE_KERNEL_WAVE_PAIRS forces the pairs,
+ *                                MPX_HE_KERNEL_WAVE_SERIAL one wave per frame (A/B; same bits; 4096-sample frames are not
+ *                                affected).  MPX_HE_KERNEL_WORKGROUP: the workgroup-per-frame kernel for every shape (A/B).
  * mpx_set_option returns MPX_EINVAL for an unknown option or a value out of range. */
 #define MPX_OPT_IF0_WORKSPACE_BYTES 1
 #define MPX_OPT_HE_KERNEL 2
 #define MPX_HE_KERNEL_AUTO 0
 #define MPX_HE_KERNEL_WORKGROUP 1
-#define MPX_HE_KERNEL_WAVE_PAIRS 2   /* 8192-sample frames: a pair of waves per frame, one per half of the samples (A/B) */
+#define MPX_HE_KERNEL_WAVE_PAIRS 2   /* 8192-sample frames: a pair of waves per frame, one per half of the samples, whatever the size of the call */
+#define MPX_HE_KERNEL_WAVE_SERIAL 3  /* 8192-sample frames: one wave per frame (two passes), whatever the size of the call */
 int mpx_set_option(mpx_ctx* ctx, int option, int64_t value);
 int mpx_get_option(mpx_ctx* ctx, int option, int64_t* value);
 
