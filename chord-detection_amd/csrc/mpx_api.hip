@@ -418,63 +418,6 @@ static void pcm16_convert(const int16_t* d_pcm, long long n, float* d_out, hipSt
         hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, d_pcm, n, d_out);
 }
 
-// Harmonic Energy on a HOST signal of 4096-sample frames (the headline shape as a caller of the reference hands it over): the
-// copy in `pieces` pieces on the copy stream, the frames whose samples have arrived computed next to the copy of the next piece
-// (mpx_he.hip: he_rows_range / he_rows_sum -- the bits of the one-launch path).  *done = false: not this shape, nothing enqueued.
-static int he_host_pieces(mpx_ctx* ctx, const void* src, bool pcm16, int64_t n, int fs, const mpx_he_params* params, int frame,
-                          int hop, bool want_rows, bool* done) {
-    *done = false;
-    const int64_t nf = num_frames_of(n, frame, hop);
-    const size_t sample_bytes = pcm16 ? sizeof(int16_t) : sizeof(float);
-    // worth it from ~8 MB of copy on (a piece must outlast its own launch overheads), and only with frames to spread
-    if ((size_t)n * sample_bytes < ((size_t)8 << 20) || nf < 64 || ctx->copy_pieces < 2) return MPX_OK;
-    {   // host memory only: a signal already in HBM has no copy to hide
-        hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, src) == hipSuccess) {
-            if (attr.type == hipMemoryTypeDevice) return MPX_OK;
-        } else {
-            (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
-        }
-    }
-    if (!he_pieces_ok(ctx, fs, params, frame, hop) || !copy_stream_ready(ctx)) return MPX_OK;
-    int rc;
-    if (pcm16 && (rc = ensure(ctx, ctx->d_pcm, (size_t)n * sizeof(int16_t) + 16))) return rc;
-    const int pieces = ctx->copy_pieces;
-    float* d_sig = (float*)ctx->d_signal.p;
-    double* d_rows = (double*)ctx->d_frames_out.p;
-    hipStream_t st = ctx->stream;
-    // the staging buffers may still be read by work queued earlier on the compute stream
-    MPX_HIP(ctx, hipEventRecord(ctx->copy_ev[7], st));
-    MPX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->copy_ev[7], 0));
-    const bool whole_fast = (nf - 1) * (int64_t)hop + frame <= n;
-    int64_t s0 = 0, f0 = 0;
-    for (int k = 0; k < pieces; ++k) {
-        // piece boundaries on multiples of 8 samples (the converter's 16-byte groups, the kernels' 8-byte loads)
-        const int64_t s1 = k + 1 == pieces ? n : ((n / pieces * (k + 1)) & ~(int64_t)7);
-        if (s1 > s0) {
-            if (pcm16)
-                MPX_HIP(ctx, hipMemcpyAsync((int16_t*)ctx->d_pcm.p + s0, (const int16_t*)src + s0, (size_t)(s1 - s0) * sizeof(int16_t),
-                                            hipMemcpyDefault, ctx->copy_stream));
-            else
-                MPX_HIP(ctx, hipMemcpyAsync(d_sig + s0, (const float*)src + s0, (size_t)(s1 - s0) * sizeof(float), hipMemcpyDefault,
-                                            ctx->copy_stream));
-        }
-        MPX_HIP(ctx, hipEventRecord(ctx->copy_ev[k], ctx->copy_stream));
-        MPX_HIP(ctx, hipStreamWaitEvent(st, ctx->copy_ev[k], 0));
-        if (pcm16 && s1 > s0) pcm16_convert((const int16_t*)ctx->d_pcm.p + s0, s1 - s0, d_sig + s0, st);
-        // the frames that end inside the samples copied so far (the last piece: every frame left, the padded one included)
-        int64_t f1 = k + 1 == pieces ? nf : (s1 >= frame ? (s1 - frame) / hop + 1 : 0);
-        if (f1 > nf) f1 = nf;
-        if (f1 > f0 && (rc = he_rows_range(ctx, d_sig, n, fs, params, hop, f0, f1, whole_fast, d_rows, st))) return rc;
-        if (f1 > f0) f0 = f1;
-        s0 = s1;
-    }
-    if ((rc = he_rows_sum(ctx, d_rows, nf, (double*)ctx->d_sum.p, st))) return rc;
-    (void)want_rows;
-    *done = true;
-    return MPX_OK;
-}
-
 // int16 samples (host or device memory) -> float32 in `d_out` (device), on `st`: the copy moves 2 bytes per sample
 static int pcm16_stage(mpx_ctx* ctx, const int16_t* pcm, int64_t n, float* d_out, hipStream_t st) {
     if (!n) return MPX_OK;
@@ -496,20 +439,18 @@ static int method_host(mpx_ctx* ctx, run_fn run, const void* signal_any, bool pc
     if ((rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
-    bool piecewise = false;
-    if (run == run_he && (rc = he_host_pieces(ctx, signal_any, pcm16, n, fs, (const mpx_he_params*)params, frame, hop,
-                                              chroma_frames != nullptr, &piecewise)))
+    // (Round 6 measured the copy of a long host signal in four pieces with the frames that had arrived computed under the next
+    // piece's copy -- rows and sum bit-equal to this path: SLOWER, 0.69 -> 0.73 ms for the 33.5 MB headline signal and 0.39 ->
+    // 0.44 ms as PCM_16: the 0.04 ms of kernels it can hide are less than four copies, events and launches cost;
+    // profiles/r6/h2d_probe_copy_in_pieces_rejected.json.  Removed.)
+    if (pcm16) {
+        if ((rc = pcm16_stage(ctx, (const int16_t*)signal_any, n, (float*)ctx->d_signal.p, ctx->stream))) return rc;
+    } else if (n && (rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) {
         return rc;
-    if (!piecewise) {
-        if (pcm16) {
-            if ((rc = pcm16_stage(ctx, (const int16_t*)signal_any, n, (float*)ctx->d_signal.p, ctx->stream))) return rc;
-        } else if (n && (rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) {
-            return rc;
-        }
-        rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
-                        chroma_frames ? (double*)ctx->d_frames_out.p : nullptr, (double*)ctx->d_sum.p, ctx->stream);
-        if (rc) return rc;
     }
+    rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
+                    chroma_frames ? (double*)ctx->d_frames_out.p : nullptr, (double*)ctx->d_sum.p, ctx->stream);
+    if (rc) return rc;
     MPX_HIP(ctx, hipMemcpyAsync(chroma_sum, ctx->d_sum.p, 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (chroma_frames && nf)
         MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nf * 12 * sizeof(double),

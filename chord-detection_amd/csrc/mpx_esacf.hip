@@ -603,7 +603,10 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
             const int lo = i - 10 > 0 ? i - 10 : 0, hi = i + 11 < Mh ? i + 11 : Mh;
             double mxw = yv[lo];
             for (int n = lo + 1; n < hi; ++n) mxw = yv[n] > mxw ? yv[n] : mxw;
-            lng = mxw > yv[i] || hi - lo < 21;
+            // ... and (round 6) the peaks with a window EDGE at 0.78 of the peak's height or more: 96 % of the runaway fits the
+            // first rule misses (a slope that keeps rising out of the window), 18 % of the other peaks.  Only the ORDER of the
+            // work list depends on this: every fit that may run away starts in the kernel's first trips.
+            lng = mxw > yv[i] || hi - lo < 21 || fmax(yv[lo], yv[hi - 1]) >= 0.78 * yv[i];
         }
         const u64 bk = __ballot(kept), bl = __ballot(lng);
         if (lane == 0) {
@@ -2183,6 +2186,7 @@ constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinis
 constexpr int COOP_THREADS = 256, COOP_PAD_KB = 84;   // the cooperative kernels: one workgroup of four waves per CU (a wave per SIMD), held apart by unused LDS (more than half of the 160 KB; what is left takes a 64 KB workgroup of another context)
 constexpr int COOP_SPLIT = 4096;        // parked lists longer than this -- more than a wave per SIMD at four fits each -- run eight fits to a wave (coopfit8_kernel)
 constexpr int COOP_PASS1_TRIPS = 24;   // coopfit_kernel, first pass: trips after which a fit still open is parked again
+constexpr int EARLY_PARK_NFEV = 20, EARLY_PARK_CAP = 12288, EARLY_PARK_MAX_FRAMES = 16384;   // round 6: fits that look like runaways leave the lane kernel at once (batches of at most this many frames; peakfit_kernel)
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
 // Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
@@ -2899,7 +2903,8 @@ template <bool SAMPLES_IN_LDS>
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
     const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
     int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
-    double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev, int park_live, int park_cap) {
+    double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev, int park_live, int park_cap,
+    int early_nfev, int early_cap) {
     using namespace lm;
     __shared__ double sh[MAXM * FIT_THREADS];
     __shared__ double sh_rq[9 * FIT_THREADS];
@@ -2924,6 +2929,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     unsigned my_evals = 0;   // statistics: MINPACK function evaluations this lane has run
     bool drained = false;  // wave-uniform: some lane has found the work list empty
     bool cap_hit = false;  // wave-uniform: the cooperative kernel is full, park only from a thinned-out wave
+    bool early_full = false;   // this lane has seen the early-parking budget of the batch used up
     // per-fit state
     const double* row = y;
     double x0 = 0.0, x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1};
@@ -2990,6 +2996,19 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             may_park = !cap_hit && atomicAdd(parked_count + 2, 1) < park_cap;
             cap_hit = cap_hit || __any(!may_park);
         }
+        // Round 6, small batches (early_nfev > 0): a fit that LOOKS like a runaway -- its width or the distance of its centre from
+        // the peak has left everything a converging fit visits (40 lags; oracle statistics over 10 299 fits of the Target's
+        // signal: every fit that burns maxfev shows it by evaluation 93, 90 % by 41, and 5 % of the others, slow ones, do too)
+        // -- is handed to the cooperative kernel at once, list drained or not: a wave no longer carries such lanes for forty
+        // trips, and the kernel ends when its ordinary fits do.  Which kernel runs which evaluation is pure scheduling (one
+        // arithmetic, see above): the bits do not depend on it.  Bounded by a counter of its own.
+        bool early_park = false;   // parked with the list not drained: the lane fetches its next fit
+        if (early_nfev > 0 && !may_park && phase == FIT_OUTER && nfev >= early_nfev && parked != nullptr && !early_full &&
+            (fabs(x[2]) > 40.0 || fabs(x[1] - (x0 + 10.0)) > 40.0)) {
+            may_park = atomicAdd(parked_count + 7, 1) < early_cap;
+            early_full = !may_park;
+            early_park = may_park;
+        }
         if (may_park) {
             ParkedFit pf;
             pf.out = out;
@@ -3010,7 +3029,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             pf.pad = 0;
             parked[atomicAdd(parked_count, 1)] = pf;
             my_evals += (unsigned)nfev;
-            phase = FIT_DONE;
+            phase = early_park ? FIT_NEED_WORK : FIT_DONE;
         }
         if (__all(phase == FIT_DONE)) break;
 
@@ -3871,7 +3890,8 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     if ((rc = ensure(ctx, ctx->d_ws0, (size_t)((batch + 63) / 64) * ((N + BS_TILE - 1) / BS_TILE) * 64 * BS_TILE * 16))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws1, (size_t)batch * Mh * 8 + 64))) return rc;              // y
     const long long fit_resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));  // blocks
-    const size_t park_bytes = 2 * (size_t)fit_resident * FIT_THREADS * sizeof(ParkedFit);  // at most one parked fit per lane; a second list for coopfit_kernel's second pass
+    const size_t park_slots = (size_t)fit_resident * FIT_THREADS + EARLY_PARK_CAP;   // at most one end-game park per lane, and the early ones of a small batch
+    const size_t park_bytes = 2 * park_slots * sizeof(ParkedFit);  // a second list for coopfit_kernel's second pass
     if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 256 + park_bytes))) return rc;
     cx<double>* xb = (cx<double>*)ctx->d_ws0.p;
     double* y = (double*)ctx->d_ws1.p;
@@ -3883,7 +3903,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     int* peak_count = worklist + (size_t)batch * maxp;
     int* total = peak_count + batch;  // counters, see SacfArgs::total_peaks; [3] parked fits, [4] next parked fit, [8] fits parked again, [9] next of those
     ParkedFit* parked = reinterpret_cast<ParkedFit*>(((uintptr_t)(total + 16) + 63) & ~(uintptr_t)63);
-    ParkedFit* parked2 = parked + (size_t)fit_resident * FIT_THREADS;
+    ParkedFit* parked2 = parked + park_slots;
 
     for (long long f0 = 0; f0 < num_frames; f0 += batch) {
         const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
@@ -4101,7 +4121,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, dev_env_int("MPX_FIT_PARK_NFEV", nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
                                dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),
-                               dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP));
+                               dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP),
+                               park ? dev_env_int("MPX_FIT_EARLY_NFEV", nf <= EARLY_PARK_MAX_FRAMES ? EARLY_PARK_NFEV : 0) : 0,
+                               std::min(dev_env_int("MPX_FIT_EARLY_CAP", EARLY_PARK_CAP), EARLY_PARK_CAP));
             if (park) prof_mark(ctx, st, "coopfit_kernel");
             if (park) {  // the runaway fits still open when the list ran dry: eight lanes each (coopfit8_kernel), all at once
                 // Lists of up to COOP_SPLIT fits go to coopfit_kernel (16 lanes per fit: four to a wave), longer ones to

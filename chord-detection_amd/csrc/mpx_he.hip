@@ -628,7 +628,7 @@ static bool he_wave_applies(const mpx_ctx* ctx, const HePlan& plan) {
 }
 template <int HALVES>
 static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signal, int64_t n, const FrameDesc* d_desc,
-                          int64_t num_frames, int hop, double* d_out, double* d_sum, hipStream_t stream, int fast_mode = -1) {
+                          int64_t num_frames, int hop, double* d_out, double* d_sum, hipStream_t stream) {
     constexpr int N = 4096 * HALVES;
     // 8192-sample frames: both passes of a frame on ONE wave (seven per CU) by default; MPX_OPT_HE_KERNEL =
     // MPX_HE_KERNEL_WAVE_PAIRS gives a frame to TWO waves (three pairs per CU), one per pass -- same bits.  Measured (round 5,
@@ -712,11 +712,8 @@ static int he_wave_launch(mpx_ctx* ctx, const HePlan& plan, const float* d_signa
                        (paired ? (size_t)(WAVES / 2) * 64 * HEW_ROUNDS * sizeof(cx<double>) + 64 : 0);
     // every frame whole, inside the signal and (float2 loads of the 4096 kernel) 8-byte aligned: the instantiation without the
     // ragged loader (no scratch)
-    // (fast_mode >= 0: the caller launches a RANGE of a longer call's frames -- he_rows_range -- and names the instantiation the
-    // whole call would run, so that a frame's row does not depend on how the call was cut)
-    const bool all_fast = fast_mode >= 0 ? fast_mode != 0
-                                         : !d_desc && (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0 &&
-                                               (num_frames - 1) * (long long)hop + N <= n;
+    const bool all_fast = !d_desc && (hop & 1) == 0 && (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0 &&
+                          (num_frames - 1) * (long long)hop + N <= n;
     using kern_t = void (*)(HeWaveArgs, cx<double>*);
     kern_t kern;
     const char* okey;
@@ -1260,71 +1257,6 @@ int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_de
     }
     return f32 ? he_dispatch<float>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, d_chroma_sum, stream)
                : he_dispatch<double>(ctx, it->second, d_signal, n, d_desc, num_frames, frame, hop, d_chroma_frames, d_chroma_sum, stream);
-}
-
-// ---- a HOST signal of 4096-sample frames, its copy cut in pieces (round 6; mpx_api.hip: method_host) --------------------
-// The headline shape handed over as host memory is a PCIe copy (0.33 ms as PCM_16, 0.67 ms as float32) with 0.05 ms of kernels
-// behind it.  Cut in pieces, the frames whose samples have arrived run next to the copy of the next piece.  A frame's row does
-// not depend on the launch that computes it; the SUM over frames is taken in the order of the one-launch path -- per workgroup
-// run of ceil(F / g) rows, sixteen strided sub-sums per bin, then sum_all_kernel over the g runs -- by he_rows_sum below, so the
-// call returns the bits of the one-launch path (tests/test_gpu_pcm16.py, test_gpu_harmonic_energy.py).
-bool he_pieces_ok(mpx_ctx* ctx, int fs, const mpx_he_params* params, int frame, int hop) {
-    if ((ctx->flags & MPX_FLAG_F32) || frame != 4096 || fs <= 0 || (hop & 1)) return false;
-    const mpx_he_params p = params ? *params : mpx_he_params{2, 2, 2};
-    if (p.num_harmonic < 1 || p.num_octave < 1 || p.num_bins < 0 || p.num_harmonic * p.num_octave > 64) return false;
-    auto key = std::make_tuple(fs, frame, p.num_harmonic, p.num_octave, p.num_bins);
-    auto it = ctx->he_plans.find(key);
-    if (it == ctx->he_plans.end()) {
-        HePlan plan;
-        if (he_build_plan<double>(ctx, fs, frame, p, plan)) return false;   // (the one-launch path reports the error)
-        it = ctx->he_plans.emplace(key, plan).first;
-    }
-    return he_wave_applies(ctx, it->second);
-}
-
-// rows [f0, f1) of a call of `num_frames` frames over d_signal[0, n): whole_fast = the whole call's frames are all inside the signal
-int he_rows_range(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_he_params* params, int hop, int64_t f0,
-                  int64_t f1, bool whole_fast, double* d_rows, hipStream_t stream) {
-    const mpx_he_params p = params ? *params : mpx_he_params{2, 2, 2};
-    auto it = ctx->he_plans.find(std::make_tuple(fs, 4096, p.num_harmonic, p.num_octave, p.num_bins));
-    if (it == ctx->he_plans.end()) return set_error(ctx, MPX_EHIP, "internal: he_rows_range without he_pieces_ok");
-    if (f1 <= f0) return MPX_OK;
-    const bool aligned = (reinterpret_cast<uintptr_t>(d_signal) & 7) == 0;
-    return he_wave_launch<1>(ctx, it->second, d_signal + f0 * hop, n - f0 * hop, nullptr, f1 - f0, hop, d_rows + f0 * 12, nullptr,
-                             stream, whole_fast && aligned ? 1 : 0);
-}
-
-// he_wave_kernel's own sum of a workgroup's rows (mpx_he_wave.hpp, `a.partial`): the same additions in the same order
-__global__ __launch_bounds__(192) void he_rows_partial_kernel(const double* __restrict__ rows, long long num_frames, long long per,
-                                                             double* __restrict__ partial) {
-    __shared__ double sh[16 * 12];
-    const int tid = threadIdx.x, bin = tid % 12, sub = tid / 12;
-    const long long g0 = (long long)blockIdx.x * per;
-    long long g1 = g0 + per;
-    if (g1 > num_frames) g1 = num_frames;
-    double t = 0.0;
-    for (long long f = g0 + sub; f < g1; f += 16) t += rows[f * 12 + bin];
-    sh[sub * 12 + bin] = t;
-    __syncthreads();
-    if (tid < 12) {
-        double u = 0.0;
-        for (int j = 0; j < 16; ++j) u += sh[j * 12 + tid];
-        partial[(long long)blockIdx.x * 12 + tid] = u;
-    }
-}
-
-int he_rows_sum(mpx_ctx* ctx, const double* d_rows, int64_t num_frames, double* d_sum, hipStream_t stream) {
-    // the grid of he_wave_launch for the whole call: one workgroup per CU, each a contiguous run of frames
-    long long g = ctx->num_cus < num_frames ? ctx->num_cus : num_frames;
-    const long long per = (num_frames + g - 1) / g;
-    g = (num_frames + per - 1) / per;
-    int rc = ensure(ctx, ctx->d_partials, (size_t)g * 12 * sizeof(double));
-    if (rc) return rc;
-    hipLaunchKernelGGL(he_rows_partial_kernel, dim3((unsigned)g), dim3(192), 0, stream, d_rows, (long long)num_frames, per,
-                       (double*)ctx->d_partials.p);
-    hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(256), 0, stream, (const double*)ctx->d_partials.p, g, d_sum);
-    MPX_HIP(ctx, hipGetLastError());
-    return MPX_OK;
 }
 
 // Debug tap: the bin of every window's first maximum, [F, nwin] (MultipitchHarmonicEnergy.dft_maxes, harmonic_energy.py:57-65).

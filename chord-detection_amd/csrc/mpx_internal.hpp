@@ -132,11 +132,6 @@ int he_argmax_run(mpx_ctx* ctx, const float* d_signal, int64_t n, int64_t num_fr
 int he_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
            int fs, const mpx_he_params* params, int frame, int hop, double* d_chroma_frames,
            double* d_chroma_sum, hipStream_t stream);
-// a host signal of 4096-sample frames in pieces (mpx_he.hip, mpx_api.hip method_host)
-bool he_pieces_ok(mpx_ctx* ctx, int fs, const mpx_he_params* params, int frame, int hop);
-int he_rows_range(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs, const mpx_he_params* params, int hop, int64_t f0,
-                  int64_t f1, bool whole_fast, double* d_rows, hipStream_t stream);
-int he_rows_sum(mpx_ctx* ctx, const double* d_rows, int64_t num_frames, double* d_sum, hipStream_t stream);
 // segmented sum of per-frame chroma: out[s] = sum_{f in [seg[s], seg[s+1])} frames[f]
 int segment_sum(mpx_ctx* ctx, const double* d_frames, const long long* d_seg, int num_seg,
                 int64_t num_frames, double* d_out, hipStream_t stream);

@@ -10,6 +10,8 @@ import chord_detection_amd as cd
 import bench, bench_esacf as B
 eng = cd.Engine(0); dev = torch.device("cuda", 0)
 for label, fs, mode in (("clips 44.1 kHz", 44100, "frame"), ("clips 22.05 kHz", 22050, "frame"), ("stft 4096/1024", 44100, "stft")):
+    if os.environ.get("ESACF_TIME_ONLY") and os.environ["ESACF_TIME_ONLY"] != mode:
+        continue
     if mode == "stft":
         x = bench.synth_signal_device(20260101, dev); frame, hop = 4096, 1024
         if os.environ.get("ESACF_TIME_FRAMES"):   # a shorter signal: that many frames

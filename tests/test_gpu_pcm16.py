@@ -24,7 +24,8 @@ def _pcm(seed, n):
     t = np.arange(n) / FS
     x = sum(a * np.sin(2 * np.pi * f * t) for a, f in ((0.4, 261.63), (0.3, 329.63), (0.2, 392.0))) + 0.01 * rng.standard_normal(n)
     pcm = np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16)
-    pcm[:4] = (-32768, 32767, 0, -1)          # the ends of the int16 range convert exactly too
+    ends = np.array([-32768, 32767, 0, -1], dtype=np.int16)          # the ends of the int16 range convert exactly too
+    pcm[:min(n, 4)] = ends[:min(n, 4)]
     return pcm
 
 
@@ -105,33 +106,3 @@ def test_a_pcm16_wav_file_by_path_takes_the_int16_route_and_matches_the_oracle(e
     # samples assigned by the caller replace the file's
     obj.x = x[:8192]
     assert not isinstance(obj._samples(), cd.Pcm16) and obj._samples().shape[0] == 8192
-
-
-@pytest.mark.parametrize("extra", [0, 1000, 1023, 4097])
-def test_a_long_host_signal_goes_over_in_pieces_and_returns_the_one_launch_bits(eng, extra):
-    """Round 6 (csrc/mpx_api.hip he_host_pieces): a HOST signal of 4096-sample frames of 8 MB or more is copied in pieces and the
-    frames that have arrived run next to the next piece's copy; rows and sum must be the bits of the one-launch path -- the
-    same signal handed over as DEVICE memory (one launch: mpx_harmonic_energy on a device pointer, and the _dev entry) -- for
-    float32 and PCM_16, hop 1024 and hop = frame, whole signals and ragged tails (the last frame zero padded)."""
-    import torch
-    import chord_detection_amd as cd
-    rng = np.random.default_rng(5 + extra)
-    for hop, nf in ((1024, 4200), (4096, 1100)):
-        n = (nf - 1) * hop + 4096 + extra
-        pcm = rng.integers(-20000, 20000, n).astype(np.int16)
-        x = pcm.astype(np.float32) / np.float32(32768.0)
-        assert x.nbytes >= (8 << 20) and pcm.nbytes >= (8 << 20)
-        xd = torch.from_numpy(x).cuda()
-        want, want_rows = eng.harmonic_energy(xd, 44100, 4096, hop, return_frames=True)        # device memory: one launch
-        d_sum = torch.zeros(12, dtype=torch.float64, device="cuda")
-        d_rows = torch.zeros((want_rows.shape[0], 12), dtype=torch.float64, device="cuda")
-        eng.harmonic_energy_dev(xd.data_ptr(), n, 44100, 4096, hop, d_rows.data_ptr(), d_sum.data_ptr())
-        eng.synchronize()
-        assert np.array_equal(d_sum.cpu().numpy(), want) and np.array_equal(d_rows.cpu().numpy(), want_rows)
-        for src in (x, cd.Pcm16(pcm)):
-            got, rows = eng.harmonic_energy(src, 44100, 4096, hop, return_frames=True)         # host memory: in pieces
-            assert np.array_equal(rows, want_rows), (hop, extra, type(src).__name__)
-            assert np.array_equal(got, want), (hop, extra, type(src).__name__)
-            assert np.array_equal(eng.harmonic_energy(src, 44100, 4096, hop), want)            # sum only
-    from oracle import harmonic_energy as o_he
-    np.testing.assert_allclose(want_rows[-2:], o_he.he_frames(x, 44100, 4096, 4096)[-2:], rtol=1e-9)   # the padded tail too
