@@ -209,6 +209,12 @@ void mpx_destroy(mpx_ctx* ctx) {
     for (hipEvent_t e : ctx->copy_ev)
         if (e) hipEventDestroy(e);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->side_ev)
+        if (e) hipEventDestroy(e);
+    if (ctx->side_stream) {
+        hipStreamSynchronize(ctx->side_stream);
+        hipStreamDestroy(ctx->side_stream);
+    }
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->stream) hipStreamDestroy(ctx->stream);

@@ -2186,6 +2186,7 @@ constexpr int PARK_LIVE = 8;   // park from waves with at most this many unfinis
 constexpr int COOP_THREADS = 256, COOP_PAD_KB = 84;   // the cooperative kernels: one workgroup of four waves per CU (a wave per SIMD), held apart by unused LDS (more than half of the 160 KB; what is left takes a 64 KB workgroup of another context)
 constexpr int COOP_SPLIT = 4096;        // parked lists longer than this -- more than a wave per SIMD at four fits each -- run eight fits to a wave (coopfit8_kernel)
 constexpr int COOP_PASS1_TRIPS = 24;   // coopfit_kernel, first pass: trips after which a fit still open is parked again
+constexpr int EARLY_PARK_SLOW_NFEV = 100;   // ... and the slow ones (2 % of the fits need 100 ... 400 evaluations; the median is 56)
 constexpr int EARLY_PARK_NFEV = 20, EARLY_PARK_CAP = 12288, EARLY_PARK_MAX_FRAMES = 16384;   // round 6: fits that look like runaways leave the lane kernel at once (batches of at most this many frames; peakfit_kernel)
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
@@ -2894,6 +2895,367 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
 }
 
 
+
+// ---- the cooperative fit as a LIVE consumer (round 6): coopfit_live_kernel -----------------------------------------------
+// The runaway fits are ONE serial chain of ~200 LM steps each; the lane kernel is what the other 96 % of the fits need.  Until
+// round 6 the chain waited for the lane kernel: a fit parked at evaluation 160 (0.8 ms into the kernel) was picked up when the
+// kernel ended (1.3 ms).  This kernel runs NEXT TO the lane kernel, on a stream of its own, one wave per SIMD (the lane kernel
+// keeps the other wave slot and its 256 registers), and takes a parked fit as soon as its record is published: eight lanes per
+// fit, the arithmetic of coopfit8_kernel line for line (the trip body below is that kernel's, generated from the same text),
+// as a state machine -- a row whose fit ends fetches the next record at the top of the following trip.
+// Hand-off (cdna_hip_programming.md, Guideline 16, R1 with 8-byte agent atomics on both sides): the lane writes the record's
+// first fourteen words with agent-scope 8-byte stores, waits for them (s_waitcnt vmcnt(0)), then the fifteenth -- nfev in the
+// low half, the batch's TAG (never 0, unique per batch of a context: no stale record of an earlier batch can match) in the high
+// half; a row claims an index only when the published count is ahead of the claim counter, polls that ONE word, and reads the
+// record with agent-scope loads.  Nobody waits for anything that is not already on its way: a wave of this kernel leaves when the
+// lane kernel's waves have all signed off (`done` == lane_waves), every published record is claimed and its own rows are idle -- or,
+// if no record was EVER published, after `idle_us` of waiting (the two kernels were not run side by side: the lists then go to the
+// cooperative launches behind the lane kernel, as before round 6; nothing was claimed, nothing is lost).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) int gi32;
+__device__ __forceinline__ unsigned long long ld_agent(const void* p) {
+    return __hip_atomic_load((gu64*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int ld_agent_i(const int* p) {
+    return __hip_atomic_load((gi32*)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(void* p, unsigned long long v) {
+    __hip_atomic_store((gu64*)(uintptr_t)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double u2d(unsigned long long v) { return __longlong_as_double((long long)v); }
+static_assert(sizeof(ParkedFit) == 120, "fifteen 8-byte words: the last one carries nfev and the tag");
+// the lane kernel's side: publish one record
+__device__ __forceinline__ void publish_parked(ParkedFit* slot, const ParkedFit& pf, unsigned tag) {
+    const unsigned long long* w = reinterpret_cast<const unsigned long long*>(&pf);
+#pragma unroll
+    for (int i = 0; i < 14; ++i) st_agent(reinterpret_cast<unsigned long long*>(slot) + i, w[i]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_agent(reinterpret_cast<unsigned long long*>(slot) + 14, (unsigned long long)(unsigned)pf.nfev | ((unsigned long long)tag << 32));
+}
+
+__global__ __launch_bounds__(256) void coopfit_live_kernel(const ParkedFit* parked, const int* parked_count, int* next_parked,
+                                                         const int* lane_done, int lane_waves, unsigned tag,
+                                                         const double* __restrict__ y, double* center, int* ok, int maxfev,
+                                                         int* evals, int idle_us, int* live_stats) {
+    using namespace lm;
+    __shared__ double exp_tab[64];
+    if (threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
+    __syncthreads();
+    const int l = threadIdx.x & 7;
+    unsigned my_evals = 0, my_fits = 0;
+    const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
+    const double eps = sqrt(EPSMCH);
+    // per-row state (the registers coopfit8_kernel keeps across the trips of one fit)
+    bool have = false, ona = false, onb = false, onc = false, need_outer = true;
+    int pending = -1;   // an index claimed but not yet published
+    long long outw = 0, row_off = 0;
+    double x0w = 0.0;
+    int mw = 0, nfev0 = 0;
+    D3 px = {0, 0, 0}, py = {0, 0, 0}, f = {0, 0, 0};
+    double x[NP] = {0, 0, 0}, diag[NP] = {1, 1, 1};
+    double par = 0.0, delta = 0.0, xnorm = 0.0, fnorm = 0.0, gnorm = 0.0;
+    int it = 1, nfev = 0;
+    int ipvt[NP] = {0, 1, 2};
+    double qtf[NP] = {0.0, 0.0, 0.0}, r[NP * NP];
+#pragma unroll
+    for (int i = 0; i < NP * NP; ++i) r[i] = 0.0;
+    auto resid = [&](const double* p) -> D3 {
+        const GaussEval g = gauss_prep(p, exp_tab);
+        const double ra = gauss_resid(g, px.a, py.a), rb = gauss_resid(g, px.b, py.b), rc = gauss_resid(g, px.c, py.c);
+        return {ona ? ra : 0.0, onb ? rb : 0.0, onc ? rc : 0.0};
+    };
+    __builtin_amdgcn_s_setprio(3);   // a wave of this kernel issues one instruction in ten clocks (a dependent chain): it goes first, the lane kernel's wave on the same SIMD keeps the other nine
+    const long long t_start = wall_clock64();   // 100 MHz
+    bool seen_any = false;   // wave-uniform: a record has been published in this batch
+    for (;;) {
+        // ---------------- fetch: idle rows look for a published record
+        if (!have) {
+            int got = -1;
+            if (l == 0) {
+                if (pending < 0) {
+                    const int nx = ld_agent_i(next_parked), c = ld_agent_i(parked_count);
+                    if (nx < c) pending = atomicAdd(next_parked, 1);   // (may overshoot c by the rows racing here: such a claim waits for a later record, or for the end)
+                }
+                if (pending >= 0) {
+                    const unsigned long long w14 = ld_agent(reinterpret_cast<const unsigned long long*>(parked + pending) + 14);
+                    if ((unsigned)(w14 >> 32) == tag && pending < ld_agent_i(parked_count)) {
+                        got = pending;
+                        pending = -1;
+                    }
+                }
+            }
+            got = __shfl(got, 0, 8);
+            if (got >= 0) {
+                const unsigned long long* w = reinterpret_cast<const unsigned long long*>(parked + got);
+                outw = (long long)ld_agent(w + 0);
+                row_off = (long long)ld_agent(w + 1);
+                x0w = u2d(ld_agent(w + 2));
+                x[0] = u2d(ld_agent(w + 3));
+                x[1] = u2d(ld_agent(w + 4));
+                x[2] = u2d(ld_agent(w + 5));
+                diag[0] = u2d(ld_agent(w + 6));
+                diag[1] = u2d(ld_agent(w + 7));
+                diag[2] = u2d(ld_agent(w + 8));
+                par = u2d(ld_agent(w + 9));
+                delta = u2d(ld_agent(w + 10));
+                xnorm = u2d(ld_agent(w + 11));
+                fnorm = u2d(ld_agent(w + 12));
+                const unsigned long long w13 = ld_agent(w + 13), w14 = ld_agent(w + 14);
+                mw = (int)(unsigned)w13;
+                it = (int)(unsigned)(w13 >> 32);
+                nfev = nfev0 = (int)(unsigned)w14;
+                ona = l < mw;
+                onb = l + 8 < mw;
+                onc = l + 16 < mw;
+                px = {x0w + (double)l, x0w + (double)(l + 8), x0w + (double)(l + 16)};
+                py = {ona ? y[row_off + l] : 0.0, onb ? y[row_off + l + 8] : 0.0, onc ? y[row_off + l + 16] : 0.0};
+                f = resid(x);
+                need_outer = true;
+                gnorm = 0.0;
+                have = true;
+            }
+        }
+        if (!__any(have)) {
+            // nothing to do in this wave: leave when the lane kernel is done and every published record is claimed
+            const int dn = ld_agent_i(lane_done);
+            const int c = ld_agent_i(parked_count);   // (read AFTER `done`: a wave signs off after its last publication's count)
+            seen_any = seen_any || c > 0;
+            const bool mine = l == 0 && pending >= 0 && pending < c;   // a claim of ours that a record stands (or will stand) behind
+            if (dn >= lane_waves && !__any(mine) && ld_agent_i(next_parked) >= c) break;
+            if (!seen_any && dn == 0 && (wall_clock64() - t_start) > (long long)idle_us * 100) break;   // never ran side by side
+            __builtin_amdgcn_s_sleep(24);
+            continue;
+        }
+        int info = 0;
+        if (have) {
+            if (need_outer) {
+            // forward-difference jacobian: this lane's three rows
+                D3 J0, J1, J2;
+                {
+                    if (x[0] != 0.0) {
+                        const double inv_a = lm_rcp(x[0]);
+                        J0 = {ona ? (f.a + py.a) * inv_a : 0.0, onb ? (f.b + py.b) * inv_a : 0.0, onc ? (f.c + py.c) * inv_a : 0.0};
+                    } else {
+                        x[0] = eps;
+                        const D3 w = resid(x);
+                        J0 = {(w.a - f.a) * (1.0 / eps), (w.b - f.b) * (1.0 / eps), (w.c - f.c) * (1.0 / eps)};
+                        x[0] = 0.0;
+                    }
+                    const FdStep fs = fd_prep(x, gauss_prep(x, exp_tab).ninv, eps);
+                    if (!fd_big(fs, x0w - x[1], x0w + (double)(mw - 1) - x[1])) {
+                        fd_row(fs, px.a - x[1], f.a + py.a, J1.a, J2.a);
+                        fd_row(fs, px.b - x[1], f.b + py.b, J1.b, J2.b);
+                        fd_row(fs, px.c - x[1], f.c + py.c, J1.c, J2.c);
+                        J1 = {ona ? J1.a : 0.0, onb ? J1.b : 0.0, onc ? J1.c : 0.0};
+                        J2 = {ona ? J2.a : 0.0, onb ? J2.b : 0.0, onc ? J2.c : 0.0};
+                    } else {   // a row outside the series' range (a width far below a lag): the two exponentials per row
+                        const double keep1 = x[1], keep2 = x[2];
+                        x[1] = fs.mu1;
+                        const D3 w1 = resid(x);
+                        x[1] = keep1;
+                        x[2] = keep2 + (eps * fabs(keep2) == 0.0 ? eps : eps * fabs(keep2));
+                        const D3 w2 = resid(x);
+                        x[2] = keep2;
+                        J1 = {(w1.a - f.a) * fs.inv_h1, (w1.b - f.b) * fs.inv_h1, (w1.c - f.c) * fs.inv_h1};
+                        J2 = {(w2.a - f.a) * fs.inv_h2, (w2.b - f.b) * fs.inv_h2, (w2.c - f.c) * fs.inv_h2};
+                    }
+                }
+                nfev += NP;
+                ipvt[0] = 0;
+                ipvt[1] = 1;
+                ipvt[2] = 2;
+                double acnorm[NP], rdiag[NP], wa[NP];
+                acnorm[0] = lm_sqrt(coop8_sum(l, 0, J0, J0));
+                acnorm[1] = lm_sqrt(coop8_sum(l, 0, J1, J1));
+                acnorm[2] = lm_sqrt(coop8_sum(l, 0, J2, J2));
+#pragma unroll
+                for (int j = 0; j < NP; ++j) rdiag[j] = wa[j] = acnorm[j];
+                D3 w4 = f;  // becomes Q^T fvec
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    int kmax = j;
+                    double rmax = rdiag[j];
+#pragma unroll
+                    for (int k = j + 1; k < NP; ++k)
+                        if (rdiag[k] > rmax) {
+                            kmax = k;
+                            rmax = rdiag[k];
+                        }
+                    if (kmax != j) {
+                        D3& cjs = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                        D3& cks = kmax == 1 ? J1 : J2;
+                        const D3 t0 = cjs;
+                        cjs = cks;
+                        cks = t0;
+                        put3(rdiag, kmax, rdiag[j]);
+                        put3(wa, kmax, wa[j]);
+                        const int t = ipvt[j];
+                        ipvt[j] = sel3(ipvt, kmax);
+                        put3(ipvt, kmax, t);
+                    }
+                    D3& cj = j == 0 ? J0 : (j == 1 ? J1 : J2);
+                    const bool below = l >= j;  // rows j..7 of the first slot; the other two slots (rows 8.., 16..) are always below
+                    double ajnorm = lm_sqrt(coop8_sum(l, j, cj, cj));
+                    if (ajnorm != 0.0) {
+                        if (half_bcast(cj.a, j) < 0.0) ajnorm = -ajnorm;
+                        const double inv_aj = lm_rcp(ajnorm);
+                        if (below) cj.a *= inv_aj;
+                        cj.b *= inv_aj;
+                        cj.c *= inv_aj;
+                        if (l == j) cj.a += 1.0;
+                        const double inv_ajj = lm_rcp(half_bcast(cj.a, j));
+#pragma unroll
+                        for (int k = j + 1; k < NP; ++k) {
+                            D3& ck = k == 1 ? J1 : J2;
+                            const double temp = coop8_sum(l, j, cj, ck) * inv_ajj;
+                            if (below) ck.a = fma_as_written(-temp, cj.a, ck.a);
+                            ck.b = fma_as_written(-temp, cj.b, ck.b);
+                            ck.c = fma_as_written(-temp, cj.c, ck.c);
+                            if (rdiag[k] != 0.0) {
+                                const double t = lm_div(half_bcast(ck.a, j), rdiag[k]);
+                                const double u = fma(-t, t, 1.0);
+                                rdiag[k] *= lm_sqrt(u > 0.0 ? u : 0.0);
+                                const double q = lm_div(rdiag[k], wa[k]);
+                                if (0.05 * q * q <= EPSMCH) {
+                                    rdiag[k] = lm_sqrt(coop8_sum(l, j + 1, ck, ck));
+                                    wa[k] = rdiag[k];
+                                }
+                            }
+                        }
+                        const double temp = -coop8_sum(l, j, cj, w4) * inv_ajj;
+                        if (below) w4.a = fma_as_written(cj.a, temp, w4.a);
+                        w4.b = fma_as_written(cj.b, temp, w4.b);
+                        w4.c = fma_as_written(cj.c, temp, w4.c);
+                    }
+                    rdiag[j] = -ajnorm;
+                    qtf[j] = half_bcast(w4.a, j);
+                }
+                if (it == 1) {
+                    double wa3[NP];
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        diag[j] = acnorm[j] != 0.0 ? acnorm[j] : 1.0;
+                        wa3[j] = diag[j] * x[j];
+                    }
+                    xnorm = enorm3(wa3);
+                    delta = factor * xnorm;
+                    if (delta == 0.0) delta = factor;
+                }
+                // replicate the 3x3 upper triangle R (row i lives in lane i of the fit's eight, first slot; its diagonal is rdiag)
+#pragma unroll
+                for (int i = 0; i < NP; ++i) {
+                    r[i * NP + 0] = i == 0 ? rdiag[0] : half_bcast(J0.a, i);
+                    r[i * NP + 1] = i == 1 ? rdiag[1] : half_bcast(J1.a, i);
+                    r[i * NP + 2] = i == 2 ? rdiag[2] : half_bcast(J2.a, i);
+                }
+                gnorm = 0.0;
+                if (fnorm != 0.0) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        const double an = sel3(acnorm, ipvt[j]);
+                        if (an != 0.0) {
+                            double s2 = 0.0;
+#pragma unroll
+                            for (int i = 0; i <= j; ++i) s2 = fma(r[i * NP + j], lm_div(qtf[i], fnorm), s2);
+                            const double g = fabs(lm_div(s2, an));
+                            gnorm = g > gnorm ? g : gnorm;
+                        }
+                    }
+                }
+                if (gnorm <= gtol) {
+                    info = 4;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) diag[j] = diag[j] > acnorm[j] ? diag[j] : acnorm[j];
+                }
+            }
+            if (info == 0) {
+                double rr[NP * NP], p[NP], xnew[NP], wa3[NP], sd[NP];
+#pragma unroll
+                for (int i = 0; i < NP * NP; ++i) rr[i] = r[i];
+                par = lmpar(rr, ipvt, diag, qtf, delta, par, p, sd);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    p[j] = -p[j];
+                    xnew[j] = x[j] + p[j];
+                    wa3[j] = diag[j] * p[j];
+                }
+                const double pnorm = enorm3(wa3);
+                if (it == 1) delta = delta < pnorm ? delta : pnorm;
+                const D3 fn = resid(xnew);
+                ++nfev;
+                const double fnorm1 = lm_sqrt(coop8_sum(l, 0, fn, fn));
+                double actred = -1.0;
+                if (0.1 * fnorm1 < fnorm) {
+                    const double q = lm_div(fnorm1, fnorm);
+                    actred = fma(-q, q, 1.0);
+                }
+#pragma unroll
+                for (int j = 0; j < NP; ++j) wa3[j] = 0.0;
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const double temp = sel3(p, ipvt[j]);
+#pragma unroll
+                    for (int i = 0; i <= j; ++i) wa3[i] = fma(r[i * NP + j], temp, wa3[i]);
+                }
+                const double temp1 = lm_div(enorm3(wa3), fnorm);
+                const double temp2 = lm_div(lm_sqrt(par) * pnorm, fnorm);
+                const double prered = fma(temp1, temp1, temp2 * temp2 / 0.5);
+                const double dirder = -fma(temp1, temp1, temp2 * temp2);
+                const double ratio = prered != 0.0 ? lm_div(actred, prered) : 0.0;
+                if (ratio <= 0.25) {
+                    double temp = actred >= 0.0 ? 0.5 : lm_div(0.5 * dirder, dirder + 0.5 * actred);
+                    if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                    const double p10 = lm_div(pnorm, 0.1), dm = delta < p10 ? delta : p10;
+                    delta = temp * dm;
+                    par = lm_div(par, temp);
+                } else if (par == 0.0 || ratio >= 0.75) {
+                    delta = pnorm / 0.5;
+                    par = 0.5 * par;
+                }
+                if (ratio >= 1e-4) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) {
+                        x[j] = xnew[j];
+                        wa3[j] = diag[j] * x[j];
+                    }
+                    f = fn;
+                    xnorm = enorm3(wa3);
+                    fnorm = fnorm1;
+                    ++it;
+                }
+                const bool c1 = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+                if (c1) info = 1;
+                if (delta <= xtol * xnorm) info = 2;
+                if (c1 && info == 2) info = 3;
+                if (info == 0) {
+                    if (nfev >= maxfev) info = 5;
+                    if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1.0) info = 6;
+                    if (delta <= EPSMCH * xnorm) info = 7;
+                    if (gnorm <= EPSMCH) info = 8;
+                }
+                need_outer = ratio >= 1e-4;   // accepted: a new jacobian next trip; rejected: the next trial with the same R
+            }
+            if (info != 0) {
+                if (l == 0) {
+                    ok[outw] = (info >= 1 && info <= 4) ? 1 : 0;
+                    center[outw] = x[1];
+                    my_evals += (unsigned)(nfev - nfev0);
+                    ++my_fits;
+                }
+                have = false;
+            }
+        }
+    }
+    count_evals(evals, my_evals);   // total[6..7]
+    if (live_stats) {
+        unsigned v = my_fits;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(live_stats, (int)v);
+    }
+}
+
 // SAMPLES_IN_LDS = true (batches with enough fits to fill the machine several times over): the lane's 21 samples live in
 // LDS and fvec is recomputed -- no global loads inside the trip loop (10 % faster per 2.1 M fits, 1/31 of the traffic).
 // false (small batches, where the kernel's time is the number of dependent trips of its longest fits, not throughput): the
@@ -2904,7 +3266,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
     int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
     double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev, int park_live, int park_cap,
-    int early_nfev, int early_cap) {
+    int early_nfev, int early_cap, unsigned live_tag, int* lane_done) {
     using namespace lm;
     __shared__ double sh[MAXM * FIT_THREADS];
     __shared__ double sh_rq[9 * FIT_THREADS];
@@ -3004,7 +3366,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         // arithmetic, see above): the bits do not depend on it.  Bounded by a counter of its own.
         bool early_park = false;   // parked with the list not drained: the lane fetches its next fit
         if (early_nfev > 0 && !may_park && phase == FIT_OUTER && nfev >= early_nfev && parked != nullptr && !early_full &&
-            (fabs(x[2]) > 40.0 || fabs(x[1] - (x0 + 10.0)) > 40.0)) {
+            (fabs(x[2]) > 40.0 || fabs(x[1] - (x0 + 10.0)) > 40.0 || nfev >= EARLY_PARK_SLOW_NFEV)) {
             may_park = atomicAdd(parked_count + 7, 1) < early_cap;
             early_full = !may_park;
             early_park = may_park;
@@ -3027,7 +3389,10 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             pf.it = it;
             pf.nfev = nfev;
             pf.pad = 0;
-            parked[atomicAdd(parked_count, 1)] = pf;
+            if (live_tag)   // coopfit_live_kernel is running next to this kernel: the record is published word by word, its tag last
+                publish_parked(parked + atomicAdd(parked_count, 1), pf, live_tag);
+            else
+                parked[atomicAdd(parked_count, 1)] = pf;
             my_evals += (unsigned)nfev;
             phase = early_park ? FIT_NEED_WORK : FIT_DONE;
         }
@@ -3360,6 +3725,9 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
         }
     }
     count_evals(parked_count + 3, my_evals);   // total[6..7]
+    // this wave will publish nothing more (every count it added was returned to it before this line): coopfit_live_kernel's
+    // waves leave when all of the lane kernel's waves have signed off
+    if (lane_done != nullptr && lane == 0) atomicAdd(lane_done, 1);
 }
 
 #pragma clang fp contract(fast)
@@ -3742,6 +4110,25 @@ static int sacf_launch(mpx_ctx* ctx, const SacfArgs& a, long long frames, hipStr
     return MPX_OK;
 }
 
+// the stream coopfit_live_kernel runs on and its two events exist together or not at all (a failure: the batch runs without it)
+static bool side_stream_ready(mpx_ctx* ctx) {
+    if (ctx->side_ready) return true;
+    bool ok = hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; ok && k < 2; ++k) ok = hipEventCreateWithFlags(&ctx->side_ev[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int k = 0; k < 2; ++k) {
+            if (ctx->side_ev[k]) (void)hipEventDestroy(ctx->side_ev[k]);
+            ctx->side_ev[k] = nullptr;
+        }
+        if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+        ctx->side_stream = nullptr;
+        return false;
+    }
+    ctx->side_ready = true;
+    return true;
+}
+
 int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d_desc, int64_t num_frames,
               int fs, const mpx_esacf_params* params, int frame, int hop, double* d_chroma_frames, int stage,
               double* d_stage_out, hipStream_t st) {
@@ -3922,7 +4309,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                d_stage_out + (size_t)f0 * N);
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
         prof_mark(ctx, st, nullptr);
-        MPX_HIP(ctx, hipMemsetAsync(total, 0, 12 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts; [6..7] evaluations
+        MPX_HIP(ctx, hipMemsetAsync(total, 0, 16 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts; [6..7] evaluations; [10] early parks; [11] lane-kernel waves signed off; [12] fits the live kernel finished
         SacfArgs a;
         a.xb = xb;
         a.N = N;
@@ -4117,13 +4504,42 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
 #else
             auto fit_kernel = peakfit_kernel<true>;
 #endif
+            // Round 6, small batches: the fits that look like runaways leave the lane kernel at once (early_nfev), and
+            // coopfit_live_kernel takes every parked fit WHILE the lane kernel runs: on a stream of its own, one workgroup of
+            // four waves per CU behind the same LDS padding as the cooperative launches below (a wave per SIMD), the lane
+            // kernel on half its usual grid (ONE wave per SIMD: 256 + ~200 registers and 62 + 84 KB of LDS fit side by side
+            // whichever of the two the dispatcher places first).
+            // (Early parking WITHOUT the live kernel was measured and loses: the lane kernel of the 8192-frame Target is as long
+            // with it -- 1.28 against 1.30 ms: its ordinary fits decide that -- and the cooperative launches behind it get twice the
+            // fits, 2.12 against 1.54 ms; gpurun_out -> profiles/r6/fit_early_sweep.txt.  The two come together or not at all.)
+            const bool live = park && dev_env_int("MPX_FIT_LIVE", nf <= EARLY_PARK_MAX_FRAMES ? 1 : 0) != 0 && side_stream_ready(ctx);
+            const int early_nfev = live ? dev_env_int("MPX_FIT_EARLY_NFEV", EARLY_PARK_NFEV) : 0;
+            unsigned live_tag = 0;
+            if (live) {
+                if (++ctx->live_epoch == 0) ++ctx->live_epoch;
+                live_tag = ctx->live_epoch;
+                const long long half = std::max<long long>(1, fit_resident / 2);
+                if (blocks > half) blocks = half;
+                const int lp = dev_env_int("MPX_COOP_PAD_KB", COOP_PAD_KB);
+                if (lp) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit_live_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lp * 1024));
+                MPX_HIP(ctx, hipEventRecord(ctx->side_ev[0], st));                       // the rows and the work list are complete
+                MPX_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_ev[0], 0));
+                hipLaunchKernelGGL(coopfit_live_kernel, dim3((unsigned)ctx->num_cus), dim3(COOP_THREADS), (size_t)lp * 1024, ctx->side_stream,
+                                   parked, total + 3, total + 4, total + 11, (int)(blocks * (FIT_THREADS / 64)), live_tag, y, center, okf,
+                                   maxfev, total + 6, dev_env_int("MPX_FIT_LIVE_IDLE_US", 1000),
+                                   dev_env("MPX_DEBUG_FITS") ? total + 12 : (int*)nullptr);
+            }
             hipLaunchKernelGGL(fit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, dev_env_int("MPX_FIT_PARK_NFEV", nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
                                dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),
                                dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP),
-                               park ? dev_env_int("MPX_FIT_EARLY_NFEV", nf <= EARLY_PARK_MAX_FRAMES ? EARLY_PARK_NFEV : 0) : 0,
-                               std::min(dev_env_int("MPX_FIT_EARLY_CAP", EARLY_PARK_CAP), EARLY_PARK_CAP));
+                               early_nfev, std::min(dev_env_int("MPX_FIT_EARLY_CAP", EARLY_PARK_CAP), EARLY_PARK_CAP),
+                               live ? live_tag : 0u, live ? total + 11 : (int*)nullptr);
+            if (live) {   // the cooperative launches below take what the live kernel left (normally nothing): behind BOTH kernels
+                MPX_HIP(ctx, hipEventRecord(ctx->side_ev[1], ctx->side_stream));
+                MPX_HIP(ctx, hipStreamWaitEvent(st, ctx->side_ev[1], 0));
+            }
             if (park) prof_mark(ctx, st, "coopfit_kernel");
             if (park) {  // the runaway fits still open when the list ran dry: eight lanes each (coopfit8_kernel), all at once
                 // Lists of up to COOP_SPLIT fits go to coopfit_kernel (16 lanes per fit: four to a wave), longer ones to
@@ -4151,11 +4567,11 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         }
         prof_mark(ctx, st, nullptr);
         if (dev_env("MPX_DEBUG_FITS")) {  // profiling aid: work-list counters of this batch
-            int h[9];
+            int h[13];
             MPX_HIP(ctx, hipMemcpyAsync(h, total, sizeof(h), hipMemcpyDeviceToHost, st));
             MPX_HIP(ctx, hipStreamSynchronize(st));
-            fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d, open after the first cooperative pass %d\n", nf,
-                    h[0] + h[2], h[0], h[3], h[8]);
+            fprintf(stderr, "mpx esacf: frames %lld fits %d (queued first: %d) parked %d (early attempts %d), finished by the live kernel %d, "
+                            "open after the first cooperative pass %d\n", nf, h[0] + h[2], h[0], h[3], h[10], h[12], h[8]);
         }
         if (ctx->prof_on) {  // fit statistics of the profiled call (mpx_esacf_fit_stats): one small synchronous copy per batch
             unsigned h[8];

@@ -61,6 +61,10 @@ struct mpx_ctx {
     hipEvent_t copy_ev[8] = {};
     bool copy_ready = false;                  // copy_stream and all of copy_ev exist
     int copy_pieces = 4;                      // pieces of a large host batch (1: no overlap); fixed at mpx_create
+    hipStream_t side_stream = nullptr;        // ESACF, small batches: coopfit_live_kernel runs here, next to the lane kernel (mpx_esacf.hip)
+    hipEvent_t side_ev[2] = {};
+    bool side_ready = false;
+    unsigned live_epoch = 0;                  // tag of the parked records of the current batch (never 0)
     size_t if0_ws_cap = (size_t)32 << 30;     // MPX_OPT_IF0_WORKSPACE_BYTES
     int he_kernel = 0;                        // MPX_OPT_HE_KERNEL
     hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -24,7 +24,8 @@ dev = torch.device("cuda", 0)
 
 
 def run(x, fs, frame, hop, env):
-    for k in ("MPX_FIT_PARK_NFEV", "MPX_FIT_NOPARK", "MPX_FIT_PARK_LIVE", "MPX_FIT_PARK_CAP", "MPX_DETERMINISTIC", "MPX_FIT_SAMPLES"):
+    for k in ("MPX_FIT_PARK_NFEV", "MPX_FIT_NOPARK", "MPX_FIT_PARK_LIVE", "MPX_FIT_PARK_CAP", "MPX_DETERMINISTIC", "MPX_FIT_SAMPLES",
+              "MPX_FIT_EARLY_NFEV", "MPX_FIT_EARLY_CAP"):
         os.environ.pop(k, None)
     os.environ.update(env)
     n = x.numel()
@@ -55,7 +56,11 @@ for label, fs, hop_mode in (("clips 44.1 kHz", 44100, "frame"), ("clips 22.05 kH
     for env in ({}, {"MPX_FIT_PARK_NFEV": "40"}, {"MPX_FIT_PARK_NFEV": "100"}, {"MPX_FIT_PARK_NFEV": "300"},
                 {"MPX_FIT_PARK_NFEV": "60", "MPX_FIT_PARK_LIVE": "64", "MPX_FIT_PARK_CAP": "100000000"},
                 {"MPX_FIT_SAMPLES": "0"}, {"MPX_FIT_SAMPLES": "1"}, {"MPX_FIT_SAMPLES": "1", "MPX_FIT_NOPARK": "1"},
-                {"MPX_FIT_SAMPLES": "0", "MPX_FIT_PARK_NFEV": "100"}):
+                {"MPX_FIT_SAMPLES": "0", "MPX_FIT_PARK_NFEV": "100"},
+                # round 6: fits that look like runaways leave the lane kernel early (default for small batches only: forced
+                # on for every shape here, from three points of the iteration on, with a small and the full budget; and off)
+                {"MPX_FIT_EARLY_NFEV": "0"}, {"MPX_FIT_EARLY_NFEV": "8"}, {"MPX_FIT_EARLY_NFEV": "20"},
+                {"MPX_FIT_EARLY_NFEV": "48", "MPX_FIT_EARLY_CAP": "700"}, {"MPX_FIT_EARLY_NFEV": "20", "MPX_FIT_PARK_NFEV": "60"}):
         got, ms = run(x, fs, frame, hop, env)
         diff = int((got != ref).any(axis=1).sum())
         bad += diff
