@@ -2187,7 +2187,7 @@ constexpr int COOP_THREADS = 256, COOP_PAD_KB = 84;   // the cooperative kernels
 constexpr int COOP_SPLIT = 4096;        // parked lists longer than this -- more than a wave per SIMD at four fits each -- run eight fits to a wave (coopfit8_kernel)
 constexpr int COOP_PASS1_TRIPS = 24;   // coopfit_kernel, first pass: trips after which a fit still open is parked again
 constexpr int EARLY_PARK_SLOW_NFEV = 100;   // ... and the slow ones (2 % of the fits need 100 ... 400 evaluations; the median is 56)
-constexpr int EARLY_PARK_NFEV = 20, EARLY_PARK_CAP = 12288, EARLY_PARK_MAX_FRAMES = 16384;   // round 6: fits that look like runaways leave the lane kernel at once (batches of at most this many frames; peakfit_kernel)
+constexpr int EARLY_PARK_CAP = 12288;   // round 6, development builds: budget of the early hand-off (fits that look like runaways leave the lane kernel at once; peakfit_kernel)
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
 // Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
@@ -2896,7 +2896,16 @@ __global__ __launch_bounds__(256) void coopfit8_kernel(const ParkedFit* __restri
 
 
 
-// ---- the cooperative fit as a LIVE consumer (round 6): coopfit_live_kernel -----------------------------------------------
+// ---- the cooperative fit as a LIVE consumer (round 6): coopfit_live_kernel -- MEASURED, NOT ADOPTED ----------------------
+// Verdict (MI355X, the 8192-frame Target, profiles/r6/fit_live_ab*.txt; every variant bit-identical to the lane kernel alone,
+// tests/tools/esacf_bitcheck.py: 0 differing rows): next to a lane kernel on HALF its grid (what leaves the registers for a
+// wave of this kernel on every SIMD) with fits that look like runaways handed over from evaluation 20 on, the fits take 3.2-3.4
+// ms against 2.85 for lane kernel + cooperative launches one after the other: a lone lane wave per SIMD is 1.6 x slower at
+// the lane kernel's work, fits that start late in it and run away push the end out, and a cooperative trip slows down next to
+// a lane wave.  Behind a FULL lane grid (this kernel's workgroups become resident as the lane kernel's exit) it takes the tail
+// 0-3 % faster at 8192 frames (4.07-4.18 against 4.19-4.21 ms per call) and 13 % slower at 1024 -- not a result.  The lane
+// kernel needs the whole register file for its throughput and the runaway fits' chain cannot start without registers of its
+// own: the two phases stay one after the other.  What follows is the design as built.
 // The runaway fits are ONE serial chain of ~200 LM steps each; the lane kernel is what the other 96 % of the fits need.  Until
 // round 6 the chain waited for the lane kernel: a fit parked at evaluation 160 (0.8 ms into the kernel) was picked up when the
 // kernel ended (1.3 ms).  This kernel runs NEXT TO the lane kernel, on a stream of its own, one wave per SIMD (the lane kernel
@@ -2933,10 +2942,11 @@ __device__ __forceinline__ void publish_parked(ParkedFit* slot, const ParkedFit&
     st_agent(reinterpret_cast<unsigned long long*>(slot) + 14, (unsigned long long)(unsigned)pf.nfev | ((unsigned long long)tag << 32));
 }
 
+#ifdef MPX_DEV_KNOBS   // measured, not adopted (see the verdict below): development builds only
 __global__ __launch_bounds__(256) void coopfit_live_kernel(const ParkedFit* parked, const int* parked_count, int* next_parked,
                                                          const int* lane_done, int lane_waves, unsigned tag,
                                                          const double* __restrict__ y, double* center, int* ok, int maxfev,
-                                                         int* evals, int idle_us, int* live_stats) {
+                                                         int* evals, int idle_us, int* live_stats, int poll_mask) {
     using namespace lm;
     __shared__ double exp_tab[64];
     if (threadIdx.x < 64) exp_tab[threadIdx.x] = exp2((double)threadIdx.x * (1.0 / 64.0));
@@ -2967,9 +2977,13 @@ __global__ __launch_bounds__(256) void coopfit_live_kernel(const ParkedFit* park
     __builtin_amdgcn_s_setprio(3);   // a wave of this kernel issues one instruction in ten clocks (a dependent chain): it goes first, the lane kernel's wave on the same SIMD keeps the other nine
     const long long t_start = wall_clock64();   // 100 MHz
     bool seen_any = false;   // wave-uniform: a record has been published in this batch
+    int trip = 0;
     for (;;) {
-        // ---------------- fetch: idle rows look for a published record
-        if (!have) {
+        // ---------------- fetch: idle rows look for a published record (while other rows of the wave are at work: every
+        // poll_mask + 1 trips only -- the agent-scope loads are a microsecond of latency the whole wave waits for)
+        ++trip;
+        const bool wave_at_work = __any(have);
+        if (!have && ((trip & poll_mask) == 0 || !wave_at_work)) {
             int got = -1;
             if (l == 0) {
                 if (pending < 0) {
@@ -3255,6 +3269,7 @@ __global__ __launch_bounds__(256) void coopfit_live_kernel(const ParkedFit* park
         if ((threadIdx.x & 63) == 0 && v) atomicAdd(live_stats, (int)v);
     }
 }
+#endif
 
 // SAMPLES_IN_LDS = true (batches with enough fits to fill the machine several times over): the lane's 21 samples live in
 // LDS and fvec is recomputed -- no global loads inside the trip loop (10 % faster per 2.1 M fits, 1/31 of the traffic).
@@ -3358,7 +3373,8 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             may_park = !cap_hit && atomicAdd(parked_count + 2, 1) < park_cap;
             cap_hit = cap_hit || __any(!may_park);
         }
-        // Round 6, small batches (early_nfev > 0): a fit that LOOKS like a runaway -- its width or the distance of its centre from
+        // Round 6, development builds (early_nfev > 0; measured, not adopted -- with or without coopfit_live_kernel next to this
+        // kernel the call is slower, profiles/r6/fit_early_sweep.txt): a fit that LOOKS like a runaway -- its width or the distance of its centre from
         // the peak has left everything a converging fit visits (40 lags; oracle statistics over 10 299 fits of the Target's
         // signal: every fit that burns maxfev shows it by evaluation 93, 90 % by 41, and 5 % of the others, slow ones, do too)
         // -- is handed to the cooperative kernel at once, list drained or not: a wave no longer carries such lanes for forty
@@ -4504,22 +4520,24 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
 #else
             auto fit_kernel = peakfit_kernel<true>;
 #endif
-            // Round 6, small batches: the fits that look like runaways leave the lane kernel at once (early_nfev), and
-            // coopfit_live_kernel takes every parked fit WHILE the lane kernel runs: on a stream of its own, one workgroup of
-            // four waves per CU behind the same LDS padding as the cooperative launches below (a wave per SIMD), the lane
-            // kernel on half its usual grid (ONE wave per SIMD: 256 + ~200 registers and 62 + 84 KB of LDS fit side by side
-            // whichever of the two the dispatcher places first).
+            // Round 6, measured and not adopted (coopfit_live_kernel above): fits that look like runaways leave the lane kernel at
+            // once (early_nfev), and coopfit_live_kernel takes every parked fit WHILE the lane kernel runs: on a stream of its
+            // own, one workgroup of four waves per CU behind the same LDS padding as the cooperative launches below (a wave per
+            // SIMD), the lane kernel on half its usual grid with MPX_FIT_LIVE_HALF=1 (ONE wave per SIMD: 256 + 216 registers and
+            // 62 + 84 KB of LDS fit side by side whichever of the two the dispatcher places first).
             // (Early parking WITHOUT the live kernel was measured and loses: the lane kernel of the 8192-frame Target is as long
             // with it -- 1.28 against 1.30 ms: its ordinary fits decide that -- and the cooperative launches behind it get twice the
             // fits, 2.12 against 1.54 ms; gpurun_out -> profiles/r6/fit_early_sweep.txt.  The two come together or not at all.)
-            const bool live = park && dev_env_int("MPX_FIT_LIVE", nf <= EARLY_PARK_MAX_FRAMES ? 1 : 0) != 0 && side_stream_ready(ctx);
-            const int early_nfev = live ? dev_env_int("MPX_FIT_EARLY_NFEV", EARLY_PARK_NFEV) : 0;
+            // Development builds only (MPX_FIT_LIVE=1, MPX_FIT_LIVE_HALF, MPX_FIT_EARLY_NFEV=20: what was measured), off by default.
+            const bool live = park && dev_env_int("MPX_FIT_LIVE", 0) != 0 && side_stream_ready(ctx);
+            const int early_nfev = live ? dev_env_int("MPX_FIT_EARLY_NFEV", 0) : 0;
             unsigned live_tag = 0;
+#ifdef MPX_DEV_KNOBS
             if (live) {
                 if (++ctx->live_epoch == 0) ++ctx->live_epoch;
                 live_tag = ctx->live_epoch;
                 const long long half = std::max<long long>(1, fit_resident / 2);
-                if (blocks > half) blocks = half;
+                if (blocks > half && dev_env_int("MPX_FIT_LIVE_HALF", 0)) blocks = half;
                 const int lp = dev_env_int("MPX_COOP_PAD_KB", COOP_PAD_KB);
                 if (lp) MPX_HIP(ctx, hipFuncSetAttribute((const void*)coopfit_live_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lp * 1024));
                 MPX_HIP(ctx, hipEventRecord(ctx->side_ev[0], st));                       // the rows and the work list are complete
@@ -4527,8 +4545,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                 hipLaunchKernelGGL(coopfit_live_kernel, dim3((unsigned)ctx->num_cus), dim3(COOP_THREADS), (size_t)lp * 1024, ctx->side_stream,
                                    parked, total + 3, total + 4, total + 11, (int)(blocks * (FIT_THREADS / 64)), live_tag, y, center, okf,
                                    maxfev, total + 6, dev_env_int("MPX_FIT_LIVE_IDLE_US", 1000),
-                                   dev_env("MPX_DEBUG_FITS") ? total + 12 : (int*)nullptr);
+                                   dev_env("MPX_DEBUG_FITS") ? total + 12 : (int*)nullptr, dev_env_int("MPX_FIT_LIVE_POLL", 7));
             }
+#endif
             hipLaunchKernelGGL(fit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
                                (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, dev_env_int("MPX_FIT_PARK_NFEV", nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
