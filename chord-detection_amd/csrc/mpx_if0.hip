@@ -633,17 +633,21 @@ __device__ __forceinline__ void if0_block_maxima(double m, int lane, int i0, int
     if (lane == 0 && i0 + 64 <= nl) b64[i0 >> 6] = m;
 }
 
-__global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a) {   // (four workgroups per CU = 128 registers: the gather of the overlapping-window case had taken the kernel to 129 and three -- 2.61 -> 3.05 ms per 600 s; a register cap brings 2.70 back, the gather as a function of its own the same)
+// BIG (round 6): spectra of more than 16 384 bins (frame sizes 8193 ... 16384): twice the tables, one more level of the sparse
+// table; the default instantiation is the round-5 kernel unchanged.
+template <bool BIG>
+__global__ __launch_bounds__(PER_T, BIG ? 2 : 4) void if0_periodicity_kernel(If0PerArgs a) {   // (four workgroups per CU = 128 registers: the gather of the overlapping-window case had taken the kernel to 129 and three -- 2.61 -> 3.05 ms per 600 s; a register cap brings 2.70 back, the gather as a function of its own the same)
     __shared__ double tau_low[32], tau_up[32], smax[32];
     __shared__ double um[128];    // [interval * 64 + harmonic]: range maxima
     __shared__ double wts[128];   // [interval * 64 + harmonic]: m fs / tau_up + epsilon2
     // Range maxima in O(1) loads per range (round 5): e8 = maxima of the 8-bin blocks of the residual, st[k][b] = maximum of the 64-bin
     // blocks b .. b + 2^k - 1 (a sparse table; st[0] is what bmax was).  A range [lo, hi] is at most 7 + 7 bins, 7 + 7 entries of e8
     // and two entries of st -- few enough for ONE LANE per range (see lane_range_max).
-    __shared__ double e8[2048];      // n <= 16384
-    __shared__ double st[8][256];
+    constexpr int NB = BIG ? 512 : 256, LEV = BIG ? 9 : 8;   // 64-bin blocks of a row, levels of the sparse table
+    __shared__ double e8[NB * 8];      // n <= 16384 (BIG: 32768)
+    __shared__ double st[LEV][NB];
     __shared__ int qbest_sh;
-    __shared__ unsigned char dirty[256];   // 64-bin blocks of the residual a cancellation step has changed
+    __shared__ unsigned char dirty[NB];   // 64-bin blocks of the residual a cancellation step has changed
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n;
     // One workgroup per frame, as before -- but the pair of scratch rows (residual and detected spectrum, 2 x 128 KB at the
@@ -700,15 +704,23 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
             if (i0 + u * PER_T < nl) if0_block_maxima(m[u], lane, i0 + u * PER_T, nl, e8, st[0]);   // (uniform)
     }
     if (tid < 256) dirty[tid] = 0;
+    if constexpr (BIG) dirty[256 + tid] = 0;
     __syncthreads();
     __threadfence_block();
     const int nb64 = nl >> 6;   // whole 64-bin blocks (what a range's block part can reach: hi < nl)
     auto build_levels = [&]() {   // st[k] from st[k - 1]; one barrier per level (eight per voice at most)
-        for (int k = 1; k < 8; ++k) {
+        for (int k = 1; k < LEV; ++k) {
             const int half = 1 << (k - 1);
             if (tid + 2 * half <= nb64) {
                 const double x = st[k - 1][tid], y = st[k - 1][tid + half];
                 st[k][tid] = y > x ? y : x;
+            }
+            if constexpr (BIG) {
+                const int t2 = tid + PER_T;
+                if (t2 + 2 * half <= nb64) {
+                    const double x = st[k - 1][t2], y = st[k - 1][t2 + half];
+                    st[k][t2] = y > x ? y : x;
+                }
             }
             __syncthreads();
         }
@@ -763,7 +775,7 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
         {
             const int cnt = whole64 ? z64 - a64 : 1;
             const int kk = 31 - __builtin_clz(cnt);
-            const int k = kk < 7 ? kk : 7;   // (256 blocks -- n = 16384, a range over all of them -- are two windows of 128)
+            const int k = kk < LEV - 1 ? kk : LEV - 1;   // (256 blocks -- n = 16384, a range over all of them -- are two windows of 128)
             const double v1 = st[k][whole64 ? a64 : 0], v2 = st[k][whole64 ? z64 - (1 << k) : 0];
             mm = whole64 && v1 > mm ? v1 : mm;
             mm = whole64 && v2 > mm ? v2 : mm;
@@ -932,7 +944,7 @@ __global__ __launch_bounds__(PER_T, 4) void if0_periodicity_kernel(If0PerArgs a)
                 for (int j = lowk; j <= highk && j < n; ++j) {
                     const double d = uk[j] - 1.0 * ud[j];  // cancellation_weight = 1.0
                     ur[j] = d > 0.0 ? d : 0.0;
-                    dirty[j >> 6] = 1;   // (index <= 255 for n <= 16384)
+                    dirty[j >> 6] = 1;   // (index <= NB - 1: n <= 64 NB)
                 }
             }
         }
@@ -1161,7 +1173,18 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
             v.x /= L;
             v.y /= L;
         }
-        if (L > 8192) {
+        if (L > 16384) {   // four residues (if0_spectrum_blue4_kernel): [r][k] = bin 4 k + r, then W_L^{m r} for r = 1 .. 3, m < 8192
+            std::vector<cx<double>> fr((size_t)7 * LE);
+            for (int r = 0; r < 4; ++r)
+                for (int k = 0; k < LE; ++k) fr[(size_t)r * LE + k] = filt[(size_t)4 * k + r];
+            for (int r = 1; r < 4; ++r)
+                for (int m = 0; m < LE; ++m) {
+                    const long long e = ((long long)m * r) % L;   // exact phase reduction
+                    const long double ang = -2.0L * M_PIl * (long double)e / (long double)L;
+                    fr[(size_t)(3 + r) * LE + m] = {(double)cosl(ang), (double)sinl(ang)};
+                }
+            filt.swap(fr);
+        } else if (L > 8192) {
             std::vector<cx<double>> fr((size_t)3 * LE);
             for (int r = 0; r < 2; ++r)
                 for (int k = 0; k < LE; ++k) fr[(size_t)r * LE + k] = filt[(size_t)2 * k + r];
@@ -1648,6 +1671,94 @@ __global__ __launch_bounds__(T) void if0_spectrum_blue2_kernel(const double* __r
   }
 }
 
+// 8193 ... 16384 samples (round 6): the convolution has 32768 points -- FOUR residues of 8192 around a radix-4 step that stays in
+// the workgroup.  Forward by decimation in frequency: the input a[n] (windowed frame times the conjugate chirp) is zero from
+// NF <= 2 M on, so residue r of the spectrum, A[4 j + r], is the M-point transform of u_r[m] = (a[m] + (-i)^r a[m + M]) W_L^{m r};
+// the filter spectrum per residue; inverse by decimation in time: y[k + M q] = sum_r i^{q r} conj(W_L^{k r}) v_r[k] for the
+// k + M q <= NF (q <= 2: the one bin 2 M = NF at NF = 16384).  The partial sums wait in per-workgroup rows in HBM (element k of
+// row q: written and read by the same thread; the grid is one persistent workgroup per CU, the rows stay in L2).  Eight
+// 8192-point transforms per channel: correct, untuned, like every chirp-z frame size.
+template <int T>
+__global__ __launch_bounds__(T) void if0_spectrum_blue4_kernel(const double* __restrict__ yc, const If0Frame* __restrict__ frames,
+                                                               int NF, int channels, double power,
+                                                               const double* __restrict__ window, const cx<double>* __restrict__ tw,
+                                                               const cx<double>* __restrict__ chirp, const cx<double>* __restrict__ bhat_r,
+                                                               double* __restrict__ ut, long long nframes, cx<double>* acc_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int M = 8192, R = 4;
+    cx<double>* buf = reinterpret_cast<cx<double>*>(smem);
+    const cx<double>* __restrict__ twL = bhat_r + (size_t)R * M;   // [r - 1][m] = W_L^{m r}, r = 1 .. 3, L = 4 M
+    cx<double>* accq = acc_rows + (size_t)blockIdx.x * 3 * M;      // [q][k], q = 0 .. 2
+  for (long long f = blockIdx.x; f < nframes; f += gridDim.x) {
+    const If0Frame fr = frames[f];
+    double* row = ut + (size_t)f * 2 * NF;   // the sums over the channels accumulate in the row itself (a bin belongs to one thread)
+    for (int k = threadIdx.x; k <= NF; k += T) row[k] = 0.0;
+    cx<double> regs[M / T];
+    const double* src = yc + fr.yc_base;
+    for (int ch = 0; ch < channels; ++ch) {
+        const double* x = src + (size_t)ch * fr.ch_stride;
+#pragma nounroll
+        for (int r = 0; r < R; ++r) {
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));   // nothing below is hoisted out of the loops (twiddle and table addresses: registers)
+            for (int m = tid; m < M; m += T) {
+                // a[m] and a[m + M]: (x w)[n] conj(chirp[n]), zero from NF on
+                cx<double> a0 = {0.0, 0.0}, a1 = {0.0, 0.0};
+                if (m < NF) {
+                    const double xw = (m < fr.valid ? x[m] : 0.0) * window[m];
+                    const cx<double> c = chirp[m];
+                    a0 = {xw * c.x, -(xw * c.y)};
+                }
+                if (m + M < NF) {
+                    const double xw = (m + M < fr.valid ? x[m + M] : 0.0) * window[m + M];
+                    const cx<double> c = chirp[m + M];
+                    a1 = {xw * c.x, -(xw * c.y)};
+                }
+                // (-i)^r a1: r = 1: (y, -x), 2: (-x, -y), 3: (-y, x)
+                const cx<double> b1 = r == 0 ? a1 : (r == 1 ? cx<double>{a1.y, -a1.x} : (r == 2 ? cx<double>{-a1.x, -a1.y} : cx<double>{-a1.y, a1.x}));
+                cx<double> v = {a0.x + b1.x, a0.y + b1.y};
+                if (r) v = cmul(v, twL[(size_t)(r - 1) * M + m]);
+                buf[lds_slot(m)] = v;
+            }
+            __syncthreads();
+            fft_lds<M, T, false, double>(buf, tw, regs, tid);
+            for (int k = tid; k < M; k += T) {   // swapped: the forward transform of (im, re) is the swapped inverse transform
+                const cx<double> v = cmul(buf[lds_slot(k)], bhat_r[(size_t)r * M + k]);
+                buf[lds_slot(k)] = {v.y, v.x};
+            }
+            __syncthreads();
+            fft_lds<M, T, false, double>(buf, tw, regs, tid);
+            for (int k = tid; k < M; k += T) {
+                const cx<double> sw = buf[lds_slot(k)];
+                cx<double> v = {sw.y, sw.x};
+                if (r) {   // conj(W_L^{k r}) v
+                    const cx<double> w = twL[(size_t)(r - 1) * M + k];
+                    v = {v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y};
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    if ((long long)k + (long long)M * q <= NF) {
+                        // i^{q r} v
+                        const int e = (q * r) & 3;
+                        const cx<double> t = e == 0 ? v : (e == 1 ? cx<double>{-v.y, v.x} : (e == 2 ? cx<double>{-v.x, -v.y} : cx<double>{v.y, -v.x}));
+                        cx<double> acc = r == 0 ? cx<double>{0.0, 0.0} : accq[(size_t)q * M + k];
+                        acc = {acc.x + t.x, acc.y + t.y};
+                        if (r + 1 < R) {
+                            accq[(size_t)q * M + k] = acc;
+                        } else {
+                            const double mag = hypot(acc.x, acc.y);
+                            row[k + M * q] += power == 1.0 ? mag : pow(mag, power);
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // buf is rewritten by the next residue / channel
+        }
+    }
+    for (int k = threadIdx.x + 1; k < NF; k += T) row[2 * NF - k] = row[k];   // |X[N-k]| = |X[k]| for a real frame
+  }
+}
+
 static int if0_spectrum_blue_launch(mpx_ctx* ctx, const double* yc, const If0Frame* frames, long long nf, int NF, int channels,
                                     double power, const If0Plan& plan, double* ut, hipStream_t st) {
     if (2 * NF <= 4096) {
@@ -1657,6 +1768,16 @@ static int if0_spectrum_blue_launch(mpx_ctx* ctx, const double* yc, const If0Fra
         MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(kern, dim3((unsigned)nf), dim3(T), lds, st, yc, frames, NF, channels, power, plan.d_window, plan.d_tw,
                            plan.d_twn, plan.d_twn_r, ut);
+    } else if (2 * NF > 16384) {   // 8193 ... 16384 samples: four residues
+        constexpr int T = 512;
+        const size_t lds = sizeof(cx<double>) * lds_slots(8192);
+        const long long grid = nf < ctx->num_cus ? nf : ctx->num_cus;   // persistent: one workgroup per CU (139 KB of LDS)
+        int rc = ensure(ctx, ctx->d_ws4, (size_t)grid * 3 * 8192 * sizeof(cx<double>));
+        if (rc) return rc;
+        auto kern = if0_spectrum_blue4_kernel<T>;
+        MPX_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T), lds, st, yc, frames, NF, channels, power, plan.d_window, plan.d_tw,
+                           plan.d_twn, plan.d_twn_r, ut, nf, (cx<double>*)ctx->d_ws4.p);
     } else if (2 * NF > 8192) {
         constexpr int T = 512;
         const size_t lds = sizeof(cx<double>) * lds_slots(8192);
@@ -1728,11 +1849,11 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                  hipStream_t stream) {
     mpx_if0_params p = params ? *params
                               : mpx_if0_params{8192, 1.0, 70, 2.3, 0.39, 4, 1.0 / 2100.0, 1.0 / 40.0, 0.0000001, 20, 20, 20, 320, 0.66, MPX_NOTES_UNICODE};
-    // 1024 / 2048 / 4096 / 8192: the tuned kernels; any other size up to 8191 samples: chirp-z (if0_spectrum_blue_kernel up to
-    // 4095, if0_spectrum_blue2_kernel above)
+    // 1024 / 2048 / 4096 / 8192: the tuned kernels; any other size up to 16384 samples: chirp-z (if0_spectrum_blue_kernel up to
+    // 4095, if0_spectrum_blue2_kernel up to 8191, if0_spectrum_blue4_kernel above -- round 6)
     const bool blue = p.frame_size != 1024 && p.frame_size != 2048 && p.frame_size != 4096 && p.frame_size != 8192;
-    if (p.frame_size < 16 || p.frame_size > 8192)
-        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 8192)", p.frame_size);
+    if (p.frame_size < 16 || p.frame_size > 16384)
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 16384)", p.frame_size);
     if (p.channels < 1 || p.channels > IF0_MAXCH || p.max_voices < 1 || p.max_voices > 8 || p.Q < 2 || p.Q > 32 || p.M < 2 ||
         p.M > 64 || !(p.tau_min > 0) || !(p.tau_max > p.tau_min) || fs <= 0)
         return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
@@ -2037,12 +2158,17 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if (!dev_io && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
     // the period search runs ONCE, behind the last slice, on persistent workgroups with a scratch pair each
-    if (!ctx->occupancy.count("if0_periodicity")) {
+    const bool per_big = n2 > 16384;   // spectra of more than 16 384 bins: the instantiation with the larger tables
+    const char* per_key = per_big ? "if0_periodicity_big" : "if0_periodicity";
+    if (!ctx->occupancy.count(per_key)) {
         int occ = 0;
-        MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel, PER_T, 0));
-        ctx->occupancy["if0_periodicity"] = occ > 0 ? occ : 1;
+        if (per_big)
+            MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<true>, PER_T, 0));
+        else
+            MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<false>, PER_T, 0));
+        ctx->occupancy[per_key] = occ > 0 ? occ : 1;
     }
-    const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy["if0_periodicity"]);   // scratch slots
+    const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy[per_key]);   // scratch slots
     (void)max_slice_frames;
     if ((rc = ensure(ctx, ctx->d_ws1, ((size_t)nframes + 2 * (size_t)per_grid) * n2 * sizeof(double)))) return rc;   // ut | ur | ud
     if (sliced && (rc = ensure(ctx, ctx->d_ws2, state_bytes))) return rc;
@@ -2146,7 +2272,10 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     //  135 ms: its re-reads of the spectrum rows (6.9 x their bytes, through L2) slow the LDS/L2-bound spectra down by more
     //  than its own 25 ms.)
     prof_mark(ctx, st, "if0_periodicity_kernel");
-    hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    if (per_big)
+        hipLaunchKernelGGL(if0_periodicity_kernel<true>, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    else
+        hipLaunchKernelGGL(if0_periodicity_kernel<false>, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
     prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
     if (dev_io) {
@@ -2178,20 +2307,25 @@ int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes,
         return set_error(ctx, MPX_EINVAL, "bad iterative-F0 params");
     if (p.note_names != MPX_NOTES_UNICODE && p.note_names != MPX_NOTES_ASCII)
         return set_error(ctx, MPX_EINVAL, "iterative F0: unknown note_names %d", p.note_names);
-    if (p.frame_size < 16 || p.frame_size > 8192)
-        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 8192)", p.frame_size);
+    if (p.frame_size < 16 || p.frame_size > 16384)
+        return set_error(ctx, MPX_EUNSUPPORTED, "iterative F0: frame_size %d (supported: any size in 16 ... 16384)", p.frame_size);
     if ((p.M - 1) * ((double)p.frame_size / fs) / p.tau_min + 1.5 >= n2)
         return set_error(ctx, MPX_EINVAL, "iterative F0: harmonic %d of tau_min falls outside the %d-bin spectrum (the "
                          "reference raises ValueError on the empty slice)", p.M - 1, n2);
     if (nframes == 0) return MPX_OK;
     hipStream_t st = ctx->stream;
     int rc;
-    if (!ctx->occupancy.count("if0_periodicity")) {
+    const bool per_big = n2 > 16384;
+    const char* per_key = per_big ? "if0_periodicity_big" : "if0_periodicity";
+    if (!ctx->occupancy.count(per_key)) {
         int occ = 0;
-        MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel, PER_T, 0));
-        ctx->occupancy["if0_periodicity"] = occ > 0 ? occ : 1;
+        if (per_big)
+            MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<true>, PER_T, 0));
+        else
+            MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<false>, PER_T, 0));
+        ctx->occupancy[per_key] = occ > 0 ? occ : 1;
     }
-    const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy["if0_periodicity"]);
+    const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy[per_key]);
     if ((rc = ensure(ctx, ctx->d_ws1, ((size_t)nframes + 2 * (size_t)per_grid) * n2 * sizeof(double)))) return rc;   // ut | ur | ud
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)nframes * (12 + 16) * sizeof(double)))) return rc;   // chroma rows | voices rows
     double* ut_all = (double*)ctx->d_ws1.p;
@@ -2225,7 +2359,10 @@ int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes,
     a.slot_busy = (unsigned*)ctx->d_queue.p;
     a.num_slots = (int)per_grid;
     prof_mark(ctx, st, "if0_periodicity_kernel");
-    hipLaunchKernelGGL(if0_periodicity_kernel, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    if (per_big)
+        hipLaunchKernelGGL(if0_periodicity_kernel<true>, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
+    else
+        hipLaunchKernelGGL(if0_periodicity_kernel<false>, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
     prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
     MPX_HIP(ctx, hipMemcpyAsync(chroma_frames, ctx->d_frames_out.p, (size_t)nframes * 12 * sizeof(double), hipMemcpyDeviceToHost, st));

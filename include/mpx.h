@@ -244,8 +244,9 @@ int mpx_prime_multif0_dev(mpx_ctx* ctx, const float* d_signal, int64_t n, int fs
  * WHOLE signal (quirk A.1 kept), warped-FIR compression, full-wave rectifier, (y + LP(y, fc))/2,
  * frames of `frame_size` x Hamming zero-padded to 2*frame_size, sum over channels of |FFT|^power, then the iterative
  * period search / harmonic cancellation per frame.  frame_size (iterative_f0.py:25 takes any integer): 1024, 2048, 4096 and
- * the default 8192 run on the tuned power-of-two kernels; any other size in 16 ... 8191 by chirp-z (correct, untuned: such
- * a call runs in one piece, without the time slices of MPX_OPT_IF0_WORKSPACE_BYTES); MPX_EUNSUPPORTED above 8192 samples.
+ * the default 8192 run on the tuned power-of-two kernels; any other size in 16 ... 16384 by chirp-z (correct, untuned: such
+ * a call runs in one piece, without the time slices of MPX_OPT_IF0_WORKSPACE_BYTES; above 8192 samples -- round 6 -- the
+ * 32768-point convolution is four residues of 8192 points); MPX_EUNSUPPORTED above 16384 samples.
  * Long signals are filtered in chunks of up to 262144 samples, each with a zero-state run-in of
  * mpx_iterative_f0_warmup samples (40960 for the defaults: the chain has decayed to fp64 rounding by then), so
  * chunks run in parallel and shard across GPUs. */

@@ -76,7 +76,7 @@ def test_spectra_and_batch_vs_oracle(eng, clips):
         np.testing.assert_allclose(got[3], o_if0.iterative_f0_compute(batch[3], FS), rtol=1e-5, atol=0)
     assert np.array_equal(got, eng.iterative_f0_batch(batch, FS))      # deterministic
     with pytest.raises(NotImplementedError):
-        eng.iterative_f0(x, FS, frame_size=8193)       # above 8192 samples there is no kernel
+        eng.iterative_f0(x, FS, frame_size=16385)      # above 16384 samples there is no kernel (round 6: 8193 ... 16384 run)
     with pytest.raises(NotImplementedError):
         eng.iterative_f0(x, FS, frame_size=8)
     with pytest.raises(ValueError):
@@ -309,6 +309,45 @@ def test_any_frame_size_by_chirp_z_vs_oracle(eng, frame_size, power, channels):
         np.testing.assert_allclose(got[0], o_if0.iterative_f0_compute(batch[0], FS, **kw), rtol=1e-5, atol=1e-300)
         np.testing.assert_allclose(got[2], o_if0.iterative_f0_compute(batch[2], FS, **kw), rtol=1e-5, atol=1e-300)
     assert np.all(got[1] == 0)
+
+
+@pytest.mark.parametrize("frame_size,power,channels,fs", [(12000, 1.0, 70, 22050), (16384, 1.0, 70, 22050), (8193, 0.5, 33, 22050),
+                                                          (16383, 1.0, 64, 44100), (10000, 2.0, 70, 44100)])
+def test_frame_sizes_above_8192_vs_oracle(eng, frame_size, power, channels, fs):
+    """Round 6: iterative_f0.py:25 takes any integer frame_size; 8193 ... 16384 samples run the 2 x frame_size-point spectrum
+    as a chirp-z transform of 32768 points -- four residues of 8192 around a radix-4 step (if0_spectrum_blue4_kernel) -- and the
+    period search on spectra of up to 32768 bins (if0_periodicity_kernel<true>: twice the tables).  The review's two sizes
+    (12000, 16384), the ends of the range, both sample rates, three powers; spectra 1e-9, per-frame chroma 1e-5; the
+    estimator object of the drop-in class at such a window; a batch."""
+    import chord_detection_amd as cd
+    from oracle import iterative_f0 as o_if0
+    rng = np.random.default_rng(9000 + frame_size)
+    kw = dict(frame_size=frame_size, power=power, channels=channels)
+    n = 2 * frame_size + frame_size // 3 + 5
+    x = _poly(rng, n) + (1e-3 * rng.standard_normal(n)).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        wper, wut = o_if0.iterative_f0_frames(x, fs, **kw)
+    ut = eng.iterative_f0_spectra(x, fs, **kw)
+    tot, per = eng.iterative_f0(x, fs, return_frames=True, **kw)
+    assert ut.shape == wut.shape == (3, 2 * frame_size)
+    np.testing.assert_allclose(ut, wut, rtol=1e-9, atol=1e-9 * np.abs(wut).max())
+    np.testing.assert_allclose(per, wper, rtol=1e-5, atol=1e-300)
+    np.testing.assert_allclose(tot, wper.sum(0), rtol=1e-5, atol=1e-300)
+    assert np.array_equal(eng.iterative_f0_periodicity(ut, fs, frame_size=frame_size), per)     # the search alone, same bits
+    batch = [x[:frame_size + 9], np.zeros(0, dtype=np.float32), x[:frame_size - 1]]
+    got = eng.iterative_f0_batch(batch, fs, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.testing.assert_allclose(got[0], o_if0.iterative_f0_compute(batch[0], fs, **kw), rtol=1e-5, atol=1e-300)
+        np.testing.assert_allclose(got[2], o_if0.iterative_f0_compute(batch[2], fs, **kw), rtol=1e-5, atol=1e-300)
+    assert np.all(got[1] == 0)
+    if frame_size == 12000:
+        obj = cd.MultipitchIterativeF0((x, fs), frame_size=frame_size)
+        np.testing.assert_allclose(obj.compute_pitches().as_array(), wper.sum(0) if channels == 70 and power == 1.0 else tot, rtol=1e-5, atol=1e-300)
+        c, (sal, tau) = obj.periodicity_estimator.compute(wut[0])
+        np.testing.assert_allclose(c.as_array(), wper[0], rtol=1e-5, atol=1e-300)
+        assert sal.shape == (4,) and tau[0] > 0
 
 
 @pytest.mark.parametrize("frame_size,nfr,channels", [(900, 49, 70), (1000, 13, 70), (777, 30, 64), (1500, 9, 33)])

@@ -46,6 +46,7 @@ SCRATCH_FREE = [
     "mpx::if0_frontend_kernel<false>", "mpx::if0_frontend2_kernel<false>",
     "mpx::if0_frontend_kernel<true>", "mpx::if0_frontend2_kernel<true>",     # time slices (MPX_OPT_IF0_WORKSPACE_BYTES)
     "mpx::if0_spectrum_blue_kernel<4096, 256>", "mpx::if0_spectrum_blue_kernel<8192, 512>", "mpx::if0_spectrum_blue2_kernel<512>",   # chirp-z frame sizes
+    "mpx::if0_spectrum_blue4_kernel<512>", "mpx::if0_periodicity_kernel<true>",   # frame sizes 8193 ... 16384 (round 6)
 ]
 # kernels that are known to spill, with the ceiling they must not grow past (bytes per lane).  Every ceiling is the value
 # hipcc reports TODAY (ROCm 7.2), no headroom: a spill that grows by one slot fails here and has to be looked at (round 5
@@ -53,7 +54,7 @@ SCRATCH_FREE = [
 SCRATCH_CEILING = {
     "mpx::prime_wave_kernel<1024, 7>": 36,             # two items per wave at two waves per SIMD: loop-carried item state (slots, pointers), touched once per iteration outside the transforms
     "mpx::pv_enhance_kernel<true, 2>": 24,             # three workgroups per CU since round 5 (168 registers): 0.85 -> 0.66 ms per 8192 frames with the spill
-    "mpx::if0_periodicity_kernel": 108,                # held at four workgroups per CU (128 registers); fourteen loads in flight per lane in the range maxima: 1.59 -> 1.49 ms per 600 s WITH the spill
+    "mpx::if0_periodicity_kernel<false>": 108,                # held at four workgroups per CU (128 registers); fourteen loads in flight per lane in the range maxima: 1.59 -> 1.49 ms per 600 s WITH the spill
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1, false>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
     "mpx::he_wave_kernel<7, 4, false, false, 4294967295u, 2, false>": 32,
     "mpx::he_wave_kernel<6, 4, false, true, 4294967295u, 2, true>": 20,     # the pairs-of-waves arrangement (an option, not the default)
@@ -69,7 +70,7 @@ OCCUPANCY = {
     "mpx::prime_wave_kernel<2048, 4>": 1,
     "mpx::peakfit_kernel<true>": 2,
     "mpx::pv_enhance_kernel<true, 2>": 3,
-    "mpx::if0_periodicity_kernel": 4,                  # round 5 shipped it at 129 registers = 3 for a while: 17 % slower
+    "mpx::if0_periodicity_kernel<false>": 4,                  # round 5 shipped it at 129 registers = 3 for a while: 17 % slower
 }
 
 
