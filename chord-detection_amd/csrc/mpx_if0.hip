@@ -635,8 +635,11 @@ __device__ __forceinline__ void if0_block_maxima(double m, int lane, int i0, int
 
 // BIG (round 6): spectra of more than 16 384 bins (frame sizes 8193 ... 16384): twice the tables, one more level of the sparse
 // table; the default instantiation is the round-5 kernel unchanged.
+#ifndef IF0_PER_WGS
+#define IF0_PER_WGS 4   // workgroups per CU the register allocation is held to (A/B: scripts/dev/spill_ab.sh builds a library with 3 = scratch-free)
+#endif
 template <bool BIG>
-__global__ __launch_bounds__(PER_T, BIG ? 2 : 4) void if0_periodicity_kernel(If0PerArgs a) {   // (four workgroups per CU = 128 registers: the gather of the overlapping-window case had taken the kernel to 129 and three -- 2.61 -> 3.05 ms per 600 s; a register cap brings 2.70 back, the gather as a function of its own the same)
+__global__ __launch_bounds__(PER_T, BIG ? 2 : IF0_PER_WGS) void if0_periodicity_kernel(If0PerArgs a) {   // (four workgroups per CU = 128 registers: the gather of the overlapping-window case had taken the kernel to 129 and three -- 2.61 -> 3.05 ms per 600 s; a register cap brings 2.70 back, the gather as a function of its own the same)
     __shared__ double tau_low[32], tau_up[32], smax[32];
     __shared__ double um[128];    // [interval * 64 + harmonic]: range maxima
     __shared__ double wts[128];   // [interval * 64 + harmonic]: m fs / tau_up + epsilon2

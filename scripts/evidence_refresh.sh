@@ -11,7 +11,7 @@ cd $R
 timeout 1500 python3 -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/gputest.txt; cat $O/gputest.txt
 export PMC_REPS=1
 bash scripts/pmc_collect.sh $TAG/pmc_after > $O/pmc.log 2>&1
-python3 scripts/pmc_to_traffic.py $O/pmc_after/pmc.json 5 > /dev/null
+python3 scripts/pmc_to_traffic.py $O/pmc_after/pmc.json ${ROUND:-6} > /dev/null
 cp profiles/traffic_latest.json $O/traffic_latest.json
 timeout 900 python3 bench.py --steps 2000 --warmup 200 --full-json $O/bench_plain_full.json > $O/bench_plain.json 2> $O/bench_plain.err
 cd /tmp; export TMPDIR=/tmp
@@ -27,4 +27,5 @@ if [ -f $DEV ]; then
   MPX_LIB_PATH=$DEV timeout 900 python3 tests/tools/esacf_bitcheck.py 2>&1 | grep -v amdgpu > $O/esacf_bitcheck.txt; tail -1 $O/esacf_bitcheck.txt
   MPX_LIB_PATH=$DEV timeout 300 python3 scripts/h2d_probe.py > $O/h2d_probe.json 2> /dev/null
 fi
+if [ -f $R/chord-detection_amd/libmpx_hip_per3.so ]; then bash scripts/dev/spill_ab.sh run > $O/spill_ab.txt 2>&1; fi
 head -c 300 $O/bench_driver_short.json
