@@ -67,6 +67,10 @@ def compact_record(out, full_path=None):
         e.update(_pick(r, ("kernel", "kernel_ms", "bound", "frac", "traffic", "compulsory_bytes", "wasted_traffic_ratio")))
         if "hbm_frac_whole_path" in w:
             e["hbm_frac_whole_path"] = w["hbm_frac_whole_path"]
+        if "traffic_vs_sample_bytes" in w:   # Iterative-F0: every kernel's HBM bytes / the samples' own bytes (the fp64 hand-off)
+            e["traffic_vs_sample_bytes"] = w["traffic_vs_sample_bytes"]
+        if (w.get("roofline") or {}).get("traffic_vs_compulsory_plus_intermediate") is not None:
+            e["traffic_vs_compulsory_plus_intermediate"] = w["roofline"]["traffic_vs_compulsory_plus_intermediate"]
         km = w.get("kernels_ms") or w.get("kernels_ms_total")
         if km:
             e["kernels_ms"] = {k: v for k, v in sorted(km.items(), key=lambda kv: -kv[1])[:6]}

@@ -331,6 +331,13 @@ def wl_if0_stream(c):
             # (the PMC passes ran a 600 s stream, scripts/pmc_workloads.py: scaled to this rank's share)
             with_traffic(r, "if0_stream", k, launches=prof_samples / (600.0 * fs))
         rec["hbm_frac_whole_path"] = (4.0 * n + 96.0 * total_frames) / wall / K.HBM_PEAK   # samples in once, 12 doubles per frame out (warm pass)
+        # What the three kernels move through HBM together (the last PMC collection, scaled to this rank's share) against the
+        # bytes of the samples themselves: the fp64 70-channel hand-off between front end and spectra dominates it -- the
+        # per-kernel `traffic_vs_compulsory_plus_intermediate` figures (~1.0-1.2: no re-reads) do not show that.
+        tr = [r.get("traffic") for r in rec["rooflines"].values()]
+        if tr and all(t is not None for t in tr):
+            rec["traffic_whole_path_bytes"] = float(sum(tr))
+            rec["traffic_vs_sample_bytes"] = float(sum(tr)) / (4.0 * prof_samples)
     if _cpu_rec(c, "if0"):
         rec["cpu_baseline"] = _cpu_rec(c, "if0")
     return rec
@@ -393,7 +400,7 @@ def wl_he_default(c):
                       "frames_per_gpu": frames, "entry": "mpx_harmonic_energy_batch, clips in HBM; kernel_ms: mpx_harmonic_energy_dev"},
            "kernels_ms": {"he_kernel": kern_ms}, "oracle_spot_check": ok,
            "roofline": {"bound": "hbm", "achieved": hbm / 1e9, "peak": K.HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm / K.HBM_PEAK,
-                        "kernel": "he_wave_kernel<7,4,...,2> (two passes per 8192-sample frame)", "kernel_ms": kern_ms, "units_per_launch": frames, "unit_of_work": "frame",
+                        "kernel": "he_wave_kernel<6,4,...,2,pairs> (a pair of waves per 8192-sample frame: a streamed call, round 6)", "kernel_ms": kern_ms, "units_per_launch": frames, "unit_of_work": "frame",
                         "bytes_per_unit": b_alg, "flops_per_unit": f_alg, "hbm_frac": hbm / K.HBM_PEAK,
                         "valu_f64_frac": fl / K.F64_PEAK, "compulsory_bytes": b_alg * frames, "traffic": None},
            "hbm_frac_whole_path": b_alg * frames / wall / K.HBM_PEAK}
