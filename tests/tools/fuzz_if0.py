@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the Iterative-F0 path against the oracle: random frame sizes (1024/2048/4096/8192 and any size 16..8191 by chirp-z), channel counts
+"""Differential fuzz of the Iterative-F0 path against the oracle: random frame sizes (1024/2048/4096/8192 and any size 16..16384 by chirp-z), channel counts
 (incl. > 64: two front-end waves, and < 64), powers, clip lengths around chunk / frame boundaries; summary spectra to
 1e-9, per-frame chroma to 1e-5.  Not part of the suite (the oracle's 70-channel filterbank is seconds per clip)."""
 import os, sys, warnings
@@ -16,7 +16,8 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     for case in range(cases):
         fs = 22050
-        NF = int(rng.choice([1024, 2048, 4096, 8192, int(rng.integers(16, 4096)), int(rng.integers(16, 4096)), int(rng.integers(4097, 8192))]))   # tuned powers of two and chirp-z sizes
+        NF = int(rng.choice([1024, 2048, 4096, 8192, int(rng.integers(16, 4096)), int(rng.integers(16, 4096)), int(rng.integers(4097, 8192)),
+                             int(rng.integers(8193, 16385))]))   # tuned powers of two and chirp-z sizes (round 6: up to 16384)
         ch = int(rng.choice([5, 31, 64, 65, 70]))
         power = float(rng.choice([1.0, 0.5, 2.0]))
         n = int(rng.choice([NF // 2, NF, NF + 1, 2 * NF + 17, 16384 + 100, 3 * NF - 1, 40000, 70001, 140000, 300000]))
