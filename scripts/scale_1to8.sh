@@ -25,7 +25,8 @@ while [ $# -gt 0 ]; do
 done
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1
-HAVE=$(python3 -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
+# (SCALE_ASSUME_GPUS: tests only -- with bench.py's stand-in engine, MPX_BENCH_STUB, the ranks run over gloo on CPU)
+HAVE=${SCALE_ASSUME_GPUS:-$(python3 -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)}
 PLAIN=""
 BASE=$(mktemp)   # the N = 1 launcher record of this sweep: what every later N is divided by
 for N in $GPUS; do

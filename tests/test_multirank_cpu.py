@@ -95,6 +95,29 @@ def test_bench_py_eight_ranks():
     assert w["if0_stream_1h"]["scaling"] == "strong" and w["if0_stream_1h"]["value"] > 0
 
 
+def test_scale_script_prints_efficiency_against_its_own_n1_launch():
+    """scripts/scale_1to8.sh -- the 1/2/4/8-GPU sweep as the driver launches it -- with the stand-in engine over gloo for N = 1, 2:
+    one JSON object per N; every object carries value, value_steps_only, gather_ms and, from the N = 1 launch of the sweep on,
+    efficiency_vs_n1 = value_N / (N x value_1) for the headline, the headline without its gather and every workload."""
+    env = dict(os.environ, PYTHONPATH=ROOT, MPX_BENCH_STUB="tests.bench_stub", SCALE_ASSUME_GPUS="2", OMP_NUM_THREADS="1",
+               MASTER_PORT=str(_free_port()))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    out = subprocess.run(["bash", "scripts/scale_1to8.sh", "--steps", "4", "--warmup", "1", "--gpus", "1 2 4", "--workloads",
+                          "corpus_4096_all_methods"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [r["n_gpus"] for r in recs] == [1, 2, 4] and recs[2].get("skipped") == "only 2 GPU(s) visible"
+    one, two = recs[0], recs[1]
+    assert "failed" not in one and "failed" not in two, (one, two)
+    assert one["efficiency_vs_n1"] == 1.0 and one["efficiency_vs_n1_steps_only"] == 1.0 and one["gather_ms"] is not None
+    assert one["launcher_equals_plain_within_5pct"] in (True, False) and one["plain_bench_value"] > 0
+    assert np.isclose(two["efficiency_vs_n1"], two["value"] / (2 * one["value"]), rtol=1e-12)
+    assert np.isclose(two["efficiency_vs_n1_steps_only"], two["value_steps_only"] / (2 * one["value_steps_only"]), rtol=1e-12)
+    w1, w2 = one["workloads"]["corpus_4096_all_methods"], two["workloads"]["corpus_4096_all_methods"]
+    assert w1["efficiency_vs_n1"] == 1.0 and np.isclose(w2["efficiency_vs_n1"], w2["value"] / (2 * w1["value"]), rtol=1e-12)
+
+
 def test_bench_py_one_rank_stub_matches_contract():
     env = dict(os.environ, PYTHONPATH=ROOT, MPX_BENCH_STUB="tests.bench_stub", MPX_BENCH_CPU_BUDGET="0.2")
     import tempfile
