@@ -69,6 +69,32 @@ int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_
     return MPX_OK;
 }
 
+int d2h_results_sync(mpx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
+    if (bytes > 8192) {
+        if (ctx->h_results_bytes < bytes) {
+            if (ctx->h_results) (void)hipHostFree(ctx->h_results);
+            ctx->h_results = nullptr;
+            ctx->h_results_bytes = 0;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, bytes + bytes / 4, hipHostMallocDefault) == hipSuccess) {
+                ctx->h_results = p;
+                ctx->h_results_bytes = bytes + bytes / 4;
+            } else {
+                (void)hipGetLastError();   // no pinned memory: the direct copy below
+            }
+        }
+        if (ctx->h_results) {
+            MPX_HIP(ctx, hipMemcpyAsync(ctx->h_results, src_dev, bytes, hipMemcpyDeviceToHost, st));
+            MPX_HIP(ctx, hipStreamSynchronize(st));
+            std::memcpy(dst_host, ctx->h_results, bytes);
+            return MPX_OK;
+        }
+    }
+    MPX_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+    MPX_HIP(ctx, hipStreamSynchronize(st));
+    return MPX_OK;
+}
+
 void prof_mark_slow(mpx_ctx* ctx, hipStream_t st, const char* name) {
     if (ctx->prof_marks.size() >= (size_t)1 << 20) return;  // bounded: a forgotten mpx_profile_end must not eat the host
     hipEvent_t ev = nullptr;
@@ -208,6 +234,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     for (hipEvent_t e : ctx->copy_ev)
         if (e) hipEventDestroy(e);
+    if (ctx->h_results) hipHostFree(ctx->h_results);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t e : ctx->side_ev)
         if (e) hipEventDestroy(e);
@@ -551,9 +578,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if ((rc = segment_sum(ctx, (const double*)ctx->d_frames_out.p, (const long long*)ctx->d_offsets.p, num_clips, nf,
                           (double*)ctx->d_sum.p, st)))
         return rc;
-    MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double),
-                                hipMemcpyDeviceToHost, st));
-    MPX_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = d2h_results_sync(ctx, chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), st))) return rc;
     ctx->batch_layout.swap(layout);   // d_desc / d_offsets hold this layout now (a failed call leaves the cache empty)
     ctx->batch_layout_frames = nf;
     return MPX_OK;

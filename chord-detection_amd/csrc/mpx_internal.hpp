@@ -65,6 +65,8 @@ struct mpx_ctx {
     hipEvent_t side_ev[2] = {};
     bool side_ready = false;
     unsigned live_epoch = 0;                  // tag of the parked records of the current batch (never 0)
+    void* h_results = nullptr;                // pinned staging for result copies of batches ([clips, 12] doubles): d2h_results
+    size_t h_results_bytes = 0;
     size_t if0_ws_cap = (size_t)32 << 30;     // MPX_OPT_IF0_WORKSPACE_BYTES
     int he_kernel = 0;                        // MPX_OPT_HE_KERNEL
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -117,6 +119,9 @@ int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
 void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failure (error set)
 // Samples (host or device memory) into device memory, enqueued on `st` (see mpx_api.hip for the measured rates).
 int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
+// Results of a batch back to the caller's (pageable) buffer and the stream synchronised: above 8 KB through a pinned buffer of the
+// context's -- the runtime's own path for a pageable destination stages and waits per piece -- then one host memcpy.
+int d2h_results_sync(mpx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, hipStream_t st);
 // While profiling is on: record an event on `st`; the time to the next mark is booked on `name` (nullptr: on nothing).
 void prof_mark_slow(mpx_ctx* ctx, hipStream_t st, const char* name);
 inline void prof_mark(mpx_ctx* ctx, hipStream_t st, const char* name) {
