@@ -669,6 +669,25 @@ __device__ __forceinline__ double mag067_libm(double re, double im) { return exp
     __shared__ double pow_tab[p067::TAB_DOUBLES];                           \
     for (int i_ = (tid); i_ < p067::TAB_DOUBLES; i_ += (nthreads)) pow_tab[i_] = (a).pow_tab[i_]
 
+// The truncation regime of esacf.py:108-129 (every rate's "stretched" copy is a prefix of the row: < 1024 lags, or the no-op mode) in
+// ONE round.  Round r = 2 .. n_peaks_elim of the reference clips, subtracts the first round(Mh / r) lags from themselves (v - v:
+// NaN and inf become NaN like x - x does), clips.  The prefixes are NESTED -- round-half-even(Mh / r) does not grow with r -- and
+// clipping is idempotent: after round 2, the longest prefix, a lag is 0 (or NaN) inside it and max(v, 0) outside, and rounds
+// 3 .. n_peaks_elim change nothing (0 - 0 = 0, NaN stays).  Until round 6 every lag ran all the rounds, a double-precision DIVISION
+// each (Mh / r): 20 divisions per thread and frame of 2046 samples, 18 % of sacf_pfa_kernel<2>'s VALU instructions.
+// cut2 = enhance_cut2(...) once per thread: round(Mh / 2) (0.5 Mh is exact), 0 in the no-op mode.
+__device__ __forceinline__ int enhance_cut2(int Mh, int enhance_mode) {
+    return enhance_mode == MPX_ENHANCE_LIBROSA010 ? (int)nearbyint(0.5 * (double)Mh) : 0;
+}
+__device__ __forceinline__ double enhance_truncate(double v, int n, int n_peaks_elim, int cut2) {
+    if (n_peaks_elim >= 2) {
+        v = v < 0.0 ? 0.0 : v;          // clip
+        if (n < cut2) v = v - v;        // minus the "stretched" copy (== itself for a <=2-frame STFT)
+        v = v < 0.0 ? 0.0 : v;          // clip
+    }
+    return v;
+}
+
 template <int L, bool BLUE>
 __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
     constexpr int T = L / 8;
@@ -794,15 +813,9 @@ __global__ __launch_bounds__(L / 8, 4) void sacf_kernel(SacfArgs a) {
         }
         // ---- enhancement (esacf.py:108-129)
         // (every lag is touched by one thread only, the same one in every pass: registers, one store, one barrier)
+        const int cut2 = enhance_cut2(Mh, a.enhance_mode);
         for (int n = tid; n < Mh; n += T) {
-            double v = yh[n];
-            for (int r = 2; r <= a.n_peaks_elim; ++r) {
-                int cut = 0;
-                if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-                v = v < 0.0 ? 0.0 : v;          // clip
-                if (n < cut) v = v - v;         // minus the "stretched" copy (== itself for a <=2-frame STFT)
-                v = v < 0.0 ? 0.0 : v;          // clip
-            }
+            const double v = enhance_truncate(yh[n], n, a.n_peaks_elim, cut2);
             yh[n] = v;
             yrow[n] = v;
         }
@@ -903,15 +916,9 @@ __global__ __launch_bounds__(L / 8, 2) void sacf_rz_kernel(SacfArgs a) {
         for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
         return;
     }
+    const int cut2 = enhance_cut2(Mh, a.enhance_mode);
     for (int n = tid; n < Mh; n += T) {   // enhancement without the vocoder (no-op mode, or fewer than two rates): see sacf_kernel
-        double v = yv[n];
-        for (int r = 2; r <= a.n_peaks_elim; ++r) {
-            int cut = 0;
-            if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-            v = v < 0.0 ? 0.0 : v;
-            if (n < cut) v = v - v;
-            v = v < 0.0 ? 0.0 : v;
-        }
+        const double v = enhance_truncate(yv[n], n, a.n_peaks_elim, cut2);
         yv[n] = v;
         yrow[n] = v;
     }
@@ -1257,15 +1264,9 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
         if (a.defer_enhance) {
             for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
         } else {
-            for (int n = tid; n < Mh; n += T) {   // enhancement (esacf.py:108-129), truncation regime: see sacf_kernel
-                double v = yv[n];
-                for (int r = 2; r <= a.n_peaks_elim; ++r) {
-                    int cut = 0;
-                    if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-                    v = v < 0.0 ? 0.0 : v;
-                    if (n < cut) v = v - v;
-                    v = v < 0.0 ? 0.0 : v;
-                }
+            const int cut2 = enhance_cut2(Mh, a.enhance_mode);
+            for (int n = tid; n < Mh; n += T) {   // enhancement (esacf.py:108-129), truncation regime: see enhance_truncate
+                const double v = enhance_truncate(yv[n], n, a.n_peaks_elim, cut2);
                 yv[n] = v;
                 yrow[n] = v;
             }
@@ -1342,16 +1343,9 @@ __global__ __launch_bounds__(T) void sacf_big_kernel(SacfArgs a) {
         for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
         return;
     }
-    for (int r = 2; r <= a.n_peaks_elim; ++r) {
-        int cut = 0;
-        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-        for (int n = tid; n < Mh; n += T) {
-            double v = yv[n];
-            v = v < 0.0 ? 0.0 : v;
-            if (n < cut) v = v - v;
-            v = v < 0.0 ? 0.0 : v;
-            yv[n] = v;
-        }
+    {   // the truncation regime in one round (enhance_truncate)
+        const int cut2 = enhance_cut2(Mh, a.enhance_mode);
+        for (int n = tid; n < Mh; n += T) yv[n] = enhance_truncate(yv[n], n, a.n_peaks_elim, cut2);
         __syncthreads();
     }
     for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
@@ -1478,16 +1472,9 @@ __global__ __launch_bounds__(T) void sacf_split_kernel(SacfArgs a) {
         for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
         return;
     }
-    for (int r = 2; r <= a.n_peaks_elim; ++r) {
-        int cut = 0;
-        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-        for (int n = tid; n < Mh; n += T) {
-            double v = yv[n];
-            v = v < 0.0 ? 0.0 : v;
-            if (n < cut) v = v - v;
-            v = v < 0.0 ? 0.0 : v;
-            yv[n] = v;
-        }
+    {   // the truncation regime in one round (enhance_truncate)
+        const int cut2 = enhance_cut2(Mh, a.enhance_mode);
+        for (int n = tid; n < Mh; n += T) yv[n] = enhance_truncate(yv[n], n, a.n_peaks_elim, cut2);
         __syncthreads();
     }
     for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
@@ -1952,16 +1939,9 @@ __global__ __launch_bounds__(T) void enhance_pick_big_kernel(SacfArgs a) {
     double* row = a.y_out + f * (long long)Mh;
     for (int n = tid; n < Mh; n += T) yv[n] = row[n];
     __syncthreads();
-    for (int r = 2; r <= a.n_peaks_elim; ++r) {
-        int cut = 0;
-        if (a.enhance_mode == MPX_ENHANCE_LIBROSA010) cut = (int)nearbyint((double)Mh / (double)r);
-        for (int n = tid; n < Mh; n += T) {
-            double v = yv[n];
-            v = v < 0.0 ? 0.0 : v;
-            if (n < cut) v = v - v;
-            v = v < 0.0 ? 0.0 : v;
-            yv[n] = v;
-        }
+    {   // the truncation regime in one round (enhance_truncate)
+        const int cut2 = enhance_cut2(Mh, a.enhance_mode);
+        for (int n = tid; n < Mh; n += T) yv[n] = enhance_truncate(yv[n], n, a.n_peaks_elim, cut2);
         __syncthreads();
     }
     for (int n = tid; n < Mh; n += T) row[n] = yv[n];
