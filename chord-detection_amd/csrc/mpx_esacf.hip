@@ -1191,6 +1191,8 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
         const long long f = blockIdx.x;
         const int tid = threadIdx.x;
         const cx<double>* xin = a.xb + band_index(f, 0, N);
+        int plag[4], pmir[4];   // positions of the lags n = tid + r T, r < 4 (n < Mh), and of their mirrors N - n: read with the
+                                // gather's own table loads (until round 6: eight dependent L2 loads per thread in front of the lags)
         {
             constexpr int PER = (N + T - 1) / T;
             cx<double> xv[PER];
@@ -1202,8 +1204,15 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
                 xv[r] = xin[(size_t)(nc >> 4) * (64 * BS_TILE) + (nc & 15)];
             }
 #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = tid + r * T;
+                pmir[r] = pos[n >= 1 && n < Mh ? N - n : 0];
+            }
+#pragma unroll
             for (int r = 0; r < PER; ++r)
                 if (tid + r * T < N) buf[pv[r]] = xv[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) plag[r] = r < PER ? pv[r] : 0;
         }
         __syncthreads();
         if (!(a.ablate & 8)) pfa_dft<A0, false>(buf, cs31, cs11, tid);
@@ -1246,7 +1255,7 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
             if (n < Mh) {
                 // the real-input transform keeps residues 0..15 of axis 31; lag n at one of the others is read from lag
                 // N - n (S is real and even, so is its transform)
-                const int p0 = pos[n], p1 = pos[N - n > N - 1 ? 0 : N - n];
+                const int p0 = plag[r], p1 = pmir[r];   // (lag 0: p0 % 31 <= 15 -- position 0 -- so its mirror is never read)
                 lag[r] = buf[p0 % 31 > 15 ? p1 : p0].x * inv_n;
             }
         }
