@@ -1172,17 +1172,11 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
     cx<double>* cs31 = reinterpret_cast<cx<double>*>(smem + PFA_TAB_OFF(N, Mh));   // [16][16]
     cx<double>* cs11 = cs31 + 256;                                                    // [6][5]
     __shared__ double pow_tab[p067::TAB_DOUBLES];
-    {
-        // all three table loads are issued before the first of them is stored: one L2 round trip, not three
-        const int tid = threadIdx.x;
-        const cx<double> v31 = a.pfa_cs31[tid];
-        const cx<double> v11 = a.pfa_cs11[tid < 30 ? tid : 0];
-        const double vp = A0 == 1 ? 0.0 : a.pow_tab[tid < p067::TAB_DOUBLES ? tid : 0];
-        cs31[tid] = v31;
-        if (tid < 30) cs11[tid] = v11;
-        if (A0 != 1 && tid < p067::TAB_DOUBLES) pow_tab[tid] = vp;
-    }
-    __syncthreads();
+    // all three table loads are issued before the first of them is stored, and (round 6) the frame's own loads with them: one
+    // L2 / HBM round trip and ONE barrier in front of the first transform, not two of each
+    const cx<double> v31 = a.pfa_cs31[threadIdx.x];
+    const cx<double> v11 = a.pfa_cs11[threadIdx.x < 30 ? threadIdx.x : 0];
+    const double vp = A0 == 1 ? 0.0 : a.pow_tab[threadIdx.x < p067::TAB_DOUBLES ? threadIdx.x : 0];
     const double inv_n = 1.0 / (double)N;
     {
         // (one workgroup per frame: as persistent workgroups looping over frames the compiler hoisted the loop-invariant
@@ -1191,6 +1185,8 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
         const long long f = blockIdx.x;
         const int tid = threadIdx.x;
         const cx<double>* xin = a.xb + band_index(f, 0, N);
+        constexpr int NPAIRS = N / 2 + 1, PPER = (NPAIRS + T - 1) / T;   // mirror pairs k <= N - k: k = 0 .. N/2 (host: pfa_npairs)
+        unsigned pairq[PPER];    // this thread's pairs (position of k | position of N - k << 16): loaded with the gather, used behind the first transform
         int plag[4], pmir[4];   // positions of the lags n = tid + r T, r < 4 (n < Mh), and of their mirrors N - n: read with the
                                 // gather's own table loads (until round 6: eight dependent L2 loads per thread in front of the lags)
         {
@@ -1209,6 +1205,14 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
                 pmir[r] = pos[n >= 1 && n < Mh ? N - n : 0];
             }
 #pragma unroll
+            for (int r = 0; r < PPER; ++r) {
+                const int i = tid + r * T;
+                pairq[r] = reinterpret_cast<const unsigned*>(a.pfa_pairs)[i < NPAIRS ? i : 0];
+            }
+            cs31[tid] = v31;
+            if (tid < 30) cs11[tid] = v11;
+            if (A0 != 1 && tid < p067::TAB_DOUBLES) pow_tab[tid] = vp;
+#pragma unroll
             for (int r = 0; r < PER; ++r)
                 if (tid + r * T < N) buf[pv[r]] = xv[r];
 #pragma unroll
@@ -1219,14 +1223,12 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
         // S[k] = |X_lo[k]|^0.67 + |X_hi[k]|^0.67 from Z[k] and its mirror bin Z[N-k]: one thread per pair, both positions
         // get the (real, even) value; nobody else touches the pair
         {
-            constexpr int NPAIRS = N / 2 + 1, PER = (NPAIRS + T - 1) / T;   // k <= N - k: k = 0 .. N/2 (host: pfa_npairs)
+            constexpr int PER = PPER;
             int pp[PER], qq[PER];
 #pragma unroll
             for (int r = 0; r < PER; ++r) {
-                const int i = tid + r * T, ic = i < NPAIRS ? i : 0;
-                const ushort2 pq = reinterpret_cast<const ushort2*>(a.pfa_pairs)[ic];
-                pp[r] = pq.x;
-                qq[r] = pq.y;
+                pp[r] = (int)(pairq[r] & 0xffffu);
+                qq[r] = (int)(pairq[r] >> 16);
             }
 #pragma unroll
             for (int r = 0; r < PER; ++r) {
@@ -1255,30 +1257,32 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
             if (n < Mh) {
                 // the real-input transform keeps residues 0..15 of axis 31; lag n at one of the others is read from lag
                 // N - n (S is real and even, so is its transform)
-                const int p0 = plag[r], p1 = pmir[r];   // (lag 0: p0 % 31 <= 15 -- position 0 -- so its mirror is never read)
+// (A0 = 1, N = 1023: measured SLOWER with the positions kept -- 4.98-5.04 against 4.00-4.04 ms per 176 k frames, same box,
+//  profiles/r6/pfa_ab.txt -- so that instantiation reads them here as before; A0 = 2: 4.56-4.69 against 4.66-4.79)
+#ifndef PFA_KEEP_POS_A1
+#define PFA_KEEP_POS_A1 0
+#endif
+                constexpr bool KEEP = A0 == 2 || PFA_KEEP_POS_A1;
+                const int p0 = KEEP ? plag[r] : (int)pos[n], p1 = KEEP ? pmir[r] : (int)pos[N - n > N - 1 ? 0 : N - n];   // (lag 0: p0 % 31 <= 15 -- position 0 -- so its mirror is never read)
                 lag[r] = buf[p0 % 31 > 15 ? p1 : p0].x * inv_n;
             }
         }
         __syncthreads();   // buf is dead from here on: the peak-picking scratch and yv alias it
+        // the lags leave the registers enhanced (esacf.py:108-129, truncation regime: enhance_truncate) -- until round 6 they went
+        // to yv raw, a barrier, and a second pass over yv did the rounds
+        double* yrow = a.y_out + f * (long long)Mh;
+        const int cut2 = enhance_cut2(Mh, a.enhance_mode);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = tid + r * T;
             if (n < Mh) {
-                yv[n] = lag[r];
                 if (a.sacf_out) a.sacf_out[f * (long long)Mh + n] = lag[r];
-            }
-        }
-        __syncthreads();
-        double* yrow = a.y_out + f * (long long)Mh;
-        if (a.defer_enhance) {
-            for (int n = tid; n < Mh; n += T) yrow[n] = yv[n];
-        } else {
-            const int cut2 = enhance_cut2(Mh, a.enhance_mode);
-            for (int n = tid; n < Mh; n += T) {   // enhancement (esacf.py:108-129), truncation regime: see enhance_truncate
-                const double v = enhance_truncate(yv[n], n, a.n_peaks_elim, cut2);
+                const double v = a.defer_enhance ? lag[r] : enhance_truncate(lag[r], n, a.n_peaks_elim, cut2);
                 yv[n] = v;
                 yrow[n] = v;
             }
+        }
+        if (!a.defer_enhance) {
             __syncthreads();
             if (!(a.ablate & (2 | 16))) peak_pick<T>(a, f, yv, smem, tid);
         }
