@@ -472,23 +472,20 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     __shared__ double sh_red[2 * NW];
     __shared__ int sh_base[2];
     const u64 lt_mask = (1ull << lane) - 1ull;
-    // ---- threshold
+    // ---- threshold, and the words of "dy[i] != 0" in the same pass over the row (round 6: one pass and one barrier fewer -- the
+    //      barrier inside block_minmax publishes the words)
+    const int E = (Mh + T - 1) / T, nwords = E * NW;
     double mx = -INFINITY, mn = INFINITY;
-    for (int n = tid; n < Mh; n += T) {
-        const double v = yv[n];
-        mx = v > mx ? v : mx;
-        mn = v < mn ? v : mn;
+    for (int e = 0; e < E; ++e) {
+        const int i = tid + e * T;
+        const double v = yv[i < Mh ? i : 0], vn = yv[i < D ? i + 1 : 0];
+        mx = i < Mh && v > mx ? v : mx;
+        mn = i < Mh && v < mn ? v : mn;
+        const u64 b = __ballot(i < D && vn != v);
+        if (lane == 0) nzw[e * NW + wave] = b;
     }
     block_minmax<T>(sh_red, mx, mn);
     const double thres = a.peak_thresh * (mx - mn) + mn;
-    // ---- words of "dy[i] != 0"
-    const int E = (Mh + T - 1) / T, nwords = E * NW;
-    for (int e = 0; e < E; ++e) {
-        const int i = tid + e * T;
-        const u64 b = __ballot(i < D && yv[i + 1] != yv[i]);
-        if (lane == 0) nzw[e * NW + wave] = b;
-    }
-    __syncthreads();
     if (D <= 0 || !__any((lane < nwords && nzw[lane < nwords ? lane : 0] != 0) ||
                          (WIDE && lane + 64 < nwords && nzw[lane + 64 < nwords ? lane + 64 : 0] != 0))) {
         if (tid == 0) a.peak_count[f] = 0;  // totally flat signal: no peaks (peakutils returns [])
