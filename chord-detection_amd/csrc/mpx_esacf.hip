@@ -1281,7 +1281,12 @@ __global__ __launch_bounds__(PFA_T, 4) void sacf_pfa_kernel(SacfArgs a) {
         }
         if (!a.defer_enhance) {
             __syncthreads();
-            if (!(a.ablate & (2 | 16))) peak_pick<T>(a, f, yv, smem, tid);
+            if (!(a.ablate & (2 | 16))) {
+                // (Round 6, measured and rejected: peak picking by ONE wave -- the other three finished, s_barrier counts the
+                //  surviving waves only, the phases ordered by the wave's own LDS queue: 4.82-5.09 against 4.61-4.74 ms at N = 2046,
+                //  3.97 against 4.01 ms at N = 1023, same bits; profiles/r6/pfa_pick_one_wave_rejected.txt.)
+                peak_pick<T>(a, f, yv, smem, tid);
+            }
         }
         __syncthreads();   // the next frame overwrites buf (peak-picking scratch) and yv
     }
