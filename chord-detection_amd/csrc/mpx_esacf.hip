@@ -634,8 +634,13 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
     }
     if (tid == 0) {
         a.peak_count[f] = n_kept;
-        sh_base[0] = n_long ? atomicAdd(a.total_peaks, n_long) : 0;
-        sh_base[1] = n_kept - n_long ? a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, n_kept - n_long) : 0;
+        if (a.ablate & 32) {   // (development ablation: what the two returning atomics on the work list's counters cost -- results are garbage)
+            sh_base[0] = 0;
+            sh_base[1] = a.worklist_cap - 1;
+        } else {
+            sh_base[0] = n_long ? atomicAdd(a.total_peaks, n_long) : 0;
+            sh_base[1] = n_kept - n_long ? a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, n_kept - n_long) : 0;
+        }
     }
     __syncthreads();
     for (int q = 0; q < Q; ++q) {
