@@ -251,9 +251,11 @@ struct SacfArgs {
     double* y_out;      // [F,Mh] enhanced SACF
     int* peak_count;    // [F]
     int* peak_idx;      // [F,maxp]
-    int* total_peaks;   // [0] long fits queued, [1] next work item (fit kernel), [2] other fits queued
-    int* worklist;      // [worklist_cap] packed (frame << 12 | slot): long fits from the front, others from the back
-    int worklist_cap;
+    int* total_peaks;   // [0] long fits queued, [1] next work item (fit kernel), [2] other fits queued  ([0], [2]: written by the fit kernel from the shards)
+    int* worklist;      // packed (frame << 12 | slot).  WL_SHARDS regions of `shard_cap` items: frame f queues in region f % WL_SHARDS, long fits from its front, others from its back
+    int worklist_cap;   // = WL_SHARDS * shard_cap
+    int shard_cap;      // items per region: ceil(frames / WL_SHARDS) * maxp
+    unsigned long long* shard_cnt;   // [WL_SHARDS], 128 bytes apart: long fits queued (low half) | other fits queued (high half)
     long long num_frames;  // frames in this launch
     int pair;              // 1: a workgroup takes two frames and shares the second DFT between them
     int ablate;         // profiling knob (env MPX_SACF_ABLATE): 1 no pow, 2 no peak picking, 4 no 2nd DFT, 8 no 1st DFT
@@ -456,6 +458,16 @@ __device__ __forceinline__ bool peak_rounds_in_lanes(const int* cand, const doub
     return true;
 }
 
+// The work list of the gaussian fits (round 6: sharded).  Until round 6 every frame reserved its places with two returning
+// atomics on two counters of ONE cache line: 360 448 atomics per clip batch on one line of the memory-side atomic unit, ~11 ns each --
+// 22 ns per frame against the 25 ns a frame of sacf_pfa_kernel takes altogether; without them (development ablation,
+// profiles/r6/pfa_atomics_ablation.txt) the kernel ran 4.70 -> 3.94 ms at N = 2046 and 4.02 -> 2.9 ms at N = 1023.  Now ONE 64-bit
+// atomic per frame (long count | other count << 32) on one of WL_SHARDS counters, each in a cache line of its own; a shard's items
+// live in a region of their own (long fits from its front, the others from its back), and the fit kernel maps its running item
+// number onto the shards through their prefix sums (peakfit_kernel).  Which fit is fetched when is scheduling: nothing computed
+// depends on it.
+constexpr int WL_SHARDS = 32, WL_SHARD_STRIDE = 16;   // counters: 16 x 8 B = 128 bytes apart
+
 template <int T, bool WIDE = false>
 __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double* yv, char* scratch, int tid) {
     typedef unsigned long long u64;
@@ -627,19 +639,24 @@ __device__ __forceinline__ void peak_pick(const SacfArgs& a, long long f, double
             for (int c = 0; c < ncand && p < a.maxp; ++c)
                 if (state[c] == 1) out[p++] = cand[c];
             a.peak_count[f] = p;
-            const int back = a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, p);
+            const int sh = (int)(f % WL_SHARDS);
+            const unsigned long long old = atomicAdd(a.shard_cnt + sh * WL_SHARD_STRIDE, (unsigned long long)p << 32);
+            const int back = (sh + 1) * a.shard_cap - 1 - (int)(old >> 32);
             for (int j = 0; j < p; ++j) a.worklist[back - j] = (int)(f << 12) | j;
         }
         return;
     }
     if (tid == 0) {
         a.peak_count[f] = n_kept;
-        if (a.ablate & 32) {   // (development ablation: what the two returning atomics on the work list's counters cost -- results are garbage)
-            sh_base[0] = 0;
-            sh_base[1] = a.worklist_cap - 1;
-        } else {
-            sh_base[0] = n_long ? atomicAdd(a.total_peaks, n_long) : 0;
-            sh_base[1] = n_kept - n_long ? a.worklist_cap - 1 - atomicAdd(a.total_peaks + 2, n_kept - n_long) : 0;
+        const int sh = (int)(f % WL_SHARDS);
+        if (a.ablate & 32) {   // (development ablation: what the returning atomic on the work list's counters costs -- results are garbage)
+            sh_base[0] = sh * a.shard_cap;
+            sh_base[1] = (sh + 1) * a.shard_cap - 1;
+        } else if (n_kept) {
+            const unsigned long long old = atomicAdd(a.shard_cnt + sh * WL_SHARD_STRIDE,
+                                                     (unsigned long long)(unsigned)n_long | ((unsigned long long)(unsigned)(n_kept - n_long) << 32));
+            sh_base[0] = sh * a.shard_cap + (int)(unsigned)old;
+            sh_base[1] = (sh + 1) * a.shard_cap - 1 - (int)(old >> 32);
         }
     }
     __syncthreads();
@@ -3278,8 +3295,8 @@ __global__ __launch_bounds__(256) void coopfit_live_kernel(const ParkedFit* park
 // The two compute the SAME BITS (fvec recomputed is fvec stored), so the choice is pure scheduling.
 template <bool SAMPLES_IN_LDS>
 __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kernel(
-    const int* __restrict__ total_peaks, int* next_item, const int* __restrict__ worklist,
-    int worklist_cap, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
+    int* total_peaks, int* next_item, const int* __restrict__ worklist,
+    int shard_cap, const unsigned long long* __restrict__ shard_cnt, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
     double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev, int park_live, int park_cap,
     int early_nfev, int early_cap, unsigned live_tag, int* lane_done) {
     using namespace lm;
@@ -3298,7 +3315,44 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     double* ysl = sh + (size_t)wave * MAXM * 64 + lane;
     double* fvec = ysl;   // SAMPLES_IN_LDS == false: the same space holds fvec (element i at fvec[i * 64])
     double* rq = sh_rq + (size_t)wave * 9 * 64 + lane;      // R (6) and Q^T f (3) between OUTER and INNER
-    const int n_long = total_peaks[0], total = n_long + total_peaks[2];
+    // The work list is WL_SHARDS regions (peak_pick): item number wi of the kernel's one running counter is long fit wi of the
+    // concatenated shards' long fits, or -- past all of those -- other fit wi - n_long of the concatenated others.  Prefix sums of
+    // the shards' counts in LDS (every workgroup its own copy), a five-step search per fetched item.
+    __shared__ int wl_long_pre[WL_SHARDS + 1], wl_other_pre[WL_SHARDS + 1];
+    if (threadIdx.x < 64) {
+        const unsigned long long c = threadIdx.x < WL_SHARDS ? shard_cnt[threadIdx.x * WL_SHARD_STRIDE] : 0ull;
+        int pl = (int)(unsigned)c, po = (int)(c >> 32);
+#pragma unroll
+        for (int off = 1; off < WL_SHARDS; off <<= 1) {   // inclusive scans over the lanes 0 .. WL_SHARDS - 1
+            const int ql = __shfl_up(pl, off), qo = __shfl_up(po, off);
+            if ((int)threadIdx.x >= off) {
+                pl += ql;
+                po += qo;
+            }
+        }
+        if (threadIdx.x < WL_SHARDS) {
+            wl_long_pre[threadIdx.x + 1] = pl;
+            wl_other_pre[threadIdx.x + 1] = po;
+        }
+        if (threadIdx.x == 0) wl_long_pre[0] = wl_other_pre[0] = 0;
+    }
+    __syncthreads();
+    const int n_long = wl_long_pre[WL_SHARDS], total = n_long + wl_other_pre[WL_SHARDS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the batch's totals where the host and the statistics read them
+        total_peaks[0] = n_long;
+        total_peaks[2] = total - n_long;
+    }
+    auto wl_item = [&](int wi) -> int {
+        const bool is_long = wi < n_long;
+        const int k = is_long ? wi : wi - n_long;
+        const int* pre = is_long ? wl_long_pre : wl_other_pre;
+        int s = 0;
+#pragma unroll
+        for (int step = WL_SHARDS / 2; step >= 1; step >>= 1)
+            if (pre[s + step] <= k) s += step;          // the last shard whose prefix is <= k
+        const int r = k - pre[s];
+        return worklist[is_long ? s * shard_cap + r : (s + 1) * shard_cap - 1 - r];
+    };
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const double eps = sqrt(EPSMCH);
 
@@ -3328,7 +3382,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
             if (wi >= total) {
                 phase = FIT_DONE;
             } else {
-                const int item = worklist[wi < n_long ? wi : worklist_cap - 1 - (wi - n_long)];
+                const int item = wl_item(wi);
                 const long long f = item >> 12;
                 const int j = item & 0xfff;
                 const int i = peak_idx[f * maxp + j];
@@ -4295,7 +4349,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     const long long fit_resident = (long long)ctx->num_cus * (4 * FIT_WAVES_PER_SIMD / (FIT_THREADS / 64));  // blocks
     const size_t park_slots = (size_t)fit_resident * FIT_THREADS + EARLY_PARK_CAP;   // at most one end-game park per lane, and the early ones of a small batch
     const size_t park_bytes = 2 * park_slots * sizeof(ParkedFit);  // a second list for coopfit_kernel's second pass
-    if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 20 + (size_t)batch * 4 + 256 + park_bytes))) return rc;
+    // (the work list is WL_SHARDS regions of ceil(batch / WL_SHARDS) * maxp items: up to WL_SHARDS * maxp more than batch * maxp)
+    const size_t wl_items = (size_t)WL_SHARDS * (size_t)((batch + WL_SHARDS - 1) / WL_SHARDS) * maxp;
+    const size_t shard_bytes = (size_t)WL_SHARDS * WL_SHARD_STRIDE * sizeof(unsigned long long);
+    if ((rc = ensure(ctx, ctx->d_ws3, (size_t)batch * maxp * 16 + wl_items * 4 + (size_t)batch * 4 + 512 + shard_bytes + park_bytes))) return rc;
     cx<double>* xb = (cx<double>*)ctx->d_ws0.p;
     double* y = (double*)ctx->d_ws1.p;
     char* w3 = (char*)ctx->d_ws3.p;
@@ -4303,9 +4360,10 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     int* peak_idx = (int*)(w3 + (size_t)batch * maxp * 8);
     int* okf = peak_idx + (size_t)batch * maxp;
     int* worklist = okf + (size_t)batch * maxp;
-    int* peak_count = worklist + (size_t)batch * maxp;
+    int* peak_count = worklist + wl_items;
     int* total = peak_count + batch;  // counters, see SacfArgs::total_peaks; [3] parked fits, [4] next parked fit, [8] fits parked again, [9] next of those
-    ParkedFit* parked = reinterpret_cast<ParkedFit*>(((uintptr_t)(total + 16) + 63) & ~(uintptr_t)63);
+    unsigned long long* shard_cnt = reinterpret_cast<unsigned long long*>(((uintptr_t)(total + 16) + 127) & ~(uintptr_t)127);   // [WL_SHARDS] x 128 B
+    ParkedFit* parked = reinterpret_cast<ParkedFit*>(((uintptr_t)(shard_cnt + WL_SHARDS * WL_SHARD_STRIDE) + 63) & ~(uintptr_t)63);
     ParkedFit* parked2 = parked + park_slots;
 
     for (long long f0 = 0; f0 < num_frames; f0 += batch) {
@@ -4325,6 +4383,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                d_stage_out + (size_t)f0 * N);
         if (stage >= 0 && stage <= MPX_STAGE_XHI) continue;
         prof_mark(ctx, st, nullptr);
+        MPX_HIP(ctx, hipMemsetAsync(shard_cnt, 0, shard_bytes, st));
         MPX_HIP(ctx, hipMemsetAsync(total, 0, 16 * sizeof(int), st));  // see SacfArgs::total_peaks; [5] parking attempts; [6..7] evaluations; [10] early parks; [11] lane-kernel waves signed off; [12] fits the live kernel finished
         SacfArgs a;
         a.xb = xb;
@@ -4346,7 +4405,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
         a.peak_idx = peak_idx;
         a.total_peaks = total;
         a.worklist = worklist;
-        a.worklist_cap = (int)(nf * maxp);
+        a.shard_cap = (int)(((nf + WL_SHARDS - 1) / WL_SHARDS) * maxp);
+        a.worklist_cap = WL_SHARDS * a.shard_cap;
+        a.shard_cnt = shard_cnt;
         a.num_frames = nf;
         // measured, not adopted: pairing saves 0.85 ms per 176 k frames, but the rounding-level cross-talk between the
         // two frames makes results depend on the batch neighbour and flips 0.075 % of the frames (ill-conditioned fits)
@@ -4549,7 +4610,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
             }
 #endif
             hipLaunchKernelGGL(fit_kernel, dim3((unsigned)blocks), dim3(FIT_THREADS), 0, st, total, total + 1, worklist,
-                               (int)(nf * maxp), y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
+                               a.shard_cap, (const unsigned long long*)shard_cnt, y, Mh, maxp, peak_idx, center, okf, maxfev, park ? parked : nullptr,
                                total + 3, dev_env_int("MPX_FIT_PARK_NFEV", nf < 2048 ? PARK_NFEV_SMALL : PARK_NFEV),
                                dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),
                                dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP),
