@@ -2205,7 +2205,6 @@ constexpr int COOP_SPLIT = 4096;        // parked lists longer than this -- more
 constexpr int COOP_PASS1_TRIPS = 24;   // coopfit_kernel, first pass: trips after which a fit still open is parked again
 constexpr int EARLY_PARK_SLOW_NFEV = 100;   // ... and the slow ones (2 % of the fits need 100 ... 400 evaluations; the median is 56)
 constexpr int EARLY_PARK_CAP = 12288;   // round 6, development builds: budget of the early hand-off (fits that look like runaways leave the lane kernel at once; peakfit_kernel)
-constexpr int FIT_FETCH_CHUNK = 0;   // items a wave of the lane kernel reserves per atomic at most (0: what it needs, as until round 6)
 constexpr int PARK_CAP = 16384;  // ... or while fewer fits than this have asked (about what coopfit_kernel holds at once)
 
 // Cross-lane traffic of the cooperative fit on DPP (register-to-register, ~8 cycles) instead of ds_bpermute
@@ -3299,7 +3298,7 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     int* total_peaks, int* next_item, const int* __restrict__ worklist,
     int shard_cap, const unsigned long long* __restrict__ shard_cnt, const double* __restrict__ y, int Mh, int maxp, const int* __restrict__ peak_idx,
     double* center, int* ok, int maxfev, ParkedFit* parked, int* parked_count, int park_nfev, int park_live, int park_cap,
-    int early_nfev, int early_cap, unsigned live_tag, int* lane_done, int fetch_chunk) {
+    int early_nfev, int early_cap, unsigned live_tag, int* lane_done) {
     using namespace lm;
     __shared__ double sh[MAXM * FIT_THREADS];
     __shared__ double sh_rq[9 * FIT_THREADS];
@@ -3358,7 +3357,6 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
     const double eps = sqrt(EPSMCH);
 
     int phase = FIT_NEED_WORK;
-    int pool_next = 0, pool_end = 0;   // wave-uniform: items this wave has reserved and not yet handed to a lane
     unsigned my_evals = 0;   // statistics: MINPACK function evaluations this lane has run
     bool drained = false;  // wave-uniform: some lane has found the work list empty
     bool cap_hit = false;  // wave-uniform: the cooperative kernel is full, park only from a thinned-out wave
@@ -3373,33 +3371,14 @@ __global__ __launch_bounds__(FIT_THREADS, FIT_WAVES_PER_SIMD) void peakfit_kerne
 
     for (;;) {
         // ---------------- fetch
-        // Items are taken from the kernel's one running counter in CHUNKS per wave (round 6): a wave that needs `cnt` items and has
-        // fewer left in its pool reserves max(cnt - left, chunk) more with ONE returning atomic, chunk = what is left of the list
-        // spread over four rounds of all waves, at most fetch_chunk -- towards the end of the list a wave reserves what it needs and
-        // nothing more, so no item waits in a pool while another wave idles.  (Until then: one atomic per wave and trip with a free
-        // lane, half a million of them per clip batch on one word.)  Wave-uniform bookkeeping, outside the divergent fetch.
-        const unsigned long long need = __ballot(phase == FIT_NEED_WORK);
-        int wi = 0;
-        if (need) {
+        if (phase == FIT_NEED_WORK) {
+            const unsigned long long need = __ballot(1);  // lanes inside this branch
             const int cnt = __popcll(need);
             const int rank = __popcll(need & ((1ull << lane) - 1ull));
-            const int left = pool_end - pool_next;
-            if (cnt > left) {
-                int chunk = fetch_chunk > 0 ? (int)(((long long)total - pool_end) >> 13) : 0;   // (2048 waves x 4)
-                chunk = chunk > fetch_chunk ? fetch_chunk : chunk;
-                const int want = cnt - left > chunk ? cnt - left : chunk;
-                int base = 0;
-                if (lane == __ffsll((long long)need) - 1) base = atomicAdd(next_item, want);
-                base = __shfl(base, __ffsll((long long)need) - 1);
-                wi = rank < left ? pool_next + rank : base + (rank - left);
-                pool_next = base + (cnt - left);
-                pool_end = base + want;
-            } else {
-                wi = pool_next + rank;
-                pool_next += cnt;
-            }
-        }
-        if (phase == FIT_NEED_WORK) {
+            int base = 0;
+            if (rank == 0) base = atomicAdd(next_item, cnt);
+            base = __shfl(base, __ffsll((long long)need) - 1);
+            const int wi = base + rank;
             if (wi >= total) {
                 phase = FIT_DONE;
             } else {
@@ -4636,7 +4615,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
                                dev_env_int("MPX_FIT_PARK_LIVE", PARK_LIVE),
                                dev_env_int("MPX_FIT_PARK_CAP", PARK_CAP),
                                early_nfev, std::min(dev_env_int("MPX_FIT_EARLY_CAP", EARLY_PARK_CAP), EARLY_PARK_CAP),
-                               live ? live_tag : 0u, live ? total + 11 : (int*)nullptr, dev_env_int("MPX_FIT_CHUNK", FIT_FETCH_CHUNK));
+                               live ? live_tag : 0u, live ? total + 11 : (int*)nullptr);
             if (live) {   // the cooperative launches below take what the live kernel left (normally nothing): behind BOTH kernels
                 MPX_HIP(ctx, hipEventRecord(ctx->side_ev[1], ctx->side_stream));
                 MPX_HIP(ctx, hipStreamWaitEvent(st, ctx->side_ev[1], 0));
