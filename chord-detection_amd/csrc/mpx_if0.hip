@@ -17,6 +17,7 @@
 //  3. if0_periodicity_kernel one workgroup per frame: periodicity.py:48-163 -- interval-halving period
 //                           search (one wave per harmonic m for the range maxima), harmonic
 //                           cancellation, pitch-class scatter (quirks A.10-A.13, A.18).
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -78,13 +79,13 @@ constexpr int IF0_STATE_PIPE = 66, IF0_STATE_SEQ = 22;   // doubles per lane: pi
 // TAIL = false: a wave of 64 channels of ONE chunk -- chunk, input pointer and output rows are wave-uniform (scalar
 // loads, plain pointer arithmetic).  TAIL = true: a wave of leftover channels of several chunks -- per-lane chunk,
 // input pointer and an LDS table of output rows.  (One body for both had cost the common case 16 % of its speed.)
-template <bool TAIL, bool SLICED>
+template <bool TAIL, bool SLICED, int TW = IF0_TW>   // TW: samples per channel the tile collects (64; 32: half the LDS, see if0_run_host)
 __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                   long long num_chunks, int channels,
                                                   const If0ChanCoef* __restrict__ coefs, const If0Wfir& wf,
                                                   double* __restrict__ yc, const int* __restrict__ tail_list,
                                                   const If0TailGroup* __restrict__ tail_groups,
-                                                  double (*tile)[IF0_TW + 1], long long* rowbase, long long ck_u, int ch0_u,
+                                                  double (*tile)[TW + 1], long long* rowbase, long long ck_u, int ch0_u,
                                                   int nch_u, const If0TailGroup g, int lg_nf, const If0Slice sl, const int warm_cap,
                                                   const double* __restrict__ hwin, const int wmask) {
 #pragma clang fp contract(off)
@@ -184,10 +185,13 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         tb_first = sl_t0 + PF;
     }
     fetch(tb_first);
-    double wv_next = hwin[lane & wmask];   // window of the first tile of this launch (a slice starts on a frame)
+    // the flush: a store instruction writes 64 / TW rows, lane -> (row rsub of the instruction's rows, sample col of the tile)
+    constexpr int RPI = 64 / TW;
+    const int col = lane & (TW - 1), rsub = lane / TW;
+    double wv_next = hwin[col & wmask];   // window of the first tile of this launch (a slice starts on a frame)
     for (int tb = tb_first; tb < c_end + DEPTH; tb += PF) {
         const int t0 = tb - DEPTH;                             // this block produces the outputs t0 .. t0 + 15
-        const int tcol = t0 >= 0 ? (t0 & (IF0_TW - 1)) : 0;   // their columns in the tile (the run-in's outputs are dropped)
+        const int tcol = t0 >= 0 ? (t0 & (TW - 1)) : 0;   // their columns in the tile (the run-in's outputs are dropped)
         float xs[PF];
 #pragma unroll
         for (int q = 0; q < PF; ++q) xs[q] = nx[q];
@@ -252,7 +256,7 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
         // bytes of ONE channel row (64 lanes x 8 B) where 16-sample tiles wrote four 128-byte pieces of four rows -- a thousand
         // waves x 64 rows of scattered 128-byte lines held the whole launch at ~2 TB/s of HBM writes (the front end of the 1 h
         // stream took the same 2.05 TB/s with 64 and with 70 channels).
-        if (t0 >= 0 && t0 < c_end && (tcol == IF0_TW - PF || t0 + PF >= c_end)) {   // uniform: a full tile, or the chunk's last block
+        if (t0 >= 0 && t0 < c_end && (tcol == TW - PF || t0 + PF >= c_end)) {   // uniform: a full tile, or the chunk's last block
             const int tg = t0 - tcol, ncols = tcol + PF;   // first sample and width of what the tile holds
             const int ts = tg - sl_t0;                      // ... counted from the first output of this launch
             // where sample tg of channel 0 of this frame sits relative to frame 0, channel 0 (a tile never straddles a frame)
@@ -266,25 +270,26 @@ __device__ __forceinline__ void if0_frontend_body(const float* __restrict__ sig,
             // (fetched one tile ahead: under a launch that writes 2 TB/s a load issued here returned after microseconds, and the
             //  first store of the flush waited for it -- 44 -> 55 ms per hour of audio)
             const double wv = wv_next;
-            wv_next = hwin[((int)((ts + IF0_TW) & ((1 << lg_nf) - 1)) + lane) & wmask];
+            wv_next = hwin[((int)((ts + TW) & ((1 << lg_nf) - 1)) + col) & wmask];
+            const size_t lane_off = foff + ((size_t)rsub << lg_nf) + col;   // (TW = 64: foff + lane)
             wave_lds_fence();
 #pragma unroll
-            for (int h = 0; h < 64 / 16; ++h) {
+            for (int h = 0; h < 64 / (16 * RPI); ++h) {
                 double tv[16];
                 long long rbv[16];
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    tv[q] = tile[16 * h + q][lane];   // row 16 h + q, sample tg + lane
-                    if (TAIL) rbv[q] = rowbase[16 * h + q];
+                    tv[q] = tile[(16 * h + q) * RPI + rsub][col];   // row (16 h + q) RPI + rsub, sample tg + col
+                    if (TAIL) rbv[q] = rowbase[(16 * h + q) * RPI + rsub];
                 }
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const int r = 16 * h + q;
-                    if (lane < ncols) {
+                    const int r0 = (16 * h + q) * RPI;   // the instruction's first row (uniform)
+                    if (col < ncols) {
                         if (TAIL) {
-                            if (rbv[q] >= 0) yc[rbv[q] + foff + lane] = tv[q] * wv;
-                        } else if (r < nch_u) {
-                            out[((size_t)r << lg_nf) + foff + lane] = tv[q] * wv;
+                            if (rbv[q] >= 0) yc[rbv[q] + foff + col] = tv[q] * wv;
+                        } else if (r0 + rsub < nch_u) {
+                            (out + ((size_t)r0 << lg_nf))[lane_off] = tv[q] * wv;
                         }
                     }
                 }
@@ -464,14 +469,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void
         if0_frontend_seq_body<true, SLICED>(sig, chunks, channels, coefs, wf, yc, tail_list, tile, rowbase, 0, 0, 0, g, lg_nf, sl, warm_tail, hwin, wmask);
 }
 
-template <bool SLICED>
+template <bool SLICED, int TW = IF0_TW>
 __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restrict__ sig, const If0Chunk* __restrict__ chunks,
                                                           long long num_chunks, int channels,
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc, const int* __restrict__ tail_list,
                                                           const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf,
                                                           If0Slice sl, int warm_tail, const double* __restrict__ hwin, int wmask) {
-    __shared__ double tile[64][IF0_TW + 1];
+    __shared__ double tile[64][TW + 1];
     __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
     const int full = channels >> 6;
     If0TailGroup g = {0, 0};
@@ -483,16 +488,16 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
     // slower per step, no longer carry the longest run-in as well and stopped being the ones a launch waits for.
     if ((long long)blockIdx.x >= num_tail_groups) {
         const long long b = (long long)blockIdx.x - num_tail_groups;
-        if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
+        if0_frontend_body<false, SLICED, TW>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
                                  b / full, (channels & 63) + (int)(b % full) * 64, 64, g, lg_nf, sl, 0x7fffffff, hwin, wmask);
         return;
     }
     g = tail_groups[blockIdx.x];
     if (g.count == 1)   // a lone set of leftover channels (small batches: the host does not pack them) on the uniform path
-        if0_frontend_body<false, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
+        if0_frontend_body<false, SLICED, TW>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase,
                                  tail_list[g.first], 0, channels & 63, g, lg_nf, sl, warm_tail, hwin, wmask);
     else
-        if0_frontend_body<true, SLICED>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
+        if0_frontend_body<true, SLICED, TW>(sig, chunks, num_chunks, channels, coefs, wf, yc, tail_list, tail_groups, tile, rowbase, 0, 0,
                                 0, g, lg_nf, sl, warm_tail, hwin, wmask);
 }
 
@@ -1863,6 +1868,25 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if (p.note_names != MPX_NOTES_UNICODE && p.note_names != MPX_NOTES_ASCII)
         return set_error(ctx, MPX_EINVAL, "iterative F0: unknown note_names %d", p.note_names);
     const int NF = p.frame_size, n2 = 2 * NF;
+#ifdef MPX_DEV_KNOBS   // MPX_IF0_TICKS=1: where the HOST time of a call goes (stderr, microseconds between the marks)
+    static const bool ticks_on = std::getenv("MPX_IF0_TICKS") != nullptr;
+    std::vector<std::pair<const char*, double>> ticks;
+    auto tick = [&](const char* what) {
+        if (ticks_on) ticks.push_back({what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count()});
+    };
+    auto ticks_out = [&]() {
+        if (!ticks_on) return;
+        fprintf(stderr, "mpx if0 host ticks:");
+        for (size_t i = 1; i < ticks.size(); ++i) fprintf(stderr, " %s %.0f", ticks[i].first, ticks[i].second - ticks[i - 1].second);
+        fprintf(stderr, " | total %.0f us\n", ticks.empty() ? 0.0 : ticks.back().second - ticks.front().second);
+    };
+    tick("enter");
+#define IF0_TICK(w) tick(w)
+#define IF0_TICKS_OUT() ticks_out()
+#else
+#define IF0_TICK(w) ((void)0)
+#define IF0_TICKS_OUT() ((void)0)
+#endif
     // periodicity.py indexes Ur up to M*K/tau_min: must stay inside the 2*frame spectrum
     if ((p.M - 1) * ((double)NF / fs) / p.tau_min + 1.5 >= n2)
         return set_error(ctx, MPX_EINVAL, "iterative F0: harmonic %d of tau_min falls outside the %d-bin spectrum (the "
@@ -2073,6 +2097,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     }
     const int64_t total = offsets[num_clips];
     hipStream_t st = stream ? stream : ctx->stream;
+    IF0_TICK("plan+chunks");
     if (nframes == 0) {
         if (chroma_sums && dev_io) MPX_HIP(ctx, hipMemsetAsync(chroma_sums, 0, (size_t)num_clips * 12 * sizeof(double), st));
         else if (chroma_sums) std::memset(chroma_sums, 0, (size_t)num_clips * 12 * sizeof(double));
@@ -2159,7 +2184,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     const long long fe_blocks = nchunks * full_groups + (long long)tail_groups.size();
     const size_t state_bytes = sliced ? (size_t)fe_blocks * 64 * sizeof(double) * (fe_sequential ? IF0_STATE_SEQ : IF0_STATE_PIPE) : 0;
     if (!dev_io && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
+    IF0_TICK("slices");
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
+    IF0_TICK("ws0");
     // the period search runs ONCE, behind the last slice, on persistent workgroups with a scratch pair each
     const bool per_big = n2 > 16384;   // spectra of more than 16 384 bins: the instantiation with the larger tables
     const char* per_key = per_big ? "if0_periodicity_big" : "if0_periodicity";
@@ -2173,7 +2200,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     }
     const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy[per_key]);   // scratch slots
     (void)max_slice_frames;
+    IF0_TICK("occ");
     if ((rc = ensure(ctx, ctx->d_ws1, ((size_t)nframes + 2 * (size_t)per_grid) * n2 * sizeof(double)))) return rc;   // ut | ur | ud
+    IF0_TICK("ws1");
     if (sliced && (rc = ensure(ctx, ctx->d_ws2, state_bytes))) return rc;
     if ((rc = ensure(ctx, ctx->d_desc, chunks.size() * sizeof(If0Chunk) + up_frames.size() * sizeof(If0Frame) + tail_list.size() * sizeof(int) +
                                        tail_groups.size() * sizeof(If0TailGroup) + sl_rows.size() * sizeof(int) + 256))) return rc;
@@ -2181,6 +2210,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     ctx->batch_layout.clear();   // d_desc / d_offsets are about to hold this call's tables (method_batch's cache)
     if ((rc = ensure(ctx, ctx->d_offsets, seg.size() * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
+    IF0_TICK("small");
     If0Chunk* d_chunks = (If0Chunk*)ctx->d_desc.p;
     If0Frame* d_frames = (If0Frame*)((char*)ctx->d_desc.p + ((chunks.size() * sizeof(If0Chunk) + 15) & ~(size_t)15));
     If0TailGroup* d_tail_groups = (If0TailGroup*)((char*)d_frames + ((up_frames.size() * sizeof(If0Frame) + 15) & ~(size_t)15));
@@ -2197,6 +2227,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     if (sliced) MPX_HIP(ctx, hipMemcpyAsync(d_rows, sl_rows.data(), sl_rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     if (dev_io || sliced) MPX_HIP(ctx, hipStreamSynchronize(st));   // the tables above are host vectors of this call
+    IF0_TICK("tables+sync");
     double* yc = (double*)ctx->d_ws0.p;
     double* ut_all = (double*)ctx->d_ws1.p;              // [F, n2], slice after slice
     double* ur = ut_all + (size_t)nframes * n2;          // [per_grid, n2]
@@ -2262,6 +2293,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
             }
         }
     }
+    IF0_TICK("slice launches");
     a.out_row = sliced ? d_rows : nullptr;
     a.num_frames = nframes;
     if (ctx->d_queue.bytes < (size_t)per_grid * sizeof(unsigned)) {
@@ -2281,7 +2313,9 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         hipLaunchKernelGGL(if0_periodicity_kernel<false>, dim3((unsigned)nframes), dim3(PER_T), 0, st, a);
     prof_mark(ctx, st, nullptr);
     MPX_HIP(ctx, hipGetLastError());
+    IF0_TICK("period launch");
     if (dev_io) {
+        IF0_TICKS_OUT();
         if (chroma_sums) return segment_sum(ctx, a.chroma, (const long long*)ctx->d_offsets.p, num_clips, nframes, chroma_sums, st);
         return MPX_OK;
     }
@@ -2294,6 +2328,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
         MPX_HIP(ctx, hipMemcpyAsync(chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), hipMemcpyDeviceToHost, st));
     }
     MPX_HIP(ctx, hipStreamSynchronize(st));
+    IF0_TICK("sync");
+    IF0_TICKS_OUT();
     return MPX_OK;
 }
 

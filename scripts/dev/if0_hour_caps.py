@@ -12,7 +12,7 @@ torch.cuda.synchronize(); torch.cuda.empty_cache()
 ref = None
 for gib in [float(a) for a in (sys.argv[1:] or ["4", "8", "16", "32", "90"])]:
     eng = cd.Engine(0)
-    if hasattr(eng.lib, "mpx_set_option") and not os.environ.get("MPX_LIB_PATH"):
+    if hasattr(eng.lib, "mpx_set_option"):
         eng.set_option("if0_workspace_bytes", int(gib * (1 << 30)))
     d_frames = torch.empty((stream.num_frames(x.numel(), 8192), 12), dtype=torch.float64, device="cuda:0")
     walls = []
