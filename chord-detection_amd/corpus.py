@@ -94,6 +94,37 @@ def _engine_compute(method, clips, fs, device, note_names="unicode"):
 
 
 _SECOND_ENGINE = {}
+
+
+SIDE_THREADS_WAIT = True   # False: the side threads start at once (rounds 3-5; scripts/dev/corpus_order.py A/B)
+
+
+def _start_side(th, main_engine, main_done):
+    """Start a side thread (Iterative-F0 / Prime-multiF0 on contexts of their own) so that its kernels reach the GPU BEHIND the
+    main thread's first ones.  Iterative-F0's front end fills every SIMD's registers with long-lived one-wave workgroups, and
+    ESACF's multi-wave workgroups then find no CU with room until it has drained: when the front end won the race to the
+    GPU -- it does whenever the main context has a new clip layout to describe first -- ESACF ran AFTER the 131 ms of
+    Iterative-F0 instead of beside it, 160 ms per 4096-clip group instead of 151 (profiles/r6/corpus_head_start.txt: every
+    one of four fresh processes, and three of this project's eleven evidence runs).  The thread waits until the main context's
+    stream has work queued (Engine.busy), the main thread is through with its methods, or 50 ms have passed."""
+    if not SIDE_THREADS_WAIT or main_engine is None:
+        th.start()
+        return
+    real_run = th.run
+
+    def gated():
+        t_end = time.perf_counter() + 0.05
+        try:
+            while not main_done.is_set() and time.perf_counter() < t_end and not main_engine.busy():
+                time.sleep(0.0002)
+        except Exception:   # no runtime to ask: start as before
+            pass
+        real_run()
+
+    th.run = gated
+    th.start()
+
+
 LAST_SYNTH_SECONDS = 0.0   # input synthesis inside the last run_corpus call of this process (reported next to the wall clock)
 
 
@@ -211,6 +242,11 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
             spent[mi] += time.perf_counter() - t0
 
         side = None
+        main_done = threading.Event()
+        main_engine = None
+        if overlap and engine_path and any(m not in (3, 4) for m in methods):
+            from .engine import get_engine
+            main_engine = get_engine(device)
         if overlap and engine_path and 3 in methods and len(methods) > 1:
             # Iterative-F0's front end is one serial chain per lane and leaves most issue slots of a SIMD free: it runs on
             # a second context and stream (ctypes releases the GIL) while the other methods go through the first one
@@ -225,7 +261,7 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
                 return np.asarray(eng2.iterative_f0_batch(clips, fs, note_names=note_names))
 
             side = threading.Thread(target=run, args=(mi3, 3, if0_pieces))
-            side.start()
+            _start_side(side, main_engine, main_done)
         side4 = None
         if side is not None and 4 in methods and len(methods) > 2 and os.environ.get("MPX_CORPUS_CONTEXTS", "3") == "3":
             # ... and Prime-multiF0 (seven million small workgroups, latency-bound) on a third one
@@ -233,7 +269,7 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
             eng3 = _second_engine((device, 3))
             side4 = threading.Thread(target=run, args=(mi4, 4, lambda: eng3.prime_multif0_batch(clips, fs,
                                                                                                note_names=note_names)))
-            side4.start()
+            _start_side(side4, main_engine, main_done)
         for mi, m in enumerate(methods):
             if (side is not None and m == 3) or (side4 is not None and m == 4):
                 continue
@@ -243,6 +279,7 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
                 run(mi, m, lambda m=m: compute(m, clips, fs, device))
             if failed:
                 break
+        main_done.set()
         if side is not None:
             side.join()
         if side4 is not None:

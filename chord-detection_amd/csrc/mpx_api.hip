@@ -1,6 +1,7 @@
 // C ABI (include/mpx.h): context, workspaces, host<->device staging.
 #include <cmath>
 #include <cstdarg>
+#include <chrono>
 #include <cstring>
 
 #include "mpx_internal.hpp"
@@ -24,17 +25,46 @@ int set_error(mpx_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+// Blocks a workspace has outgrown.  hipFree / hipHostFree wait for the whole DEVICE, other contexts' streams included, and a
+// corpus driver runs the methods on three contexts at once: a context that outgrows a workspace behind another context's
+// queued kernels would wait for all of them.  So an outgrown block is RETIRED: kept until the context is destroyed, or until
+// more than RETIRED_MAX bytes of device memory are held that way -- then (a large workspace: the 12 -> 83 GiB hand-off buffer
+// of a long stream) everything retired is freed at once, with the wait.  Measured on the corpus group whose workspaces grow
+// inside the timed call (scripts/dev/corpus_growth_trial.py, MPX_ENSURE_FREE=1 = the old way; profiles/r6/corpus_growth_ab.txt):
+// 161-163 -> 160-161 ms -- the 10 ms that group loses against a warm one are the start ORDER of the contexts' kernels
+// (corpus._start_side), not this wait.
+constexpr size_t RETIRED_MAX = (size_t)1 << 30;
+static void release_retired(mpx_ctx* ctx) {
+    if (ctx->retired.empty() && ctx->retired_host.empty()) return;
+    hipStreamSynchronize(ctx->stream);   // work queued on our stream may still use them
+    for (void* p : ctx->retired) (void)hipFree(p);
+    for (void* p : ctx->retired_host) (void)hipHostFree(p);
+    ctx->retired.clear();
+    ctx->retired_host.clear();
+    ctx->retired_bytes = 0;
+}
+void release_retired_blocks(mpx_ctx* ctx) { release_retired(ctx); }   // mpx_destroy
+
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes <= b.bytes) return MPX_OK;
     if (b.p) {
-        // the old block may still be in use by work queued on our stream
-        hipStreamSynchronize(ctx->stream);
-        hipFree(b.p);
+        ctx->retired.push_back(b.p);
+        ctx->retired_bytes += b.bytes;
         b.p = nullptr;
         b.bytes = 0;
+        if (ctx->retired_bytes > RETIRED_MAX || dev_env_on("MPX_ENSURE_FREE")) release_retired(ctx);   // (the knob: rounds 1-5, for the A/B)
     }
     size_t want = bytes + bytes / 4 + 256;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
+    if (dev_env_on("MPX_ENSURE_TRACE"))
+        fprintf(stderr, "mpx ensure: ctx %p hipMalloc(%zu) took %.0f us\n", (void*)ctx, want,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    if (e != hipSuccess && !ctx->retired.empty()) {   // what the retired blocks hold may be what is missing
+        (void)hipGetLastError();
+        release_retired(ctx);
+        e = hipMalloc(&b.p, want);
+    }
     if (e != hipSuccess) {
         b.p = nullptr;
         return set_error(ctx, MPX_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
@@ -72,11 +102,17 @@ int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_
 int d2h_results_sync(mpx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
     if (bytes > 8192) {
         if (ctx->h_results_bytes < bytes) {
-            if (ctx->h_results) (void)hipHostFree(ctx->h_results);
+            if (ctx->h_results) ctx->retired_host.push_back(ctx->h_results);   // (hipHostFree waits for the device: see ensure)
+            if (dev_env_on("MPX_ENSURE_FREE")) release_retired_blocks(ctx);
             ctx->h_results = nullptr;
             ctx->h_results_bytes = 0;
             void* p = nullptr;
-            if (hipHostMalloc(&p, bytes + bytes / 4, hipHostMallocDefault) == hipSuccess) {
+            const auto t0 = std::chrono::steady_clock::now();
+            const hipError_t he = hipHostMalloc(&p, bytes + bytes / 4, hipHostMallocDefault);
+            if (dev_env_on("MPX_ENSURE_TRACE"))
+                fprintf(stderr, "mpx ensure: ctx %p hipHostMalloc(%zu) took %.0f us\n", (void*)ctx, bytes + bytes / 4,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+            if (he == hipSuccess) {
                 ctx->h_results = p;
                 ctx->h_results_bytes = bytes + bytes / 4;
             } else {
@@ -226,6 +262,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    release_retired_blocks(ctx);
     for (void* p : ctx->owned) hipFree(p);
     for (DevBuf* b : {&ctx->d_pcm, &ctx->d_pcm_f32, &ctx->d_signal, &ctx->d_frames_out, &ctx->d_partials, &ctx->d_sum, &ctx->d_desc,
                       &ctx->d_offsets, &ctx->d_ws0, &ctx->d_ws1, &ctx->d_ws2, &ctx->d_ws3, &ctx->d_ws4, &ctx->d_counter, &ctx->d_queue})
@@ -236,6 +273,12 @@ void mpx_destroy(mpx_ctx* ctx) {
         if (e) hipEventDestroy(e);
     if (ctx->h_results) hipHostFree(ctx->h_results);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : {ctx->if0_ev_fe[0], ctx->if0_ev_fe[1], ctx->if0_ev_sp[0], ctx->if0_ev_sp[1]})
+        if (e) hipEventDestroy(e);
+    if (ctx->if0_sp_stream) {
+        hipStreamSynchronize(ctx->if0_sp_stream);
+        hipStreamDestroy(ctx->if0_sp_stream);
+    }
     for (hipEvent_t e : ctx->side_ev)
         if (e) hipEventDestroy(e);
     if (ctx->side_stream) {

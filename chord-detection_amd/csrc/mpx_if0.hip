@@ -18,6 +18,7 @@
 //                           search (one wave per harmonic m for the range maxima), harmonic
 //                           cancellation, pitch-class scatter (quirks A.10-A.13, A.18).
 #include <chrono>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -475,7 +476,9 @@ __global__ __launch_bounds__(64) void if0_frontend_kernel(const float* __restric
                                                           const If0ChanCoef* __restrict__ coefs, If0Wfir wf,
                                                           double* __restrict__ yc, const int* __restrict__ tail_list,
                                                           const If0TailGroup* __restrict__ tail_groups, int num_tail_groups, int lg_nf,
-                                                          If0Slice sl, int warm_tail, const double* __restrict__ hwin, int wmask) {
+                                                          If0Slice sl, int warm_tail, const double* __restrict__ hwin, int wmask,
+                                                          int wave_prio) {
+    if (wave_prio) __builtin_amdgcn_s_setprio(3);   // next to another kernel's waves (if0_run_host): this wave's chain goes first
     __shared__ double tile[64][TW + 1];
     __shared__ long long rowbase[64];   // TAIL: per lane, index in yc of its output row, -1 for an idle lane
     const int full = channels >> 6;
@@ -1081,6 +1084,30 @@ static void if0_host_fft(std::vector<cx<double>>& a) {  // in-place radix-2, for
             }
 }
 
+// Overlapped time slices (below, in if0_run_host): measured and not adopted -- development builds only, MPX_IF0_OVERLAP=1
+static int if0_overlap_mode(mpx_ctx*) { return DEV_KNOBS ? dev_env_int("MPX_IF0_OVERLAP", 0) : 0; }
+// the spectra's stream and the four hand-over events; false (and the call runs without overlap) if they cannot be had
+static bool if0_overlap_ready(mpx_ctx* ctx) {
+    if (ctx->if0_overlap_made) return ctx->if0_sp_stream != nullptr;
+    ctx->if0_overlap_made = true;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    bool ok = hipStreamCreateWithPriority(&ctx->if0_sp_stream, hipStreamNonBlocking, least) == hipSuccess;
+    for (int k = 0; ok && k < 2; ++k)
+        ok = hipEventCreateWithFlags(&ctx->if0_ev_fe[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&ctx->if0_ev_sp[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        for (hipEvent_t* e : {&ctx->if0_ev_fe[0], &ctx->if0_ev_fe[1], &ctx->if0_ev_sp[0], &ctx->if0_ev_sp[1]}) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+        if (ctx->if0_sp_stream) (void)hipStreamDestroy(ctx->if0_sp_stream);
+        ctx->if0_sp_stream = nullptr;
+    }
+    return ok;
+}
+
 static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan) {
     char keyb[256];
     snprintf(keyb, sizeof keyb, "if0r4_%d_%d_%d_%.17g_%.17g", fs, p.frame_size, p.channels, p.zeta0, p.zeta1);
@@ -1133,20 +1160,32 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
     const int NF = p.frame_size;
     std::vector<double> win(NF);
     for (int i = 0; i < NF; ++i) win[i] = 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (double)(NF - 1));
+    // W_2NF^k, k <= NF, and W_NF^j = W_2NF^(2j) -- for a power of two the same long double angle, hence the same bits, as
+    // -2 pi j / NF computed on its own (rounds 1-5 did; the 32 770 long double sines and cosines of the default frame size were
+    // 3.3 of the 5.6 ms by which the FIRST call of a process at a new sample rate was slower than the second: this table is
+    // half of them, on four threads).  Chirp-z frame sizes build their own tables below and skip these.
+    const bool tuned = NF == 1024 || NF == 2048 || NF == 4096 || NF == 8192;
     std::vector<cx<double>> tw(NF), twn(NF + 1);
-    for (int j = 0; j < NF; ++j) {
-        const long double ang = -2.0L * M_PIl * j / (long double)NF;
-        tw[j] = {(double)cosl(ang), (double)sinl(ang)};
-    }
-    for (int k = 0; k <= NF; ++k) {
-        const long double ang = -2.0L * M_PIl * k / (long double)(2 * NF);
-        twn[k] = {(double)cosl(ang), (double)sinl(ang)};
+    if (tuned) {
+        auto fill = [&](int k0, int k1) {
+            for (int k = k0; k < k1; ++k) {
+                const long double ang = -2.0L * M_PIl * k / (long double)(2 * NF);
+                twn[(size_t)k] = {(double)cosl(ang), (double)sinl(ang)};
+            }
+        };
+        constexpr int TH = 4;
+        std::thread th[TH - 1];
+        const int per = (NF + TH) / TH;
+        for (int t = 1; t < TH; ++t) th[t - 1] = std::thread(fill, t * per, std::min(NF + 1, (t + 1) * per));
+        fill(0, per);
+        for (auto& t : th) t.join();
+        for (int j = 0; j < NF; ++j) tw[(size_t)j] = twn[(size_t)2 * j];
     }
     plan.d_coefs = (If0ChanCoef*)upload(ctx, coefs.data(), coefs.size() * sizeof(If0ChanCoef));
     plan.d_window = (double*)upload(ctx, win.data(), win.size() * sizeof(double));
     plan.d_tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
     plan.d_twn = (cx<double>*)upload(ctx, twn.data(), twn.size() * sizeof(cx<double>));
-    if (NF == 1024 || NF == 2048 || NF == 4096 || NF == 8192) {
+    if (tuned) {
         const int H = NF / 2, T = H / 8;
         std::vector<cx<double>> tr((size_t)2 * H);
         for (int P = 0; P < 2; ++P)
@@ -2114,8 +2153,12 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     for (const If0Chunk& ck : chunks) maxlen = std::max<long long>(maxlen, ck.len);
     long long slice = maxlen;
     bool sliced = false;
+    // Two hand-off buffers of half the cap each (pipelined front end only): the summary spectra of slice s run NEXT TO the
+    // front end of slice s + 1 -- see the slice loop below.
+    const bool two_buffers = !blue && !fe_sequential && !ut_out && if0_overlap_mode(ctx) != 0;
+    const size_t buf_cap = two_buffers ? ctx->if0_ws_cap / 2 : ctx->if0_ws_cap;
     if (!blue && (size_t)yc_rows * p.channels * sizeof(double) > ctx->if0_ws_cap) {   // (chirp-z frame sizes: one piece)
-        long long fit = (long long)(ctx->if0_ws_cap / ((size_t)nchunks * p.channels * sizeof(double))) / NF * NF;
+        long long fit = (long long)(buf_cap / ((size_t)nchunks * p.channels * sizeof(double))) / NF * NF;
         if (fit < NF) fit = NF;
         if (fit < maxlen) {
             // Among the slice lengths that fit, the one whose launches waste the least: the summary-spectrum kernel runs two
@@ -2187,6 +2230,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     IF0_TICK("slices");
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
     IF0_TICK("ws0");
+    const bool overlap = two_buffers && sliced && nslices >= 2 && if0_overlap_ready(ctx);
+    if (overlap && (rc = ensure(ctx, ctx->d_ws3, yc_bytes))) return rc;
     // the period search runs ONCE, behind the last slice, on persistent workgroups with a scratch pair each
     const bool per_big = n2 > 16384;   // spectra of more than 16 384 bins: the instantiation with the larger tables
     const char* per_key = per_big ? "if0_periodicity_big" : "if0_periodicity";
@@ -2254,31 +2299,64 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     a.epsilon2 = p.epsilon2;
     a.gamma = p.gamma;
     a.chroma = (dev_io && chroma_frames) ? chroma_frames : (double*)ctx->d_frames_out.p;
+    // Overlap (round 6, development builds, MPX_IF0_OVERLAP=1; measured and NOT adopted): the front end is one wave per SIMD on a
+    // 17-stage recurrence (fp64 issue), the summary spectra are bound by LDS round trips and barriers -- each leaves idle what
+    // the other needs.  With two hand-off buffers the spectra of slice s go to a second stream and run beside the front end of
+    // slice s + 1 (which depends on the front end of slice s alone: the carried filter state); the front end of slice s + 2
+    // waits for the spectra of slice s to let go of its buffer.  For the two to share a CU the front end's tile must be 32
+    // samples wide (if0_frontend_kernel<true, 32>: 17 KB of LDS per wave; four of them and ONE 64 KB spectrum workgroup fit in
+    // 160 KB, 216 + 2 x 128 registers per SIMD).  Same bits (scripts/dev/if0_hour_caps.py 12 24o), and the hour takes 100-102 ms
+    // instead of 91-92 (profiles/r6/if0_overlap_ab.txt): the 32-sample tile alone costs the front end 42.8 -> 66.4 ms (256-byte
+    // pieces of 64 rows per flush: the HBM write pattern the 64-sample tile was built to avoid), and the spectra at ONE
+    // workgroup per CU beside it take 75 ms instead of 42.6 -- the slower of the two sets the pace.  s_setprio on the front
+    // end's waves changes nothing (64.6 / 74.2 ms without it).
+    hipStream_t sp_st = overlap ? ctx->if0_sp_stream : st;
     for (long long sidx = 0; sidx < nslices; ++sidx) {
         If0Slice sl;
         sl.t0 = (int)(sidx * slice);
         sl.t1 = sliced ? (int)((sidx + 1) * slice) : 0x7fffffff;
         sl.state = sliced ? (double*)ctx->d_ws2.p : nullptr;
         const long long nf_s = sl_off[(size_t)sidx + 1] - sl_off[(size_t)sidx];
+        const int bi = overlap ? (int)(sidx & 1) : 0;
+        double* yc_s = bi ? (double*)ctx->d_ws3.p : yc;
+        if (overlap && sidx >= 2) MPX_HIP(ctx, hipStreamWaitEvent(st, ctx->if0_ev_sp[bi], 0));   // the buffer's last reader
         prof_mark(ctx, st, "if0_frontend_kernel");
-        auto fe_kernel = !fe_sequential ? (sliced ? if0_frontend_kernel<true> : if0_frontend_kernel<false>)
-                                        : (sliced ? if0_frontend2_kernel<true> : if0_frontend2_kernel<false>);
-        hipLaunchKernelGGL(fe_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st, d_in, d_chunks, nchunks, p.channels,
-                           plan.d_coefs, plan.wf, yc, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl, (int)warm_tail,
-                           blue ? plan.d_one : plan.d_window, blue ? 0 : NF - 1);   // the window goes on in the front end's tile flush
+        const bool tw32 = sliced && !fe_sequential && (overlap || dev_env_on("MPX_IF0_TW32"));
+        if (fe_sequential) {
+            auto fe_kernel = sliced ? if0_frontend2_kernel<true> : if0_frontend2_kernel<false>;
+            hipLaunchKernelGGL(fe_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st, d_in, d_chunks, nchunks, p.channels,
+                               plan.d_coefs, plan.wf, yc_s, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl, (int)warm_tail,
+                               blue ? plan.d_one : plan.d_window, blue ? 0 : NF - 1);   // the window goes on in the front end's tile flush
+        } else {
+            auto fe_kernel = sliced ? if0_frontend_kernel<true> : if0_frontend_kernel<false>;
+            if constexpr (DEV_KNOBS != 0)
+                if (tw32) fe_kernel = if0_frontend_kernel<true, 32>;
+            hipLaunchKernelGGL(fe_kernel, dim3((unsigned)fe_blocks), dim3(64), 0, st, d_in, d_chunks, nchunks, p.channels,
+                               plan.d_coefs, plan.wf, yc_s, d_tail_list, d_tail_groups, (int)tail_groups.size(), lg_nf, sl, (int)warm_tail,
+                               blue ? plan.d_one : plan.d_window, blue ? 0 : NF - 1, overlap ? dev_env_int("MPX_IF0_FE_PRIO", 1) : 0);
+        }
         MPX_HIP(ctx, hipGetLastError());
-        if (nf_s == 0) continue;
+        if (overlap) {
+            prof_mark(ctx, st, nullptr);
+            MPX_HIP(ctx, hipEventRecord(ctx->if0_ev_fe[bi], st));
+            MPX_HIP(ctx, hipStreamWaitEvent(sp_st, ctx->if0_ev_fe[bi], 0));
+        }
+        if (nf_s == 0) {
+            if (overlap) MPX_HIP(ctx, hipEventRecord(ctx->if0_ev_sp[bi], sp_st));
+            continue;
+        }
         const If0Frame* d_fr = d_frames + sl_off[(size_t)sidx];
         double* ut = ut_all + (size_t)sl_off[(size_t)sidx] * n2;
-        prof_mark(ctx, st, "if0_spectrum_kernel");
-        if (blue) rc = if0_spectrum_blue_launch(ctx, yc, d_fr, nf_s, NF, p.channels, p.power, plan, ut, st);
-        else if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
-        else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
-        else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
-        else rc = if0_spectrum_launch<8192, 512>(ctx, yc, d_fr, nf_s, p.channels, p.power, plan, ut, st);
+        prof_mark(ctx, sp_st, "if0_spectrum_kernel");
+        if (blue) rc = if0_spectrum_blue_launch(ctx, yc_s, d_fr, nf_s, NF, p.channels, p.power, plan, ut, sp_st);
+        else if (NF == 1024) rc = if0_spectrum_launch<1024, 64>(ctx, yc_s, d_fr, nf_s, p.channels, p.power, plan, ut, sp_st);
+        else if (NF == 2048) rc = if0_spectrum_launch<2048, 128>(ctx, yc_s, d_fr, nf_s, p.channels, p.power, plan, ut, sp_st);
+        else if (NF == 4096) rc = if0_spectrum_launch<4096, 256>(ctx, yc_s, d_fr, nf_s, p.channels, p.power, plan, ut, sp_st);
+        else rc = if0_spectrum_launch<8192, 512>(ctx, yc_s, d_fr, nf_s, p.channels, p.power, plan, ut, sp_st);
         if (rc) return rc;
-        prof_mark(ctx, st, nullptr);
-        if (ut_out) {
+        prof_mark(ctx, sp_st, nullptr);
+        if (overlap) MPX_HIP(ctx, hipEventRecord(ctx->if0_ev_sp[bi], sp_st));
+        if (ut_out) {   // (never with two buffers)
             if (!sliced) {
                 MPX_HIP(ctx, hipMemcpyAsync(ut_out, ut, (size_t)nframes * n2 * sizeof(double), hipMemcpyDeviceToHost, st));
             } else {   // a run of local rows that belongs to one chunk is a run of the call's rows
@@ -2292,6 +2370,10 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                 }
             }
         }
+    }
+    if (overlap) {   // the period search reads every slice's spectra
+        MPX_HIP(ctx, hipStreamWaitEvent(st, ctx->if0_ev_sp[(nslices - 1) & 1], 0));
+        if (nslices >= 2) MPX_HIP(ctx, hipStreamWaitEvent(st, ctx->if0_ev_sp[(nslices - 2) & 1], 0));
     }
     IF0_TICK("slice launches");
     a.out_row = sliced ? d_rows : nullptr;

@@ -68,6 +68,9 @@ struct mpx_ctx {
     void* h_results = nullptr;                // pinned staging for result copies of batches ([clips, 12] doubles): d2h_results
     size_t h_results_bytes = 0;
     size_t if0_ws_cap = (size_t)32 << 30;     // MPX_OPT_IF0_WORKSPACE_BYTES
+    hipStream_t if0_sp_stream = nullptr;      // development builds, MPX_IF0_OVERLAP=1: the summary spectra's stream (if0_run_host)
+    hipEvent_t if0_ev_fe[2] = {}, if0_ev_sp[2] = {};
+    bool if0_overlap_made = false;
     int he_kernel = 0;                        // MPX_OPT_HE_KERNEL
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
@@ -84,6 +87,8 @@ struct mpx_ctx {
     std::vector<int64_t> batch_layout;
     int64_t batch_layout_frames = 0;
     std::vector<void*> owned;  // plan tables, freed in mpx_destroy
+    std::vector<void*> retired, retired_host;   // blocks a workspace / the pinned result staging has outgrown (ensure, mpx_api.hip)
+    size_t retired_bytes = 0;
     // per-kernel timing (mpx_profile_begin / mpx_profile_end): an event in front of every launch while enabled
     struct ProfMark {
         const char* name;  // kernel launched right after the event; nullptr closes the previous region

@@ -11,6 +11,8 @@ import numpy as np
 
 from . import _lib
 
+_HIP_RT = None
+
 _engines = {}
 _lock = threading.Lock()
 
@@ -133,6 +135,16 @@ class Engine:
     @property
     def stream(self):
         return self.lib.mpx_stream(self.ctx)
+
+    def busy(self):
+        """True while work queued on this context's stream has not finished (hipStreamQuery on mpx_stream(): non-blocking).
+        The corpus driver's side threads use it to let the main context's kernels reach the GPU first (corpus.run_corpus)."""
+        global _HIP_RT
+        if _HIP_RT is None:
+            _HIP_RT = C.CDLL("libamdhip64.so")   # the runtime libmpx_hip.so is linked against: already in the process
+            _HIP_RT.hipStreamQuery.argtypes = [C.c_void_p]
+            _HIP_RT.hipStreamQuery.restype = C.c_int
+        return _HIP_RT.hipStreamQuery(C.c_void_p(self.stream)) != 0   # hipErrorNotReady
 
     def set_option(self, name, value):
         """mpx_set_option: "if0_workspace_bytes" (cap of one Iterative-F0 pass' hand-off buffer) or "he_kernel"
