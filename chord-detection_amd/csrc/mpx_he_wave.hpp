@@ -416,7 +416,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void he_wave_kernel(HeWaveArgs a, cx
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int PASS = decltype(pass_tag)::value;   // PAIRED: this wave's pass, a compile-time constant of its loop
         float2 raw[32];
-        long long f = PAIRED ? g0 + (wave >> 1) : grab();
+        // (PAIRED: the wave's number through readfirstlane -- as `tid >> 6` the frame index, the next one and the pending one were
+        //  64-bit VECTOR values, eight registers of a kernel that is short of them: 20 bytes of scratch, reloaded in the frame loop)
+        long long f = PAIRED ? g0 + (__builtin_amdgcn_readfirstlane(wave) >> 1) : grab();
         const long long f0 = f;
         (void)f0;
         if (f < g1) {   // the first frame is on its way while the tables are filled

@@ -26,6 +26,7 @@ SCRATCH_FREE = [
     "mpx::he_wave_kernel<8, 4, false, true, 4294967295u, 1, false>",    # the same loader, window shapes / sample rates that need every row
     "mpx::he_wave_kernel<8, 4, false, false, 2146439166u, 1, false>",   # ragged / unaligned frames at 44.1 kHz
     "mpx::he_wave_kernel<7, 4, false, true, 4294967295u, 2, false>",    # 8192-sample frames (the reference's default), whole and aligned: two passes per frame
+    "mpx::he_wave_kernel<6, 4, false, true, 4294967295u, 2, true>",     # ... a pair of waves per frame: the default for calls of >= 32 MiB (round 6: 20 B of scratch until the frame index became a scalar)
     "mpx::he_kernel<4096, 256, double>",
     "mpx::sacf_pfa_kernel<1>", "mpx::sacf_pfa_kernel<2>",
     "mpx::sacf_kernel<4096, false>", "mpx::sacf_kernel<4096, true>", "mpx::sacf_kernel<2048, true>",
@@ -43,8 +44,8 @@ SCRATCH_FREE = [
     "mpx::if0_spectrum_split_kernel<4096, true, 1>", "mpx::if0_spectrum_split_kernel<4096, false, 0>",
     "mpx::if0_spectrum_split_kernel<2048, true, 1>", "mpx::if0_spectrum_split_kernel<2048, false, 0>",
     "mpx::if0_spectrum_split_kernel<1024, true, 1>", "mpx::if0_spectrum_split_kernel<1024, false, 0>",
-    "mpx::if0_frontend_kernel<false>", "mpx::if0_frontend2_kernel<false>",
-    "mpx::if0_frontend_kernel<true>", "mpx::if0_frontend2_kernel<true>",     # time slices (MPX_OPT_IF0_WORKSPACE_BYTES)
+    "mpx::if0_frontend_kernel<false, 64>", "mpx::if0_frontend2_kernel<false>",
+    "mpx::if0_frontend_kernel<true, 64>", "mpx::if0_frontend2_kernel<true>",     # time slices (MPX_OPT_IF0_WORKSPACE_BYTES)
     "mpx::if0_spectrum_blue_kernel<4096, 256>", "mpx::if0_spectrum_blue_kernel<8192, 512>", "mpx::if0_spectrum_blue2_kernel<512>",   # chirp-z frame sizes
     "mpx::if0_spectrum_blue4_kernel<512>", "mpx::if0_periodicity_kernel<true>",   # frame sizes 8193 ... 16384 (round 6)
 ]
@@ -57,8 +58,7 @@ SCRATCH_CEILING = {
     "mpx::if0_periodicity_kernel<false>": 108,                # held at four workgroups per CU (128 registers); fourteen loads in flight per lane in the range maxima: 1.59 -> 1.49 ms per 600 s WITH the spill
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1, false>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
     "mpx::he_wave_kernel<7, 4, false, false, 4294967295u, 2, false>": 32,
-    "mpx::he_wave_kernel<6, 4, false, true, 4294967295u, 2, true>": 20,     # the pairs-of-waves arrangement (an option, not the default)
-    "mpx::he_wave_kernel<6, 4, false, false, 4294967295u, 2, true>": 44,   # 8192-sample frames, ragged / unaligned (clips: the last frame of each)
+    "mpx::he_wave_kernel<6, 4, false, false, 4294967295u, 2, true>": 12,   # 8192-sample frames, ragged / unaligned (clips: the last frame of each)
 }
 # occupancy (waves per SIMD) the launch geometry of the host code counts on
 OCCUPANCY = {
