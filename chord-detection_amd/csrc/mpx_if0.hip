@@ -18,13 +18,13 @@
 //                           search (one wave per harmonic m for the range maxima), harmonic
 //                           cancellation, pitch-class scatter (quirks A.10-A.13, A.18).
 #include <chrono>
-#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 
 #include "mpx_fft_dif.hpp"
+#include "mpx_if0_tables.hpp"
 #include "mpx_internal.hpp"
 
 namespace mpx {
@@ -1160,30 +1160,11 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
     const int NF = p.frame_size;
     std::vector<double> win(NF);
     for (int i = 0; i < NF; ++i) win[i] = 0.54 - 0.46 * std::cos(2.0 * M_PI * i / (double)(NF - 1));
-    // W_2NF^k, k <= NF, and W_NF^j.  For j < NF/2, W_NF^j = W_2NF^(2j) -- for a power of two the same long double angle, hence the
-    // same bits, as -2 pi j / NF computed on its own (rounds 1-5 did; the 32 770 long double sines and cosines of the default
-    // frame size were 3.3 of the 5.6 ms by which the FIRST call of a process at a new sample rate was slower than the second).
-    // The upper half of W_NF is computed as before (a reflection would not round the same way): 1.5 NF angles instead of
-    // 2 NF, on four threads.  Chirp-z frame sizes build their own tables below and skip these.
+    // W_NF^j, j < NF, and W_2NF^k, k <= NF (mpx_if0_tables.hpp).  Chirp-z frame sizes build their own tables below and skip these.
     const bool tuned = NF == 1024 || NF == 2048 || NF == 4096 || NF == 8192;
     std::vector<cx<double>> tw(NF), twn(NF + 1);
-    if (tuned) {
-        auto fill = [&](int q) {   // quarter q of both tables
-            for (int k = q * (NF / 4); k < (q + 1) * (NF / 4) + (q == 3 ? 1 : 0); ++k) {
-                const long double ang = -2.0L * M_PIl * k / (long double)(2 * NF);
-                twn[(size_t)k] = {(double)cosl(ang), (double)sinl(ang)};
-            }
-            for (int j = NF / 2 + q * (NF / 8); j < NF / 2 + (q + 1) * (NF / 8); ++j) {
-                const long double ang = -2.0L * M_PIl * j / (long double)NF;
-                tw[(size_t)j] = {(double)cosl(ang), (double)sinl(ang)};
-            }
-        };
-        std::thread th[3];
-        for (int q = 1; q < 4; ++q) th[q - 1] = std::thread(fill, q);
-        fill(0);
-        for (auto& t : th) t.join();
-        for (int j = 0; j < NF / 2; ++j) tw[(size_t)j] = twn[(size_t)2 * j];
-    }
+    static_assert(sizeof(cx<double>) == 2 * sizeof(double), "cx<double> is (x, y)");
+    if (tuned) if0_unit_roots(NF, reinterpret_cast<double*>(tw.data()), reinterpret_cast<double*>(twn.data()));
     plan.d_coefs = (If0ChanCoef*)upload(ctx, coefs.data(), coefs.size() * sizeof(If0ChanCoef));
     plan.d_window = (double*)upload(ctx, win.data(), win.size() * sizeof(double));
     plan.d_tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
