@@ -52,6 +52,7 @@ _sp = C.POINTER(C.c_int16)
 # name -> (restype, argtypes); every symbol include/mpx.h declares
 SIGNATURES = {
     "mpx_abi_version": (C.c_int, []),
+    "mpx_launch_count": (C.c_uint, [_vp]),
     "mpx_dev_knobs": (C.c_int, []),
     "mpx_device_count": (C.c_int, []),
     "mpx_create": (_vp, [C.c_int, C.c_int]),

@@ -96,6 +96,7 @@ def _engine_compute(method, clips, fs, device, note_names="unicode"):
 _SECOND_ENGINE = {}
 
 
+LAST_GATE_SECONDS = (0.0, 0)   # how long the last gated side thread waited, and how many polls that took (diagnostics)
 SIDE_THREADS_WAIT = True   # False: the side threads start at once (rounds 3-5; scripts/dev/corpus_order.py A/B)
 
 
@@ -104,21 +105,30 @@ def _start_side(th, main_engine, main_done):
     main thread's first ones.  Iterative-F0's front end fills every SIMD's registers with long-lived one-wave workgroups, and
     ESACF's multi-wave workgroups then find no CU with room until it has drained: when the front end won the race to the
     GPU -- it does whenever the main context has a new clip layout to describe first -- ESACF ran AFTER the 131 ms of
-    Iterative-F0 instead of beside it, 160 ms per 4096-clip group instead of 151 (profiles/r6/corpus_head_start.txt: every
-    one of four fresh processes, and three of this project's eleven evidence runs).  The thread waits until the main context's
-    stream has work queued (Engine.busy), the main thread is through with its methods, or 50 ms have passed."""
+    Iterative-F0 instead of beside it, 160 ms per 4096-clip group instead of 152 (profiles/r6/corpus_head_start.txt: every
+    one of four fresh processes, and three of this project's eleven evidence runs).  The thread waits until the main context
+    has enqueued a kernel (mpx_launch_count moves), the main thread is through with its methods, or 50 ms have passed.
+    (hipStreamQuery on the main context's stream does not do: it waits behind the main thread's hipStreamSynchronize and
+    answers "idle" when the call is over -- profiles/r6/corpus_gate_stream_query.txt.)"""
     if not SIDE_THREADS_WAIT or main_engine is None:
         th.start()
         return
     real_run = th.run
+    try:
+        count0 = main_engine.launch_count()
+    except Exception:   # a library without the counter: start as before
+        th.start()
+        return
 
     def gated():
-        t_end = time.perf_counter() + 0.05
-        try:
-            while not main_done.is_set() and time.perf_counter() < t_end and not main_engine.busy():
-                time.sleep(0.0002)
-        except Exception:   # no runtime to ask: start as before
-            pass
+        global LAST_GATE_SECONDS
+        t_in = time.perf_counter()
+        t_end = t_in + 0.05
+        polls = 0
+        while not main_done.is_set() and time.perf_counter() < t_end and main_engine.launch_count() == count0:
+            time.sleep(0.0001)
+            polls += 1
+        LAST_GATE_SECONDS = (time.perf_counter() - t_in, polls)
         real_run()
 
     th.run = gated
@@ -269,7 +279,7 @@ def run_corpus(n_clips, methods=(1, 2, 3, 4), fs=22050, seconds=2.0, chunk=1024,
             eng3 = _second_engine((device, 3))
             side4 = threading.Thread(target=run, args=(mi4, 4, lambda: eng3.prime_multif0_batch(clips, fs,
                                                                                                note_names=note_names)))
-            _start_side(side4, main_engine, main_done)
+            side4.start()   # (at once: its waves do not keep ESACF's workgroups out, and it is over before the front end's first round)
         for mi, m in enumerate(methods):
             if (side is not None and m == 3) or (side4 is not None and m == 4):
                 continue

@@ -332,6 +332,8 @@ void mpx_host_free(void* p) {
 
 const char* mpx_last_error(const mpx_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+unsigned mpx_launch_count(const mpx_ctx* ctx) { return ctx ? ctx->launches.load(std::memory_order_relaxed) : 0u; }
+
 int mpx_synchronize(mpx_ctx* ctx) {
     if (!ctx) return MPX_EINVAL;
     MPX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -95,6 +96,7 @@ struct mpx_ctx {
         hipEvent_t ev;
     };
     long long fit_stats[3] = {0, 0, 0};   // gaussian fits, MINPACK function evaluations, parked fits since mpx_profile_begin
+    std::atomic<unsigned> launches{0};   // mpx_launch_count
     bool prof_on = false;
     std::vector<ProfMark> prof_marks;
     std::vector<hipEvent_t> prof_pool;
@@ -130,6 +132,7 @@ int d2h_results_sync(mpx_ctx* ctx, void* dst_host, const void* src_dev, size_t b
 // While profiling is on: record an event on `st`; the time to the next mark is booked on `name` (nullptr: on nothing).
 void prof_mark_slow(mpx_ctx* ctx, hipStream_t st, const char* name);
 inline void prof_mark(mpx_ctx* ctx, hipStream_t st, const char* name) {
+    if (name) ctx->launches.fetch_add(1u, std::memory_order_relaxed);   // mpx_launch_count: a kernel (group) is about to be enqueued
     if (ctx->prof_on) prof_mark_slow(ctx, st, name);
 }
 

@@ -11,14 +11,22 @@ import numpy as np
 
 from . import _lib
 
-_HIP_RT = None
-
 _engines = {}
 _lock = threading.Lock()
 
 
 class MpxError(RuntimeError):
     pass
+
+
+def _wait_for_producer(t):
+    """The host waits until what torch's CURRENT stream has queued so far on tensor t's device is done: an event recorded there
+    and waited for, which involves that stream alone (`stream.synchronize()` on the default stream is the wider wait)."""
+    import torch
+    with torch.cuda.device(t.device):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(t.device))
+        ev.synchronize()
 
 
 class _DevFlat:
@@ -96,7 +104,7 @@ class Engine:
             import torch
             if x.dim() != 1 or x.dtype != torch.float32 or not x.is_contiguous():
                 raise ValueError("a device signal must be a contiguous 1-D float32 tensor")
-            torch.cuda.current_stream(x.device).synchronize()
+            _wait_for_producer(x)
             return _DevFlat(x)
         x = np.asarray(x)
         if x.ndim != 1:
@@ -111,7 +119,7 @@ class Engine:
             import torch
             if clips.dim() != 2 or clips.dtype != torch.float32 or not clips.is_contiguous():
                 raise ValueError("device clips must be a contiguous float32 [clips, samples] tensor")
-            torch.cuda.current_stream(clips.device).synchronize()   # complete before the library's stream reads it
+            _wait_for_producer(clips)   # complete before the library's stream reads it
             return _DevFlat(clips), np.arange(clips.shape[0] + 1, dtype=np.int64) * clips.shape[1]
         if isinstance(clips, np.ndarray) and clips.ndim == 2:
             # [C, L] array of equal-length clips: already packed back to back, no copy if float32 C-contiguous
@@ -136,15 +144,10 @@ class Engine:
     def stream(self):
         return self.lib.mpx_stream(self.ctx)
 
-    def busy(self):
-        """True while work queued on this context's stream has not finished (hipStreamQuery on mpx_stream(): non-blocking).
-        The corpus driver's side threads use it to let the main context's kernels reach the GPU first (corpus.run_corpus)."""
-        global _HIP_RT
-        if _HIP_RT is None:
-            _HIP_RT = C.CDLL("libamdhip64.so")   # the runtime libmpx_hip.so is linked against: already in the process
-            _HIP_RT.hipStreamQuery.argtypes = [C.c_void_p]
-            _HIP_RT.hipStreamQuery.restype = C.c_int
-        return _HIP_RT.hipStreamQuery(C.c_void_p(self.stream)) != 0   # hipErrorNotReady
+    def launch_count(self):
+        """mpx_launch_count: kernels this context has enqueued so far (non-blocking; callable from another thread while a method
+        call runs on the context).  The corpus driver's side threads wait for it to move (corpus._start_side)."""
+        return int(self.lib.mpx_launch_count(self.ctx))
 
     def set_option(self, name, value):
         """mpx_set_option: "if0_workspace_bytes" (cap of one Iterative-F0 pass' hand-off buffer) or "he_kernel"

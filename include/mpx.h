@@ -76,6 +76,12 @@ int mpx_synchronize(mpx_ctx* ctx);
 /* The context's hipStream_t (as void*), for callers that want to order their
  * own work after ours. */
 void* mpx_stream(mpx_ctx* ctx);
+/* How many kernels (groups of launches that belong together) the context has enqueued since it was created; wraps at 2^32.
+ * Non-blocking, and the one entry point that may be called from ANOTHER thread while a method call is running on the context:
+ * a driver that keeps several contexts busy on one GPU orders their first launches with it -- chord-detection_amd/corpus.py
+ * starts Iterative-F0's context once the main context's counter has moved (round 6; the reference has no counterpart: its
+ * methods run one after the other, chord_detection/cli.py). */
+unsigned mpx_launch_count(const mpx_ctx* ctx);
 
 /* ---- per-context options (ABI 3) ----------------------------------------------
  * Settings of a context that are not kwargs of the reference's constructors: how much device memory one pass may take and

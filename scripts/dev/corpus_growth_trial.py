@@ -15,6 +15,7 @@ print("---- the timed group", file=sys.stderr, flush=True)
 t0 = time.perf_counter()
 lo, hi, out, spent = corpus.run_corpus(n, (1, 2, 3, 4), fs, 2.0, 1024, 0, 1, 0, synth_device=dev, resident=block)
 wall = time.perf_counter() - t0
+print("gate: waited %.2f ms in %d polls" % (1e3 * corpus.LAST_GATE_SECONDS[0], corpus.LAST_GATE_SECONDS[1]), file=sys.stderr, flush=True)
 print("---- the same group again", file=sys.stderr, flush=True)
 t0 = time.perf_counter()
 corpus.run_corpus(n, (1, 2, 3, 4), fs, 2.0, 1024, 0, 1, 0, synth_device=dev, resident=block)

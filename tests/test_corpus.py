@@ -229,3 +229,36 @@ def test_full_100k_clip_corpus_on_one_gpu_properties():
     # the checksum of checksums the 8-GPU job would print
     res = corpus.summarise(full, (1, 2, 3, 4), spent, n, wall)
     assert res["clips"] == n and set(res["methods"]) == {"1", "2", "3", "4"}
+
+
+@pytest.mark.gpu
+def test_side_threads_wait_for_the_main_context_and_rows_do_not_depend_on_it():
+    """corpus._start_side: Iterative-F0 / Prime-multiF0 start once the main context has enqueued a kernel (mpx_launch_count).
+    The counter moves with every call and is readable while a call is in flight; the driver's rows are the same bits whether
+    the side threads wait or start at once."""
+    import torch
+    import chord_detection_amd as cd
+    eng = cd.Engine(0)
+    try:
+        c0 = eng.launch_count()
+        x = (0.1 * torch.randn(30 * 22050, device="cuda:0")).contiguous()
+        rows = torch.zeros((-(-x.numel() // 8192), 12), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        eng.iterative_f0_dev(x.data_ptr(), x.numel(), 22050, rows.data_ptr(), None)   # enqueued, not waited for
+        c1 = eng.launch_count()
+        assert c1 >= c0 + 3          # front end, summary spectra, period search
+        eng.synchronize()
+        assert eng.launch_count() == c1
+    finally:
+        eng.close()
+    n, fs = 5, 22050
+    old = corpus.SIDE_THREADS_WAIT
+    try:
+        corpus.SIDE_THREADS_WAIT = True
+        a = corpus.run_corpus(n, (1, 2, 3, 4), fs, 2.0, chunk=4, synth_device="cuda:0")[2]
+        corpus.SIDE_THREADS_WAIT = False
+        b = corpus.run_corpus(n, (1, 2, 3, 4), fs, 2.0, chunk=4, synth_device="cuda:0")[2]
+    finally:
+        corpus.SIDE_THREADS_WAIT = old
+    np.testing.assert_array_equal(a, b)
+    assert a.shape == (n, 4, 12) and np.abs(a[:, 1]).sum() > 0
