@@ -45,6 +45,14 @@ static void release_retired(mpx_ctx* ctx) {
 }
 void release_retired_blocks(mpx_ctx* ctx) { release_retired(ctx); }   // mpx_destroy
 
+// Is p device memory (hipMalloc'ed, a torch tensor's storage ...)?  The host entry points read such samples in place.
+bool samples_on_device(const void* p) {
+    hipPointerAttribute_t attr;
+    if (p && hipPointerGetAttributes(&attr, p) == hipSuccess) return attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
+    return false;
+}
+
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes <= b.bytes) return MPX_OK;
     if (b.p) {
@@ -560,14 +568,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     const int64_t nf = cached ? ctx->batch_layout_frames : (int64_t)descs.size();
     ctx->batch_layout.clear();
     // where the samples live (include/mpx.h): clips already in HBM are read IN PLACE, no copy into the context's buffer
-    bool on_device = false;
-    {
-        hipPointerAttribute_t attr;
-        if (total && hipPointerGetAttributes(&attr, signals) == hipSuccess)
-            on_device = attr.type == hipMemoryTypeDevice;
-        else
-            (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
-    }
+    const bool on_device = total && samples_on_device(signals);
     if (!on_device && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
     const float* d_in = on_device ? signals : (const float*)ctx->d_signal.p;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;

@@ -2210,7 +2210,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                          yc_bytes >> 30);
     const long long fe_blocks = nchunks * full_groups + (long long)tail_groups.size();
     const size_t state_bytes = sliced ? (size_t)fe_blocks * 64 * sizeof(double) * (fe_sequential ? IF0_STATE_SEQ : IF0_STATE_PIPE) : 0;
-    if (!dev_io && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
+    const bool in_dev = dev_io || (total && samples_on_device(signals));   // (round 6: clips already in HBM are read in place by the host entry points too)
+    if (!in_dev && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
     IF0_TICK("slices");
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;
     IF0_TICK("ws0");
@@ -2245,8 +2246,8 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     If0TailGroup* d_tail_groups = (If0TailGroup*)((char*)d_frames + ((up_frames.size() * sizeof(If0Frame) + 15) & ~(size_t)15));
     int* d_tail_list = (int*)((char*)d_tail_groups + ((tail_groups.size() * sizeof(If0TailGroup) + 15) & ~(size_t)15));
     int* d_rows = (int*)((char*)d_tail_list + ((tail_list.size() * sizeof(int) + 15) & ~(size_t)15));
-    if (!dev_io && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
-    const float* d_in = dev_io ? signals : (const float*)ctx->d_signal.p;   // the front end reads inside the clips only
+    if (!in_dev && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
+    const float* d_in = in_dev ? signals : (const float*)ctx->d_signal.p;   // the front end reads inside the clips only
     MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
     MPX_HIP(ctx, hipMemcpyAsync(d_frames, up_frames.data(), up_frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
     if (nt) {
