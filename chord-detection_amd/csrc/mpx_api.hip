@@ -522,7 +522,8 @@ static int method_host(mpx_ctx* ctx, run_fn run, const void* signal_any, bool pc
     if (rc) return rc;
     if (!chroma_sum) return set_error(ctx, MPX_EINVAL, "chroma_sum must not be NULL");
     const int64_t nf = num_frames_of(n, frame, hop);
-    if ((rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
+    const bool on_device = !pcm16 && n && samples_on_device(signal);   // float32 samples already in HBM: read in place (include/mpx.h)
+    if (!on_device && (rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
     // (Round 6 measured the copy of a long host signal in four pieces with the frames that had arrived computed under the next
@@ -531,10 +532,10 @@ static int method_host(mpx_ctx* ctx, run_fn run, const void* signal_any, bool pc
     // profiles/r6/h2d_probe_copy_in_pieces_rejected.json.  Removed.)
     if (pcm16) {
         if ((rc = pcm16_stage(ctx, (const int16_t*)signal_any, n, (float*)ctx->d_signal.p, ctx->stream))) return rc;
-    } else if (n && (rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) {
+    } else if (n && !on_device && (rc = stage_h2d(ctx, ctx->d_signal.p, signal, (size_t)n * sizeof(float), ctx->stream))) {
         return rc;
     }
-    rc = method_dev(ctx, run, (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
+    rc = method_dev(ctx, run, on_device ? signal : (const float*)ctx->d_signal.p, n, fs, params, frame, hop,
                     chroma_frames ? (double*)ctx->d_frames_out.p : nullptr, (double*)ctx->d_sum.p, ctx->stream);
     if (rc) return rc;
     MPX_HIP(ctx, hipMemcpyAsync(chroma_sum, ctx->d_sum.p, 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

@@ -114,9 +114,10 @@ int mpx_get_option(mpx_ctx* ctx, int option, int64_t* value);
 
 /* ---- where the samples live -------------------------------------------------
  * `signal` / `signals` of the entry points below (all but the *_dev ones, which run in place) may point to
- *   - memory of the context's device: copied inside HBM (a corpus synthesised or decoded on the GPU need not travel to
- *     the host and back).  The buffer must be complete when the call is made: the copy runs on the context's stream,
- *     not on the producer's;
+ *   - memory of the context's device: read IN PLACE (a corpus synthesised or decoded on the GPU need not travel to the
+ *     host and back; until round 6 only the framed methods' batch entry points did so, the others copied inside HBM; 16-bit
+ *     samples are converted into a buffer of the context).  The buffer must be complete when the call is made -- the kernels
+ *     run on the context's stream, not on the producer's -- and must not change until the call returns;
  *   - host memory, pageable or pinned (mpx_host_alloc, hipHostMalloc, torch pin_memory): one asynchronous copy over
  *     PCIe.  Measured for the 33.5 MB headline signal: 45 GB/s from pageable memory (the runtime pins the pages and
  *     DMAs from them), 49 GB/s from pinned memory, against the 63 GB/s of the link.

@@ -146,6 +146,16 @@ def test_device_resident_clips_equal_host_clips():
     np.testing.assert_array_equal(eng.iterative_f0(x_dev, 22050), eng.iterative_f0(x_host, 22050))
     np.testing.assert_array_equal(eng.prime_multif0(x_dev, 22050), eng.prime_multif0(x_host, 22050))
     np.testing.assert_array_equal(eng.esacf(x_dev, 22050, 1023), eng.esacf(x_host, 22050, 1023))
+    # ... read IN PLACE since round 6: a view that starts on an odd sample (4-byte aligned only) must give the host's bits too
+    flat = dev_clips.reshape(-1)
+    v_dev = flat[12345:12345 + 40001]
+    v_host = v_dev.cpu().numpy()
+    assert v_dev.data_ptr() % 8 == 4
+    np.testing.assert_array_equal(eng.harmonic_energy(v_dev, 22050, frame=4096, hop=1024), eng.harmonic_energy(v_host, 22050, frame=4096, hop=1024))
+    np.testing.assert_array_equal(eng.harmonic_energy(v_dev, 22050), eng.harmonic_energy(v_host, 22050))
+    np.testing.assert_array_equal(eng.esacf(v_dev, 22050, 1023), eng.esacf(v_host, 22050, 1023))
+    np.testing.assert_array_equal(eng.iterative_f0(v_dev, 22050), eng.iterative_f0(v_host, 22050))
+    np.testing.assert_array_equal(eng.prime_multif0(v_dev, 22050), eng.prime_multif0(v_host, 22050))
 
 
 def _oracle_all(method, x, fs, note_names="unicode"):
