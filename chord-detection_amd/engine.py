@@ -113,7 +113,7 @@ class Engine:
     def _pack(clips):
         if hasattr(clips, "is_cuda") and clips.is_cuda:
             # [C, L] float32 tensor already on the device (e.g. a synthesised corpus chunk): handed over in place, the
-            # library copies inside HBM (include/mpx.h, "where the samples live") instead of device -> host -> device
+            # library reads it there (include/mpx.h, "where the samples live") instead of device -> host -> device
             import torch
             if clips.dim() != 2 or clips.dtype != torch.float32 or not clips.is_contiguous():
                 raise ValueError("device clips must be a contiguous float32 [clips, samples] tensor")
