@@ -45,10 +45,11 @@ static void release_retired(mpx_ctx* ctx) {
 }
 void release_retired_blocks(mpx_ctx* ctx) { release_retired(ctx); }   // mpx_destroy
 
-// Is p device memory (hipMalloc'ed, a torch tensor's storage ...)?  The host entry points read such samples in place.
-bool samples_on_device(const void* p) {
+// Is p memory of the context's OWN device (hipMalloc'ed, a torch tensor's storage ...)?  The host entry points read such samples
+// in place; another device's memory goes through the staging copy like host memory (hipMemcpyDefault finds its way).
+bool samples_on_device(const mpx_ctx* ctx, const void* p) {
     hipPointerAttribute_t attr;
-    if (p && hipPointerGetAttributes(&attr, p) == hipSuccess) return attr.type == hipMemoryTypeDevice;
+    if (p && hipPointerGetAttributes(&attr, p) == hipSuccess) return attr.type == hipMemoryTypeDevice && attr.device == ctx->device;
     (void)hipGetLastError();   // plain pageable memory is "invalid value" to this query, not an error
     return false;
 }
@@ -522,7 +523,7 @@ static int method_host(mpx_ctx* ctx, run_fn run, const void* signal_any, bool pc
     if (rc) return rc;
     if (!chroma_sum) return set_error(ctx, MPX_EINVAL, "chroma_sum must not be NULL");
     const int64_t nf = num_frames_of(n, frame, hop);
-    const bool on_device = !pcm16 && n && samples_on_device(signal);   // float32 samples already in HBM: read in place (include/mpx.h)
+    const bool on_device = !pcm16 && n && samples_on_device(ctx, signal);   // float32 samples already in HBM: read in place (include/mpx.h)
     if (!on_device && (rc = ensure(ctx, ctx->d_signal, (size_t)(n ? n : 1) * sizeof(float)))) return rc;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, 12 * sizeof(double)))) return rc;
@@ -569,7 +570,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     const int64_t nf = cached ? ctx->batch_layout_frames : (int64_t)descs.size();
     ctx->batch_layout.clear();
     // where the samples live (include/mpx.h): clips already in HBM are read IN PLACE, no copy into the context's buffer
-    const bool on_device = total && samples_on_device(signals);
+    const bool on_device = total && samples_on_device(ctx, signals);
     if (!on_device && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
     const float* d_in = on_device ? signals : (const float*)ctx->d_signal.p;
     if ((rc = ensure(ctx, ctx->d_frames_out, (size_t)(nf ? nf : 1) * 12 * sizeof(double)))) return rc;

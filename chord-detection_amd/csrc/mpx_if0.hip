@@ -2210,7 +2210,7 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
                          yc_bytes >> 30);
     const long long fe_blocks = nchunks * full_groups + (long long)tail_groups.size();
     const size_t state_bytes = sliced ? (size_t)fe_blocks * 64 * sizeof(double) * (fe_sequential ? IF0_STATE_SEQ : IF0_STATE_PIPE) : 0;
-    const bool in_dev = dev_io || (total && samples_on_device(signals));   // (round 6: clips already in HBM are read in place by the host entry points too)
+    const bool in_dev = dev_io || (total && samples_on_device(ctx, signals));   // (round 6: clips already in HBM are read in place by the host entry points too)
     if (!in_dev && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float) + 64))) return rc;
     IF0_TICK("slices");
     if ((rc = ensure(ctx, ctx->d_ws0, yc_bytes))) return rc;

@@ -123,7 +123,7 @@ inline bool dev_env_on(const char* name) { return dev_env_int(name, 0) != 0; }
 
 int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
-bool samples_on_device(const void* p);
+bool samples_on_device(const mpx_ctx* ctx, const void* p);
 void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failure (error set)
 // Samples (host or device memory) into device memory, enqueued on `st` (see mpx_api.hip for the measured rates).
 int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);

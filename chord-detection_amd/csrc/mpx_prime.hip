@@ -1214,7 +1214,7 @@ int prime_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, i
     hipStream_t st = stream ? stream : ctx->stream;
     // (round 6: the batch entry point reads clips that are already in HBM in place too, like mpx_*_batch of the framed methods --
     //  until then it copied them into the context's buffer: 0.9 GB more to allocate and 0.3 ms per 4096 two-second clips)
-    const bool in_dev = dev_io || (total && samples_on_device(signals));
+    const bool in_dev = dev_io || (total && samples_on_device(ctx, signals));
     if (!in_dev && (rc = ensure(ctx, ctx->d_signal, (size_t)(total ? total : 1) * sizeof(float)))) return rc;
     const size_t nitems = (size_t)slot;
     size_t item_bytes = 0;
