@@ -101,13 +101,15 @@ SIDE_THREADS_WAIT = True   # False: the side threads start at once (rounds 3-5; 
 
 
 def _start_side(th, main_engine, main_done):
-    """Start a side thread (Iterative-F0 / Prime-multiF0 on contexts of their own) so that its kernels reach the GPU BEHIND the
-    main thread's first ones.  Iterative-F0's front end fills every SIMD's registers with long-lived one-wave workgroups, and
-    ESACF's multi-wave workgroups then find no CU with room until it has drained: when the front end won the race to the
-    GPU -- it does whenever the main context has a new clip layout to describe first -- ESACF ran AFTER the 131 ms of
-    Iterative-F0 instead of beside it, 160 ms per 4096-clip group instead of 152 (profiles/r6/corpus_head_start.txt: every
-    one of four fresh processes, and three of this project's eleven evidence runs).  The thread waits until the main context
-    has enqueued a kernel (mpx_launch_count moves), the main thread is through with its methods, or 50 ms have passed.
+    """Start a side thread (Iterative-F0 on a context of its own) so that its kernels reach the GPU BEHIND the main thread's
+    first ones.  Iterative-F0's front end fills every SIMD's registers with long-lived one-wave workgroups, and ESACF's
+    multi-wave workgroups then find no CU with room until it has drained: whenever the front end won the race to the GPU, ESACF
+    ran AFTER the 131 ms of Iterative-F0 instead of beside it -- 160 ms per 4096-clip group instead of 150
+    (profiles/r6/corpus_head_start.txt: every one of four fresh processes, and three of this project's eleven evidence runs).
+    It won whenever something held the main thread's call up: in those runs the library's hipFree of an outgrown workspace, a
+    device-wide wait (csrc/mpx_api.hip `ensure`: such blocks are retired now, profiles/r6/corpus_retire_cap_ab.txt).  The gate
+    makes the order independent of such stalls: the thread waits until the main context has enqueued a kernel
+    (mpx_launch_count moves), the main thread is through with its methods, or 50 ms have passed.
     (hipStreamQuery on the main context's stream does not do: it waits behind the main thread's hipStreamSynchronize and
     answers "idle" when the call is over -- profiles/r6/corpus_gate_stream_query.txt.)"""
     if not SIDE_THREADS_WAIT or main_engine is None:

@@ -26,14 +26,14 @@ int set_error(mpx_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 // Blocks a workspace has outgrown.  hipFree / hipHostFree wait for the whole DEVICE, other contexts' streams included, and a
-// corpus driver runs the methods on three contexts at once: a context that outgrows a workspace behind another context's
-// queued kernels would wait for all of them.  So an outgrown block is RETIRED: kept until the context is destroyed, or until
-// more than RETIRED_MAX bytes of device memory are held that way -- then (a large workspace: the 12 -> 83 GiB hand-off buffer
-// of a long stream) everything retired is freed at once, with the wait.  Measured on the corpus group whose workspaces grow
-// inside the timed call (scripts/dev/corpus_growth_trial.py, MPX_ENSURE_FREE=1 = the old way; profiles/r6/corpus_growth_ab.txt):
-// 161-163 -> 160-161 ms -- the 10 ms that group loses against a warm one are the start ORDER of the contexts' kernels
-// (corpus._start_side), not this wait.
-constexpr size_t RETIRED_MAX = (size_t)1 << 30;
+// corpus driver runs the methods on three contexts at once: a context that outgrows a workspace next to another context's
+// running kernels waits for all of them.  Measured with MPX_TICKS=1 (development library, profiles/r6/corpus_cold_ticks.txt): the
+// ESACF call of the first 4096-clip group of a process sat 24.7 ms between its plan lookup and its first launch -- the length of
+// the Prime-multiF0 kernel running beside it -- and Iterative-F0, which waits for that launch (corpus._start_side), with it.
+// So an outgrown block is RETIRED: kept until the context is destroyed, until an allocation fails, or until more than
+// ctx->retired_cap bytes are held that way (an eighth of the device's memory, at least 8 GiB: the 12 -> 83 GiB hand-off buffer
+// of a long stream retires 12 GiB) -- then everything retired is freed at once, with the wait.  (A first cap of 1 GiB was below
+// what the 1024-clip workspaces of that driver add up to and changed nothing: profiles/r6/corpus_growth_ab.txt.)
 static void release_retired(mpx_ctx* ctx) {
     if (ctx->retired.empty() && ctx->retired_host.empty()) return;
     hipStreamSynchronize(ctx->stream);   // work queued on our stream may still use them
@@ -61,7 +61,7 @@ int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes) {
         ctx->retired_bytes += b.bytes;
         b.p = nullptr;
         b.bytes = 0;
-        if (ctx->retired_bytes > RETIRED_MAX || dev_env_on("MPX_ENSURE_FREE")) release_retired(ctx);   // (the knob: rounds 1-5, for the A/B)
+        if (ctx->retired_bytes > ctx->retired_cap || dev_env_on("MPX_ENSURE_FREE")) release_retired(ctx);   // (the knob: rounds 1-5, for the A/B)
     }
     size_t want = bytes + bytes / 4 + 256;
     const auto t0 = std::chrono::steady_clock::now();
@@ -255,8 +255,10 @@ mpx_ctx* mpx_create(int device, int flags) {
     ctx->copy_pieces = ctx->copy_pieces < 1 ? 1 : (ctx->copy_pieces > 7 ? 7 : ctx->copy_pieces);
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
             ctx->num_cus = prop.multiProcessorCount;
+            if (prop.totalGlobalMem / 8 > ctx->retired_cap) ctx->retired_cap = prop.totalGlobalMem / 8;   // (ensure, above)
+        }
     }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
@@ -281,6 +283,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     for (hipEvent_t e : ctx->copy_ev)
         if (e) hipEventDestroy(e);
     if (ctx->h_results) hipHostFree(ctx->h_results);
+    if (ctx->h_tables) hipHostFree(ctx->h_tables);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t e : {ctx->if0_ev_fe[0], ctx->if0_ev_fe[1], ctx->if0_ev_sp[0], ctx->if0_ev_sp[1]})
         if (e) hipEventDestroy(e);
@@ -554,6 +557,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if (num_clips < 0 || !offsets || (num_clips > 0 && !chroma_sums))
         return set_error(ctx, MPX_EINVAL, "bad batch arguments");
     if (num_clips == 0) return MPX_OK;
+    dev_tick(ctx, "method_batch: enter");
     const int64_t total = offsets[num_clips];
     int rc = check_common(ctx, signals, total, frame, hop);
     if (rc) return rc;
@@ -568,6 +572,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if (!cached && build_descs(offsets, num_clips, frame, hop, descs, seg))
         return set_error(ctx, MPX_EINVAL, "offsets must be non-decreasing");
     const int64_t nf = cached ? ctx->batch_layout_frames : (int64_t)descs.size();
+    dev_tick(ctx, "method_batch: descriptors");
     ctx->batch_layout.clear();
     // where the samples live (include/mpx.h): clips already in HBM are read IN PLACE, no copy into the context's buffer
     const bool on_device = total && samples_on_device(ctx, signals);
@@ -578,10 +583,37 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     if ((rc = ensure(ctx, ctx->d_offsets, (size_t)(num_clips + 1) * sizeof(long long)))) return rc;
     if ((rc = ensure(ctx, ctx->d_sum, (size_t)num_clips * 12 * sizeof(double)))) return rc;
     hipStream_t st = ctx->stream;
+    dev_tick(ctx, "method_batch: workspaces");
     if (!cached) {   // (the buffers only grow: a layout that was cached fits them as they are)
-        if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
-        MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+        // Through PINNED staging: a copy from pageable memory keeps the calling thread until it has run, and it runs as a kernel
+        // that needs room on every SIMD -- next to another context's persistent kernel (the corpus driver's Prime-multiF0 call)
+        // this thread sat 26 ms in front of its own first launch (profiles/r6/corpus_first_launch.txt).  From pinned memory the
+        // copies are queued like the kernels behind them and the thread goes on.
+        const size_t db = (size_t)nf * sizeof(FrameDesc), sb = seg.size() * sizeof(long long);
+        if (ctx->h_tables_bytes < db + sb) {
+            if (ctx->h_tables) ctx->retired_host.push_back(ctx->h_tables);   // (hipHostFree waits for the device: see ensure)
+            ctx->h_tables = nullptr;
+            ctx->h_tables_bytes = 0;
+            void* hp = nullptr;
+            if (hipHostMalloc(&hp, db + sb + (db + sb) / 4, hipHostMallocDefault) == hipSuccess) {
+                ctx->h_tables = hp;
+                ctx->h_tables_bytes = db + sb + (db + sb) / 4;
+            } else {
+                (void)hipGetLastError();   // no pinned memory: the pageable copies below
+            }
+        }
+        const char* src_d = (const char*)descs.data();
+        const char* src_s = (const char*)seg.data();
+        if (ctx->h_tables) {
+            if (db) std::memcpy(ctx->h_tables, descs.data(), db);
+            std::memcpy((char*)ctx->h_tables + db, seg.data(), sb);
+            src_d = (const char*)ctx->h_tables;
+            src_s = (const char*)ctx->h_tables + db;
+        }
+        if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, src_d, db, hipMemcpyHostToDevice, st));
+        MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, src_s, sb, hipMemcpyHostToDevice, st));
     }
+    dev_tick(ctx, "method_batch: tables queued");
     bool did_sum = false;
     // A large batch in HOST memory goes over PCIe in pieces on a second stream, the kernels of piece k running next to
     // the copy of piece k+1 (ESACF, 4096 clips: the 1.4 GB copy and the 27 ms of kernels take about as long as each
@@ -623,6 +655,7 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
                 return rc;
         }
     }
+    dev_tick(ctx, "method_batch: kernels queued");
     if ((rc = segment_sum(ctx, (const double*)ctx->d_frames_out.p, (const long long*)ctx->d_offsets.p, num_clips, nf,
                           (double*)ctx->d_sum.p, st)))
         return rc;

@@ -4229,7 +4229,9 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     BandCoef coef;
     int rc = band_coefs(ctx, fs, coef);
     if (rc) return rc;
+    dev_tick(ctx, "esacf_run: enter");
     const BandCut bcut = band_cut(ctx, fs, N, coef);
+    dev_tick(ctx, "esacf_run: band_cut");
     EsacfPlan plan;
     HugeArgs hg{};
     if (huge) {
@@ -4369,6 +4371,7 @@ int esacf_run(mpx_ctx* ctx, const float* d_signal, int64_t n, const FrameDesc* d
     for (long long f0 = 0; f0 < num_frames; f0 += batch) {
         const long long nf = (num_frames - f0 < batch) ? num_frames - f0 : batch;
         double* xw = (stage == MPX_STAGE_WFIR) ? d_stage_out + (size_t)f0 * N : nullptr;
+        dev_tick(ctx, "esacf_run: before bandsplit");
         prof_mark(ctx, st, "bandsplit_kernel");
         const dim3 bs_grid((unsigned)((nf + 63) / 64), (unsigned)band_cut_pieces(bcut, N));
         if (xw)

@@ -3,7 +3,9 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cmath>
 #include <cstdint>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -68,6 +70,8 @@ struct mpx_ctx {
     unsigned live_epoch = 0;                  // tag of the parked records of the current batch (never 0)
     void* h_results = nullptr;                // pinned staging for result copies of batches ([clips, 12] doubles): d2h_results
     size_t h_results_bytes = 0;
+    void* h_tables = nullptr;                 // pinned staging for the frame descriptors / segment table a batch call uploads (method_batch)
+    size_t h_tables_bytes = 0;
     size_t if0_ws_cap = (size_t)32 << 30;     // MPX_OPT_IF0_WORKSPACE_BYTES
     hipStream_t if0_sp_stream = nullptr;      // development builds, MPX_IF0_OVERLAP=1: the summary spectra's stream (if0_run_host)
     hipEvent_t if0_ev_fe[2] = {}, if0_ev_sp[2] = {};
@@ -90,6 +94,7 @@ struct mpx_ctx {
     std::vector<void*> owned;  // plan tables, freed in mpx_destroy
     std::vector<void*> retired, retired_host;   // blocks a workspace / the pinned result staging has outgrown (ensure, mpx_api.hip)
     size_t retired_bytes = 0;
+    size_t retired_cap = (size_t)8 << 30;       // ... freed together once they hold more than this (mpx_create: an eighth of the device's memory)
     // per-kernel timing (mpx_profile_begin / mpx_profile_end): an event in front of every launch while enabled
     struct ProfMark {
         const char* name;  // kernel launched right after the event; nullptr closes the previous region
@@ -120,6 +125,21 @@ inline int dev_env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 inline bool dev_env_on(const char* name) { return dev_env_int(name, 0) != 0; }
+// MPX_TICKS=1 (development builds): where the HOST time of a call goes -- microseconds since the calling thread's previous tick
+#ifdef MPX_DEV_KNOBS
+inline void dev_tick(const void* ctx, const char* what) {
+    static const bool on = getenv("MPX_TICKS") != nullptr;
+    if (!on) return;
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double now = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+    static thread_local double prev = 0.0;
+    fprintf(stderr, "mpx tick %p %-28s +%.0f us (t = %.3f ms)\n", ctx, what, prev ? now - prev : 0.0, std::fmod(now * 1e-3, 1e6));
+    prev = now;
+}
+#else
+inline void dev_tick(const void*, const char*) {}
+#endif
 
 int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
