@@ -283,7 +283,6 @@ void mpx_destroy(mpx_ctx* ctx) {
     for (hipEvent_t e : ctx->copy_ev)
         if (e) hipEventDestroy(e);
     if (ctx->h_results) hipHostFree(ctx->h_results);
-    if (ctx->h_tables) hipHostFree(ctx->h_tables);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t e : {ctx->if0_ev_fe[0], ctx->if0_ev_fe[1], ctx->if0_ev_sp[0], ctx->if0_ev_sp[1]})
         if (e) hipEventDestroy(e);
@@ -585,33 +584,8 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
     hipStream_t st = ctx->stream;
     dev_tick(ctx, "method_batch: workspaces");
     if (!cached) {   // (the buffers only grow: a layout that was cached fits them as they are)
-        // Through PINNED staging: a copy from pageable memory keeps the calling thread until it has run, and it runs as a kernel
-        // that needs room on every SIMD -- next to another context's persistent kernel (the corpus driver's Prime-multiF0 call)
-        // this thread sat 26 ms in front of its own first launch (profiles/r6/corpus_first_launch.txt).  From pinned memory the
-        // copies are queued like the kernels behind them and the thread goes on.
-        const size_t db = (size_t)nf * sizeof(FrameDesc), sb = seg.size() * sizeof(long long);
-        if (ctx->h_tables_bytes < db + sb) {
-            if (ctx->h_tables) ctx->retired_host.push_back(ctx->h_tables);   // (hipHostFree waits for the device: see ensure)
-            ctx->h_tables = nullptr;
-            ctx->h_tables_bytes = 0;
-            void* hp = nullptr;
-            if (hipHostMalloc(&hp, db + sb + (db + sb) / 4, hipHostMallocDefault) == hipSuccess) {
-                ctx->h_tables = hp;
-                ctx->h_tables_bytes = db + sb + (db + sb) / 4;
-            } else {
-                (void)hipGetLastError();   // no pinned memory: the pageable copies below
-            }
-        }
-        const char* src_d = (const char*)descs.data();
-        const char* src_s = (const char*)seg.data();
-        if (ctx->h_tables) {
-            if (db) std::memcpy(ctx->h_tables, descs.data(), db);
-            std::memcpy((char*)ctx->h_tables + db, seg.data(), sb);
-            src_d = (const char*)ctx->h_tables;
-            src_s = (const char*)ctx->h_tables + db;
-        }
-        if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, src_d, db, hipMemcpyHostToDevice, st));
-        MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, src_s, sb, hipMemcpyHostToDevice, st));
+        if (nf) MPX_HIP(ctx, hipMemcpyAsync(ctx->d_desc.p, descs.data(), (size_t)nf * sizeof(FrameDesc), hipMemcpyHostToDevice, st));
+        MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
     }
     dev_tick(ctx, "method_batch: tables queued");
     bool did_sum = false;

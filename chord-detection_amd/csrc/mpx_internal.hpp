@@ -70,8 +70,6 @@ struct mpx_ctx {
     unsigned live_epoch = 0;                  // tag of the parked records of the current batch (never 0)
     void* h_results = nullptr;                // pinned staging for result copies of batches ([clips, 12] doubles): d2h_results
     size_t h_results_bytes = 0;
-    void* h_tables = nullptr;                 // pinned staging for the frame descriptors / segment table a batch call uploads (method_batch)
-    size_t h_tables_bytes = 0;
     size_t if0_ws_cap = (size_t)32 << 30;     // MPX_OPT_IF0_WORKSPACE_BYTES
     hipStream_t if0_sp_stream = nullptr;      // development builds, MPX_IF0_OVERLAP=1: the summary spectra's stream (if0_run_host)
     hipEvent_t if0_ev_fe[2] = {}, if0_ev_sp[2] = {};
