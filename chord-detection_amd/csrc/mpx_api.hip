@@ -54,6 +54,27 @@ bool samples_on_device(const mpx_ctx* ctx, const void* p) {
     return false;
 }
 
+// Pinned staging for tables a call builds on the host and uploads: a copy from PAGEABLE memory keeps the calling thread until it
+// has run, one copy after the other, and next to other contexts' kernels each waits for room on the GPU -- Iterative-F0's six
+// table uploads took 5-6 ms in the corpus driver where they take 75 us alone (MPX_IF0_TICKS, profiles/r6/corpus_cold_ticks.txt).
+// From pinned memory they are queued like the kernels behind them.  One buffer per context, reused by the next call: a caller
+// whose call RETURNS before its copies have run (the *_dev entry points) synchronises first.
+void* pinned_tables(mpx_ctx* ctx, size_t bytes) {
+    if (ctx->h_tables_bytes >= bytes) return ctx->h_tables;
+    if (ctx->h_tables) ctx->retired_host.push_back(ctx->h_tables);   // (hipHostFree waits for the device: see ensure)
+    ctx->h_tables = nullptr;
+    ctx->h_tables_bytes = 0;
+    void* hp = nullptr;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&hp, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    ctx->h_tables = hp;
+    ctx->h_tables_bytes = want;
+    return hp;
+}
+
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes) {
     if (bytes <= b.bytes) return MPX_OK;
     if (b.p) {
@@ -283,6 +304,7 @@ void mpx_destroy(mpx_ctx* ctx) {
     for (hipEvent_t e : ctx->copy_ev)
         if (e) hipEventDestroy(e);
     if (ctx->h_results) hipHostFree(ctx->h_results);
+    if (ctx->h_tables) hipHostFree(ctx->h_tables);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t e : {ctx->if0_ev_fe[0], ctx->if0_ev_fe[1], ctx->if0_ev_sp[0], ctx->if0_ev_sp[1]})
         if (e) hipEventDestroy(e);

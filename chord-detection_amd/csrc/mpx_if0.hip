@@ -2248,15 +2248,37 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     int* d_rows = (int*)((char*)d_tail_list + ((tail_list.size() * sizeof(int) + 15) & ~(size_t)15));
     if (!in_dev && (rc = stage_h2d(ctx, ctx->d_signal.p, signals, (size_t)total * sizeof(float), st))) return rc;
     const float* d_in = in_dev ? signals : (const float*)ctx->d_signal.p;   // the front end reads inside the clips only
-    MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
-    MPX_HIP(ctx, hipMemcpyAsync(d_frames, up_frames.data(), up_frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
-    if (nt) {
-        MPX_HIP(ctx, hipMemcpyAsync(d_tail_groups, tail_groups.data(), tail_groups.size() * sizeof(If0TailGroup), hipMemcpyHostToDevice, st));
-        MPX_HIP(ctx, hipMemcpyAsync(d_tail_list, tail_list.data(), tail_list.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    // the tables as ONE image of their block of d_desc, through the context's pinned staging (pinned_tables, mpx_api.hip)
+    {
+        const size_t o_fr = (size_t)((char*)d_frames - (char*)d_chunks), o_tg = (size_t)((char*)d_tail_groups - (char*)d_chunks),
+                     o_tl = (size_t)((char*)d_tail_list - (char*)d_chunks), o_rw = (size_t)((char*)d_rows - (char*)d_chunks);
+        const size_t img = o_rw + (sliced ? sl_rows.size() * sizeof(int) : 0), img_al = (img + 15) & ~(size_t)15;
+        const size_t seg_bytes = seg.size() * sizeof(long long);
+        char* h = (char*)pinned_tables(ctx, img_al + seg_bytes);
+        if (h) {
+            std::memcpy(h, chunks.data(), chunks.size() * sizeof(If0Chunk));
+            std::memcpy(h + o_fr, up_frames.data(), up_frames.size() * sizeof(If0Frame));
+            if (nt) {
+                std::memcpy(h + o_tg, tail_groups.data(), tail_groups.size() * sizeof(If0TailGroup));
+                std::memcpy(h + o_tl, tail_list.data(), tail_list.size() * sizeof(int));
+            }
+            if (sliced) std::memcpy(h + o_rw, sl_rows.data(), sl_rows.size() * sizeof(int));
+            std::memcpy(h + img_al, seg.data(), seg_bytes);
+            MPX_HIP(ctx, hipMemcpyAsync(d_chunks, h, img, hipMemcpyHostToDevice, st));
+            MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, h + img_al, seg_bytes, hipMemcpyHostToDevice, st));
+            if (dev_io) MPX_HIP(ctx, hipStreamSynchronize(st));   // this call returns before its kernels have run: the staging is the next call's
+        } else {   // no pinned memory: the vectors themselves, and the wait
+            MPX_HIP(ctx, hipMemcpyAsync(d_chunks, chunks.data(), chunks.size() * sizeof(If0Chunk), hipMemcpyHostToDevice, st));
+            MPX_HIP(ctx, hipMemcpyAsync(d_frames, up_frames.data(), up_frames.size() * sizeof(If0Frame), hipMemcpyHostToDevice, st));
+            if (nt) {
+                MPX_HIP(ctx, hipMemcpyAsync(d_tail_groups, tail_groups.data(), tail_groups.size() * sizeof(If0TailGroup), hipMemcpyHostToDevice, st));
+                MPX_HIP(ctx, hipMemcpyAsync(d_tail_list, tail_list.data(), tail_list.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            }
+            if (sliced) MPX_HIP(ctx, hipMemcpyAsync(d_rows, sl_rows.data(), sl_rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
+            if (dev_io || sliced) MPX_HIP(ctx, hipStreamSynchronize(st));   // the tables above are host vectors of this call
+        }
     }
-    if (sliced) MPX_HIP(ctx, hipMemcpyAsync(d_rows, sl_rows.data(), sl_rows.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    MPX_HIP(ctx, hipMemcpyAsync(ctx->d_offsets.p, seg.data(), seg.size() * sizeof(long long), hipMemcpyHostToDevice, st));
-    if (dev_io || sliced) MPX_HIP(ctx, hipStreamSynchronize(st));   // the tables above are host vectors of this call
     IF0_TICK("tables+sync");
     double* yc = (double*)ctx->d_ws0.p;
     double* ut_all = (double*)ctx->d_ws1.p;              // [F, n2], slice after slice

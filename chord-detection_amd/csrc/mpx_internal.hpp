@@ -70,6 +70,8 @@ struct mpx_ctx {
     unsigned live_epoch = 0;                  // tag of the parked records of the current batch (never 0)
     void* h_results = nullptr;                // pinned staging for result copies of batches ([clips, 12] doubles): d2h_results
     size_t h_results_bytes = 0;
+    void* h_tables = nullptr;                 // pinned staging for host-built tables a call uploads (pinned_tables, mpx_api.hip)
+    size_t h_tables_bytes = 0;
     size_t if0_ws_cap = (size_t)32 << 30;     // MPX_OPT_IF0_WORKSPACE_BYTES
     hipStream_t if0_sp_stream = nullptr;      // development builds, MPX_IF0_OVERLAP=1: the summary spectra's stream (if0_run_host)
     hipEvent_t if0_ev_fe[2] = {}, if0_ev_sp[2] = {};
@@ -142,6 +144,7 @@ inline void dev_tick(const void*, const char*) {}
 int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
 bool samples_on_device(const mpx_ctx* ctx, const void* p);
+void* pinned_tables(mpx_ctx* ctx, size_t bytes);   // >= bytes of pinned host memory owned by the context, or nullptr
 void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failure (error set)
 // Samples (host or device memory) into device memory, enqueued on `st` (see mpx_api.hip for the measured rates).
 int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
