@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <chrono>
+#include <mutex>
 #include <cstring>
 
 #include "mpx_internal.hpp"
@@ -44,6 +45,28 @@ static void release_retired(mpx_ctx* ctx) {
     ctx->retired_bytes = 0;
 }
 void release_retired_blocks(mpx_ctx* ctx) { release_retired(ctx); }   // mpx_destroy
+
+// hipOccupancyMaxActiveBlocksPerMultiprocessor costs 1.3 ms the first time a CONTEXT asks (MPX_IF0_TICKS, "occ"), whatever the
+// process has asked before: the answers are kept per (device, kernel) for the whole process as well.
+static std::mutex g_occ_mutex;
+static std::map<std::pair<int, std::string>, int> g_occ;
+bool occupancy_lookup(mpx_ctx* ctx, const std::string& key, int* v) {
+    auto it = ctx->occupancy.find(key);
+    if (it != ctx->occupancy.end()) {
+        *v = it->second;
+        return true;
+    }
+    std::lock_guard<std::mutex> lock(g_occ_mutex);
+    auto g = g_occ.find({ctx->device, key});
+    if (g == g_occ.end()) return false;
+    ctx->occupancy[key] = *v = g->second;
+    return true;
+}
+void occupancy_store(mpx_ctx* ctx, const std::string& key, int v) {
+    ctx->occupancy[key] = v;
+    std::lock_guard<std::mutex> lock(g_occ_mutex);
+    g_occ[{ctx->device, key}] = v;
+}
 
 // Is p memory of the context's OWN device (hipMalloc'ed, a torch tensor's storage ...)?  The host entry points read such samples
 // in place; another device's memory goes through the staging copy like host memory (hipMemcpyDefault finds its way).

@@ -18,6 +18,8 @@
 //                           search (one wave per harmonic m for the range maxima), harmonic
 //                           cancellation, pitch-class scatter (quirks A.10-A.13, A.18).
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -1164,7 +1166,20 @@ static int if0_plan(mpx_ctx* ctx, int fs, const mpx_if0_params& p, If0Plan& plan
     const bool tuned = NF == 1024 || NF == 2048 || NF == 4096 || NF == 8192;
     std::vector<cx<double>> tw(NF), twn(NF + 1);
     static_assert(sizeof(cx<double>) == 2 * sizeof(double), "cx<double> is (x, y)");
-    if (tuned) if0_unit_roots(NF, reinterpret_cast<double*>(tw.data()), reinterpret_cast<double*>(twn.data()));
+    if (tuned) {
+        // (the tables depend on the frame size alone: a second context of the process, or a second sample rate, copies the first's)
+        static std::mutex roots_mutex;
+        static std::map<int, std::pair<std::vector<cx<double>>, std::vector<cx<double>>>> roots;
+        std::lock_guard<std::mutex> lock(roots_mutex);
+        auto it = roots.find(NF);
+        if (it == roots.end()) {
+            if0_unit_roots(NF, reinterpret_cast<double*>(tw.data()), reinterpret_cast<double*>(twn.data()));
+            roots.emplace(NF, std::make_pair(tw, twn));
+        } else {
+            tw = it->second.first;
+            twn = it->second.second;
+        }
+    }
     plan.d_coefs = (If0ChanCoef*)upload(ctx, coefs.data(), coefs.size() * sizeof(If0ChanCoef));
     plan.d_window = (double*)upload(ctx, win.data(), win.size() * sizeof(double));
     plan.d_tw = (cx<double>*)upload(ctx, tw.data(), tw.size() * sizeof(cx<double>));
@@ -2220,13 +2235,13 @@ int if0_run_host(mpx_ctx* ctx, const float* signals, const int64_t* offsets, int
     // the period search runs ONCE, behind the last slice, on persistent workgroups with a scratch pair each
     const bool per_big = n2 > 16384;   // spectra of more than 16 384 bins: the instantiation with the larger tables
     const char* per_key = per_big ? "if0_periodicity_big" : "if0_periodicity";
-    if (!ctx->occupancy.count(per_key)) {
+    if (int have = 0; !occupancy_lookup(ctx, per_key, &have)) {
         int occ = 0;
         if (per_big)
             MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<true>, PER_T, 0));
         else
             MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<false>, PER_T, 0));
-        ctx->occupancy[per_key] = occ > 0 ? occ : 1;
+        occupancy_store(ctx, per_key, occ > 0 ? occ : 1);
     }
     const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy[per_key]);   // scratch slots
     (void)max_slice_frames;
@@ -2445,13 +2460,13 @@ int if0_periodicity_host(mpx_ctx* ctx, const double* spectra, long long nframes,
     int rc;
     const bool per_big = n2 > 16384;
     const char* per_key = per_big ? "if0_periodicity_big" : "if0_periodicity";
-    if (!ctx->occupancy.count(per_key)) {
+    if (int have = 0; !occupancy_lookup(ctx, per_key, &have)) {
         int occ = 0;
         if (per_big)
             MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<true>, PER_T, 0));
         else
             MPX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, if0_periodicity_kernel<false>, PER_T, 0));
-        ctx->occupancy[per_key] = occ > 0 ? occ : 1;
+        occupancy_store(ctx, per_key, occ > 0 ? occ : 1);
     }
     const long long per_grid = std::min<long long>(nframes, 2LL * ctx->num_cus * ctx->occupancy[per_key]);
     if ((rc = ensure(ctx, ctx->d_ws1, ((size_t)nframes + 2 * (size_t)per_grid) * n2 * sizeof(double)))) return rc;   // ut | ur | ud

@@ -144,7 +144,9 @@ inline void dev_tick(const void*, const char*) {}
 int set_error(mpx_ctx* ctx, int code, const char* fmt, ...);
 int ensure(mpx_ctx* ctx, DevBuf& b, size_t bytes);
 bool samples_on_device(const mpx_ctx* ctx, const void* p);
-void* pinned_tables(mpx_ctx* ctx, size_t bytes);   // >= bytes of pinned host memory owned by the context, or nullptr
+void* pinned_tables(mpx_ctx* ctx, size_t bytes);
+bool occupancy_lookup(mpx_ctx* ctx, const std::string& key, int* v);   // the context's cache, then the process's (per device)
+void occupancy_store(mpx_ctx* ctx, const std::string& key, int v);   // >= bytes of pinned host memory owned by the context, or nullptr
 void* upload(mpx_ctx* ctx, const void* host, size_t bytes);  // nullptr on failure (error set)
 // Samples (host or device memory) into device memory, enqueued on `st` (see mpx_api.hip for the measured rates).
 int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
