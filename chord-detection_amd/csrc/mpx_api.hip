@@ -152,30 +152,34 @@ int stage_h2d(mpx_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_
     return MPX_OK;
 }
 
+// The context's pinned staging for batch results ([clips, 12] doubles), at least `bytes` long; nullptr without pinned memory.
+static void* pinned_results(mpx_ctx* ctx, size_t bytes) {
+    if (ctx->h_results_bytes >= bytes) return ctx->h_results;
+    if (ctx->h_results) ctx->retired_host.push_back(ctx->h_results);   // (hipHostFree waits for the device: see ensure)
+    if (dev_env_on("MPX_ENSURE_FREE")) release_retired_blocks(ctx);
+    ctx->h_results = nullptr;
+    ctx->h_results_bytes = 0;
+    void* p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t he = hipHostMalloc(&p, bytes + bytes / 4, hipHostMallocDefault);
+    if (dev_env_on("MPX_ENSURE_TRACE"))
+        fprintf(stderr, "mpx ensure: ctx %p hipHostMalloc(%zu) took %.0f us\n", (void*)ctx, bytes + bytes / 4,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    if (he != hipSuccess) {
+        (void)hipGetLastError();   // no pinned memory: the caller copies directly
+        return nullptr;
+    }
+    ctx->h_results = p;
+    ctx->h_results_bytes = bytes + bytes / 4;
+    return p;
+}
+
 int d2h_results_sync(mpx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes, hipStream_t st) {
     if (bytes > 8192) {
-        if (ctx->h_results_bytes < bytes) {
-            if (ctx->h_results) ctx->retired_host.push_back(ctx->h_results);   // (hipHostFree waits for the device: see ensure)
-            if (dev_env_on("MPX_ENSURE_FREE")) release_retired_blocks(ctx);
-            ctx->h_results = nullptr;
-            ctx->h_results_bytes = 0;
-            void* p = nullptr;
-            const auto t0 = std::chrono::steady_clock::now();
-            const hipError_t he = hipHostMalloc(&p, bytes + bytes / 4, hipHostMallocDefault);
-            if (dev_env_on("MPX_ENSURE_TRACE"))
-                fprintf(stderr, "mpx ensure: ctx %p hipHostMalloc(%zu) took %.0f us\n", (void*)ctx, bytes + bytes / 4,
-                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
-            if (he == hipSuccess) {
-                ctx->h_results = p;
-                ctx->h_results_bytes = bytes + bytes / 4;
-            } else {
-                (void)hipGetLastError();   // no pinned memory: the direct copy below
-            }
-        }
-        if (ctx->h_results) {
-            MPX_HIP(ctx, hipMemcpyAsync(ctx->h_results, src_dev, bytes, hipMemcpyDeviceToHost, st));
+        if (void* h = pinned_results(ctx, bytes)) {
+            MPX_HIP(ctx, hipMemcpyAsync(h, src_dev, bytes, hipMemcpyDeviceToHost, st));
             MPX_HIP(ctx, hipStreamSynchronize(st));
-            std::memcpy(dst_host, ctx->h_results, bytes);
+            std::memcpy(dst_host, h, bytes);
             return MPX_OK;
         }
     }
@@ -675,10 +679,20 @@ static int method_batch(mpx_ctx* ctx, run_fn run, const float* signals, const in
         }
     }
     dev_tick(ctx, "method_batch: kernels queued");
+    // The per-clip sums are written by the kernel straight into the context's pinned (device-mapped) staging when there is one: a
+    // copy of its own costs a launch and its latency (round 6: 148 -> 140 us per 1366-clip Harmonic-Energy call, same-box A/B with
+    // MPX_RESULTS_BY_COPY=1 in the development library, profiles/r6/batch_results_in_place_ab.txt).
+    const size_t rbytes = (size_t)num_clips * 12 * sizeof(double);
+    void* hres = rbytes > 8192 && !dev_env_on("MPX_RESULTS_BY_COPY") ? pinned_results(ctx, rbytes) : nullptr;
     if ((rc = segment_sum(ctx, (const double*)ctx->d_frames_out.p, (const long long*)ctx->d_offsets.p, num_clips, nf,
-                          (double*)ctx->d_sum.p, st)))
+                          hres ? (double*)hres : (double*)ctx->d_sum.p, st)))
         return rc;
-    if ((rc = d2h_results_sync(ctx, chroma_sums, ctx->d_sum.p, (size_t)num_clips * 12 * sizeof(double), st))) return rc;
+    if (hres) {
+        MPX_HIP(ctx, hipStreamSynchronize(st));
+        std::memcpy(chroma_sums, hres, rbytes);
+    } else if ((rc = d2h_results_sync(ctx, chroma_sums, ctx->d_sum.p, rbytes, st))) {
+        return rc;
+    }
     ctx->batch_layout.swap(layout);   // d_desc / d_offsets hold this layout now (a failed call leaves the cache empty)
     ctx->batch_layout_frames = nf;
     return MPX_OK;
