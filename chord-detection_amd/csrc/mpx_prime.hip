@@ -673,15 +673,24 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
         }
         // An all-zero frame has an all-zero spectrum in the reference; next to a loud partner it would come out as that
         // partner's rounding noise, so such a frame is flagged and its magnitudes are the exact zeros (as in prime_pers_kernel).
-        const unsigned long long class_mask = L == 1024 ? (parity ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull) : ~0ull;
-        const bool live_a = (__ballot(nza) & class_mask) != 0, live_b = (__ballot(nzb) & class_mask) != 0;
+        // (the class's half of the ballot by SCALAR masks and a select on the parity: as a per-lane 64-bit mask the constant sat in
+        //  two register pairs of a kernel that has none to spare, was spilled, and was reloaded behind the prefetch)
+        const unsigned long long bal_a = __ballot(nza), bal_b = __ballot(nzb);
+        bool live_a, live_b;
+        if constexpr (L == 1024) {
+            // (readfirstlane: the four answers are pinned as scalars -- left alone the compiler folds the select back into the mask)
+            const int ea = __builtin_amdgcn_readfirstlane((int)((bal_a & 0x5555555555555555ull) != 0));
+            const int oa = __builtin_amdgcn_readfirstlane((int)((bal_a & 0xAAAAAAAAAAAAAAAAull) != 0));
+            const int eb = __builtin_amdgcn_readfirstlane((int)((bal_b & 0x5555555555555555ull) != 0));
+            const int ob = __builtin_amdgcn_readfirstlane((int)((bal_b & 0xAAAAAAAAAAAAAAAAull) != 0));
+            live_a = (parity ? oa : ea) != 0;
+            live_b = (parity ? ob : eb) != 0;
+        } else {
+            live_a = bal_a != 0;
+            live_b = bal_b != 0;
+        }
         const long long cur_slot = it.slot;
         const bool cur_b = it.vb > 0;
-        // the next item's samples travel under this item's transforms
-        advance();
-        const bool more = __builtin_amdgcn_readfirstlane((int)live_here()) != 0;   // (lane 0: the even class's item; wave-uniform)
-        it = item_here();
-        fetch(it, xa, xb);
         hw_phase();
         pw_fft1024<true>(z, xbuf, theta_lds);   // z[p] = U_class[(lane >> 1) + 32 br5(p)]
         hw_phase();
@@ -743,6 +752,16 @@ __global__ __launch_bounds__(WAVES * 64, 1) void prime_wave_kernel(const float* 
             }
             wave_lds_fence();
         }
+        // The next item's samples are requested HERE, behind the second transform, and travel under the magnitudes and the
+        // arg-max rounds.  Until the end of round 6 they were requested in front of the first transform: 44 registers more across
+        // both transforms, which the 1024-point kernel does not have -- the compiler loaded four of them, WAITED for them
+        // (s_waitcnt vmcnt(0) inside the prefetch, twice per lane class), spilled them and reloaded them at the top of the next
+        // iteration: 36 bytes of scratch and four exposed memory latencies per iteration.
+        advance();
+        const bool more = __builtin_amdgcn_readfirstlane((int)live_here()) != 0;   // (lane 0: the even class's item; wave-uniform)
+        it = item_here();
+        fetch(it, xa, xb);
+        hw_phase();
         // 4 |X_a[k]|^2 and 4 |X_b[k]|^2 (-inf from `half` on).  X[k] = conj(chirp[k]) y[k] and X[-k] = conj(chirp[k]) y[-k] (the
         // chirp is even); X_a = (X[k] + conj X[-k]) / 2, X_b = (X[k] - conj X[-k]) / 2i.  Times conj(chirp[k]) once more -- a
         // factor of modulus 1 -- the two are t +- conj(y[-k]) with t = conj(chirp[k])^2 y[k]: one complex product per bin; the

@@ -36,6 +36,7 @@ SCRATCH_FREE = [
     "mpx::coopfit_kernel", "mpx::coopfit8_kernel",   # the cooperative fit kernels (four / eight fits to a wave)
     "mpx::peakfit_kernel<true>",                      # samples in LDS, fvec recomputed: every batch (the round-2 arrangement, 40 B of scratch, is a development-build option)
     "mpx::prime_wave_kernel<2048, 4>",                # Prime-multiF0, 2048-point chirp-z: a wave per SIMD, 512 registers each
+    "mpx::prime_wave_kernel<1024, 7>",                # ... 1024 points, two items per wave at two waves per SIMD: 36 B of scratch until the lane-class masks of its ballots became scalars (round 6)
     "mpx::prime_pers_kernel<4096>",
     "mpx::if0_spectrum_split_kernel<8192, true, 1>",   # Iterative-F0 summary spectra at the default frame size, power 1
     # ... and every other instantiation a caller can reach through frame_size / power (iterative_f0.py:22-33); round 3 shipped
@@ -53,7 +54,6 @@ SCRATCH_FREE = [
 # hipcc reports TODAY (ROCm 7.2), no headroom: a spill that grows by one slot fails here and has to be looked at (round 5
 # shipped these with up to 4 bytes of slack and a 36-byte allowance for two kernels that no longer spill at all).
 SCRATCH_CEILING = {
-    "mpx::prime_wave_kernel<1024, 7>": 36,             # two items per wave at two waves per SIMD: loop-carried item state (slots, pointers), touched once per iteration outside the transforms
     "mpx::pv_enhance_kernel<true, 2>": 24,             # three workgroups per CU since round 5 (168 registers): 0.85 -> 0.66 ms per 8192 frames with the spill
     "mpx::if0_periodicity_kernel<false>": 108,                # held at four workgroups per CU (128 registers); fourteen loads in flight per lane in the range maxima: 1.59 -> 1.49 ms per 600 s WITH the spill
     "mpx::he_wave_kernel<8, 4, false, false, 4294967295u, 1, false>": 24,   # ragged / unaligned frames, every row: the loader with per-sample guards
