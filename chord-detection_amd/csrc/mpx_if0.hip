@@ -1432,13 +1432,23 @@ __device__ __forceinline__ void if0_split_body(cx<double>* buf, const double* __
     const double* src = yc + fr.yc_base;
     cx<double> xn[8];
     // (the samples arrive Hamming-windowed: the front end's tile flush multiplies them, see if0_frontend_body)
+    // FULL: plain 16-byte loads.  Otherwise (round 6) through a buffer descriptor of exactly the samples that exist -- base = the
+    // channel's row, size = 8 x valid bytes: a sample from `valid` on comes back as zero from the hardware's range check, one
+    // 8-byte load per sample so that a load is either inside or outside (no compare, no select: those were 8 % of the kernel's
+    // vector instructions and kept the body of a clip's last frame from fetching ahead).
     auto fetch = [&](const double* __restrict__ p, int tid) {
+        if constexpr (FULL) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int m = tid + r * T;
-            const cx<double> v = *reinterpret_cast<const cx<double>*>(p + 2 * m);
-            if (FULL) xn[r] = v;
-            else xn[r] = {2 * m < fr.valid ? v.x : 0.0, 2 * m + 1 < fr.valid ? v.y : 0.0};
+            for (int r = 0; r < 8; ++r) xn[r] = *reinterpret_cast<const cx<double>*>(p + 2 * (tid + r * T));
+        } else {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, fr.valid > 0 ? 8 * fr.valid : 0, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int voff = 16 * (tid + r * T);
+                const auto lo = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, 0, 0);
+                const auto hi = __builtin_amdgcn_raw_buffer_load_b64(rs, voff + 8, 0, 0);
+                xn[r] = {__builtin_bit_cast(double, lo), __builtin_bit_cast(double, hi)};
+            }
         }
     };
     fetch(src, tid0);
@@ -1582,9 +1592,9 @@ __global__ __launch_bounds__(NF / 16, if0_split_waves(NF, POW1)) void if0_spectr
         if (P) if0_split_body<NF, 1, POW1, PF, true>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
         else if0_split_body<NF, 0, POW1, PF, true>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
     } else {
-        // (the rare kind -- the last frame of a clip -- fetches the next channel after the split: the selects' registers)
-        if (P) if0_split_body<NF, 1, POW1, 0, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
-        else if0_split_body<NF, 0, POW1, 0, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+        // (the last frame of a clip: the same schedule, its samples through a buffer descriptor -- if0_split_body's fetch)
+        if (P) if0_split_body<NF, 1, POW1, PF, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
+        else if0_split_body<NF, 0, POW1, PF, false>(buf, yc, fr, channels, power, window, twNF, twn, twn_r, row);
     }
 }
 
